@@ -1,0 +1,199 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.npz by running the REAL reference
+(/root/reference, imported through oracle/ref_harness.py) on deterministic synthetic
+checkpoints (oracle/synth.py).  Run in the build container only:
+
+    python -m oracle.make_golden
+
+The reference ships no golden vectors / tests of its own, so these
+reference-produced fixtures are what pins oracle/restatement.py and, through it, the
+HIP path.  Fixtures are small (B<=4) so they can live in git.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_harness as rh
+from . import spec as SP
+from . import synth
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+WEIGHT_SEED = 1
+
+
+def load_synth(m, spec, seed=WEIGHT_SEED, perturb=True):
+    ssd = synth.synth_state_dict(spec, seed=seed, perturb=perturb, prefix="")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+    return ssd
+
+
+def random_valid_tokens(spec, B, mask_frac, g):
+    tokens = torch.empty(B, spec.seq_len, dtype=torch.long)
+    for a in range(spec.n_attr):
+        ids = torch.as_tensor(spec.full_ids(a))
+        # any live class except MASK (pad allowed)
+        tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (B, spec.max_elem), generator=g)]
+    mk = torch.rand(B, spec.seq_len, generator=g) < mask_frac
+    tokens[mk] = spec.mask_id
+    return tokens
+
+
+def step_cases(m, spec, ts, B=2):
+    """Teacher-forced single-step pieces from the reference: transformer logits
+    (nn_lib.py:191-237), predict_start (base.py:127-146), q_posterior
+    (constrained.py:135-206)."""
+    from trainer.models.categorical_diffusion.util import index_to_log_onehot
+
+    g = torch.Generator().manual_seed(123)
+    out = {"ts": np.array(ts, np.int32)}
+    for t in ts:
+        tokens = random_valid_tokens(spec, B, t / (spec.n_step - 1), g)
+        tt = torch.full((B,), t, dtype=torch.long)
+        with torch.no_grad():
+            logits = m.transformer(tokens, timestep=tt)["logits"]
+            lz = index_to_log_onehot(tokens, spec.n_class)
+            x0 = m.predict_start(lz, tt)
+            post = m.q_posterior(x0, lz, tt)
+        out[f"tokens_{t}"] = tokens.numpy().astype(np.int16)
+        out[f"logits_{t}"] = logits.numpy()
+        out[f"post_{t}"] = post.numpy()
+        if t == ts[0]:
+            out[f"x0_{t}"] = x0.numpy()
+    return out
+
+
+def trajectory(m, spec, B, cfg, cond=None, seed=0):
+    """Full reference sample() with intermediate results (base.py:293-371), plus for
+    every visited state the reference's own greedy (argmax) next tokens — i.e. a
+    teacher-forced per-step known-answer table covering every t."""
+    from trainer.models.categorical_diffusion.util import index_to_log_onehot
+    import copy
+
+    torch.manual_seed(seed)
+    c = copy.deepcopy(cond)
+    inter = m.sample(batch_size=B, cond=c, sampling_cfg=cfg, get_intermediate_results=True)
+    states = torch.stack(inter)  # (T, B, S): state AFTER each step
+    T = states.shape[0]
+    if cond is None:
+        start = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.long)
+    else:
+        start = cond["seq"].clone()
+    prev_states = torch.cat([start[None], states[:-1]])  # state BEFORE each step
+    det = rh.sampling_cfg("deterministic")
+    for k in cfg:
+        if k.startswith("refine") or k.startswith("relation"):
+            det[k] = cfg[k]
+    greedy = []
+    steps = [int(i * spec.n_step / T) for i in range(T - 1, -1, -1)]
+    for i, t in enumerate(steps):
+        lz = index_to_log_onehot(prev_states[i], spec.n_class)
+        tt = torch.full((B,), t, dtype=torch.long)
+        cc = copy.deepcopy(c)  # already holds weak_* keys for refinement
+        nz = m._sample_single_step(lz, tt, skip_step=0, sampling_cfg=det, cond=cc)
+        greedy.append(nz.argmax(1))
+    return {
+        "steps": np.array(steps, np.int32),
+        "states_before": prev_states.numpy().astype(np.int16),
+        "states_after": states.numpy().astype(np.int16),
+        "greedy_next": torch.stack(greedy).numpy().astype(np.int16),
+    }
+
+
+def capture_probs(m, spec, tokens, t, cfg, cond=None):
+    """Probabilities the reference feeds torch.multinomial (helpers/sampling.py:119-127)."""
+    from trainer.models.categorical_diffusion.util import index_to_log_onehot
+    import copy
+
+    captured = {}
+    orig = torch.multinomial
+
+    def fake(probs, num_samples, *a, **k):
+        captured["p"] = probs.detach().clone()
+        return probs.argmax(dim=-1, keepdim=True)
+
+    torch.multinomial = fake
+    try:
+        lz = index_to_log_onehot(tokens, spec.n_class)
+        tt = torch.full((tokens.shape[0],), t, dtype=torch.long)
+        m._sample_single_step(lz, tt, skip_step=0, sampling_cfg=cfg, cond=copy.deepcopy(cond))
+    finally:
+        torch.multinomial = orig
+    B, S = tokens.shape
+    return captured["p"].view(B, S, spec.n_class).permute(0, 2, 1).contiguous()  # (B,C,S)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for ds in ("rico25", "publaynet"):
+        spec = SP.SPECS[ds]
+        m, tok = rh.build_reference_model(ds, seed=0)
+        # schedule buffers + key/shape manifest straight from the reference
+        sd0 = m.state_dict()
+        np.savez_compressed(
+            os.path.join(OUT, f"{ds}_schedule.npz"),
+            **{k: v.numpy() for k, v in sd0.items() if "_log_" in k},
+        )
+        with open(os.path.join(OUT, f"{ds}_state_dict_manifest.txt"), "w") as f:
+            for k, v in rh.state_dict_layoutdm_keys(m).items():
+                f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+        load_synth(m, spec)
+        np.savez_compressed(os.path.join(OUT, f"{ds}_step_cases.npz"), **step_cases(m, spec, [99, 60, 20, 1, 0]))
+
+        if ds == "rico25":
+            tr = trajectory(m, spec, 4, rh.sampling_cfg("random"), None, seed=0)
+            np.savez_compressed(os.path.join(OUT, "rico25_uncond_trajectory.npz"), **tr)
+            torch.manual_seed(0)
+            full = m.sample(batch_size=4, cond=None, sampling_cfg=rh.sampling_cfg("deterministic"),
+                            get_intermediate_results=True)
+            np.savez_compressed(os.path.join(OUT, "rico25_uncond_greedy_loop.npz"),
+                                states_after=torch.stack(full).numpy().astype(np.int16))
+            # strided schedule (num_timesteps=25 -> skip_step=3): base.py:227-235
+            torch.manual_seed(0)
+            cfg = rh.sampling_cfg("deterministic", num_timesteps=25)
+            full = m.sample(batch_size=2, cond=None, sampling_cfg=cfg, get_intermediate_results=True)
+            np.savez_compressed(os.path.join(OUT, "rico25_uncond_greedy_T25.npz"),
+                                states_after=torch.stack(full).numpy().astype(np.int16))
+            # refinement: cond built like helpers/task.py:126-138 (LayoutDM branch)
+            c = synth.synth_cond_c(spec, 3, seed=5)
+            g = torch.Generator().manual_seed(9)
+            seq_orig = torch.from_numpy(c["seq"]).clone()
+            for a in range(1, spec.n_attr):
+                ids = torch.as_tensor(spec.full_ids(a))
+                valid = torch.from_numpy(c["seq"][:, a::spec.n_attr] == spec.mask_id)
+                rnd = ids[torch.randint(0, spec.n_bin, (3, spec.max_elem), generator=g)]
+                seq_orig[:, a::spec.n_attr] = torch.where(valid, rnd, seq_orig[:, a::spec.n_attr])
+            cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]),
+                    "type": "refinement", "seq_orig": seq_orig}
+            cfg = rh.sampling_cfg("random", refine_mode="uniform", refine_offset_ratio=0.1, refine_lambda=3.0)
+            tr = trajectory(m, spec, 3, cfg, cond, seed=3)
+            tr["cond_seq"] = c["seq"].astype(np.int16)
+            tr["cond_mask"] = c["mask"]
+            tr["seq_orig"] = seq_orig.numpy().astype(np.int16)
+            # the (C,C) prior table the reference builds (helpers/task.py:154-201), lambda applied
+            from trainer.helpers.task import _index_to_smoothed_log_onehot
+            table = _index_to_smoothed_log_onehot(torch.arange(spec.n_class)[None], tok, mode="uniform",
+                                                  offset_ratio=0.1)[0].T.contiguous() * 3.0
+            tr["weak_table"] = table.numpy()  # [token, class]
+            np.savez_compressed(os.path.join(OUT, "rico25_refinement_trajectory.npz"), **tr)
+        else:
+            c = synth.synth_cond_c(spec, 4, seed=0)
+            cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": "c"}
+            cfg = rh.sampling_cfg("top_p", top_p=0.9)
+            tr = trajectory(m, spec, 4, cfg, cond, seed=1)
+            tr["cond_seq"] = c["seq"].astype(np.int16)
+            tr["cond_mask"] = c["mask"]
+            # top-p probabilities at three states of that trajectory
+            for i in (0, 50, 98):
+                toks = torch.from_numpy(tr["states_before"][i].astype(np.int64))
+                p = capture_probs(m, spec, toks[:2], int(tr["steps"][i]), cfg,
+                                  {"seq": cond["seq"][:2], "mask": cond["mask"][:2], "type": "c"})
+                tr[f"top_p_probs_{i}"] = p.numpy()
+            np.savez_compressed(os.path.join(OUT, "publaynet_cond_c_trajectory.npz"), **tr)
+        print(ds, "done", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,251 @@
+"""TEST INFRASTRUCTURE ONLY — loader for the *real* reference implementation.
+
+This module imports CyberAgentAILab/layout-dm from ``/root/reference`` (read-only,
+present only in the build container, NOT on the GPU box) with in-memory stubs for
+the third-party modules the image lacks (hydra, omegaconf, torch_geometric,
+torchvision, seaborn, prdc, pytorch_fid).  It is used by
+``oracle/make_golden.py`` to generate the fixtures under ``tests/golden/`` and by
+``tests/test_oracle_vs_reference.py`` (skipped when the reference is absent) to
+pin ``oracle/restatement.py`` against the reference itself.
+
+Nothing in the product path (``layout_dm_amd/``) may import this file.
+
+Recipe follows SURVEY.md App. H.  Reference symbols used:
+  trainer/models/categorical_diffusion/constrained.py:27  ConstrainedMaskAndReplaceDiffusion
+  trainer/helpers/layout_tokenizer.py:196                  LayoutSequenceTokenizer
+  trainer/models/base_model.py:108-116                     _init_weights
+  trainer/models/common/util.py:36-44                      shrink
+"""
+from __future__ import annotations
+
+import copy
+import dataclasses
+import importlib
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("LAYOUTDM_REFERENCE", "/root/reference")
+_TRAINER_PATH = os.path.join(REFERENCE_ROOT, "src", "trainer")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(_TRAINER_PATH, "trainer"))
+
+
+# --------------------------------------------------------------------------- stubs
+class DictConfig(dict):
+    """Attribute-dict standing in for omegaconf.DictConfig."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return DictConfig({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def to_cfg(obj):
+    if dataclasses.is_dataclass(obj):
+        if isinstance(obj, type):
+            obj = obj()
+        obj = dataclasses.asdict(obj)
+    if isinstance(obj, dict):
+        return DictConfig({k: to_cfg(v) for k, v in obj.items()})
+    if isinstance(obj, (list, tuple)):
+        return [to_cfg(v) for v in obj]
+    return obj
+
+
+class _OmegaConf:
+    @staticmethod
+    def structured(obj):
+        return to_cfg(obj)
+
+    @staticmethod
+    def create(obj=None):
+        return to_cfg(obj or {})
+
+    @staticmethod
+    def to_container(obj, **_):
+        return obj
+
+
+def _instantiate(cfg, *args, **kwargs):
+    """Minimal hydra.utils.instantiate: import _target_, recurse, call."""
+    cfg = dict(cfg)
+    target = cfg.pop("_target_")
+    cfg.pop("_partial_", None)
+    mod, name = target.rsplit(".", 1)
+    fn = getattr(importlib.import_module(mod), name)
+    kw = {}
+    for k, v in cfg.items():
+        if isinstance(v, dict) and "_target_" in v:
+            v = _instantiate(v)
+        kw[k] = v
+    kw.update(kwargs)
+    return fn(*args, **kw)
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return None
+
+
+def _stub(name: str, **attrs):
+    m = types.ModuleType(name)
+    m.__path__ = []  # behave as a package
+
+    def _getattr(attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return type(attr, (_Dummy,), {})
+
+    m.__getattr__ = _getattr
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    if "." in name:
+        parent, child = name.rsplit(".", 1)
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+_INSTALLED = False
+
+
+def install_stubs():
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True  # /root/reference must stay pristine
+    if _TRAINER_PATH not in sys.path:
+        sys.path.insert(0, _TRAINER_PATH)
+
+    def need(name):
+        try:
+            importlib.import_module(name)
+            return False
+        except Exception:
+            return True
+
+    if need("omegaconf"):
+        _stub("omegaconf", DictConfig=DictConfig, OmegaConf=_OmegaConf)
+    if need("hydra"):
+        _stub("hydra")
+        _stub("hydra.utils", instantiate=_instantiate)
+        _stub("hydra.core")
+        _stub("hydra.core.config_store")
+    if need("torch_geometric"):
+        _stub("torch_geometric")
+        for sub in ("utils", "data", "loader"):
+            _stub(f"torch_geometric.{sub}")
+        for sub in ("collate", "dataset", "makedirs", "separate"):
+            _stub(f"torch_geometric.data.{sub}")
+    if need("torchvision"):
+        _stub("torchvision")
+        _stub("torchvision.transforms")
+        _stub("torchvision.utils")
+    for name in ("seaborn", "prdc", "pytorch_fid"):
+        if need(name):
+            _stub(name)
+    if "pytorch_fid.fid_score" not in sys.modules and need("pytorch_fid.fid_score"):
+        _stub("pytorch_fid.fid_score")
+    _INSTALLED = True
+
+
+# --------------------------------------------------------------------------- configs
+DATASETS = {
+    "rico25": "trainer.datasets.rico.Rico25Dataset",
+    "publaynet": "trainer.datasets.publaynet.PubLayNetDataset",
+}
+
+
+def make_cfgs(dataset: str = "rico25"):
+    data_cfg = DictConfig(
+        num_bin_bboxes=32,
+        pad_until_max=True,
+        shared_bbox_vocab="x-y-w-h",
+        bbox_quantization="linear",
+        special_tokens=["pad", "mask"],
+        var_order="c-x-y-w-h",
+    )
+    dataset_cfg = DictConfig(_target_=DATASETS[dataset], max_seq_length=25)
+    backbone_cfg = DictConfig(
+        _target_="trainer.models.transformer_utils.TransformerEncoder",
+        encoder_layer=DictConfig(
+            _target_="trainer.models.transformer_utils.Block",
+            d_model=512,
+            nhead=8,
+            dim_feedforward=2048,
+            dropout=0.0,
+            batch_first=True,
+            norm_first=True,
+            timestep_type="adalayernorm",
+            diffusion_step=100,
+        ),
+        num_layers=4,
+    )
+    return data_cfg, dataset_cfg, backbone_cfg
+
+
+def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool = False):
+    """Instantiate the reference diffusion module with the reference's own init.
+
+    perturb=True additionally randomises every bias / LayerNorm affine parameter so
+    that no term of the forward pass is trivially 0 or 1 (used for golden vectors).
+    Returns (module, tokenizer).
+    """
+    install_stubs()
+    import torch
+    from trainer.helpers.layout_tokenizer import LayoutSequenceTokenizer
+    from trainer.models.base_model import BaseModel
+    from trainer.models.categorical_diffusion.constrained import (
+        ConstrainedMaskAndReplaceDiffusion,
+    )
+    from trainer.models.common.util import shrink
+
+    data_cfg, dataset_cfg, backbone_cfg = make_cfgs(dataset)
+    torch.manual_seed(seed)
+    tok = LayoutSequenceTokenizer(data_cfg, dataset_cfg)
+    m = ConstrainedMaskAndReplaceDiffusion(
+        backbone_cfg=shrink(backbone_cfg, 29 / 32),
+        num_classes=tok.N_total,
+        max_token_length=tok.max_token_length,
+        num_timesteps=100,
+        pos_emb="elem_attr",
+        transformer_type="flattened",
+        auxiliary_loss_weight=0.1,
+        tokenizer=tok,
+    )
+    m.apply(lambda mod: BaseModel._init_weights(None, mod))
+    if perturb:
+        g = torch.Generator().manual_seed(seed + 1234)
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if p.ndim == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+    m.eval()
+    return m, tok
+
+
+def sampling_cfg(name="deterministic", **kw):
+    cfg = DictConfig(name=name, temperature=1.0, num_timesteps=100)
+    cfg.update(kw)
+    return cfg
+
+
+def state_dict_layoutdm_keys(m):
+    """Reference checkpoint key layout: LayoutDM wraps the diffusion module in
+    CustomDataParallel => every key is prefixed 'model.module.' (layoutdm.py:52)."""
+    return {f"model.module.{k}": v.detach().clone() for k, v in m.state_dict().items()}

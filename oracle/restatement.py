@@ -1,0 +1,366 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (torch-CPU / numpy) of LayoutDM's
+discrete-diffusion sampling hot path.  It is the *checker* for the HIP path
+(tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg); the product package
+`layout_dm_amd/` must never import it.
+
+Parity status: PINNED — tests/test_oracle_golden.py checks every function here against
+fixtures under tests/golden/ that were produced by the reference itself
+(oracle/make_golden.py, which imports /root/reference via oracle/ref_harness.py), and
+tests/test_oracle_vs_reference.py re-checks live whenever /root/reference is present.
+(The reference ships no tests / golden vectors of its own: SURVEY.md §4.)
+
+Every function cites the reference lines it restates; paths are relative to
+/root/reference/src/trainer/trainer/.  State is kept as integer tokens (B,S) instead of
+the reference's (B,C,S) log-one-hot tensors; `index_to_log_onehot` converts when a
+function needs the reference's representation.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .spec import LOG_EPS, VAR_NAMES, ModelSpec
+from .synth import strip_prefix
+
+# --------------------------------------------------------------------------- weights
+
+
+def as_torch_weights(state_dict, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Reference state dict (any of the accepted prefixes) -> {bare key: CPU tensor}."""
+    out = {}
+    for k, v in strip_prefix(state_dict).items():
+        t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v)
+        out[k] = t.detach().cpu().to(dtype) if t.is_floating_point() else t.detach().cpu()
+    return out
+
+
+# --------------------------------------------------------------------------- denoiser
+
+
+def adaln_table(W, spec: ModelSpec, dtype=torch.float32) -> torch.Tensor:
+    """[T][L][2D] table of (scale, shift): Linear(SiLU(Embedding[t]))
+    (models/transformer_utils.py:67-69,80-81).  t is batch-uniform during sampling
+    (categorical_diffusion/base.py:351-353) so the table depends on (t, layer) only."""
+    rows = []
+    for i in range(spec.n_layer):
+        b = f"transformer.backbone.layers.{i}.norm1."
+        e = W[b + "emb.weight"].to(dtype)  # (T, D)
+        e = e * torch.sigmoid(e)  # SiLU
+        rows.append(e @ W[b + "linear.weight"].to(dtype).T + W[b + "linear.bias"].to(dtype))
+    return torch.stack(rows, dim=1)  # (T, L, 2D)
+
+
+def _ln(x, eps=1e-5):
+    # nn.LayerNorm: biased variance, eps inside the sqrt
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps)
+
+
+def denoiser_logits(W, spec: ModelSpec, tokens: torch.Tensor, t: int, dtype=torch.float32,
+                    return_hidden: bool = False):
+    """CategoricalTransformer.forward (models/common/nn_lib.py:191-237) +
+    ElementPositionalEmbedding (nn_lib.py:112-127) + TransformerEncoder/Block/AdaLayerNorm
+    (models/transformer_utils.py:72-83,165-210,226-246), eval mode (dropout = identity).
+
+    tokens (B,S) int64, t python int (uniform over the batch) -> logits (B,S,C).
+    """
+    D, H, dh = spec.d_model, spec.n_head, spec.d_head
+    B, S = tokens.shape
+    g = lambda k: W[k].to(dtype)
+    tr = "transformer."
+    s_idx = torch.arange(S)
+    pos = g(tr + "pos_emb.elem_emb")[s_idx // spec.n_attr] + g(tr + "pos_emb.attr_emb")[s_idx % spec.n_attr]
+    x = g(tr + "cat_emb.weight")[tokens] + pos  # nn_lib.py:204,220
+    hidden = {}
+    for i in range(spec.n_layer):
+        b = f"{tr}backbone.layers.{i}."
+        e = g(b + "norm1.emb.weight")[t]
+        e = e * torch.sigmoid(e)
+        ss = g(b + "norm1.linear.weight") @ e + g(b + "norm1.linear.bias")
+        scale, shift = ss[:D], ss[D:]  # chunk(2): transformer_utils.py:81
+        x = _ln(x) * (1 + scale) + shift  # x REPLACED by its normed value (l.175)
+        if return_hidden:
+            hidden[f"l{i}.norm1"] = x
+        qkv = x @ g(b + "self_attn.in_proj_weight").T + g(b + "self_attn.in_proj_bias")
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        q = q.view(B, S, H, dh).transpose(1, 2)
+        k = k.view(B, S, H, dh).transpose(1, 2)
+        v = v.view(B, S, H, dh).transpose(1, 2)
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+        a = (att @ v).transpose(1, 2).reshape(B, S, D)
+        if return_hidden:
+            hidden[f"l{i}.attn"] = a
+        x = x + a @ g(b + "self_attn.out_proj.weight").T + g(b + "self_attn.out_proj.bias")
+        if return_hidden:
+            hidden[f"l{i}.x1"] = x
+        h = _ln(x) * g(b + "norm2.weight") + g(b + "norm2.bias")
+        h = torch.relu(h @ g(b + "linear1.weight").T + g(b + "linear1.bias"))
+        x = x + h @ g(b + "linear2.weight").T + g(b + "linear2.bias")
+        if return_hidden:
+            hidden[f"l{i}.x2"] = x
+    y = _ln(x) * g(tr + "head.0.weight") + g(tr + "head.0.bias")
+    logits = y @ g(tr + "head.1.weight").T  # no bias: nn_lib.py:186-189
+    if return_hidden:
+        return logits, hidden
+    return logits
+
+
+# --------------------------------------------------------------------------- log-space helpers
+
+
+def log_add_exp(a, b):  # util.py:19-21
+    m = torch.max(a, b)
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+def index_to_log_onehot(tokens: torch.Tensor, C: int) -> torch.Tensor:  # util.py:34-40
+    oh = F.one_hot(tokens, C).permute(0, 2, 1)
+    return torch.log(oh.float().clamp(min=1e-30))
+
+
+def predict_start_from_logits(logits: torch.Tensor) -> torch.Tensor:
+    """Tail of predict_start (categorical_diffusion/base.py:131-144): drop the MASK
+    logit, log_softmax over the remaining C-1 classes in float64, cast to f32, append
+    a -70 row for MASK, clamp to [-70, 0].  (B,S,C) -> (B,C,S)."""
+    out = logits[:, :, :-1].permute(0, 2, 1)
+    log_pred = F.log_softmax(out.double(), dim=1).float()
+    B, _, S = log_pred.shape
+    log_pred = torch.cat([log_pred, torch.full((B, 1, S), -70.0)], dim=1)
+    return torch.clamp(log_pred, -70, 0)
+
+
+def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Tensor, t: int) -> torch.Tensor:
+    """ConstrainedMaskAndReplaceDiffusion.q_posterior
+    (categorical_diffusion/constrained.py:135-206, helpers q_pred 112-133 and
+    q_pred_one_timestep 92-110; Converter gather/scatter helpers/layout_tokenizer.py:540-557).
+
+    log_x_start (B,C,S) f32 = predict_start output; tokens (B,S) = x_t; t python int.
+    Returns log p_theta(x_{t-1}|x_t) over the FULL vocabulary, (B,C,S), dead classes =
+    log(1e-30).  Token form: log_x_t one-hot rows are synthesised per attribute.
+    """
+    B, C, S = log_x_start.shape
+    A, T = spec.n_attr, spec.n_step
+    assert 0 <= t < T  # constrained.py:139
+    u = (t - 1 + (T + 1)) % (T + 1)  # constrained.py:114
+    out = torch.full((B, C, S), LOG_EPS, dtype=torch.float32)  # p_to_f_log fill, layout_tokenizer.py:544
+    for a, key in enumerate(VAR_NAMES):
+        full = torch.as_tensor(spec.full_ids(a))  # partial -> full id
+        K = full.numel()
+        buf = lambda n: W[f"{key}_{n}"].float()
+        la, lb, lc = buf("log_at")[t], buf("log_bt")[t], buf("log_ct")[t]
+        LA, LB, LC = buf("log_cumprod_at")[t], buf("log_cumprod_bt")[t], buf("log_cumprod_ct")[t]
+        LAu, LBu, LCu = buf("log_cumprod_at")[u], buf("log_cumprod_bt")[u], buf("log_cumprod_ct")[u]
+        L1Cu = buf("log_1_min_cumprod_ct")[u]
+
+        tok_a = tokens[:, a::A]  # (B,E) full ids
+        lxs = log_x_start[:, :, a::A][:, full, :]  # f_to_p_log: (B,K,E)
+        # one-hot log_x_t in the partial vocabulary (util.py:34-40 then gather)
+        part = (tok_a.unsqueeze(1) == full.view(1, K, 1))
+        lxt = torch.log(part.float().clamp(min=1e-30))
+        is_mask = (tok_a == spec.mask_id).unsqueeze(1)  # (B,1,E)
+
+        # q(xt|x0) rows 0..K-2 (constrained.py:166-173)
+        log_qt = log_add_exp(lxt[:, :-1, :] + LA, LB)
+        log_qt = torch.where(is_mask, LC.expand_as(log_qt), log_qt)
+        # q(xt|xt-1) (constrained.py:175-185)
+        q1 = log_add_exp(lxt[:, :-1, :] + la, lb)
+        q1 = torch.cat([q1, torch.full((B, 1, q1.shape[2]), LOG_EPS)], dim=1)
+        ct_vec = torch.cat([lc.expand(B, K - 1, q1.shape[2]), torch.zeros(B, 1, q1.shape[2])], dim=1)
+        q1 = torch.where(is_mask, ct_vec, q1)
+        # eq.5 of VQ-Diffusion (constrained.py:188-197)
+        q = lxs[:, :-1, :] - log_qt
+        q = torch.cat([q, torch.full((B, 1, q.shape[2]), LOG_EPS)], dim=1)
+        lse = torch.logsumexp(q, dim=1, keepdim=True)
+        q = q - lse
+        r = torch.cat([
+            log_add_exp(q[:, :-1, :] + LAu, LBu),
+            log_add_exp(q[:, -1:, :] + L1Cu, LCu),
+        ], dim=1)
+        ev = torch.clamp(r + q1 + lse, -70, 0)
+        # p_to_f_log scatter + interleave (constrained.py:198-204)
+        sub = out[:, :, a::A]
+        sub[:, full, :] = ev
+    return out
+
+
+def apply_cond(spec: ModelSpec, logp: torch.Tensor, cond: Optional[dict]) -> torch.Tensor:
+    """Constraint injection of _sample_single_step (categorical_diffusion/base.py:243-284),
+    except cond=relation's gradient update (logit_adjustment.py) which stays in PyTorch."""
+    if not cond:
+        return logp
+    B, C, S = logp.shape
+    seq = torch.as_tensor(cond["seq"])
+    if "mask" in cond:
+        strong = torch.as_tensor(cond["mask"]).view(B, 1, S)
+        logp = torch.where(strong, index_to_log_onehot(seq, C), logp)
+    if cond.get("type") == "refinement":
+        wm = torch.as_tensor(cond["weak_mask"])
+        logp = torch.where(wm, logp + torch.as_tensor(cond["weak_logits"]), logp)
+    if cond.get("type") in ("c", "cwh", "refinement", "relation"):
+        pos = torch.arange(S).view(1, S)
+        pad_mask = (pos % spec.n_attr != 0) & (seq != spec.pad_id)  # (B,S)
+        logp = logp.clone()
+        logp[:, spec.pad_id, :] = torch.where(pad_mask, torch.tensor(LOG_EPS), logp[:, spec.pad_id, :])
+    return logp
+
+
+# --------------------------------------------------------------------------- sampler
+
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32(counter, key, rounds: int = 10):
+    """Philox4x32-10 (Salmon et al. 2011), numpy uint64 arithmetic, vectorised over
+    the leading axis of `counter` (N,4) / `key` (N,2).  NOT part of the reference (which
+    uses torch.multinomial): this is OUR sampler's RNG, restated here so stochastic
+    draws of the HIP path can be checked draw-for-draw."""
+    c = np.asarray(counter, dtype=np.uint64).copy()
+    k = np.asarray(key, dtype=np.uint64).copy()
+    M32 = np.uint64(0xFFFFFFFF)
+    for _ in range(rounds):
+        p0 = np.uint64(PHILOX_M0) * c[:, 0]
+        p1 = np.uint64(PHILOX_M1) * c[:, 2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & M32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & M32
+        c = np.stack([hi1 ^ c[:, 1] ^ k[:, 0], lo1, hi0 ^ c[:, 3] ^ k[:, 1], lo0], axis=1) & M32
+        k = np.stack([(k[:, 0] + np.uint64(PHILOX_W0)) & M32, (k[:, 1] + np.uint64(PHILOX_W1)) & M32], axis=1)
+    return c.astype(np.uint32)
+
+
+def token_uniforms(seed: int, first_layout: int, B: int, S: int, step: int, n: int = 1) -> np.ndarray:
+    """Uniforms in (0,1) for token (layout, pos) at reverse step `step` (0-based loop
+    index): Philox counter = (pos, step, layout_lo, layout_hi), key = (seed_lo, seed_hi).
+    u = (x + 0.5) * 2^-32 evaluated in float64 then cast to float32 like the kernel does
+    (the kernel computes it as float(x>>8)*2^-24 + 2^-25).  Returns (B,S,min(n,4))."""
+    lay = (np.arange(B, dtype=np.uint64) + np.uint64(first_layout))
+    ctr = np.zeros((B, S, 4), np.uint64)
+    ctr[..., 0] = np.arange(S, dtype=np.uint64)[None, :]
+    ctr[..., 1] = np.uint64(step)
+    ctr[..., 2] = (lay & np.uint64(0xFFFFFFFF))[:, None]
+    ctr[..., 3] = (lay >> np.uint64(32))[:, None]
+    key = np.zeros((B * S, 2), np.uint64)
+    key[:, 0] = np.uint64(seed & 0xFFFFFFFF)
+    key[:, 1] = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32(ctr.reshape(-1, 4), key).reshape(B, S, 4)
+    u = ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24) + np.float32(2.0 ** -25))
+    return u[..., :n]
+
+
+def filter_logits(logp: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """The non-random part of helpers/sampling.py:81-116: temperature, top-k, top-p
+    (incl. the quirk that the threshold-crossing class is dropped too, l.101-108)."""
+    name = cfg["name"]
+    lg = logp / cfg.get("temperature", 1.0)
+    if name == "top_k":
+        v, _ = torch.topk(lg, cfg["top_k"], 1)
+        lg = lg.clone()
+        lg[lg < v[:, [-1]]] = -float("inf")
+    elif name == "top_p":
+        top_p = cfg["top_p"]
+        C = lg.size(1)
+        s_lg, s_idx = torch.sort(lg, descending=True, dim=1)
+        cum = torch.cumsum(F.softmax(s_lg, dim=1), dim=1)
+        idx = torch.arange(C).view(1, C, 1)
+        s_lg[(cum > top_p) & (idx > 0)] = -float("inf")
+        lg = s_lg.gather(dim=1, index=s_idx.argsort(dim=1))
+    elif name in ("random", "gumbel"):
+        pass
+    else:
+        raise NotImplementedError(name)
+    return lg
+
+
+def sample_probs(logp: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """Class probabilities the reference hands to torch.multinomial
+    (helpers/sampling.py:119-127) for the non-gumbel stochastic samplers. (B,C,S)."""
+    return F.softmax(filter_logits(logp, cfg), dim=1)
+
+
+def sample_tokens(logp: torch.Tensor, cfg: dict, uniforms: Optional[np.ndarray] = None,
+                  generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """helpers/sampling.py:81-130.  deterministic -> argmax over classes (first max).
+    Stochastic: with `uniforms` (B,S) the draw is the inverse-CDF rule of OUR kernel
+    (smallest class c with cumsum(p)[c] > u * sum(p)), else torch.multinomial like the
+    reference.  Returns (B,S) int64."""
+    if cfg["name"] == "deterministic":
+        return torch.argmax(logp, dim=1)
+    if cfg["name"] == "gumbel" and uniforms is None:
+        u = torch.rand(logp.shape, generator=generator)
+        logp = logp / cfg.get("temperature", 1.0) + (-torch.log(-torch.log(u + 1e-30) + 1e-30))
+        probs = F.softmax(logp, dim=1)
+    else:
+        probs = sample_probs(logp, cfg)
+    B, C, S = probs.shape
+    if uniforms is None:
+        flat = probs.permute(0, 2, 1).reshape(B * S, C)
+        return torch.multinomial(flat, 1, generator=generator).view(B, S)
+    cdf = torch.cumsum(probs.double(), dim=1)
+    thr = torch.as_tensor(uniforms, dtype=torch.float64).view(B, 1, S) * cdf[:, -1:, :]
+    idx = (cdf <= thr).sum(dim=1)
+    return idx.clamp(max=C - 1)
+
+
+# --------------------------------------------------------------------------- loop
+
+
+def timestep_list(T_model: int, T_eval: int):
+    """categorical_diffusion/base.py:310-315."""
+    assert T_eval <= T_model
+    return [int(i * T_model / T_eval) for i in range(T_eval - 1, -1, -1)]
+
+
+def single_step(W, spec, tokens, t, cfg, cond=None, skip_step: int = 0, uniforms=None, generator=None,
+                dtype=torch.float32, return_all=False):
+    """_sample_single_step (categorical_diffusion/base.py:205-291) in token form."""
+    logits = denoiser_logits(W, spec, tokens, t, dtype=dtype).float()
+    log_x0 = predict_start_from_logits(logits)
+    noise_t = t
+    td = cfg.get("time_difference", 0.0)
+    if td > 0.0:
+        noise_t = min(max(t - int(spec.n_step * td), 0), spec.n_step - 1)
+    if skip_step > 0 and noise_t > skip_step:
+        noise_t = noise_t - skip_step
+    logp = q_posterior(W, spec, log_x0, tokens, noise_t)
+    logp = apply_cond(spec, logp, cond)
+    nxt = sample_tokens(logp, cfg, uniforms=uniforms, generator=generator)
+    if return_all:
+        return nxt, logits, logp
+    return nxt
+
+
+def sample_loop(W, spec: ModelSpec, batch_size: int, cfg: dict, cond: Optional[dict] = None,
+                seed: Optional[int] = None, first_layout: int = 0, generator=None,
+                dtype=torch.float32, get_intermediate_results=False):
+    """BaseMaskAndReplaceDiffusion.sample (categorical_diffusion/base.py:293-371).
+    With `seed` the stochastic draws use the Philox inverse-CDF rule of the HIP kernel
+    (keyed by global layout index => independent of batch split); otherwise
+    torch.multinomial like the reference."""
+    T_eval = cfg.get("num_timesteps", spec.n_step)
+    steps = timestep_list(spec.n_step, T_eval)
+    if cond:
+        tokens = torch.as_tensor(cond["seq"]).clone().long()
+        if tokens.shape[0] == 1 and batch_size > 1:  # duplicate_cond, helpers/task.py:235-248
+            tokens = tokens.repeat(batch_size, 1)
+            cond = {k: (torch.as_tensor(v).repeat([batch_size] + [1] * (torch.as_tensor(v).dim() - 1))
+                        if isinstance(v, (np.ndarray, torch.Tensor)) and torch.as_tensor(v).dim() > 0 and torch.as_tensor(v).shape[0] == 1 else v)
+                    for k, v in cond.items()}
+    else:
+        tokens = torch.full((batch_size, spec.seq_len), spec.mask_id, dtype=torch.long)
+    prev = spec.n_step
+    inter = []
+    for i, t in enumerate(steps):
+        u = None
+        if seed is not None and cfg["name"] != "deterministic":
+            u = token_uniforms(seed, first_layout, batch_size, spec.seq_len, i)[..., 0]
+        tokens = single_step(W, spec, tokens, t, cfg, cond, skip_step=prev - t - 1, uniforms=u,
+                             generator=generator, dtype=dtype)
+        prev = t
+        if get_intermediate_results:
+            inter.append(tokens.clone())
+    return inter if get_intermediate_results else tokens
