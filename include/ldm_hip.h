@@ -1,0 +1,139 @@
+/* ldm_hip.h — C-ABI of the MI355X-native LayoutDM sampling hot path (libldm_hip.so).
+ *
+ * The reference (CyberAgentAILab/layout-dm) is 100 % Python/PyTorch and has no FFI layer;
+ * its narrowest seam that contains exactly the hot path is the Python method
+ *   ConstrainedMaskAndReplaceDiffusion.sample(batch_size, cond, sampling_cfg, ...)
+ *     src/trainer/trainer/models/categorical_diffusion/base.py:293-371
+ * reached from LayoutDM.sample (models/layoutdm.py:77-88) and test.py:195-200.
+ * These entry points are what a ctypes binding placed at that seam calls (the binding is
+ * shown in INTEGRATION.md and implemented in layout_dm_amd/binding.py).
+ *
+ * Conventions: every pointer named d_* is a DEVICE pointer owned by the caller (e.g. a torch
+ * tensor's data_ptr()); h_* are host pointers.  `stream` is a hipStream_t passed as void*.
+ * Return value 0 = OK, negative = error (text via ldm_last_error).  A handle is bound to one
+ * device and is not thread-safe.  No entry point synchronises the device except
+ * ldm_create / ldm_finalize_weights / ldm_destroy and the *_sync helpers.
+ */
+#ifndef LDM_HIP_H
+#define LDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDM_ABI_VERSION 1
+
+typedef struct ldm_handle ldm_handle;
+
+/* numerics mode of the denoiser GEMMs / attention */
+enum {
+  LDM_PREC_EXACT_F32 = 0, /* v_mfma_f32_32x32x2_f32: exact fp32 (== fmaf chain) */
+  LDM_PREC_FAST_F16 = 1,  /* fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) */
+  LDM_PREC_SPLIT_F16 = 2  /* fp16 hi+lo split operands, 3 MFMA passes, ~fp32 accuracy */
+};
+
+/* sampler kinds: trainer/helpers/sampling.py:13-59,81-130 */
+enum {
+  LDM_SAMPLE_DETERMINISTIC = 0,
+  LDM_SAMPLE_RANDOM = 1,
+  LDM_SAMPLE_TOP_P = 2,
+  LDM_SAMPLE_TOP_K = 3,
+  LDM_SAMPLE_GUMBEL = 4
+};
+
+/* Model geometry.  Mirrors what the reference derives from its hydra config:
+ * vocabulary (helpers/layout_tokenizer.py:79-82,152-153), backbone
+ * (config/backbone/medium.yaml shrunk 29/32 at models/layoutdm.py:54), T (layoutdm.py:33). */
+typedef struct {
+  int32_t abi_version; /* LDM_ABI_VERSION */
+  int32_t n_category;  /* 25 (Rico25) / 5 (PubLayNet) */
+  int32_t n_bin;       /* bins per coordinate (32) */
+  int32_t max_elem;    /* 25 */
+  int32_t n_attr;      /* 5 : c,x,y,w,h */
+  int32_t d_model;     /* 464 */
+  int32_t n_head;      /* 8 */
+  int32_t d_ff;        /* 1856 */
+  int32_t n_layer;     /* 4 */
+  int32_t n_step;      /* T = 100 */
+  int32_t precision;   /* LDM_PREC_* */
+  int32_t max_batch;   /* largest B any call will use (workspace is sized for it) */
+  int32_t chunk;       /* layouts processed per pass through the network (0 = auto) so that the
+                          activation working set stays inside the 256 MiB Infinity Cache */
+} ldm_config;
+
+/* sampling_cfg of the reference (helpers/sampling.py dataclasses) */
+typedef struct {
+  int32_t kind;      /* LDM_SAMPLE_* */
+  float temperature; /* logits / temperature (stochastic kinds only) */
+  float top_p;       /* LDM_SAMPLE_TOP_P */
+  int32_t top_k;     /* LDM_SAMPLE_TOP_K */
+} ldm_sampler;
+
+/* Optional constraints == the `cond` dict consumed at base.py:243-284. All may be NULL/0. */
+typedef struct {
+  const int32_t* d_cond_seq;    /* (B,S) cond["seq"] */
+  const uint8_t* d_strong_mask; /* (B,S) cond["mask"]: 1 = token fixed to cond_seq (base.py:245-251) */
+  const float* d_weak_logits;   /* (B,C,S) refinement prior, added where !strong (base.py:254-258) */
+  int32_t pad_disable;          /* cond["type"] in {c,cwh,refinement,relation} (base.py:272-284) */
+} ldm_cond;
+
+/* ---- lifecycle ---------------------------------------------------------------------- */
+int ldm_create(const ldm_config* cfg, int device, ldm_handle** out);
+void ldm_destroy(ldm_handle* h);
+const char* ldm_last_error(const ldm_handle* h); /* h may be NULL: last create error */
+
+/* ---- weights: the reference checkpoint format ------------------------
+ * key = reference state_dict key with or without the "model.module." prefix; data = host
+ * float32, C-contiguous, shape as in the checkpoint.  Replaces model.load_state_dict
+ * (models/common/util.py:47-57, test.py:144-149).  The handle owns repacked device copies. */
+int ldm_load_weight(ldm_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim);
+/* builds the (S,D) positional table (nn_lib.py:112-127), the [T][L][2D] AdaLN table
+ * (transformer_utils.py:79-81), fp16 weight copies; fails if a required key is missing. */
+int ldm_finalize_weights(ldm_handle* h);
+
+/* ---- parity hooks (one stage each) --------------------------------------------------- */
+/* CategoricalTransformer.forward (nn_lib.py:191-237): tokens (B,S) -> logits (B,S,C) fp32 */
+int ldm_denoise_logits(ldm_handle* h, const int32_t* d_tokens, int t, int B, float* d_logits, void* stream);
+/* predict_start tail + q_posterior + cond overrides (base.py:131-144, constrained.py:135-206,
+ * base.py:243-284): logits (B,S,C), tokens (B,S) -> log p(x_{t-1}|x_t) (B,C,S) fp32.
+ * t_post = the timestep handed to q_posterior (noise_t [- skip_step], base.py:218-240). */
+int ldm_posterior(ldm_handle* h, const float* d_logits, const int32_t* d_tokens, int t_post, int B,
+                  const ldm_cond* cond, float* d_logp, void* stream);
+/* helpers/sampling.py:81-130 on a (B,C,S) log-prob tensor -> (B,S) int32 tokens */
+int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_sampler* s, uint64_t seed,
+                      uint64_t first_layout, int step, int B, int32_t* d_tokens_out, void* stream);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+/* One reverse step (_sample_single_step, base.py:205-291), fused: tokens (B,S) -> tokens. */
+int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
+                    int t_post, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,
+                    uint64_t first_layout, int step, int B, void* stream);
+/* The T-step reverse loop (BaseMaskAndReplaceDiffusion.sample, base.py:293-371).
+ * d_tokens_inout: initial state (all [MASK] for unconditional, cond["seq"] otherwise) -> final.
+ * h_t_model / h_t_post: host arrays of n_steps timesteps (diffusion_list and the posterior's t).
+ * d_intermediates: optional (n_steps,B,S) int32 (get_intermediate_results=True).
+ * use_graph != 0: the whole loop is captured once per (B, schedule, sampler, cond layout) into
+ * a hipGraph and replayed (seed / first_layout live in device memory so replays may change them). */
+int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const int32_t* h_t_model,
+                    const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
+                    uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream);
+
+/* ---- introspection ------------------------------------------------------------------- */
+/* average device time (ms) of the most recent ldm_sample_loop, measured with HIP events on the
+ * stream it ran on; blocks until that loop has finished. */
+int ldm_last_loop_ms(ldm_handle* h, float* ms);
+/* name + accumulated ms + launches of every kernel class timed when profiling is enabled
+ * (ldm_set_profiling(h,1) brackets each launch with HIP events; slow, for bench/roofline only) */
+int ldm_set_profiling(ldm_handle* h, int enable);
+int ldm_profile_count(ldm_handle* h);
+int ldm_profile_get(ldm_handle* h, int idx, const char** name, double* total_ms, int64_t* launches,
+                    double* flops, double* bytes);
+int ldm_profile_reset(ldm_handle* h);
+int ldm_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_HIP_H */

@@ -1,0 +1,279 @@
+"""ctypes binding of libldm_hip.so (include/ldm_hip.h) — the only way Python reaches the HIP path.
+
+PyTorch is used for device memory and streams only: tensors are handed over as raw
+`data_ptr()`s together with the current HIP stream handle.  There is no CPU / eager fallback:
+if the shared library or a GPU is missing every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
+ABI_VERSION = 1
+
+PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16 = 0, 1, 2
+PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16,
+              "f32": PREC_EXACT_F32, "f16": PREC_FAST_F16, "f16x3": PREC_SPLIT_F16}
+SAMPLERS = {"deterministic": 0, "random": 1, "top_p": 2, "top_k": 3, "gumbel": 4}
+
+EXPORTS = (
+    "ldm_create", "ldm_destroy", "ldm_last_error", "ldm_load_weight", "ldm_finalize_weights",
+    "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
+    "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
+    "ldm_abi_version",
+)
+
+
+class LdmConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "n_category", "n_bin", "max_elem", "n_attr", "d_model", "n_head", "d_ff",
+        "n_layer", "n_step", "precision", "max_batch", "chunk")]
+
+
+class LdmSampler(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32)]
+
+
+class LdmCond(C.Structure):
+    _fields_ = [("d_cond_seq", C.c_void_p), ("d_strong_mask", C.c_void_p), ("d_weak_logits", C.c_void_p),
+                ("pad_disable", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libldm_hip.so and declare the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: the MI355X HIP extension is not built (run `python -m layout_dm_amd.build` "
+            "or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    lib.ldm_abi_version.restype = C.c_int
+    lib.ldm_create.argtypes = [C.POINTER(LdmConfig), i32, C.POINTER(vp)]
+    lib.ldm_destroy.argtypes = [vp]
+    lib.ldm_destroy.restype = None
+    lib.ldm_last_error.argtypes = [vp]
+    lib.ldm_last_error.restype = C.c_char_p
+    lib.ldm_load_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]
+    lib.ldm_finalize_weights.argtypes = [vp]
+    lib.ldm_denoise_logits.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ldm_posterior.argtypes = [vp, vp, vp, i32, i32, C.POINTER(LdmCond), vp, vp]
+    lib.ldm_sample_tokens.argtypes = [vp, vp, C.POINTER(LdmSampler), u64, u64, i32, i32, vp, vp]
+    lib.ldm_sample_step.argtypes = [vp, vp, vp, i32, i32, C.POINTER(LdmCond), C.POINTER(LdmSampler), u64, u64,
+                                    i32, i32, vp]
+    lib.ldm_sample_loop.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
+                                    C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
+    lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ldm_set_profiling.argtypes = [vp, i32]
+    lib.ldm_profile_count.argtypes = [vp]
+    lib.ldm_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ldm_profile_reset.argtypes = [vp]
+    for name in EXPORTS:
+        if name not in ("ldm_destroy", "ldm_last_error"):
+            getattr(lib, name).restype = C.c_int
+    if lib.ldm_abi_version() != ABI_VERSION:
+        raise RuntimeError("libldm_hip.so ABI version mismatch — rebuild the extension")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def make_sampler(cfg) -> LdmSampler:
+    """sampling_cfg (DictConfig / dict / attr object with the reference's field names,
+    helpers/sampling.py:13-59) -> ldm_sampler."""
+    get = (lambda k, d=None: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+    name = get("name")
+    if name not in SAMPLERS:
+        raise NotImplementedError(f"sampling '{name}'")  # sampling.py:117-118
+    return LdmSampler(SAMPLERS[name], float(get("temperature", 1.0)), float(get("top_p", 1.0) or 1.0),
+                      int(get("top_k", 1) or 1))
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """One libldm_hip handle = one model replica on one GPU."""
+
+    def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
+                 d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4, n_step: int = 100,
+                 precision="exact", max_batch: int = 512, chunk: int = 0, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("layout_dm_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        self.lib = load_library()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        self.cfg = LdmConfig(ABI_VERSION, n_category, n_bin, max_elem, n_attr, d_model, n_head, d_ff, n_layer,
+                             n_step, prec, max_batch, chunk)
+        self.S = max_elem * n_attr
+        self.C = n_category + 4 * n_bin + 2
+        self.T = n_step
+        self.pad_id, self.mask_id = self.C - 2, self.C - 1
+        self.max_batch = max_batch
+        h = C.c_void_p()
+        rc = self.lib.ldm_create(C.byref(self.cfg), self.device_index, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ldm_create failed ({rc}): {self.lib.ldm_last_error(None).decode()}")
+        self._h = h
+        self._keep = {}  # tensors referenced by cached graphs must stay alive
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ldm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.ldm_last_error(self._h).decode()}")
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict: Dict[str, "torch.Tensor | np.ndarray"]):
+        """Reference checkpoint (keys of SURVEY App. C, with or without 'model.module.')."""
+        for k, v in state_dict.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            a = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._check(self.lib.ldm_load_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                        f"ldm_load_weight({k})")
+        self._check(self.lib.ldm_finalize_weights(self._h), "ldm_finalize_weights")
+
+    # ------------------------------------------------------------------ helpers
+    def _tok(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device or t.dtype != torch.int32 or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=torch.int32).contiguous()
+        return t
+
+    def make_cond(self, cond: Optional[dict], B: int):
+        """cond dict of the reference (base.py:243-284 consumers) -> (ldm_cond, keep-alive list)."""
+        if not cond:
+            return None, []
+        keep = []
+        lc = LdmCond()
+        seq = self._tok(torch.as_tensor(cond["seq"]))
+        assert seq.shape == (B, self.S), f"cond['seq'] must be ({B},{self.S})"
+        keep.append(seq)
+        lc.d_cond_seq = seq.data_ptr()
+        if "mask" in cond and cond["mask"] is not None:
+            m = torch.as_tensor(cond["mask"]).to(device=self.device, dtype=torch.uint8).contiguous()
+            keep.append(m)
+            lc.d_strong_mask = m.data_ptr()
+        if cond.get("type") == "refinement":
+            wl = torch.as_tensor(cond["weak_logits"]).to(device=self.device, dtype=torch.float32).contiguous()
+            assert wl.shape == (B, self.C, self.S)
+            # weak_mask is by construction ~mask broadcast over classes (helpers/task.py:216)
+            keep.append(wl)
+            lc.d_weak_logits = wl.data_ptr()
+        lc.pad_disable = 1 if cond.get("type") in ("c", "cwh", "refinement", "relation") else 0
+        return lc, keep
+
+    # ------------------------------------------------------------------ parity hooks
+    def denoise_logits(self, tokens: torch.Tensor, t: int) -> torch.Tensor:
+        tokens = self._tok(tokens)
+        B = tokens.shape[0]
+        out = torch.empty((B, self.S, self.C), dtype=torch.float32, device=self.device)
+        self._check(self.lib.ldm_denoise_logits(self._h, tokens.data_ptr(), int(t), B, out.data_ptr(),
+                                                _stream_ptr(self.device)), "ldm_denoise_logits")
+        return out
+
+    def posterior(self, logits: torch.Tensor, tokens: torch.Tensor, t_post: int, cond: Optional[dict] = None):
+        tokens = self._tok(tokens)
+        B = tokens.shape[0]
+        logits = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        lc, keep = self.make_cond(cond, B)
+        out = torch.empty((B, self.C, self.S), dtype=torch.float32, device=self.device)
+        self._check(self.lib.ldm_posterior(self._h, logits.data_ptr(), tokens.data_ptr(), int(t_post), B,
+                                           C.byref(lc) if lc else None, out.data_ptr(), _stream_ptr(self.device)),
+                    "ldm_posterior")
+        torch.cuda.current_stream(self.device).synchronize() if keep else None
+        return out
+
+    def sample_tokens(self, logp: torch.Tensor, sampling_cfg, seed: int = 0, first_layout: int = 0, step: int = 0):
+        logp = logp.to(device=self.device, dtype=torch.float32).contiguous()
+        B = logp.shape[0]
+        s = make_sampler(sampling_cfg)
+        out = torch.empty((B, self.S), dtype=torch.int32, device=self.device)
+        self._check(self.lib.ldm_sample_tokens(self._h, logp.data_ptr(), C.byref(s), seed, first_layout, step, B,
+                                               out.data_ptr(), _stream_ptr(self.device)), "ldm_sample_tokens")
+        return out
+
+    # ------------------------------------------------------------------ hot path
+    def sample_step(self, tokens: torch.Tensor, t_model: int, sampling_cfg, t_post: Optional[int] = None,
+                    cond: Optional[dict] = None, seed: int = 0, first_layout: int = 0, step: int = 0):
+        tokens = self._tok(tokens)
+        B = tokens.shape[0]
+        s = make_sampler(sampling_cfg)
+        lc, keep = self.make_cond(cond, B)
+        out = torch.empty_like(tokens)
+        self._check(self.lib.ldm_sample_step(self._h, tokens.data_ptr(), out.data_ptr(), int(t_model),
+                                             int(t_model if t_post is None else t_post),
+                                             C.byref(lc) if lc else None, C.byref(s), seed, first_layout, step, B,
+                                             _stream_ptr(self.device)), "ldm_sample_step")
+        if keep:
+            torch.cuda.current_stream(self.device).synchronize()
+        return out
+
+    def sample_loop(self, tokens: torch.Tensor, t_model: Sequence[int], t_post: Sequence[int], sampling_cfg,
+                    cond: Optional[dict] = None, seed: int = 0, first_layout: int = 0,
+                    intermediates: bool = False, use_graph: bool = True, lc_keep=None):
+        """In-place T-step loop on `tokens` (B,S) int32 cuda. Returns (tokens, intermediates|None)."""
+        tokens = self._tok(tokens)
+        B = tokens.shape[0]
+        n = len(t_model)
+        s = make_sampler(sampling_cfg)
+        if lc_keep is not None:
+            lc, keep = lc_keep
+        else:
+            lc, keep = self.make_cond(cond, B)
+        inter = torch.empty((n, B, self.S), dtype=torch.int32, device=self.device) if intermediates else None
+        tm = (C.c_int32 * n)(*[int(x) for x in t_model])
+        tp = (C.c_int32 * n)(*[int(x) for x in t_post])
+        self._check(self.lib.ldm_sample_loop(self._h, tokens.data_ptr(), C.byref(lc) if lc else None, tm, tp, n,
+                                             C.byref(s), seed, first_layout, B,
+                                             inter.data_ptr() if inter is not None else None,
+                                             1 if use_graph else 0, _stream_ptr(self.device)), "ldm_sample_loop")
+        if keep and lc_keep is None:
+            torch.cuda.current_stream(self.device).synchronize()
+        return tokens, inter
+
+    # ------------------------------------------------------------------ introspection
+    def last_loop_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ldm_last_loop_ms(self._h, C.byref(ms)), "ldm_last_loop_ms")
+        return float(ms.value)
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.ldm_set_profiling(self._h, 1 if on else 0), "ldm_set_profiling")
+
+    def profile(self, reset: bool = False):
+        n = self.lib.ldm_profile_count(self._h)
+        rows = []
+        for i in range(n):
+            name, ms, cnt, fl, by = C.c_char_p(), C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            self.lib.ldm_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by))
+            rows.append({"name": name.value.decode(), "ms": ms.value, "launches": cnt.value, "flops": fl.value,
+                         "bytes": by.value})
+        if reset:
+            self.lib.ldm_profile_reset(self._h)
+        return rows

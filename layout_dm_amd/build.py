@@ -1,0 +1,61 @@
+"""Builds libldm_hip.so (gfx950) in-tree with hipcc.  No torch headers, no cmake."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libldm_hip.so")
+SOURCES = ["ldm_api.cpp", "kernels_norm.hip", "kernels_gemm.hip", "kernels_attn.hip", "kernels_post.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.join(os.path.dirname(HERE), "include", "ldm_hip.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        cmd = [cc, "-x", "hip", *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

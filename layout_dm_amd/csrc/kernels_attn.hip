@@ -1,0 +1,145 @@
+// Self-attention of the denoiser: softmax(Q K^T / sqrt(dh)) V per (layout, head), no mask
+// (torch.nn.MultiheadAttention with key_padding_mask=None, attn_mask=None:
+//  trainer/models/transformer_utils.py:140-142,197-204; nn_lib.py:226-228).
+// S = 125 tokens, dh = 58: one (layout, head) problem is a single tile.
+//
+// This file holds the exact-fp32 kernel: one workgroup per (layout, head), K and V of that head
+// staged once in LDS (2 x 125 x 60 x 4 B = 60 KB), one query row per lane, two passes
+// (row max, then exp/accumulate) so the arithmetic has the same form as torch's softmax.
+// All lanes read the same K/V row => LDS broadcast reads (ds_read_b128, no bank conflicts).
+#include "ldm_kernels.h"
+
+namespace ldm {
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p) {
+  return *p;
+}
+template <>
+__device__ __forceinline__ float ldf<__half>(const __half* p) {
+  return __half2float(*p);
+}
+
+constexpr float kLoScaleA = 2048.0f;
+
+template <typename TIn, int DHP>
+__global__ __launch_bounds__(128) void attn_rows(const TIn* __restrict__ qkv, float* __restrict__ out32,
+                                                 __half* __restrict__ out16, __half* __restrict__ out16lo, int S,
+                                                 int H, int dh, int D, int ld, int ldo32, int ldo16, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                    // [S][DHP]
+  float* Vs = smem + (size_t)S * DHP;  // [S][DHP]
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t row0 = (size_t)b * S;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < S * DHP; idx += 128) {
+    const int j = idx / DHP, d = idx % DHP;
+    float kv = 0.f, vv = 0.f;
+    if (d < dh) {
+      const TIn* r = qkv + (row0 + j) * ld + h * dh + d;
+      kv = ldf<TIn>(r + D);
+      vv = ldf<TIn>(r + 2 * D);
+    }
+    Ks[idx] = kv;
+    Vs[idx] = vv;
+  }
+  __syncthreads();
+  for (int i = tid; i < S; i += 128) {
+    float q[DHP];
+    const TIn* qr = qkv + (row0 + i) * ld + h * dh;
+#pragma unroll
+    for (int d = 0; d < DHP; ++d) q[d] = (d < dh) ? ldf<TIn>(qr + d) * scale : 0.f;
+    float mx = -INFINITY;
+    for (int j = 0; j < S; ++j) {
+      const float4* kr = reinterpret_cast<const float4*>(Ks + (size_t)j * DHP);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < DHP / 4; ++d4) {
+        const float4 k4 = kr[d4];
+        s0 = fmaf(q[4 * d4 + 0], k4.x, s0);
+        s1 = fmaf(q[4 * d4 + 1], k4.y, s1);
+        s2 = fmaf(q[4 * d4 + 2], k4.z, s2);
+        s3 = fmaf(q[4 * d4 + 3], k4.w, s3);
+      }
+      mx = fmaxf(mx, (s0 + s1) + (s2 + s3));
+    }
+    float o[DHP];
+#pragma unroll
+    for (int d = 0; d < DHP; ++d) o[d] = 0.f;
+    float l = 0.f;
+    for (int j = 0; j < S; ++j) {
+      const float4* kr = reinterpret_cast<const float4*>(Ks + (size_t)j * DHP);
+      const float4* vr = reinterpret_cast<const float4*>(Vs + (size_t)j * DHP);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < DHP / 4; ++d4) {
+        const float4 k4 = kr[d4];
+        s0 = fmaf(q[4 * d4 + 0], k4.x, s0);
+        s1 = fmaf(q[4 * d4 + 1], k4.y, s1);
+        s2 = fmaf(q[4 * d4 + 2], k4.z, s2);
+        s3 = fmaf(q[4 * d4 + 3], k4.w, s3);
+      }
+      const float p = expf(((s0 + s1) + (s2 + s3)) - mx);
+      l += p;
+#pragma unroll
+      for (int d4 = 0; d4 < DHP / 4; ++d4) {
+        const float4 v4 = vr[d4];
+        o[4 * d4 + 0] = fmaf(p, v4.x, o[4 * d4 + 0]);
+        o[4 * d4 + 1] = fmaf(p, v4.y, o[4 * d4 + 1]);
+        o[4 * d4 + 2] = fmaf(p, v4.z, o[4 * d4 + 2]);
+        o[4 * d4 + 3] = fmaf(p, v4.w, o[4 * d4 + 3]);
+      }
+    }
+    const float inv = 1.0f / l;
+    const size_t orow32 = (row0 + i) * ldo32 + h * dh;
+    const size_t orow16 = (row0 + i) * ldo16 + h * dh;
+#pragma unroll
+    for (int d = 0; d < DHP; ++d) {
+      if (d < dh) {
+        const float v = o[d] * inv;
+        if (out32) out32[orow32 + d] = v;
+        if (out16) {
+          const __half hv = __float2half_rn(v);
+          out16[orow16 + d] = hv;
+          if (out16lo) out16lo[orow16 + d] = __float2half_rn((v - __half2float(hv)) * kLoScaleA);
+        }
+      }
+    }
+  }
+}
+
+template <typename TIn>
+static void launch_rows(const AttnArgs& a, hipStream_t st) {
+  const float scale = 1.0f / sqrtf((float)a.dh);
+  const int dhp = (a.dh + 3) & ~3;
+  float* o32 = a.out32;
+  __half* o16 = a.out16;
+  __half* o16lo = a.out16lo;
+  dim3 grid(a.B * a.H), block(128);
+#define LDM_ATTN_CASE(DHP)                                                                                      \
+  {                                                                                                             \
+    const size_t sh = (size_t)2 * a.S * DHP * sizeof(float);                                                    \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      hipFuncSetAttribute((const void*)attn_rows<TIn, DHP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL((attn_rows<TIn, DHP>), grid, block, sh, st, (const TIn*)a.qkv, o32, o16, o16lo, a.S, a.H, \
+                       a.dh, a.D, a.ld, a.ldo32, a.ldo16, scale);                                                          \
+  }
+  if (dhp <= 32) LDM_ATTN_CASE(32)
+  else if (dhp <= 60) LDM_ATTN_CASE(60)
+  else LDM_ATTN_CASE(64)
+#undef LDM_ATTN_CASE
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t st) {
+  if (a.in_f16)
+    launch_rows<__half>(a, st);
+  else
+    launch_rows<float>(a, st);
+}
+
+}  // namespace ldm

@@ -1,0 +1,281 @@
+// MFMA GEMMs for the denoiser's five Linear classes (QKV, attn-out, FFN1, FFN2, vocab head):
+//     C[M,N] = epilogue(A[M,K] · W[N,K]^T + bias[N])         (torch.nn.Linear convention, "NT")
+// Reference call sites: torch.nn.MultiheadAttention in/out projections
+// (trainer/models/transformer_utils.py:140-142,197-204), linear1/linear2 (l.145-147,208-209),
+// head Linear (trainer/models/common/nn_lib.py:186-189).
+//
+// gfx950 design notes
+//  * 64-lane wavefronts; a 256-thread workgroup = 4 waves in a 2x2 grid, each wave owns a 64x64
+//    sub-tile = 2x2 MFMA 32x32 accumulators (64 accumulator VGPRs).
+//  * exact mode: v_mfma_f32_32x32x2_f32 (bit-exact fmaf chain, 157 TF peak).  Lane l supplies
+//    A[i=l&31][k=l>>5]; we let each lane read 4 consecutive k (one ds_read_b128) and feed 4 MFMAs,
+//    i.e. MFMA j of a group contracts k = {k0+j, k0+4+j} — a permutation of the K order that is
+//    applied to A and W alike, so the product is unchanged.
+//  * fp16 modes: v_mfma_f32_32x32x16_f16, lane l supplies 8 consecutive k (ds_read_b128).
+//  * LDS rows are padded (+4 floats / +8 halfs) so the 16-lane ds_read_b128 groups hit 16 distinct
+//    4-bank slots (conflict-free), global->register->LDS staging is double-buffered.
+//  * workgroup -> tile mapping is XCD-aware: the 8 XCDs have private L2s and the dispatcher places
+//    block b on XCD b%8, so consecutive tile ids (same A row-panel, neighbouring W panels) are
+//    remapped onto the same XCD.
+#include "ldm_kernels.h"
+
+namespace ldm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+constexpr float kLoScaleInv = 1.0f / 2048.0f;
+constexpr float kLoScale = 2048.0f;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective for any nwg (cdna guide §5 "XCD swizzle must be bijective")
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+// ---------------------------------------------------------------- shared epilogue
+struct EpiArgs {
+  const float* bias;
+  const float* res;
+  float* C32;
+  __half* C16;
+  __half* C16lo;
+  int M, N, ldres, ldc32, ldc16, relu;
+};
+
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&acc)[2][2], int m_base, int n_base,
+                                               int lane) {
+  const int col_in = lane & 31;
+  const int row_hi = (lane >> 5) * 4;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n_base + ni * 32 + col_in;
+      if (n >= e.N) continue;
+      const float bv = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_base + mi * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+        if (m >= e.M) continue;
+        float v = acc[mi][ni][r] + bv;
+        if (e.relu) v = fmaxf(v, 0.f);
+        if (e.res) v += e.res[(size_t)m * e.ldres + n];
+        if (e.C32) e.C32[(size_t)m * e.ldc32 + n] = v;
+        if (e.C16) {
+          const __half h = __float2half_rn(v);
+          e.C16[(size_t)m * e.ldc16 + n] = h;
+          if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n] = __float2half_rn((v - __half2float(h)) * kLoScale);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- exact fp32
+constexpr int F32_BK = 16;
+constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-free b128 reads
+
+__global__ __launch_bounds__(256) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
+                                                        int lda, int ldw, int K, int tiles_n, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) float As[2][128][F32_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][128][F32_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * 128;
+  const int n0 = (tile % tiles_n) * 128;
+
+  // staging: each thread moves 2 float4 of A and 2 of W per K-tile
+  const int lrow = tid >> 2;  // 0..63
+  const int lc4 = (tid & 3) * 4;
+  float4 ra[2], rw[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + lrow + i * 64;
+      const int n = n0 + lrow + i * 64;
+      ra[i] = (m < e.M) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + kt * F32_BK + lc4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = (n < e.N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + kt * F32_BK + lc4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&As[buf][lrow + i * 64][lc4]) = ra[i];
+      *reinterpret_cast<float4*>(&Ws[buf][lrow + i * 64][lc4]) = rw[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nk = K / F32_BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int frow = lane & 31;
+  const int fk = (lane >> 5) * 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const f32x4*>(&As[buf][wm * 64 + mi * 32 + frow][kg * 8 + fk]);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        b[ni] = *reinterpret_cast<const f32x4*>(&Ws[buf][wn * 64 + ni * 32 + frow][kg * 8 + fk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------- fp16 operands, fp32 accumulate
+// NPASS = 1: fast (A·W).  NPASS = 3: split (Ahi·Whi + 2^-11·(Ahi·Wlo' + Alo'·Whi)), lo' = lo·2^11.
+constexpr int F16_BK = 32;
+constexpr int F16_LD = F16_BK + 8;  // 40 halfs = 80 B row stride (same conflict-free pattern)
+
+template <int NPASS>
+__global__ __launch_bounds__(256) void gemm_f16_128x128(const __half* __restrict__ A, const __half* __restrict__ Alo,
+                                                        const __half* __restrict__ W, const __half* __restrict__ Wlo,
+                                                        int lda, int ldw, int K, int tiles_n, EpiArgs e) {
+  constexpr int NOP = (NPASS == 3) ? 2 : 1;  // hi (+ lo) images per operand
+  __shared__ __attribute__((aligned(16))) __half As[2][NOP][128][F16_LD];
+  __shared__ __attribute__((aligned(16))) __half Ws[2][NOP][128][F16_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * 128;
+  const int n0 = (tile % tiles_n) * 128;
+
+  // staging: tile = 128 rows x 32 halfs = 4 x 16 B per row -> 512 uint4 -> 2 per thread per image
+  const int lrow = tid >> 2;
+  const int lc8 = (tid & 3) * 8;
+  uint4 ra[NOP][2], rw[NOP][2];
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + lrow + i * 64;
+      const int n = n0 + lrow + i * 64;
+      const size_t ao = (size_t)m * lda + kt * F16_BK + lc8;
+      const size_t wo = (size_t)n * ldw + kt * F16_BK + lc8;
+      ra[0][i] = (m < e.M) ? *reinterpret_cast<const uint4*>(A + ao) : z4;
+      rw[0][i] = (n < e.N) ? *reinterpret_cast<const uint4*>(W + wo) : z4;
+      if (NOP == 2) {
+        ra[NOP - 1][i] = (m < e.M) ? *reinterpret_cast<const uint4*>(Alo + ao) : z4;
+        rw[NOP - 1][i] = (n < e.N) ? *reinterpret_cast<const uint4*>(Wlo + wo) : z4;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int o = 0; o < NOP; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<uint4*>(&As[buf][o][lrow + i * 64][lc8]) = ra[o][i];
+        *reinterpret_cast<uint4*>(&Ws[buf][o][lrow + i * 64][lc8]) = rw[o][i];
+      }
+  };
+
+  f32x16 acc[2][2], acl[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[mi][ni][r] = 0.f;
+        acl[mi][ni][r] = 0.f;
+      }
+
+  const int nk = K / F16_BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int frow = lane & 31;
+  const int fk = (lane >> 5) * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < F16_BK / 16; ++ks) {
+      f16x8 a[NOP][2], b[NOP][2];
+#pragma unroll
+      for (int o = 0; o < NOP; ++o) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          a[o][mi] = *reinterpret_cast<const f16x8*>(&As[buf][o][wm * 64 + mi * 32 + frow][ks * 16 + fk]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          b[o][ni] = *reinterpret_cast<const f16x8*>(&Ws[buf][o][wn * 64 + ni * 32 + frow][ks * 16 + fk]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
+          if (NPASS == 3) {
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mi], b[NOP - 1][ni], acl[mi][ni], 0, 0, 0);
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[NOP - 1][mi], b[0][ni], acl[mi][ni], 0, 0, 0);
+          }
+        }
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (NPASS == 3) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += acl[mi][ni][r] * kLoScaleInv;
+  }
+  epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+void launch_gemm(const GemmArgs& g, hipStream_t st) {
+  const int tiles_m = (g.M + 127) / 128;
+  const int tiles_n = (g.N + 127) / 128;
+  EpiArgs e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  dim3 grid(tiles_m * tiles_n), block(256);
+  if (g.precision == 0) {
+    hipLaunchKernelGGL(gemm_f32_128x128, grid, block, 0, st, (const float*)g.A, (const float*)g.W, g.lda, g.ldw, g.K,
+                       tiles_n, e);
+  } else if (g.precision == 1) {
+    hipLaunchKernelGGL(gemm_f16_128x128<1>, grid, block, 0, st, (const __half*)g.A, (const __half*)nullptr,
+                       (const __half*)g.W, (const __half*)nullptr, g.lda, g.ldw, g.K, tiles_n, e);
+  } else {
+    hipLaunchKernelGGL(gemm_f16_128x128<3>, grid, block, 0, st, (const __half*)g.A, (const __half*)g.Alo,
+                       (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, e);
+  }
+}
+
+}  // namespace ldm

@@ -1,0 +1,346 @@
+// Fused tail of one reverse step, one 64-lane wavefront per token (lane l owns classes l, l+64,
+// l+128 of the <=192-class vocabulary), everything in registers + wave shuffles:
+//
+//   predict_start tail   log_softmax (float64) over the C-1 non-MASK classes, -70 for MASK,
+//                        clamp [-70,0]                 categorical_diffusion/base.py:131-144
+//   q_posterior          per-attribute sub-vocabulary posterior  constrained.py:135-206
+//                        (q_pred 112-133, q_pred_one_timestep 92-110, log helpers util.py:15-27,
+//                         Converter gather/scatter helpers/layout_tokenizer.py:540-557)
+//   cond overrides       strong mask / refinement prior / PAD disable   base.py:243-284
+//   sample               argmax | temperature, top-k, top-p, gumbel -> softmax -> multinomial
+//                        helpers/sampling.py:81-130
+//
+// The reference materialises (B,C,S) log-one-hot / log-prob tensors around ~170 tiny ATen launches
+// per step; here the state stays int32 tokens and the only HBM traffic is the
+// logits row in and one token out (plus the optional (B,C,S) parity dump).
+// torch.multinomial's stream is replaced by counter-based Philox4x32-10 keyed by
+// (seed, global layout index, reverse-step index, position) => results do not depend on how the
+// batch is split over calls or GPUs.
+#include "ldm_kernels.h"
+
+namespace ldm {
+
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wsumd(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wsumi(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wscan(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+// util.py:19-21
+__device__ __forceinline__ float log_add_exp(float a, float b) {
+  const float m = fmaxf(a, b);
+  return m + logf(expf(a - m) + expf(b - m));
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) {  // strictly inside (0,1), exact in fp32
+  return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;  // 2^-23
+}
+
+constexpr int NJ = 3;  // classes per lane (C <= 192)
+
+__global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
+  __shared__ float sh_lg[4][192];
+  __shared__ float sh_pr[4][192];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  const int M = p.B * p.S;
+  if (row >= M) return;  // whole wave exits together; no block-level barrier is used below
+  const int b = row / p.S, s = row % p.S;
+  const int C = p.v.n_class;
+  const int attr = s % p.v.n_attr;
+  const int pad_id = p.v.pad_id, mask_id = p.v.mask_id;
+
+  float lp[NJ];  // full-vocabulary log p(x_{t-1} | x_t) for this lane's classes
+  if (p.logp_in) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      lp[j] = (c < C) ? p.logp_in[((size_t)b * C + c) * p.S + s] : -INFINITY;
+    }
+  } else {
+    // ---- log p(x0 | xt): float64 log-softmax over classes [0, C-1)
+    const float* lrow = p.logits + (size_t)row * p.ldl;
+    float xv[NJ];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      xv[j] = (c < C - 1) ? lrow[c] : -INFINITY;
+      mx = fmaxf(mx, xv[j]);
+    }
+    mx = wmax(mx);
+    double se = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C - 1) se += exp((double)xv[j] - (double)mx);
+    }
+    se = wsumd(se);
+    const double lse0 = log(se);
+    float l0[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      float v = (c < C - 1) ? (float)(((double)xv[j] - (double)mx) - lse0) : -70.0f;
+      l0[j] = fminf(fmaxf(v, -70.0f), 0.0f);
+    }
+    // ---- constrained posterior in this token's attribute sub-vocabulary
+    const int T1 = p.T + 1;
+    const int t = p.t_post;
+    const int u = (t - 1 + T1) % T1;  // constrained.py:114
+    auto sch = [&](int kind, int idx) { return p.sched[((size_t)kind * p.v.n_attr + attr) * T1 + idx]; };
+    const float la = sch(kLogAt, t), lb = sch(kLogBt, t), lc = sch(kLogCt, t);
+    const float LA = sch(kLogCumAt, t), LB = sch(kLogCumBt, t), LC = sch(kLogCumCt, t);
+    const float LAu = sch(kLogCumAt, u), LBu = sch(kLogCumBt, u), LCu = sch(kLogCumCt, u);
+    const float L1Cu = sch(kLog1mCumCt, u);
+    const int tok = p.tokens[row];
+    const bool x_is_mask = (tok == mask_id);
+    const int start = p.v.start[attr], cnt = p.v.count[attr];
+
+    bool live[NJ];
+    float q[NJ], q1[NJ];
+    float qmx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      live[j] = (c < C) && ((c >= start && c < start + cnt) || c == pad_id || c == mask_id);
+      q[j] = -INFINITY;
+      q1[j] = 0.f;
+      if (live[j]) {
+        if (c == mask_id) {
+          q[j] = kLogEps;                       // constrained.py:189
+          q1[j] = x_is_mask ? 0.0f : kLogEps;   // l.179-185
+        } else {
+          float qt;
+          if (x_is_mask) {
+            qt = LC;   // l.169-173
+            q1[j] = lc;
+          } else {
+            const float e = (c == tok) ? 0.0f : kLogEps;  // log-one-hot of x_t (util.py:34-40)
+            qt = log_add_exp(e + LA, LB);
+            q1[j] = log_add_exp(e + la, lb);
+          }
+          q[j] = l0[j] - qt;  // l.188
+        }
+        qmx = fmaxf(qmx, q[j]);
+      }
+    }
+    qmx = wmax(qmx);
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (live[j]) qs += expf(q[j] - qmx);
+    qs = wsum(qs);
+    const float lse = logf(qs) + qmx;  // torch.logsumexp
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (live[j]) {
+        const float qn = q[j] - lse;
+        const float r = (c == mask_id) ? log_add_exp(qn + L1Cu, LCu) : log_add_exp(qn + LAu, LBu);
+        lp[j] = fminf(fmaxf((r + q1[j]) + lse, -70.0f), 0.0f);  // l.192-197
+      } else {
+        lp[j] = (c < C) ? kLogEps : -INFINITY;  // p_to_f_log fill
+      }
+    }
+    // ---- constraint injection (base.py:243-284)
+    const int cs = p.cond_seq ? p.cond_seq[row] : -1;
+    const bool strong = p.strong && p.strong[row];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c >= C) continue;
+      if (strong) lp[j] = (c == cs) ? 0.0f : kLogEps;
+      else if (p.weak) lp[j] += p.weak[((size_t)b * C + c) * p.S + s];
+      if (p.pad_disable && p.cond_seq && c == pad_id && attr != 0 && cs != pad_id) lp[j] = kLogEps;
+    }
+  }
+  if (p.logp_out) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C) p.logp_out[((size_t)b * C + c) * p.S + s] = lp[j];
+    }
+  }
+  if (!p.tokens_out) return;
+
+  // ---- categorical draw (helpers/sampling.py:81-130)
+  int result;
+  if (p.kind == 0) {  // deterministic: first maximum
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C && lp[j] > bv) { bv = lp[j]; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    result = bi;
+  } else {
+    const uint64_t seed = p.rng[0];
+    const uint64_t layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    float lg[NJ];
+    const float inv_t = 1.0f / p.temperature;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      lg[j] = (c < C) ? lp[j] / p.temperature : -INFINITY;
+    }
+    (void)inv_t;
+    if (p.kind == 4) {  // gumbel noise per class: counter word 0 = pos | (1 + c/4) << 16
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+          uint32_t r[4];
+          philox4x32_10((uint32_t)s | ((uint32_t)(1 + (c >> 2)) << 16), (uint32_t)p.step, (uint32_t)layout,
+                        (uint32_t)(layout >> 32), k0, k1, r);
+          const float uu = u01(r[c & 3]);
+          lg[j] += -logf(-logf(uu + 1e-30f) + 1e-30f);
+        }
+      }
+    }
+    if (p.kind == 2 || p.kind == 3) {
+      // softmax of lg (needed for top-p's cumulative probabilities)
+      float m1 = wmax(fmaxf(fmaxf(lg[0], lg[1]), lg[2]));
+      float ex[NJ], es = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        ex[j] = (c < C) ? expf(lg[j] - m1) : 0.f;
+        es += ex[j];
+      }
+      es = wsum(es);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) {
+          sh_lg[wave][c] = lg[j];
+          sh_pr[wave][c] = ex[j] / es;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
+      __builtin_amdgcn_wave_barrier();
+      float cum[NJ] = {0.f, 0.f, 0.f};
+      int rank[NJ] = {0, 0, 0};
+      for (int o = 0; o < C; ++o) {
+        const float ol = sh_lg[wave][o];
+        const float op = sh_pr[wave][o];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = lane + 64 * j;
+          const bool before = (ol > lg[j]) || (ol == lg[j] && o < c);  // sorted-descending position
+          if (before) { rank[j] += 1; cum[j] += op; }
+          else if (o == c) cum[j] += op;  // inclusive
+        }
+      }
+      if (p.kind == 2) {  // top-p: drop every class whose inclusive cumulative prob exceeds p (rank>0)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (cum[j] > p.top_p && rank[j] > 0) lg[j] = -INFINITY;
+      } else {  // top-k: threshold = k-th largest value (sampling.py:73-78)
+        float thr = INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C && rank[j] < p.top_k) thr = fminf(thr, lg[j]);
+        }
+        thr = -wmax(-thr);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (lg[j] < thr) lg[j] = -INFINITY;
+      }
+    }
+    // softmax -> inverse-CDF draw in class order
+    const float m2 = wmax(fmaxf(fmaxf(lg[0], lg[1]), lg[2]));
+    double pr[NJ], tot[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      pr[j] = (c < C) ? (double)expf(lg[j] - m2) : 0.0;
+    }
+    double base = 0.0;
+    double cdf[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const double sc = wscan(pr[j], lane);
+      tot[j] = __shfl(sc, 63, 64);
+      cdf[j] = base + sc;
+      base += tot[j];
+    }
+    uint32_t r[4];
+    philox4x32_10((uint32_t)s, (uint32_t)p.step, (uint32_t)layout, (uint32_t)(layout >> 32), k0, k1, r);
+    const double thr = (double)u01(r[0]) * base;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C && cdf[j] <= thr) cnt += 1;
+    }
+    cnt = wsumi(cnt);
+    result = cnt < C - 1 ? cnt : C - 1;
+  }
+  if (lane == 0) p.tokens_out[row] = result;
+}
+
+__global__ void set_rng_k(uint64_t* rng, uint64_t seed, uint64_t first_layout) {
+  rng[0] = seed;
+  rng[1] = first_layout;
+}
+void launch_set_rng(uint64_t* rng, uint64_t seed, uint64_t first_layout, hipStream_t st) {
+  hipLaunchKernelGGL(set_rng_k, dim3(1), dim3(1), 0, st, rng, seed, first_layout);
+}
+
+void launch_posterior_sample(const PostArgs& p, hipStream_t st) {
+  const int M = p.B * p.S;
+  hipLaunchKernelGGL(posterior_sample_k, dim3((M + 3) / 4), dim3(256), 0, st, p);
+}
+
+}  // namespace ldm

@@ -1,0 +1,853 @@
+// Host side of libldm_hip.so: the C-ABI declared in include/ldm_hip.h.
+// Owns the repacked weights, the per-chunk activation workspace (sized so the working set of one
+// pass through the network stays inside the 256 MiB Infinity Cache), the launch sequence of one
+// reverse step and the hipGraph cache for the T-step loop.  No torch types cross this boundary.
+#include "../../include/ldm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ldm_kernels.h"
+
+using namespace ldm;
+
+static thread_local std::string g_create_error;
+
+#define HIP_OK(h, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return (h)->fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                           __FILE__, __LINE__);                                \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Raw {  // a checkpoint tensor as uploaded (fp32, device)
+  float* d = nullptr;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct LayerW {
+  const float *w_in, *b_in, *w_out, *b_out, *w1, *b1, *w2, *b2, *g2, *be2;  // fp32 views
+  __half *w_in16, *w_in16lo, *w_out16, *w_out16lo, *w1_16, *w1_16lo, *w2_16, *w2_16lo;
+};
+
+struct ProfEntry {
+  std::string name;
+  double ms = 0;
+  int64_t launches = 0;
+  double flops = 0, bytes = 0;
+};
+
+struct PendingEvent {
+  int entry;
+  hipEvent_t a, b;
+};
+
+struct GraphKey {
+  int B, n_steps, kind, top_k, has_cond, has_strong, has_weak, pad_disable, has_inter;
+  float temperature, top_p;
+  const void *tokens, *cond_seq, *strong, *weak, *inter;
+  std::vector<int32_t> t_model, t_post;
+  bool operator==(const GraphKey& o) const {
+    return B == o.B && n_steps == o.n_steps && kind == o.kind && top_k == o.top_k && has_cond == o.has_cond &&
+           has_strong == o.has_strong && has_weak == o.has_weak && pad_disable == o.pad_disable &&
+           has_inter == o.has_inter && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
+           cond_seq == o.cond_seq && strong == o.strong && weak == o.weak && inter == o.inter &&
+           t_model == o.t_model && t_post == o.t_post;
+  }
+};
+
+struct GraphEntry {
+  GraphKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct ldm_handle {
+  ldm_config cfg{};
+  int device = 0;
+  std::string err;
+  // geometry
+  int S = 0, C = 0, D = 0, F = 0, H = 0, dh = 0, L = 0, T = 0, Dp = 0, Fp = 0, Cp = 0, chunk = 0;
+  VocabTables vocab{};
+  // weights
+  std::map<std::string, Raw> raw;
+  bool finalized = false;
+  std::vector<LayerW> layers;
+  float *pos = nullptr, *adaln = nullptr, *sched = nullptr;
+  const float *emb = nullptr, *head_g = nullptr, *head_b = nullptr, *head_w = nullptr;
+  __half *head_w16 = nullptr, *head_w16lo = nullptr;
+  std::vector<void*> owned;  // everything hipMalloc'ed by the handle
+  // workspace (one chunk)
+  float *P = nullptr, *Q = nullptr, *qkv32 = nullptr, *att32 = nullptr, *h32 = nullptr, *hid32 = nullptr,
+        *logits = nullptr;
+  __half *a16 = nullptr, *a16lo = nullptr, *qkv16 = nullptr, *att16 = nullptr, *att16lo = nullptr, *h16 = nullptr,
+         *h16lo = nullptr, *hid16 = nullptr, *hid16lo = nullptr;
+  int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
+  uint64_t* rng = nullptr;                      // device {seed, first_layout}
+  // profiling
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  std::vector<PendingEvent> pending;
+  hipEvent_t loop_a = nullptr, loop_b = nullptr;
+  bool loop_timed = false;
+  std::vector<GraphEntry> graphs;
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+
+  template <typename Tp>
+  int dalloc(Tp** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(Tp), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(-3, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+      e = hipMemset(p, 0, bytes);
+      if (e != hipSuccess) return fail(-3, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    owned.push_back(p);
+    *out = reinterpret_cast<Tp*>(p);
+    return 0;
+  }
+
+  int prof_entry(const char* name) {
+    for (size_t i = 0; i < prof.size(); ++i)
+      if (prof[i].name == name) return (int)i;
+    ProfEntry e;
+    e.name = name;
+    prof.push_back(e);
+    return (int)prof.size() - 1;
+  }
+
+  // bracket one launch with events when profiling (never during graph capture)
+  struct Scope {
+    ldm_handle* h;
+    hipStream_t st;
+    int entry = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    Scope(ldm_handle* h_, hipStream_t st_, const char* name, double flops, double bytes) : h(h_), st(st_) {
+      if (!h->profiling) return;
+      entry = h->prof_entry(name);
+      h->prof[entry].launches += 1;
+      h->prof[entry].flops += flops;
+      h->prof[entry].bytes += bytes;
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, st);
+    }
+    ~Scope() {
+      if (entry < 0) return;
+      hipEventRecord(b, st);
+      h->pending.push_back({entry, a, b});
+    }
+  };
+
+  void drain_profile() {
+    for (auto& pe : pending) {
+      hipEventSynchronize(pe.b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, pe.a, pe.b);
+      prof[pe.entry].ms += ms;
+      hipEventDestroy(pe.a);
+      hipEventDestroy(pe.b);
+    }
+    pending.clear();
+  }
+};
+
+// ------------------------------------------------------------------------------------------ create
+extern "C" int ldm_abi_version(void) { return LDM_ABI_VERSION; }
+
+extern "C" const char* ldm_last_error(const ldm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
+  auto bad = [&](const char* msg) {
+    g_create_error = msg;
+    return -1;
+  };
+  if (!cfg || !out) return bad("null argument");
+  if (cfg->abi_version != LDM_ABI_VERSION) return bad("ldm_config.abi_version mismatch");
+  if (cfg->n_attr < 1 || cfg->n_attr > kMaxAttr) return bad("n_attr out of range");
+  if (cfg->d_model % 16 || cfg->d_ff % 16 || cfg->d_model > 1024) return bad("d_model/d_ff must be multiples of 16, d_model <= 1024");
+  if (cfg->d_model % cfg->n_head) return bad("d_model must be divisible by n_head");
+  if (cfg->d_model / cfg->n_head > 64) return bad("head_dim > 64 not supported");
+  if (cfg->precision < 0 || cfg->precision > 2) return bad("unknown precision mode");
+  if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return bad("no HIP device visible: the MI355X path has no CPU fallback");
+  if (device < 0 || device >= ndev) return bad("device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+
+  auto* h = new ldm_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  h->S = cfg->max_elem * cfg->n_attr;
+  h->C = cfg->n_category + 4 * cfg->n_bin + 2;
+  h->D = cfg->d_model;
+  h->F = cfg->d_ff;
+  h->H = cfg->n_head;
+  h->dh = h->D / h->H;
+  h->L = cfg->n_layer;
+  h->T = cfg->n_step;
+  h->Dp = round_up(h->D, 32);
+  h->Fp = round_up(h->F, 32);
+  h->Cp = round_up(h->C, 32);
+  if (cfg->n_attr != 5) {
+    delete h;
+    return bad("only the c-x-y-w-h (5 attribute) vocabulary is supported");
+  }
+  if (h->C > 192) {
+    delete h;
+    return bad("vocabulary > 192 classes not supported by the fused posterior kernel");
+  }
+  // vocabulary geometry: helpers/layout_tokenizer.py:79-82,429-467
+  h->vocab.n_class = h->C;
+  h->vocab.n_attr = cfg->n_attr;
+  h->vocab.pad_id = h->C - 2;
+  h->vocab.mask_id = h->C - 1;
+  for (int a = 0; a < cfg->n_attr; ++a) {
+    h->vocab.start[a] = (a == 0) ? 0 : cfg->n_category + (a - 1) * cfg->n_bin;
+    h->vocab.count[a] = (a == 0) ? cfg->n_category : cfg->n_bin;
+  }
+  // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
+  int chunk = cfg->chunk;
+  if (chunk <= 0) chunk = 128;
+  chunk = std::min(chunk, cfg->max_batch);
+  h->chunk = chunk;
+
+  const size_t Mc = (size_t)chunk * h->S;
+  int rc = 0;
+  auto A = [&](auto** p, size_t n) {
+    if (rc == 0) rc = h->dalloc(p, n);
+  };
+  A(&h->P, Mc * h->D);
+  A(&h->Q, Mc * h->D);
+  A(&h->logits, Mc * h->Cp);
+  if (cfg->precision == LDM_PREC_EXACT_F32) {
+    A(&h->qkv32, Mc * 3 * h->D);
+    A(&h->att32, Mc * h->D);
+    A(&h->h32, Mc * h->D);
+    A(&h->hid32, Mc * h->F);
+  } else {
+    A(&h->a16, Mc * h->Dp);
+    A(&h->att16, Mc * h->Dp);
+    A(&h->h16, Mc * h->Dp);
+    A(&h->hid16, Mc * h->Fp);
+    if (cfg->precision == LDM_PREC_FAST_F16) {
+      A(&h->qkv16, Mc * 3 * h->D);
+    } else {
+      A(&h->qkv32, Mc * 3 * h->D);
+      A(&h->a16lo, Mc * h->Dp);
+      A(&h->att16lo, Mc * h->Dp);
+      A(&h->h16lo, Mc * h->Dp);
+      A(&h->hid16lo, Mc * h->Fp);
+    }
+  }
+  A(&h->tok_a, (size_t)cfg->max_batch * h->S);
+  A(&h->tok_b, (size_t)cfg->max_batch * h->S);
+  A(&h->rng, 2);
+  A(&h->sched, (size_t)kNumSched * cfg->n_attr * (h->T + 1));
+  if (rc != 0) {
+    g_create_error = h->err;
+    ldm_destroy(h);
+    return rc;
+  }
+  hipEventCreate(&h->loop_a);
+  hipEventCreate(&h->loop_b);
+  *out = h;
+  return 0;
+}
+
+extern "C" void ldm_destroy(ldm_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  h->drain_profile();
+  for (auto& g : h->graphs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+  }
+  for (auto& kv : h->raw)
+    if (kv.second.d) hipFree(kv.second.d);
+  for (void* p : h->owned) hipFree(p);
+  if (h->loop_a) hipEventDestroy(h->loop_a);
+  if (h->loop_b) hipEventDestroy(h->loop_b);
+  delete h;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+static std::string strip_prefix(const char* key) {
+  std::string k(key);
+  for (const char* p : {"model.module.", "module.", "model."}) {
+    const size_t n = strlen(p);
+    if (k.compare(0, n, p) == 0) {
+      k = k.substr(n);
+      break;
+    }
+  }
+  return k;
+}
+
+extern "C" int ldm_load_weight(ldm_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim) {
+  if (!h || !key || !h_data || (ndim > 0 && !shape)) return h ? h->fail(-1, "null argument") : -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  const std::string k = strip_prefix(key);
+  Raw r;
+  r.shape.assign(shape, shape + ndim);
+  const int64_t n = r.numel();
+  if (n <= 0) return h->fail(-1, "empty tensor for key %s", key);
+  auto it = h->raw.find(k);
+  if (it != h->raw.end()) {
+    if (it->second.numel() != n) return h->fail(-1, "key %s reloaded with a different size", key);
+    r.d = it->second.d;
+  } else {
+    HIP_OK(h, hipMalloc((void**)&r.d, n * sizeof(float)));
+  }
+  HIP_OK(h, hipMemcpy(r.d, h_data, n * sizeof(float), hipMemcpyHostToDevice));
+  h->raw[k] = r;
+  h->finalized = false;
+  return 0;
+}
+
+static int need(ldm_handle* h, const std::string& key, std::initializer_list<int64_t> shape, const float** out) {
+  auto it = h->raw.find(key);
+  if (it == h->raw.end()) return h->fail(-4, "missing checkpoint key: %s", key.c_str());
+  std::vector<int64_t> want(shape);
+  if (it->second.shape != want) {
+    std::string got;
+    for (auto s : it->second.shape) got += std::to_string(s) + ",";
+    return h->fail(-4, "checkpoint key %s has shape (%s) — does not match the configured geometry", key.c_str(),
+                   got.c_str());
+  }
+  *out = it->second.d;
+  return 0;
+}
+
+// fp16 (and split-lo) copy of a [N,K] weight with the K axis zero-padded to Kp
+static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half** hi, __half** lo) {
+  const bool split = h->cfg.precision == LDM_PREC_SPLIT_F16;
+  int rc = h->dalloc(hi, (size_t)N * Kp);
+  if (rc) return rc;
+  if (split && (rc = h->dalloc(lo, (size_t)N * Kp))) return rc;
+  if (K == Kp) {
+    launch_f32_to_f16(w, *hi, split ? *lo : nullptr, (int64_t)N * K, 0);
+  } else {
+    __half *thi = nullptr, *tlo = nullptr;
+    if ((rc = h->dalloc(&thi, (size_t)N * K))) return rc;
+    if (split && (rc = h->dalloc(&tlo, (size_t)N * K))) return rc;
+    launch_f32_to_f16(w, thi, tlo, (int64_t)N * K, 0);
+    HIP_OK(h, hipMemcpy2DAsync(*hi, (size_t)Kp * 2, thi, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
+    if (split)
+      HIP_OK(h, hipMemcpy2DAsync(*lo, (size_t)Kp * 2, tlo, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
+  }
+  return 0;
+}
+
+extern "C" int ldm_finalize_weights(ldm_handle* h) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  const int D = h->D, F = h->F, C = h->C, T = h->T, L = h->L;
+  const std::string tr = "transformer.";
+  int rc;
+  const float *elem = nullptr, *attr = nullptr;
+  if ((rc = need(h, tr + "cat_emb.weight", {C, D}, &h->emb))) return rc;
+  if ((rc = need(h, tr + "pos_emb.elem_emb", {h->cfg.max_elem, D}, &elem))) return rc;
+  if ((rc = need(h, tr + "pos_emb.attr_emb", {h->cfg.n_attr, D}, &attr))) return rc;
+  if ((rc = need(h, tr + "head.0.weight", {D}, &h->head_g))) return rc;
+  if ((rc = need(h, tr + "head.0.bias", {D}, &h->head_b))) return rc;
+  if ((rc = need(h, tr + "head.1.weight", {C, D}, &h->head_w))) return rc;
+  if (!h->pos && (rc = h->dalloc(&h->pos, (size_t)h->S * D))) return rc;
+  if (!h->adaln && (rc = h->dalloc(&h->adaln, (size_t)T * L * 2 * D))) return rc;
+  launch_pos_table(elem, attr, h->pos, h->cfg.max_elem, h->cfg.n_attr, D, 0);
+  const bool f16 = h->cfg.precision != LDM_PREC_EXACT_F32;
+  h->layers.assign(L, LayerW{});
+  for (int i = 0; i < L; ++i) {
+    const std::string b = tr + "backbone.layers." + std::to_string(i) + ".";
+    LayerW& w = h->layers[i];
+    const float *emb_t = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+    if ((rc = need(h, b + "self_attn.in_proj_weight", {3 * D, D}, &w.w_in))) return rc;
+    if ((rc = need(h, b + "self_attn.in_proj_bias", {3 * D}, &w.b_in))) return rc;
+    if ((rc = need(h, b + "self_attn.out_proj.weight", {D, D}, &w.w_out))) return rc;
+    if ((rc = need(h, b + "self_attn.out_proj.bias", {D}, &w.b_out))) return rc;
+    if ((rc = need(h, b + "linear1.weight", {F, D}, &w.w1))) return rc;
+    if ((rc = need(h, b + "linear1.bias", {F}, &w.b1))) return rc;
+    if ((rc = need(h, b + "linear2.weight", {D, F}, &w.w2))) return rc;
+    if ((rc = need(h, b + "linear2.bias", {D}, &w.b2))) return rc;
+    if ((rc = need(h, b + "norm1.emb.weight", {T, D}, &emb_t))) return rc;
+    if ((rc = need(h, b + "norm1.linear.weight", {2 * D, D}, &lin_w))) return rc;
+    if ((rc = need(h, b + "norm1.linear.bias", {2 * D}, &lin_b))) return rc;
+    if ((rc = need(h, b + "norm2.weight", {D}, &w.g2))) return rc;
+    if ((rc = need(h, b + "norm2.bias", {D}, &w.be2))) return rc;
+    launch_adaln_table(emb_t, lin_w, lin_b, h->adaln, T, D, L, i, 0);
+    if (f16) {
+      if ((rc = make_w16(h, w.w_in, 3 * D, D, h->Dp, &w.w_in16, &w.w_in16lo))) return rc;
+      if ((rc = make_w16(h, w.w_out, D, D, h->Dp, &w.w_out16, &w.w_out16lo))) return rc;
+      if ((rc = make_w16(h, w.w1, F, D, h->Dp, &w.w1_16, &w.w1_16lo))) return rc;
+      if ((rc = make_w16(h, w.w2, D, F, h->Fp, &w.w2_16, &w.w2_16lo))) return rc;
+    }
+  }
+  if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo))) return rc;
+  // schedule buffers are taken from the checkpoint, not recomputed
+  static const char* names[kNumSched] = {"log_at",         "log_bt",         "log_ct",       "log_cumprod_at",
+                                         "log_cumprod_bt", "log_cumprod_ct", "log_1_min_ct", "log_1_min_cumprod_ct"};
+  static const char* keys[5] = {"c", "x", "y", "w", "h"};
+  std::vector<float> host((size_t)kNumSched * h->cfg.n_attr * (T + 1), 0.f);
+  for (int k = 0; k < kNumSched; ++k) {
+    const bool cum = (k == kLogCumAt || k == kLogCumBt || k == kLogCumCt || k == kLog1mCumCt);
+    for (int a = 0; a < h->cfg.n_attr; ++a) {
+      const std::string key = std::string(keys[a]) + "_" + names[k];
+      const float* d = nullptr;
+      if ((rc = need(h, key, {cum ? T + 1 : T}, &d))) return rc;
+      HIP_OK(h, hipMemcpy(&host[((size_t)k * h->cfg.n_attr + a) * (T + 1)], d, (cum ? T + 1 : T) * sizeof(float),
+                          hipMemcpyDeviceToHost));
+    }
+  }
+  HIP_OK(h, hipMemcpy(h->sched, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_OK(h, hipDeviceSynchronize());
+  HIP_OK(h, hipGetLastError());
+  // graphs captured against older weights stay valid (pointers unchanged) but drop them anyway
+  for (auto& g : h->graphs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+  }
+  h->graphs.clear();
+  h->finalized = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ one pass
+static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
+
+// denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
+static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+  const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
+  const int prec = h->cfg.precision;
+  const bool f16 = prec != LDM_PREC_EXACT_F32;
+  const bool split = prec == LDM_PREC_SPLIT_F16;
+  const size_t esz = f16 ? 2 : 4;
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    {  // AdaLN (layer 0: fused with the embedding gather); P <- normed x (the residual base)
+      LnArgs a{};
+      a.x = h->P;
+      a.tokens = (i == 0) ? d_tokens : nullptr;
+      a.emb = h->emb;
+      a.pos = h->pos;
+      a.p0 = ss;
+      a.p1 = ss + D;
+      a.y32 = h->P;
+      a.y16 = f16 ? h->a16 : nullptr;
+      a.y16lo = split ? h->a16lo : nullptr;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 1;
+      ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * (4 + 4 + (f16 ? 2 : 0)));
+      launch_layernorm(a, st);
+    }
+    {  // QKV projection
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->a16 : (const void*)h->P;
+      g.Alo = h->a16lo;
+      g.W = f16 ? (const void*)w.w_in16 : (const void*)w.w_in;
+      g.Wlo = w.w_in16lo;
+      g.bias = w.b_in;
+      g.C32 = (prec == LDM_PREC_FAST_F16) ? nullptr : h->qkv32;
+      g.C16 = (prec == LDM_PREC_FAST_F16) ? h->qkv16 : nullptr;
+      g.M = M; g.N = 3 * D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D;
+      g.ldc32 = 3 * D; g.ldc16 = 3 * D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * D * esz + (double)M * 3 * D * (prec == 1 ? 2 : 4));
+      launch_gemm(g, st);
+    }
+    {  // attention
+      AttnArgs a{};
+      a.in_f16 = (prec == LDM_PREC_FAST_F16);
+      a.qkv = a.in_f16 ? (const void*)h->qkv16 : (const void*)h->qkv32;
+      a.out32 = f16 ? nullptr : h->att32;
+      a.out16 = f16 ? h->att16 : nullptr;
+      a.out16lo = split ? h->att16lo : nullptr;
+      a.B = Bc; a.S = h->S; a.H = h->H; a.dh = h->dh; a.D = D; a.ld = 3 * D; a.ldo32 = D; a.ldo16 = Dp;
+      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
+                           (double)M * 3 * D * (a.in_f16 ? 2 : 4) + (double)M * D * esz);
+      launch_attention(a, st);
+    }
+    {  // out-proj + residual onto the normed x:  Q = P + att·Wo^T + bo
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->att16 : (const void*)h->att32;
+      g.Alo = h->att16lo;
+      g.W = f16 ? (const void*)w.w_out16 : (const void*)w.w_out;
+      g.Wlo = w.w_out16lo;
+      g.bias = w.b_out;
+      g.res = h->P; g.ldres = D;
+      g.C32 = h->Q; g.ldc32 = D;
+      g.M = M; g.N = D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * D * (esz + 8));
+      launch_gemm(g, st);
+    }
+    {  // LayerNorm 2
+      LnArgs a{};
+      a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2;
+      a.y32 = f16 ? nullptr : h->h32;
+      a.y16 = f16 ? h->h16 : nullptr;
+      a.y16lo = split ? h->h16lo : nullptr;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
+      ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * (4 + esz));
+      launch_layernorm(a, st);
+    }
+    {  // FFN1 + ReLU
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
+      g.Alo = h->h16lo;
+      g.W = f16 ? (const void*)w.w1_16 : (const void*)w.w1;
+      g.Wlo = w.w1_16lo;
+      g.bias = w.b1; g.relu = 1;
+      g.C32 = f16 ? nullptr : h->hid32; g.ldc32 = F;
+      g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
+      g.M = M; g.N = F; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_ffn1", gemm_flops(M, F, D), (double)M * D * esz + (double)M * F * esz);
+      launch_gemm(g, st);
+    }
+    {  // FFN2 + residual:  P = Q + hid·W2^T + b2
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->hid16 : (const void*)h->hid32;
+      g.Alo = h->hid16lo;
+      g.W = f16 ? (const void*)w.w2_16 : (const void*)w.w2;
+      g.Wlo = w.w2_16lo;
+      g.bias = w.b2;
+      g.res = h->Q; g.ldres = D;
+      g.C32 = h->P; g.ldc32 = D;
+      g.M = M; g.N = D; g.K = f16 ? Fp : F; g.lda = f16 ? Fp : F; g.ldw = f16 ? Fp : F; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_ffn2", gemm_flops(M, D, F), (double)M * F * esz + (double)M * D * 8);
+      launch_gemm(g, st);
+    }
+  }
+  {  // head: LayerNorm + vocab projection (no bias)
+    LnArgs a{};
+    a.x = h->P; a.p0 = h->head_g; a.p1 = h->head_b;
+    a.y32 = f16 ? nullptr : h->h32;
+    a.y16 = f16 ? h->h16 : nullptr;
+    a.y16lo = split ? h->h16lo : nullptr;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
+    {
+      ldm_handle::Scope sc(h, st, "layernorm_head", 0, (double)M * D * (4 + esz));
+      launch_layernorm(a, st);
+    }
+    GemmArgs g{};
+    g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
+    g.Alo = h->h16lo;
+    g.W = f16 ? (const void*)h->head_w16 : (const void*)h->head_w;
+    g.Wlo = h->head_w16lo;
+    g.C32 = h->logits; g.ldc32 = h->Cp;
+    g.M = M; g.N = C; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+    ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, C, D), (double)M * D * esz + (double)M * C * 4);
+    launch_gemm(g, st);
+  }
+  return 0;
+}
+
+static void fill_post(ldm_handle* h, PostArgs& p, const ldm_cond* cond, const ldm_sampler* s, size_t layout_off,
+                      int Bc) {
+  p.sched = h->sched;
+  p.T = h->T;
+  p.B = Bc;
+  p.S = h->S;
+  p.v = h->vocab;
+  p.rng = h->rng;
+  if (cond) {
+    const size_t ro = layout_off * h->S;
+    p.cond_seq = cond->d_cond_seq ? cond->d_cond_seq + ro : nullptr;
+    p.strong = cond->d_strong_mask ? cond->d_strong_mask + ro : nullptr;
+    p.weak = cond->d_weak_logits ? cond->d_weak_logits + layout_off * h->C * h->S : nullptr;
+    p.pad_disable = cond->pad_disable;
+  }
+  if (s) {
+    p.kind = s->kind;
+    p.temperature = s->temperature;
+    p.top_p = s->top_p;
+    p.top_k = s->top_k;
+  }
+}
+
+static int check_ready(ldm_handle* h, int B) {
+  if (!h) return -1;
+  if (!h->finalized) return h->fail(-5, "weights not finalized: call ldm_finalize_weights first");
+  if (B < 1 || B > h->cfg.max_batch) return h->fail(-1, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
+  return 0;
+}
+
+static int check_sampler(ldm_handle* h, const ldm_sampler* s) {
+  if (!s) return h->fail(-1, "null sampler");
+  if (s->kind < 0 || s->kind > 4) return h->fail(-1, "unknown sampler kind %d", s->kind);
+  if (s->kind != LDM_SAMPLE_DETERMINISTIC && !(s->temperature > 0.f)) return h->fail(-1, "temperature must be > 0");
+  if (s->kind == LDM_SAMPLE_TOP_P && !(s->top_p > 0.f && s->top_p <= 1.f)) return h->fail(-1, "top_p must be in (0,1]");
+  if (s->kind == LDM_SAMPLE_TOP_K && (s->top_k < 1 || s->top_k > h->C)) return h->fail(-1, "top_k out of range");
+  return 0;
+}
+
+// one fused reverse step over the whole batch, chunk by chunk
+static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_model, int t_post, const ldm_cond* cond,
+                    const ldm_sampler* s, int step, int B, size_t rng_layout_off, hipStream_t st) {
+  if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
+    return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
+  for (int off = 0; off < B; off += h->chunk) {
+    const int Bc = std::min(h->chunk, B - off);
+    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st);
+    if (rc) return rc;
+    PostArgs p{};
+    fill_post(h, p, cond, s, off, Bc);
+    p.logits = h->logits;
+    p.ldl = h->Cp;
+    p.tokens = tin + (size_t)off * h->S;
+    p.tokens_out = tout + (size_t)off * h->S;
+    p.t_post = t_post;
+    p.step = step;
+    p.layout_off = (int)(rng_layout_off + off);
+    ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
+    launch_posterior_sample(p, st);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ parity hooks
+extern "C" int ldm_denoise_logits(ldm_handle* h, const int32_t* d_tokens, int t, int B, float* d_logits, void* stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if (!d_tokens || !d_logits) return h->fail(-1, "null argument");
+  if (t < 0 || t >= h->T) return h->fail(-1, "timestep out of range");
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  for (int off = 0; off < B; off += h->chunk) {
+    const int Bc = std::min(h->chunk, B - off);
+    if ((rc = denoise_chunk(h, d_tokens + (size_t)off * h->S, t, Bc, st))) return rc;
+    HIP_OK(h, hipMemcpy2DAsync(d_logits + (size_t)off * h->S * h->C, (size_t)h->C * 4, h->logits, (size_t)h->Cp * 4,
+                               (size_t)h->C * 4, (size_t)Bc * h->S, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
+extern "C" int ldm_posterior(ldm_handle* h, const float* d_logits, const int32_t* d_tokens, int t_post, int B,
+                             const ldm_cond* cond, float* d_logp, void* stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if (!d_logits || !d_tokens || !d_logp) return h->fail(-1, "null argument");
+  if (t_post < 0 || t_post >= h->T) return h->fail(-1, "timestep out of range");
+  HIP_OK(h, hipSetDevice(h->device));
+  PostArgs p{};
+  fill_post(h, p, cond, nullptr, 0, B);
+  p.logits = d_logits;
+  p.ldl = h->C;
+  p.tokens = d_tokens;
+  p.logp_out = d_logp;
+  p.t_post = t_post;
+  launch_posterior_sample(p, (hipStream_t)stream);
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
+static int set_rng(ldm_handle* h, uint64_t seed, uint64_t first_layout, hipStream_t st) {
+  launch_set_rng(h->rng, seed, first_layout, st);  // kernel args are captured by value at launch
+  return 0;
+}
+
+extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_sampler* s, uint64_t seed,
+                                 uint64_t first_layout, int step, int B, int32_t* d_tokens_out, void* stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if ((rc = check_sampler(h, s))) return rc;
+  if (!d_logp || !d_tokens_out) return h->fail(-1, "null argument");
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = set_rng(h, seed, first_layout, st))) return rc;
+  PostArgs p{};
+  fill_post(h, p, nullptr, s, 0, B);
+  p.logp_in = d_logp;
+  p.tokens_out = d_tokens_out;
+  p.step = step;
+  launch_posterior_sample(p, st);
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ hot path
+extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
+                               int t_post, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,
+                               uint64_t first_layout, int step, int B, void* stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if ((rc = check_sampler(h, s))) return rc;
+  if (!d_tokens_in || !d_tokens_out) return h->fail(-1, "null argument");
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = set_rng(h, seed, first_layout, st))) return rc;
+  if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, s, step, B, 0, st))) return rc;
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
+static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const int32_t* t_model, const int32_t* t_post,
+                         int n_steps, const ldm_sampler* s, int B, int32_t* d_inter, hipStream_t st) {
+  // state lives in tok_a / tok_b (ping-pong); chunk-major order keeps one chunk's activations and the
+  // weights resident in L2 / Infinity Cache for all T steps before moving to the next chunk
+  const size_t S = h->S;
+  for (int off = 0; off < B; off += h->chunk) {
+    const int Bc = std::min(h->chunk, B - off);
+    ldm_cond cc{};
+    if (cond) {
+      cc = *cond;
+      if (cc.d_cond_seq) cc.d_cond_seq += off * S;
+      if (cc.d_strong_mask) cc.d_strong_mask += off * S;
+      if (cc.d_weak_logits) cc.d_weak_logits += (size_t)off * h->C * S;
+    }
+    int32_t* cur = h->tok_a + off * S;
+    int32_t* nxt = h->tok_b + off * S;
+    for (int i = 0; i < n_steps; ++i) {
+      int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, s, i, Bc, off, st);
+      if (rc) return rc;
+      if (d_inter)
+        HIP_OK(h, hipMemcpyAsync(d_inter + ((size_t)i * B + off) * S, nxt, (size_t)Bc * S * 4,
+                                 hipMemcpyDeviceToDevice, st));
+      std::swap(cur, nxt);
+    }
+    if (n_steps % 2 == 1)  // result sits in tok_b: bring it back to tok_a
+      HIP_OK(h, hipMemcpyAsync(h->tok_a + off * S, h->tok_b + off * S, (size_t)Bc * S * 4, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const int32_t* h_t_model,
+                               const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
+                               uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream) {
+  int rc = check_ready(h, B);
+  if (rc) return rc;
+  if ((rc = check_sampler(h, s))) return rc;
+  if (!d_tokens_inout || !h_t_model || !h_t_post || n_steps < 1) return h->fail(-1, "bad argument");
+  for (int i = 0; i < n_steps; ++i)
+    if (h_t_model[i] < 0 || h_t_model[i] >= h->T || h_t_post[i] < 0 || h_t_post[i] >= h->T)
+      return h->fail(-1, "timestep out of range [0,%d)", h->T);
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nbytes = (size_t)B * h->S * 4;
+  HIP_OK(h, hipEventRecord(h->loop_a, st));
+  if ((rc = set_rng(h, seed, first_layout, st))) return rc;
+  HIP_OK(h, hipMemcpyAsync(h->tok_a, d_tokens_inout, nbytes, hipMemcpyDeviceToDevice, st));
+  if (use_graph && !h->profiling) {
+    GraphKey key{};
+    key.B = B; key.n_steps = n_steps; key.kind = s->kind; key.top_k = s->top_k;
+    key.temperature = s->temperature; key.top_p = s->top_p;
+    key.has_cond = cond != nullptr;
+    key.cond_seq = cond ? cond->d_cond_seq : nullptr;
+    key.strong = cond ? cond->d_strong_mask : nullptr;
+    key.weak = cond ? cond->d_weak_logits : nullptr;
+    key.pad_disable = cond ? cond->pad_disable : 0;
+    key.inter = d_intermediates;
+    key.t_model.assign(h_t_model, h_t_model + n_steps);
+    key.t_post.assign(h_t_post, h_t_post + n_steps);
+    GraphEntry* ge = nullptr;
+    for (auto& g : h->graphs)
+      if (g.key == key) ge = &g;
+    if (!ge) {
+      if (h->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest
+        if (h->graphs[0].exec) hipGraphExecDestroy(h->graphs[0].exec);
+        if (h->graphs[0].graph) hipGraphDestroy(h->graphs[0].graph);
+        h->graphs.erase(h->graphs.begin());
+      }
+      // capture on a private stream so the caller's stream state is untouched
+      hipStream_t cap = nullptr;
+      HIP_OK(h, hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+      HIP_OK(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+      rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, d_intermediates, cap);
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamEndCapture(cap, &graph);
+      hipStreamDestroy(cap);
+      if (rc) {
+        if (graph) hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e != hipSuccess) return h->fail(-2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+      GraphEntry ne;
+      ne.key = key;
+      ne.graph = graph;
+      HIP_OK(h, hipGraphInstantiate(&ne.exec, graph, nullptr, nullptr, 0));
+      h->graphs.push_back(ne);
+      ge = &h->graphs.back();
+    }
+    HIP_OK(h, hipGraphLaunch(ge->exec, st));
+  } else {
+    if ((rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, d_intermediates, st))) return rc;
+  }
+  HIP_OK(h, hipMemcpyAsync(d_tokens_inout, h->tok_a, nbytes, hipMemcpyDeviceToDevice, st));
+  HIP_OK(h, hipEventRecord(h->loop_b, st));
+  h->loop_timed = true;
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ introspection
+extern "C" int ldm_last_loop_ms(ldm_handle* h, float* ms) {
+  if (!h || !ms) return -1;
+  if (!h->loop_timed) return h->fail(-1, "no loop has run yet");
+  HIP_OK(h, hipEventSynchronize(h->loop_b));
+  HIP_OK(h, hipEventElapsedTime(ms, h->loop_a, h->loop_b));
+  return 0;
+}
+
+extern "C" int ldm_set_profiling(ldm_handle* h, int enable) {
+  if (!h) return -1;
+  h->drain_profile();
+  h->profiling = enable != 0;
+  return 0;
+}
+extern "C" int ldm_profile_count(ldm_handle* h) {
+  if (!h) return -1;
+  h->drain_profile();
+  return (int)h->prof.size();
+}
+extern "C" int ldm_profile_get(ldm_handle* h, int idx, const char** name, double* total_ms, int64_t* launches,
+                               double* flops, double* bytes) {
+  if (!h || idx < 0 || idx >= (int)h->prof.size()) return -1;
+  h->drain_profile();
+  const ProfEntry& e = h->prof[idx];
+  if (name) *name = e.name.c_str();
+  if (total_ms) *total_ms = e.ms;
+  if (launches) *launches = e.launches;
+  if (flops) *flops = e.flops;
+  if (bytes) *bytes = e.bytes;
+  return 0;
+}
+extern "C" int ldm_profile_reset(ldm_handle* h) {
+  if (!h) return -1;
+  h->drain_profile();
+  h->prof.clear();
+  return 0;
+}

@@ -1,0 +1,100 @@
+// Internal launch interface between the C-ABI host layer (ldm_api.cpp) and the gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace ldm {
+
+constexpr float kLogEps = -69.07755278982137f;  // log(1e-30): categorical_diffusion/util.py:8
+constexpr int kMaxAttr = 8;
+
+// ---- row kernels (kernels_norm.hip) -----------------------------------------------------
+// y = LN(x) * (1 + scale) + shift        (AdaLayerNorm, transformer_utils.py:79-83)   ada = 1
+// y = LN(x) * gamma + beta               (nn.LayerNorm)                               ada = 0
+// x = emb[token] + pos[s] first if tokens != nullptr (nn_lib.py:204,220)
+struct LnArgs {
+  const float* x;         // [M, D] (ignored when tokens != nullptr)
+  const int32_t* tokens;  // [M] or nullptr
+  const float* emb;       // [C, D]
+  const float* pos;       // [S, D]
+  const float* p0;        // scale (ada) or gamma   [D]
+  const float* p1;        // shift (ada) or beta    [D]
+  float* y32;             // [M, D] or nullptr
+  __half* y16;            // [M, ld16] or nullptr   (GEMM A operand, fp16 modes)
+  __half* y16lo;          // [M, ld16] or nullptr   (split mode: residual x - fp16(x), scaled by 2^11)
+  int M, D, S, ld16, ada;
+};
+void launch_layernorm(const LnArgs& a, hipStream_t st);
+
+// ---- GEMM (kernels_gemm.hip):  C[M,N] = epi(A[M,K] * W[N,K]^T + bias) ---------------------
+struct GemmArgs {
+  const void* A;      // fp32 (exact) or fp16 (fast/split) [M, lda]
+  const void* Alo;    // split mode: low halves of A
+  const void* W;      // [N, ldw] same dtype family as A
+  const void* Wlo;    // split mode
+  const float* bias;  // [N] or nullptr
+  const float* res;   // residual [M, ldres] fp32 or nullptr
+  float* C32;         // [M, ldc32] or nullptr
+  __half* C16;        // [M, ldc16] or nullptr
+  __half* C16lo;      // split mode, or nullptr
+  int M, N, K, lda, ldw, ldres, ldc32, ldc16;
+  int relu;
+  int precision;  // LDM_PREC_*
+};
+void launch_gemm(const GemmArgs& g, hipStream_t st);
+
+// ---- attention (kernels_attn.hip): softmax(QK^T/sqrt(dh)) V per (layout, head) ------------
+struct AttnArgs {
+  const void* qkv;  // [M, ld] fp32 or fp16; q cols [0,D), k [D,2D), v [2D,3D); head h = cols h*dh..
+  int in_f16;       // dtype of qkv
+  float* out32;     // [M, ldo32] or nullptr
+  __half* out16;    // [M, ldo16] or nullptr
+  __half* out16lo;  // split mode, or nullptr
+  int B, S, H, dh, D, ld, ldo32, ldo16;
+};
+void launch_attention(const AttnArgs& a, hipStream_t st);
+
+// ---- posterior + categorical draw (kernels_post.hip) ------------------------------------
+struct VocabTables {  // built on the host from the tokenizer geometry (layout_tokenizer.py:429-467)
+  int n_class, n_attr, pad_id, mask_id;
+  int start[kMaxAttr];  // first full id of the attribute's body
+  int count[kMaxAttr];  // body size (n_category or n_bin); K = count + 2
+};
+struct PostArgs {
+  const float* logits;     // [M, ldl] (cols >= n_class ignored)
+  int ldl;
+  const int32_t* tokens;   // [M] current x_t
+  int32_t* tokens_out;     // [M] or nullptr
+  float* logp_out;         // (B,C,S) or nullptr (parity hook)
+  const float* logp_in;    // (B,C,S) or nullptr: skip the posterior, only sample (ldm_sample_tokens)
+  const float* sched;      // device [8][n_attr][T+1] schedule buffers, see ScheduleRow
+  int T;                   // n_step
+  int t_post;              // timestep of q_posterior
+  const int32_t* cond_seq; // [M] or nullptr
+  const uint8_t* strong;   // [M] or nullptr
+  const float* weak;       // (B,C,S) or nullptr
+  int pad_disable;
+  int kind;                // LDM_SAMPLE_*
+  float temperature, top_p;
+  int top_k;
+  const uint64_t* rng;     // device {seed, first_layout}
+  int layout_off;          // + offset of this launch's first layout inside the call's batch
+  int step;                // reverse-loop index (RNG counter word)
+  int B, S;
+  VocabTables v;
+};
+enum ScheduleRow { kLogAt = 0, kLogBt, kLogCt, kLogCumAt, kLogCumBt, kLogCumCt, kLog1mCt, kLog1mCumCt, kNumSched };
+void launch_posterior_sample(const PostArgs& p, hipStream_t st);
+void launch_set_rng(uint64_t* rng, uint64_t seed, uint64_t first_layout, hipStream_t st);
+
+// ---- small utilities ---------------------------------------------------------------------
+void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st);
+// AdaLN table: out[t][l][2D] = Linear(SiLU(Emb[t])) (transformer_utils.py:67-69,80)
+void launch_adaln_table(const float* emb /*[T,D]*/, const float* w /*[2D,D]*/, const float* b /*[2D]*/,
+                        float* out /*[T, L, 2D] at layer offset*/, int T, int D, int L, int layer, hipStream_t st);
+void launch_pos_table(const float* elem /*[E,D]*/, const float* attr /*[A,D]*/, float* pos /*[S,D]*/, int E,
+                      int A, int D, hipStream_t st);
+
+}  // namespace ldm

@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference's diffusion class for the sampling path.
+
+`HipMaskAndReplaceDiffusion` exposes the public surface the reference's callers use on
+`ConstrainedMaskAndReplaceDiffusion` (trainer/models/categorical_diffusion/constrained.py:27,
+base.py:293-371): construct from the model geometry, `load_state_dict` with the reference's
+checkpoint keys, `.sample(batch_size, cond, sampling_cfg, get_intermediate_results)` returning a
+CPU LongTensor (B,S).  Everything numeric runs in libldm_hip.so; this file only does what
+`sample()` does on the host in the reference: the timestep list, skip-step bookkeeping, cond
+duplication and dtype plumbing.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from .binding import Engine
+
+_seed_counter = itertools.count()
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if hasattr(cfg, "get"):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def timestep_schedule(num_timesteps: int, num_timesteps_eval: int, time_difference: float = 0.0):
+    """(t_model list, t_post list) exactly as base.py:310-315 + 218-240 derive them:
+    diffusion_list = [int(i*T/T_eval)], skip_step = delta_t - 1, noise_t = clamp(t - int(T*td)),
+    posterior evaluated at noise_t - skip_step when noise_t > skip_step."""
+    assert num_timesteps_eval <= num_timesteps  # base.py:311
+    t_model, t_post = [], []
+    prev = num_timesteps
+    for i in range(num_timesteps_eval - 1, -1, -1):
+        t = int(i * num_timesteps / num_timesteps_eval)
+        delta = prev - t
+        if delta <= 0:
+            raise NotImplementedError  # base.py:361-362
+        skip = delta - 1
+        noise_t = t
+        if time_difference > 0.0:
+            noise_t = min(max(t - int(num_timesteps * time_difference), 0), num_timesteps - 1)
+        if skip > 0 and noise_t > skip:
+            noise_t = noise_t - skip
+        t_model.append(t)
+        t_post.append(noise_t)
+        prev = t
+    return t_model, t_post
+
+
+class HipMaskAndReplaceDiffusion:
+    """MI355X implementation behind the reference's Seam-2."""
+
+    def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
+                 d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4,
+                 num_timesteps: int = 100, precision: str = "exact", max_batch: int = 512, chunk: int = 0,
+                 device: Optional[int] = None, use_graph: bool = True):
+        self.engine = Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
+                             d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
+                             precision=precision, max_batch=max_batch, chunk=chunk, device=device)
+        self.num_timesteps = num_timesteps
+        self.num_classes = self.engine.C
+        self.max_token_length = self.engine.S
+        self.precision = precision
+        self.use_graph = use_graph
+        self.mask_id = self.engine.mask_id
+        self.pad_id = self.engine.pad_id
+
+    # -- nn.Module-ish surface used by the reference's callers --------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.engine.device
+
+    def to(self, *_a, **_k):
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        self.engine.load_state_dict(state_dict)
+        return self
+
+    # -- the hot path ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None,
+               get_intermediate_results: bool = False, seed: Optional[int] = None, first_layout: int = 0,
+               return_device_tensor: bool = False, **kwargs) -> Union[torch.Tensor, List[torch.Tensor]]:
+        """BaseMaskAndReplaceDiffusion.sample (base.py:293-371).  Extra keyword arguments
+        (`cond_type=...` from test.py:195-200) are accepted and ignored like the reference does.
+
+        seed: Philox key for the stochastic samplers.  None -> drawn from torch's global CPU
+        generator, so `set_seed()` (helpers/util.py:10-13) keeps runs reproducible.
+        first_layout: global index of row 0 (batch sharding across calls / GPUs)."""
+        eng = self.engine
+        T = self.num_timesteps
+        t_eval = int(_cfg_get(sampling_cfg, "num_timesteps", T))
+        td = float(_cfg_get(sampling_cfg, "time_difference", 0.0) or 0.0)
+        t_model, t_post = timestep_schedule(T, t_eval, td)
+        if cond and cond.get("type") == "relation":
+            raise NotImplementedError(
+                "cond=relation needs the autograd logit adjustment (logit_adjustment.py); use "
+                "layout_dm_amd.relation.sample_with_relation (split-step API)")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        B = int(batch_size)
+        if cond:
+            seq = torch.as_tensor(cond["seq"])
+            if seq.size(0) == 1 and B > 1:  # duplicate_cond, helpers/task.py:235-248
+                cond = dict(cond)
+                for k, v in list(cond.items()):
+                    if isinstance(v, torch.Tensor):
+                        cond[k] = v.repeat([B] + [1] * (v.dim() - 1))
+                seq = cond["seq"]
+            assert seq.size(0) == B, "cond['seq'] batch does not match batch_size"
+            tokens = seq.to(device=eng.device, dtype=torch.int32).contiguous().clone()
+        else:
+            tokens = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=eng.device)
+        outs, inters = [], []
+        for off in range(0, B, eng.max_batch):  # the reference caps a call at 512 (Converter); we chunk
+            n = min(eng.max_batch, B - off)
+            sub = None
+            if cond:
+                sub = {k: (v[off:off + n] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B else v)
+                       for k, v in cond.items()}
+            tk, inter = eng.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, sampling_cfg, cond=sub,
+                                        seed=seed, first_layout=first_layout + off,
+                                        intermediates=get_intermediate_results, use_graph=self.use_graph)
+            outs.append(tk)
+            inters.append(inter)
+        out = torch.cat(outs) if len(outs) > 1 else outs[0]
+        if get_intermediate_results:
+            inter = torch.cat(inters, dim=1) if len(inters) > 1 else inters[0]
+            return [x.long().cpu() for x in inter]
+        if return_device_tensor:
+            return out
+        return out.long().cpu()

@@ -1,0 +1,185 @@
+"""Model geometry, diffusion schedule and deterministic synthetic checkpoints for the product side
+(bench.py, the drop-in model class when no checkpoint is given).
+
+The geometry/schedule mirror the reference:
+  vocab layout     trainer/helpers/layout_tokenizer.py:79-82,152-153,429-467
+  sub-vocab sizes  trainer/models/categorical_diffusion/constrained.py:51-54
+  backbone dims    trainer/config/backbone/medium.yaml + models/layoutdm.py:54 (shrink 29/32)
+  schedule         trainer/models/categorical_diffusion/util.py:47-70, base.py:44-47
+  init             trainer/models/base_model.py:108-116, models/common/nn_lib.py:109-110
+(oracle/spec.py + oracle/synth.py hold an independent copy used by the checker;
+tests/test_synthetic_consistency.py asserts both produce identical tensors.)
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+LOG_EPS = math.log(1e-30)  # util.py:8
+VAR_NAMES = ("c", "x", "y", "w", "h")
+
+
+@dataclasses.dataclass(frozen=True)
+class ModelSpec:
+    name: str
+    n_category: int
+    n_bin: int = 32
+    max_elem: int = 25
+    n_attr: int = 5
+    d_model: int = 464
+    n_head: int = 8
+    d_ff: int = 1856
+    n_layer: int = 4
+    n_step: int = 100  # T
+
+    @property
+    def seq_len(self) -> int:  # S
+        return self.max_elem * self.n_attr
+
+    @property
+    def n_bbox(self) -> int:
+        return self.n_bin * 4
+
+    @property
+    def pad_id(self) -> int:
+        return self.n_category + self.n_bbox
+
+    @property
+    def mask_id(self) -> int:
+        return self.pad_id + 1
+
+    @property
+    def n_class(self) -> int:  # C
+        return self.mask_id + 1
+
+    @property
+    def d_head(self) -> int:
+        return self.d_model // self.n_head
+
+    def sub_vocab_size(self, attr: int) -> int:  # K, constrained.py:51-54
+        return (self.n_category if attr == 0 else self.n_bin) + 2
+
+    def full_ids(self, attr: int) -> np.ndarray:
+        """partial index -> full vocabulary id (layout_tokenizer.py:429-467)."""
+        if attr == 0:
+            body = np.arange(self.n_category)
+        else:
+            start = self.n_category + (attr - 1) * self.n_bin
+            body = np.arange(start, start + self.n_bin)
+        return np.concatenate([body, [self.pad_id, self.mask_id]]).astype(np.int64)
+
+
+RICO25 = ModelSpec("rico25", n_category=25)
+PUBLAYNET = ModelSpec("publaynet", n_category=5)
+SPECS = {"rico25": RICO25, "publaynet": PUBLAYNET}
+
+
+def alpha_schedule(num_timesteps, N, att_1=0.99999, att_T=0.000009, ctt_1=0.000009, ctt_T=0.99999):
+    """Restatement of util.py:47-70 (float64 numpy)."""
+    att = np.arange(0, num_timesteps) / (num_timesteps - 1) * (att_T - att_1) + att_1
+    att = np.concatenate(([1], att))
+    at = att[1:] / att[:-1]
+    ctt = np.arange(0, num_timesteps) / (num_timesteps - 1) * (ctt_T - ctt_1) + ctt_1
+    ctt = np.concatenate(([0], ctt))
+    one_minus_ctt = 1 - ctt
+    one_minus_ct = one_minus_ctt[1:] / one_minus_ctt[:-1]
+    ct = 1 - one_minus_ct
+    bt = (1 - at - ct) / N
+    att = np.concatenate((att[1:], [1]))
+    ctt = np.concatenate((ctt[1:], [0]))
+    btt = (1 - att - ctt) / N
+    return at, bt, ct, att, btt, ctt
+
+
+SCHEDULE_NAMES = (
+    "log_at", "log_bt", "log_ct", "log_cumprod_at", "log_cumprod_bt", "log_cumprod_ct",
+    "log_1_min_ct", "log_1_min_cumprod_ct",
+)
+
+
+def schedule_buffers(spec: ModelSpec):
+    """{f"{key}_{name}": float32 array} as registered at constrained.py:56-90.
+
+    torch.log / log_1_min_a (util.py:15-16) are evaluated in float64 then cast to
+    float32, exactly as the reference does (torch.tensor(float64) -> .float()).
+    """
+    out = {}
+    with np.errstate(divide="ignore"):
+        for a, key in enumerate(VAR_NAMES):
+            N = spec.sub_vocab_size(a) - 1
+            at, bt, ct, att, btt, ctt = alpha_schedule(spec.n_step, N)
+            log_at, log_bt, log_ct = np.log(at), np.log(bt), np.log(ct)
+            l_att, l_btt, l_ctt = np.log(att), np.log(btt), np.log(ctt)
+            log_1_min_ct = np.log(1 - np.exp(log_ct) + 1e-40)
+            log_1_min_cumprod_ct = np.log(1 - np.exp(l_ctt) + 1e-40)
+            vals = (log_at, log_bt, log_ct, l_att, l_btt, l_ctt, log_1_min_ct, log_1_min_cumprod_ct)
+            for n, v in zip(SCHEDULE_NAMES, vals):
+                out[f"{key}_{n}"] = v.astype(np.float32)
+    return out
+
+
+PREFIX = "model.module."  # CustomDataParallel wrapper, models/layoutdm.py:52
+
+
+def synth_state_dict(spec: ModelSpec, seed: int = 0, perturb: bool = False, prefix: str = PREFIX,
+                     weight_std: float = 0.02):
+    """Returns {key: np.ndarray(float32)} with the 100 reference keys."""
+    rng = np.random.default_rng(seed)
+    D, F, C, T = spec.d_model, spec.d_ff, spec.n_class, spec.n_step
+
+    def normal(*shape):
+        return (rng.standard_normal(shape) * weight_std).astype(np.float32)
+
+    def bias(n):
+        if perturb:
+            return (rng.standard_normal(n) * 0.1).astype(np.float32)
+        return np.zeros(n, np.float32)
+
+    def gamma(n):
+        if perturb:
+            return (1.0 + rng.standard_normal(n) * 0.1).astype(np.float32)
+        return np.ones(n, np.float32)
+
+    sd = {}
+    sd["Lt_history"] = np.zeros(T, np.float32)
+    sd["Lt_count"] = np.zeros(T, np.float32)
+    sd.update(schedule_buffers(spec))
+    tr = "transformer."
+    sd[tr + "cat_emb.weight"] = normal(C, D)
+    sd[tr + "pos_emb.elem_emb"] = rng.random((spec.max_elem, D)).astype(np.float32)
+    sd[tr + "pos_emb.attr_emb"] = rng.random((spec.n_attr, D)).astype(np.float32)
+    for i in range(spec.n_layer):
+        b = f"{tr}backbone.layers.{i}."
+        sd[b + "self_attn.in_proj_weight"] = normal(3 * D, D)
+        sd[b + "self_attn.in_proj_bias"] = bias(3 * D)
+        sd[b + "self_attn.out_proj.weight"] = normal(D, D)
+        sd[b + "self_attn.out_proj.bias"] = bias(D)
+        sd[b + "linear1.weight"] = normal(F, D)
+        sd[b + "linear1.bias"] = bias(F)
+        sd[b + "linear2.weight"] = normal(D, F)
+        sd[b + "linear2.bias"] = bias(D)
+        sd[b + "norm1.emb.weight"] = normal(T, D)
+        sd[b + "norm1.linear.weight"] = normal(2 * D, D)
+        sd[b + "norm1.linear.bias"] = bias(2 * D)
+        sd[b + "norm2.weight"] = gamma(D)
+        sd[b + "norm2.bias"] = bias(D)
+    sd[tr + "head.0.weight"] = gamma(D)
+    sd[tr + "head.0.bias"] = bias(D)
+    sd[tr + "head.1.weight"] = normal(C, D)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def strip_prefix(sd):
+    """Accept either LayoutDM ('model.module.') or bare diffusion-module keys."""
+    out = {}
+    for k, v in sd.items():
+        for p in (PREFIX, "module.", "model."):
+            if k.startswith(p):
+                k = k[len(p):]
+                break
+        out[k] = v
+    return out
+
+

@@ -236,8 +236,8 @@ def philox4x32(counter, key, rounds: int = 10):
 def token_uniforms(seed: int, first_layout: int, B: int, S: int, step: int, n: int = 1) -> np.ndarray:
     """Uniforms in (0,1) for token (layout, pos) at reverse step `step` (0-based loop
     index): Philox counter = (pos, step, layout_lo, layout_hi), key = (seed_lo, seed_hi).
-    u = (x + 0.5) * 2^-32 evaluated in float64 then cast to float32 like the kernel does
-    (the kernel computes it as float(x>>8)*2^-24 + 2^-25).  Returns (B,S,min(n,4))."""
+    u = ((x >> 9) + 0.5) * 2^-23, exact in float32 and strictly inside (0,1) — the same
+    expression the kernel evaluates (kernels_post.hip u01).  Returns (B,S,min(n,4))."""
     lay = (np.arange(B, dtype=np.uint64) + np.uint64(first_layout))
     ctr = np.zeros((B, S, 4), np.uint64)
     ctr[..., 0] = np.arange(S, dtype=np.uint64)[None, :]
@@ -248,7 +248,7 @@ def token_uniforms(seed: int, first_layout: int, B: int, S: int, step: int, n: i
     key[:, 0] = np.uint64(seed & 0xFFFFFFFF)
     key[:, 1] = np.uint64((seed >> 32) & 0xFFFFFFFF)
     r = philox4x32(ctr.reshape(-1, 4), key).reshape(B, S, 4)
-    u = ((r >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24) + np.float32(2.0 ** -25))
+    u = ((r >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
     return u[..., :n]
 
 
