@@ -1,0 +1,300 @@
+// fp16-operand / fp32-accumulate GEMM for the fast numerics mode:
+//     C[M,N] = epilogue(A[M,K] · W[N,K]^T + bias[N])
+// (torch.nn.Linear sites of the denoiser: trainer/models/transformer_utils.py:140-147,197-209,
+//  trainer/models/common/nn_lib.py:186-189).
+//
+// gfx950 structure (cdna_hip_programming.md §5):
+//  * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
+//    VGPR staging); NSTAGE LDS ring, tiles kt+1..kt+NSTAGE-2 stay in flight ACROSS the single
+//    s_barrier per K-tile (counted s_waitcnt vmcnt(N), never 0 in steady state).
+//  * the DMA writes LDS lane-linearly, so the bank-conflict swizzle is applied to the SOURCE
+//    address (16-B chunk index XOR f(row)) and again on the ds_read_b128 side (rule 21).
+//  * v_mfma_f32_32x32x16_f16 with SWAPPED operands (first operand = W fragment): the accumulator
+//    tile is D[i = n][j = m], so each lane owns ONE output row m and runs of 4 consecutive n —
+//    bias / residual / stores are 8- or 16-byte vector accesses instead of 2-byte scatters.
+//  * XCD-aware tile order (8 private L2s; block b runs on XCD b%8).
+//
+// Buffers are padded by the host so no load needs a bounds check: A has >= ceil(M/BM)*BM rows,
+// W has >= ceil(N/BN)*BN rows (zero rows), K is a multiple of BK with zero pad columns.
+#include "ldm_kernels.h"
+
+namespace ldm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+__device__ __forceinline__ int xcd_remap16(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Epi16 {
+  const float* bias;
+  const float* res;
+  float* C32;
+  __half* C16;
+  int M, N, ldres, ldc32, ldc16, relu;
+};
+
+// TAG only names the call site (0 qkv, 1 attn_out, 2 ffn1, 3 ffn2, 4 head) so that rocprofv3 reports
+// the five Linear classes as separate kernels.
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
+__global__ __launch_bounds__(WM* WN * 64) void gemm16_k(const __half* __restrict__ A, const __half* __restrict__ W,
+                                                         int lda, int ldw, int K, int tiles_n, Epi16 e) {
+  constexpr int NW = WM * WN;
+  constexpr int RB = BK * 2;          // bytes per tile row
+  constexpr int CPR = RB / 16;        // 16-B chunks per row (4 or 8)
+  constexpr int RPI = 64 / CPR;       // rows per 1-KiB DMA instruction
+  constexpr int NINST = (BM + BN) / RPI;
+  constexpr int LPT = NINST / NW;     // DMA instructions per wave per tile
+  static_assert(NINST % NW == 0, "tile does not split evenly over the waves");
+  constexpr int STAGE_BYTES = (BM + BN) * RB;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap16(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+
+  // ---- DMA source pointers (per lane), one per instruction slot of this wave
+  const int lrow = lane / CPR;
+  const int lchunk = lane % CPR;
+  const __half* src[LPT];
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int inst = wave + j * NW;
+    const int R = inst * RPI + lrow;  // row in the concatenated [A rows ; W rows] tile
+    const bool isA = (inst * RPI) < BM;
+    const int rt = isA ? R : R - BM;
+    const int sw = (CPR == 8) ? ((rt >> 1) & 7) : ((rt >> 2) & 3);
+    const int c = lchunk ^ sw;
+    src[j] = isA ? A + (size_t)(m0 + rt) * lda + c * 8 : W + (size_t)(n0 + rt) * ldw + c * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int inst = wave + j * NW;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(src[j] + (size_t)kt * BK), (las_ptr)(sbase + inst * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a stage)
+  const int frow = lane & 31;
+  const int hi = lane >> 5;
+  const int fsw = (CPR == 8) ? ((frow >> 1) & 7) : ((frow >> 2) & 3);
+  int offA[BK / 16], offW[BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    const int phys = (ks * 2 + hi) ^ fsw;
+    offA[ks] = (wm * (BM / WM) + frow) * RB + phys * 16;
+    offW[ks] = BM * RB + (wn * (BN / WN) + frow) * RB + phys * 16;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = min(NSTAGE - 2, nk - 1 - kt);  // tiles issued after kt that may stay in flight
+    if (NSTAGE >= 4 && rem >= 2) wait_vmcnt<2 * LPT>();
+    else if (rem >= 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    const char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f16x8 a[TM], w[TN];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const f16x8*>(sbase + offA[ks] + mi * 32 * RB);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) w[ni] = *reinterpret_cast<const f16x8*>(sbase + offW[ks] + ni * 32 * RB);
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns row m, runs of 4 consecutive n.
+  // Phase 1 issues every bias / residual load back-to-back (one latency, not one per group),
+  // phase 2 applies bias / ReLU / residual and stores 8- or 16-byte vectors.
+  const bool full_n = (n0 + BN <= e.N) && ((e.N & 3) == 0);
+  if (full_n) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      const int nb = n0 + wn * (BN / WN) + ni * 32 + hi * 4;
+      float4 bv[4];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        bv[rq] = e.bias ? *reinterpret_cast<const float4*>(e.bias + nb + rq * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 rv[TM][4];
+      if (e.res) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+          const int m = m0 + wm * (BM / WM) + mi * 32 + frow;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            rv[mi][rq] = (m < e.M) ? *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + nb + rq * 8)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * (BM / WM) + mi * 32 + frow;
+        if (m >= e.M) continue;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n = nb + rq * 8;
+          float v0 = acc[mi][ni][rq * 4 + 0] + bv[rq].x, v1 = acc[mi][ni][rq * 4 + 1] + bv[rq].y;
+          float v2 = acc[mi][ni][rq * 4 + 2] + bv[rq].z, v3 = acc[mi][ni][rq * 4 + 3] + bv[rq].w;
+          if (e.relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          if (e.res) {
+            v0 += rv[mi][rq].x; v1 += rv[mi][rq].y; v2 += rv[mi][rq].z; v3 += rv[mi][rq].w;
+          }
+          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v0, v1, v2, v3);
+          if (e.C16) {
+            const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<const unsigned*>(&h0);
+            pk.y = *reinterpret_cast<const unsigned*>(&h1);
+            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = pk;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ragged N tile (last column tile): per-group guards; groups are still 4-wide vectors when N%4==0
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int m = m0 + wm * (BM / WM) + mi * 32 + frow;
+    if (m >= e.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n0 + wn * (BN / WN) + ni * 32 + rq * 8 + hi * 4;
+        if (n >= e.N) continue;
+        if (n + 3 < e.N && (e.N & 3) == 0) {
+          float v0 = acc[mi][ni][rq * 4 + 0], v1 = acc[mi][ni][rq * 4 + 1];
+          float v2 = acc[mi][ni][rq * 4 + 2], v3 = acc[mi][ni][rq * 4 + 3];
+          if (e.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+          }
+          if (e.relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          if (e.res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+            v0 += r4.x; v1 += r4.y; v2 += r4.z; v3 += r4.w;
+          }
+          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v0, v1, v2, v3);
+          if (e.C16) {
+            const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<const unsigned*>(&h0);
+            pk.y = *reinterpret_cast<const unsigned*>(&h1);
+            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (n + i >= e.N) continue;
+            float x = acc[mi][ni][rq * 4 + i] + (e.bias ? e.bias[n + i] : 0.f);
+            if (e.relu) x = fmaxf(x, 0.f);
+            if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
+            if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
+            if (e.C16) e.C16[(size_t)m * e.ldc16 + n + i] = __float2half_rn(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG = 0>
+static void launch_cfg(const GemmArgs& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  Epi16 e{g.bias, g.res, g.C32, g.C16, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
+  auto kern = gemm16_k<BM, BN, BK, NSTAGE, WM, WN, TAG>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A,
+                     (const __half*)g.W, g.lda, g.ldw, g.K, tiles_n, e);
+}
+
+// cfg ids are stable: used by the tuning hook (ldm_dev_bench_gemm) and the LDM_GEMM_CFG override
+int gemm16_block_n(int cfg) {
+  switch (cfg) {
+    case 2: case 3: return 128;
+    case 4: case 5: return 128;
+    case 6: return 256;
+    default: return 128;
+  }
+}
+int gemm16_block_k(int cfg) {
+  switch (cfg) {
+    case 1: case 3: case 5: case 6: case 7: case 8: return 64;
+    default: return 32;
+  }
+}
+
+void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st) {
+  if (cfg == 5) {  // production configuration: one symbol per Linear class
+    switch (tag) {
+      case 0: launch_cfg<128, 128, 64, 2, 2, 2, 0>(g, st); return;
+      case 1: launch_cfg<128, 128, 64, 2, 2, 2, 1>(g, st); return;
+      case 2: launch_cfg<128, 128, 64, 2, 2, 2, 2>(g, st); return;
+      case 3: launch_cfg<128, 128, 64, 2, 2, 2, 3>(g, st); return;
+      default: launch_cfg<128, 128, 64, 2, 2, 2, 4>(g, st); return;
+    }
+  }
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 32, 3, 2, 2>(g, st); break;
+    case 1: launch_cfg<128, 128, 64, 3, 2, 2>(g, st); break;
+    case 2: launch_cfg<128, 128, 32, 4, 2, 2>(g, st); break;
+    case 3: launch_cfg<256, 128, 64, 3, 4, 2>(g, st); break;
+    case 4: launch_cfg<256, 128, 32, 4, 4, 2>(g, st); break;
+    case 6: launch_cfg<256, 256, 64, 2, 4, 2>(g, st); break;
+    case 7: launch_cfg<256, 128, 64, 2, 4, 2>(g, st); break;
+    case 8: launch_cfg<128, 256, 64, 2, 2, 4>(g, st); break;
+    case 9: launch_cfg<256, 256, 32, 3, 4, 2>(g, st); break;
+    case 10: launch_cfg<256, 256, 32, 4, 4, 2>(g, st); break;
+    default: launch_cfg<128, 128, 32, 3, 2, 2>(g, st); break;
+  }
+}
+
+}  // namespace ldm

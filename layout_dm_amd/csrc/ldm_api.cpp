@@ -106,6 +106,15 @@ struct ldm_handle {
         *logits = nullptr;
   __half *a16 = nullptr, *a16lo = nullptr, *qkv16 = nullptr, *att16 = nullptr, *att16lo = nullptr, *h16 = nullptr,
          *h16lo = nullptr, *hid16 = nullptr, *hid16lo = nullptr;
+  // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64
+  int Dq = 0, HD = 0, Fq = 0, Mpad = 0;
+  int gemm_cfg[5] = {0, 0, 0, 0, 0};  // qkv, attn_out, ffn1, ffn2, head
+  struct FastLayer {
+    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float* b_in = nullptr;
+  };
+  std::vector<FastLayer> fast;
+  __half* fast_head = nullptr;
   int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
   uint64_t* rng = nullptr;                      // device {seed, first_layout}
   // profiling
@@ -243,7 +252,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
-  if (chunk <= 0) chunk = 128;
+  if (chunk <= 0) chunk = 256;
   chunk = std::min(chunk, cfg->max_batch);
   h->chunk = chunk;
 
@@ -260,14 +269,27 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     A(&h->att32, Mc * h->D);
     A(&h->h32, Mc * h->D);
     A(&h->hid32, Mc * h->F);
+  } else if (cfg->precision == LDM_PREC_FAST_F16) {
+    h->Dq = round_up(h->D, 64);
+    h->HD = h->H * 64;
+    h->Fq = round_up(h->F, 64);
+    h->Mpad = round_up((int)Mc, 256);
+    const size_t Mp = h->Mpad;
+    A(&h->a16, Mp * h->Dq);
+    A(&h->h16, Mp * h->Dq);
+    A(&h->att16, Mp * h->HD);
+    A(&h->hid16, Mp * h->Fq);
+    A(&h->qkv16, Mp * 3 * h->HD);
+    const char* env = getenv("LDM_GEMM_CFG");  // "q,o,1,2,h" tile-config ids (tuning override)
+    int defaults[5] = {5, 5, 5, 5, 5};
+    for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
+    if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
   } else {
     A(&h->a16, Mc * h->Dp);
     A(&h->att16, Mc * h->Dp);
     A(&h->h16, Mc * h->Dp);
     A(&h->hid16, Mc * h->Fp);
-    if (cfg->precision == LDM_PREC_FAST_F16) {
-      A(&h->qkv16, Mc * 3 * h->D);
-    } else {
+    {
       A(&h->qkv32, Mc * 3 * h->D);
       A(&h->a16lo, Mc * h->Dp);
       A(&h->att16lo, Mc * h->Dp);
@@ -375,6 +397,55 @@ static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half*
   return 0;
 }
 
+// ---- fast-mode weight images (built on the host once; tiny compared with one sampling call)
+static uint16_t f2h_bits(float x) {
+  const __half hh = __float2half(x);
+  uint16_t u;
+  memcpy(&u, &hh, 2);
+  return u;
+}
+
+// dst[Np][Kp] fp16 (zero filled) with dst[rmap(n)][cmap(k)] = src[n][k]
+template <typename RM, typename CM>
+static int pack_w16(ldm_handle* h, const float* d_src, int N, int K, int Np, int Kp, RM rmap, CM cmap, __half** out) {
+  std::vector<float> src((size_t)N * K);
+  HIP_OK(h, hipMemcpy(src.data(), d_src, src.size() * sizeof(float), hipMemcpyDeviceToHost));
+  std::vector<uint16_t> dst((size_t)Np * Kp, 0);
+  for (int n = 0; n < N; ++n) {
+    const size_t ro = (size_t)rmap(n) * Kp;
+    for (int k = 0; k < K; ++k) dst[ro + cmap(k)] = f2h_bits(src[(size_t)n * K + k]);
+  }
+  int rc = h->dalloc(out, dst.size(), false);
+  if (rc) return rc;
+  HIP_OK(h, hipMemcpy(*out, dst.data(), dst.size() * 2, hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int build_fast_weights(ldm_handle* h) {
+  const int D = h->D, F = h->F, C = h->C, H = h->H, dh = h->dh, HD = h->HD, Dq = h->Dq, Fq = h->Fq;
+  auto id = [](int x) { return x; };
+  // in_proj row n = which*D + head*dh + d  ->  (which*H + head)*64 + d   (head slices padded to 64)
+  auto qkv_row = [=](int n) { return ((n / D) * H + (n % D) / dh) * 64 + (n % D) % dh; };
+  // out_proj column k = head*dh + d -> head*64 + d (matches the attention kernel's output layout)
+  auto head_col = [=](int k) { return (k / dh) * 64 + k % dh; };
+  h->fast.assign(h->L, ldm_handle::FastLayer{});
+  int rc;
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    ldm_handle::FastLayer& f = h->fast[i];
+    if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, id, &f.w_in))) return rc;
+    if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_col, &f.w_out))) return rc;
+    if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, id, &f.w1))) return rc;
+    if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, id, &f.w2))) return rc;
+    std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
+    HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
+    for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
+    if ((rc = h->dalloc(&f.b_in, bp.size(), false))) return rc;
+    HIP_OK(h, hipMemcpy(f.b_in, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  }
+  return pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, id, &h->fast_head);
+}
+
 extern "C" int ldm_finalize_weights(ldm_handle* h) {
   if (!h) return -1;
   HIP_OK(h, hipSetDevice(h->device));
@@ -411,14 +482,18 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
     if ((rc = need(h, b + "norm2.weight", {D}, &w.g2))) return rc;
     if ((rc = need(h, b + "norm2.bias", {D}, &w.be2))) return rc;
     launch_adaln_table(emb_t, lin_w, lin_b, h->adaln, T, D, L, i, 0);
-    if (f16) {
+    if (f16 && h->cfg.precision != LDM_PREC_FAST_F16) {
       if ((rc = make_w16(h, w.w_in, 3 * D, D, h->Dp, &w.w_in16, &w.w_in16lo))) return rc;
       if ((rc = make_w16(h, w.w_out, D, D, h->Dp, &w.w_out16, &w.w_out16lo))) return rc;
       if ((rc = make_w16(h, w.w1, F, D, h->Dp, &w.w1_16, &w.w1_16lo))) return rc;
       if ((rc = make_w16(h, w.w2, D, F, h->Fp, &w.w2_16, &w.w2_16lo))) return rc;
     }
   }
-  if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo))) return rc;
+  if (h->cfg.precision == LDM_PREC_FAST_F16) {
+    if ((rc = build_fast_weights(h))) return rc;
+  } else if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo))) {
+    return rc;
+  }
   // schedule buffers are taken from the checkpoint, not recomputed
   static const char* names[kNumSched] = {"log_at",         "log_bt",         "log_ct",       "log_cumprod_at",
                                          "log_cumprod_bt", "log_cumprod_ct", "log_1_min_ct", "log_1_min_cumprod_ct"};
@@ -450,8 +525,67 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
 // ------------------------------------------------------------------------------------------ one pass
 static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 
+// fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
+static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+  const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
+  auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
+                  const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
+                  double flops, double bytes) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.relu = relu; g.res = res; g.ldres = D;
+    g.C32 = C32; g.ldc32 = ldc32; g.C16 = C16; g.ldc16 = ldc16;
+    const int cfg = h->gemm_cfg[tag];
+    g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg)); g.lda = lda; g.ldw = ldw; g.precision = 1;
+    ldm_handle::Scope sc(h, st, name, flops, bytes);
+    launch_gemm16(g, cfg, tag, st);
+  };
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const ldm_handle::FastLayer& f = h->fast[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    {
+      LnArgs a{};
+      a.x = h->P; a.tokens = (i == 0) ? d_tokens : nullptr; a.emb = h->emb; a.pos = h->pos;
+      a.p0 = ss; a.p1 = ss + D; a.y32 = h->P; a.y16 = h->a16;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 1;
+      ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * 10);
+      launch_layernorm(a, st);
+    }
+    gemm("gemm_qkv", 0, h->a16, Dq, D, f.w_in, Dq, 3 * HD, f.b_in, 0, nullptr, nullptr, 0, h->qkv16,
+         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2));
+    {
+      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
+      launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
+    }
+    gemm("gemm_attn_out", 1, h->att16, HD, HD, f.w_out, HD, D, w.b_out, 0, h->P, h->Q, D, nullptr, 0,
+         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
+    {
+      LnArgs a{};
+      a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2; a.y16 = h->h16;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 0;
+      ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * 6);
+      launch_layernorm(a, st);
+    }
+    gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
+         gemm_flops(M, F, D), (double)M * (D * 2 + F * 2));
+    gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
+         gemm_flops(M, D, F), (double)M * (F * 2 + D * 8));
+  }
+  {
+    LnArgs a{};
+    a.x = h->P; a.p0 = h->head_g; a.p1 = h->head_b; a.y16 = h->h16;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 0;
+    ldm_handle::Scope sc(h, st, "layernorm_head", 0, (double)M * D * 6);
+    launch_layernorm(a, st);
+  }
+  gemm("gemm_head", 4, h->h16, Dq, D, h->fast_head, Dq, h->Cp, nullptr, 0, nullptr, h->logits, h->Cp,
+       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4));
+  return 0;
+}
+
 // denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
 static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
   const int prec = h->cfg.precision;
   const bool f16 = prec != LDM_PREC_EXACT_F32;
@@ -850,4 +984,50 @@ extern "C" int ldm_profile_reset(ldm_handle* h) {
   h->drain_profile();
   h->prof.clear();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------ dev hook
+// Tile-configuration tuning aid (not part of the public ABI): times launch_gemm16 on synthetic
+// operands.  Returns average ms per launch.
+extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float* ms_out) {
+  const int Mp = round_up(M, 256), Np = round_up(N, 256), Kp = round_up(K, 64);
+  std::vector<uint16_t> ha((size_t)Mp * Kp), hw((size_t)Np * Kp);
+  uint32_t s = 12345u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return ((float)(s >> 8) / 8388608.0f) - 1.0f;
+  };
+  for (auto& x : ha) x = f2h_bits(rnd());
+  for (auto& x : hw) x = f2h_bits(rnd() * 0.05f);
+  __half *A = nullptr, *W = nullptr, *Cc = nullptr;
+  if (hipMalloc((void**)&A, ha.size() * 2) != hipSuccess || hipMalloc((void**)&W, hw.size() * 2) != hipSuccess ||
+      hipMalloc((void**)&Cc, (size_t)Mp * Np * 2) != hipSuccess)
+    return -3;
+  hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  float* bias = nullptr;
+  hipMalloc((void**)&bias, (size_t)Np * 4);
+  hipMemset(bias, 0, (size_t)Np * 4);
+  GemmArgs g{};
+  g.A = A; g.W = W; g.C16 = Cc; g.ldc16 = Np; g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg));
+  g.lda = Kp; g.ldw = Kp; g.precision = 1; g.bias = bias; g.relu = 1;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) launch_gemm16(g, cfg, 2, 0);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) launch_gemm16(g, cfg, 2, 0);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  *ms_out = ms / iters;
+  const hipError_t e = hipGetLastError();
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  hipFree(A);
+  hipFree(W);
+  hipFree(Cc);
+  hipFree(bias);
+  return e == hipSuccess ? 0 : -2;
 }

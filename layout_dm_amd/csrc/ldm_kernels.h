@@ -45,6 +45,12 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
+// fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
+void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
+int gemm16_block_k(int cfg);
+// MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
+void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
+
 // ---- attention (kernels_attn.hip): softmax(QK^T/sqrt(dh)) V per (layout, head) ------------
 struct AttnArgs {
   const void* qkv;  // [M, ld] fp32 or fp16; q cols [0,D), k [D,2D), v [2D,3D); head h = cols h*dh..
