@@ -1,0 +1,186 @@
+"""Drop-in replacement for the reference's model class on the sampling path.
+
+    config.yaml:   model: {_target_: layout_dm_amd.layoutdm.LayoutDM, _partial_: true, q_type: constrained}
+
+Mirrors trainer/models/layoutdm.py:26-126 (LayoutDM) + trainer/models/base_model.py:124-150
+(aggregate_sampling_settings) for everything the `test` entry point touches
+(trainer/test.py:113-118,144-150,195-228): constructor signature, `.to()`, `.eval()`,
+`.load_state_dict()` with the checkpoint's `model.module.*` keys, `.tokenizer`,
+`.aggregate_sampling_settings()`, `.sample()` -> {"bbox","label","mask"} via the caller's own
+tokenizer, and `.model.sample()` (notebooks/demo.ipynb) -> LongTensor tokens.
+Training (`forward`, losses, optimizer groups) is out of scope and raises.
+
+The tokenizer is the reference's own `LayoutSequenceTokenizer` object (or anything duck-typing its
+properties): host-side encode/decode is reused as is, only the T-step reverse
+loop runs in libldm_hip.so.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import torch
+
+from .diffusion import HipMaskAndReplaceDiffusion, _cfg_get
+
+
+def _find(cfg, key):
+    """get_dim_model-style recursive lookup (trainer/models/common/util.py:21-33)."""
+    result = None
+    items = cfg.items() if hasattr(cfg, "items") else []
+    for k, v in items:
+        if k == key:
+            result = v
+        elif hasattr(v, "items"):
+            x = _find(v, key)
+            if x:
+                result = x
+    return result
+
+
+class _ModuleShim:
+    """Gives `model.model.module` / `model.model.sample` the shapes the reference exposes through
+    CustomDataParallel (models/common/nn_lib.py:17-23)."""
+
+    def __init__(self, inner: HipMaskAndReplaceDiffusion, owner: "LayoutDM"):
+        self.module = inner
+        self._owner = owner
+
+    def sample(self, *a, **k):
+        return self._owner._sample_tokens(*a, **k)
+
+    def __getattr__(self, name):
+        return getattr(self.module, name)
+
+
+class LayoutDM:
+    def __init__(self, backbone_cfg, tokenizer, transformer_type: str = "flattened", pos_emb: str = "elem_attr",
+                 num_timesteps: int = 100, auxiliary_loss_weight: float = 1e-1, q_type: str = "single",
+                 seq_type: str = "poset", precision: str = "fast", max_batch: int = 512, device: Optional[int] = None,
+                 **kwargs) -> None:
+        if q_type != "constrained":
+            raise NotImplementedError("only q_type=constrained (LayoutDM default, experiment/layoutdm.yaml:18)")
+        if transformer_type != "flattened" or pos_emb != "elem_attr":
+            raise NotImplementedError("only transformer_type=flattened / pos_emb=elem_attr")
+        assert seq_type in ["set", "poset"]
+        # make sure MASK is the last vocabulary (layoutdm.py:46)
+        assert tokenizer.id_to_name(tokenizer.N_total - 1) == "mask"
+        assert list(tokenizer.var_names) == ["c", "x", "y", "w", "h"], "var_order must be c-x-y-w-h"
+        self.tokenizer = tokenizer
+        self.pos_emb, self.seq_type = pos_emb, seq_type
+        mult = 29 / 32  # shrink(backbone_cfg, 29/32), layoutdm.py:54 + common/util.py:36-44
+        d_model = int(mult * _find(backbone_cfg, "d_model"))
+        d_ff = int(mult * _find(backbone_cfg, "dim_feedforward"))
+        n_head = int(_find(backbone_cfg, "nhead"))
+        n_layer = int(_find(backbone_cfg, "num_layers"))
+        ttype = _find(backbone_cfg, "timestep_type")
+        if ttype != "adalayernorm":
+            raise NotImplementedError(f"timestep_type={ttype}: only adalayernorm (experiment/layoutdm.yaml:13-16)")
+        dstep = int(_find(backbone_cfg, "diffusion_step") or num_timesteps)
+        assert dstep == num_timesteps
+        inner = HipMaskAndReplaceDiffusion(
+            n_category=tokenizer.N_category, n_bin=tokenizer.N_bbox_per_var, max_elem=tokenizer.max_seq_length,
+            n_attr=tokenizer.N_var_per_element, d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer,
+            num_timesteps=num_timesteps, precision=precision, max_batch=max_batch, device=device)
+        assert inner.num_classes == tokenizer.N_total and inner.max_token_length == tokenizer.max_token_length
+        self.model = _ModuleShim(inner, self)
+        self._refine_table = None
+
+    # ---- nn.Module-ish surface ------------------------------------------------------------------
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("layout_dm_amd accelerates sampling only; train with the reference")
+        return self
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        self.model.module.load_state_dict(state_dict)
+        return self
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward is out of scope (SURVEY §2.1 #10)")
+
+    __call__ = forward
+
+    # ---- base_model.py:124-150 + layoutdm.py:90-97 -------------------------------------------------
+    def aggregate_sampling_settings(self, sampling_cfg, args):
+        if args.cond == "refinement" and args.refine_lambda > 0.0:
+            sampling_cfg.refine_mode = args.refine_mode
+            sampling_cfg.refine_offset_ratio = args.refine_offset_ratio
+            sampling_cfg.refine_lambda = args.refine_lambda
+        if args.cond == "relation" and args.relation_lambda > 0.0:
+            sampling_cfg.relation_mode = args.relation_mode
+            sampling_cfg.relation_lambda = args.relation_lambda
+            sampling_cfg.relation_tau = args.relation_tau
+            sampling_cfg.relation_num_update = args.relation_num_update
+        if "num_timesteps" not in sampling_cfg:
+            if "eos" in self.tokenizer.special_tokens:
+                sampling_cfg.num_timesteps = self.tokenizer.max_token_length
+            else:
+                sampling_cfg.num_timesteps = args.num_timesteps
+        if args.time_difference > 0:
+            sampling_cfg.time_difference = args.time_difference
+        return sampling_cfg
+
+    # ---- refinement prior: helpers/task.py:154-224 --------------------------------------------------
+    def _weak_logits(self, seq_orig: torch.Tensor, sampling_cfg) -> torch.Tensor:
+        tok = self.tokenizer
+        mode = _cfg_get(sampling_cfg, "refine_mode", "uniform")
+        ratio = float(_cfg_get(sampling_cfg, "refine_offset_ratio", 0.1))
+        w = float(_cfg_get(sampling_cfg, "refine_lambda", 3.0))
+        if mode == "negative":
+            w *= -1.0
+        key = (mode, ratio)
+        if self._refine_table is None or self._refine_table[0] != key:
+            C, N = tok.N_total, tok.N_bbox_per_var
+            bbt = tok.bbox_tokenizer
+            table = torch.zeros((C, C))
+            table.fill_diagonal_(1.0)
+            shared = bbt.shared_bbox_vocab == "xywh"
+            for i, k in enumerate(bbt.var_names):
+                sl = slice(tok.N_category, tok.N_category + N) if shared else \
+                    slice(tok.N_category + i * N, tok.N_category + (i + 1) * N)
+                centers = torch.from_numpy(bbt.clustering_models[f"{k}-{N}"].cluster_centers_).view(-1)
+                ii, jj = torch.meshgrid(centers, centers, indexing="ij")
+                if mode == "uniform":
+                    table[sl, sl] = (torch.abs(ii - jj) < ratio).float()
+                elif mode == "negative":
+                    table[sl, sl] = (torch.abs(ii - jj) >= ratio).float()
+                elif mode == "gaussian":
+                    table[sl, sl] = -1.0 * (ii - jj) ** 2
+                else:
+                    raise NotImplementedError(mode)
+            self._refine_table = (key, table.float())
+        table = self._refine_table[1]
+        return (table[seq_orig.cpu().long()].permute(0, 2, 1) * w).contiguous()  # (B,C,S)
+
+    # ---- sampling --------------------------------------------------------------------------------
+    def _sample_tokens(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None,
+                       get_intermediate_results: bool = False, **kwargs):
+        inner = self.model.module
+        if cond:
+            cond = dict(cond)  # the reference mutates the caller's dict (base.py:328-336); we do not
+            ctype = cond.get("type", None)
+            if ctype == "refinement" and "weak_logits" not in cond:
+                seq_orig = cond["seq_orig"]
+                if seq_orig.size(0) == 1 and batch_size > 1:
+                    seq_orig = seq_orig.repeat(batch_size, 1)
+                cond["weak_logits"] = self._weak_logits(seq_orig, sampling_cfg)
+            if ctype == "relation":
+                from .relation import sample_with_relation
+
+                return sample_with_relation(inner, batch_size, cond, sampling_cfg, self.tokenizer,
+                                            get_intermediate_results=get_intermediate_results, **kwargs)
+        return inner.sample(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg,
+                            get_intermediate_results=get_intermediate_results, **kwargs)
+
+    def sample(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None, **kwargs):
+        """layoutdm.py:77-88: ids -> CPU -> tokenizer.decode -> {"bbox","label","mask"}."""
+        kwargs.pop("get_intermediate_results", None)
+        ids = self._sample_tokens(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg, **kwargs).cpu()
+        return self.tokenizer.decode(ids)

@@ -325,3 +325,79 @@ def test_full_batch_512_one_step_vs_oracle(cuda, precision):
     else:
         assert mism.float().mean().item() < 5e-3
         assert (margin[mism] < 0.05).all()
+
+
+# ----------------------------------------------------------------------------- drop-in layer
+class _MockTokenizer:
+    """Duck-types the properties of the reference's LayoutSequenceTokenizer that LayoutDM reads
+    (helpers/layout_tokenizer.py:123-186); decode() is the caller's own host code."""
+
+    def __init__(self, spec):
+        self.spec = spec
+        self.N_category, self.N_bbox_per_var = spec.n_category, spec.n_bin
+        self.max_seq_length, self.N_var_per_element = spec.max_elem, spec.n_attr
+        self.N_total, self.max_token_length = spec.n_class, spec.seq_len
+        self.var_names = ["c", "x", "y", "w", "h"]
+        self.special_tokens = ["pad", "mask"]
+
+    def id_to_name(self, i):
+        return {self.spec.pad_id: "pad", self.spec.mask_id: "mask"}[i]
+
+    def name_to_id(self, n):
+        return {"pad": self.spec.pad_id, "mask": self.spec.mask_id}[n]
+
+    def decode(self, ids):
+        return {"ids": ids, "mask": ids[:, ::5] != self.spec.pad_id}
+
+
+BACKBONE_CFG = {"_target_": "trainer.models.transformer_utils.TransformerEncoder",
+                "encoder_layer": {"_target_": "trainer.models.transformer_utils.Block", "d_model": 512, "nhead": 8,
+                                  "dim_feedforward": 2048, "dropout": 0.0, "batch_first": True, "norm_first": True,
+                                  "timestep_type": "adalayernorm", "diffusion_step": 100},
+                "num_layers": 4}
+
+
+def test_dropin_layoutdm_class(cuda, golden_dir):
+    """layout_dm_amd.layoutdm.LayoutDM honours the contract test.py relies on (SURVEY §8b Seam 1)."""
+    from layout_dm_amd.layoutdm import LayoutDM
+
+    spec, W = weights("rico25")
+    m = LayoutDM(backbone_cfg=BACKBONE_CFG, tokenizer=_MockTokenizer(spec), q_type="constrained",
+                 precision="exact", max_batch=8).to("cuda")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True).items()})
+    m.eval()
+    cfg = {"name": "deterministic", "num_timesteps": 100}
+    out = m.sample(batch_size=4, cond=None, sampling_cfg=cfg, cond_type="unconditional")
+    g = np.load(os.path.join(golden_dir, "rico25_uncond_greedy_loop.npz"))
+    assert torch.equal(out["ids"], torch.from_numpy(g["states_after"][-1].astype(np.int64)))
+    inter = m.model.sample(batch_size=4, sampling_cfg=cfg, get_intermediate_results=True)  # notebook usage
+    assert len(inter) == 100 and torch.equal(inter[-1], out["ids"])
+    # stochastic runs are reproducible under torch.manual_seed like the reference's set_seed()
+    rc = {"name": "random", "temperature": 1.0, "num_timesteps": 20}
+    torch.manual_seed(5)
+    a = m.sample(batch_size=3, sampling_cfg=rc)["ids"]
+    torch.manual_seed(5)
+    b = m.sample(batch_size=3, sampling_cfg=rc)["ids"]
+    assert torch.equal(a, b)
+    with pytest.raises(NotImplementedError):
+        m.train()
+
+
+def test_relation_split_step_equals_fused_with_identity_update(cuda):
+    """cond=relation split-step path (denoise -> posterior -> update_fn -> draw) with an identity
+    update_fn must reproduce the fused kernel path of cond=c (same strong mask + PAD disable)."""
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion
+    from layout_dm_amd.relation import sample_with_relation
+
+    spec = SP.PUBLAYNET
+    m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, precision="exact", max_batch=4)
+    m.load_state_dict(synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True))
+    c = synth.synth_cond_c(spec, 4, seed=0)
+    cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": "c"}
+    cfg = {"name": "random", "temperature": 1.0, "num_timesteps": 25}
+    fused = m.sample(batch_size=4, cond=cond, sampling_cfg=cfg, seed=77)
+    ident = lambda t, cond, model_log_prob, tokenizer, sampling_cfg: model_log_prob
+    rel = dict(cond, type="relation")
+    split = sample_with_relation(m, 4, rel, cfg, _MockTokenizer(spec), update_fn=ident, seed=77)
+    assert torch.equal(fused, split)
+    assert (split[cond["mask"]] == cond["seq"][cond["mask"]]).all()
