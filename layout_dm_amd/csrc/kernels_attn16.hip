@@ -94,23 +94,26 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
       sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[kt], 0, 0, 0);
     }
   }
-  // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32)
+  // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32).  VALU-lean: only the last key
+  // tile can hold padded keys; exp(scale*(s-max)) is one v_fma + one raw v_exp_f32 per score.
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = 96 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    if (key >= S) sc[3][r] = -INFINITY;
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (key >= S) sc[kt][r] = -INFINITY;
-      mx = fmaxf(mx, sc[kt][r]);
-    }
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float nmxs = -mx * scale_log2e;
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = exp2f((sc[kt][r] - mx) * scale_log2e);
+      const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], scale_log2e, nmxs));
       sc[kt][r] = p;
       sum += p;
     }

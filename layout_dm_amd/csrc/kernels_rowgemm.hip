@@ -1,0 +1,546 @@
+// Row-stationary MFMA kernels for the K<=512 Linear layers of the denoiser and the fused FFN.
+//
+// Why: with 128x128 output tiles the K=464 GEMMs move 64 FLOP per byte fetched into a CU and sit
+// on the per-CU L2->LDS fill rate (~15-20 B/clk/CU measured, tools/gemm_tune.py).  Here a workgroup
+// owns 128 token rows for the WHOLE output width: each of its 4 waves keeps its 32 rows of the
+// activation (32 x 512 fp16 = 128 VGPRs) in registers as the MFMA *B* operand for the entire
+// kernel and only the weights stream through LDS (LDS-DMA, double buffered), once per workgroup
+// => 128 FLOP per fetched byte, and the activation is read from HBM/L2 exactly once.
+//
+//   rowgemm_k      C[M,N] = epi(A[M,512] · W[N,512]^T + bias)     (QKV, attention out-proj, head)
+//   ffn_fused_k    P = Q + relu(H·W1^T + b1)·W2^T + b2            (linear1 -> ReLU -> linear2 +
+//                  residual, trainer/models/transformer_utils.py:145-147,179,208-209) — the
+//                  [M,1856] hidden activation never leaves the CU: each 32-wide slice of it is
+//                  produced in accumulator registers, biased/ReLU'd/cast in-lane and consumed at
+//                  once as the B operand of the second GEMM (the k-slot order of that MFMA is
+//                  chosen to BE the accumulator layout; W2's K axis is pre-permuted to match).
+//
+// MFMA form (everything swapped): D[i][j] += A'[i][k] B'[k][j] with A' = weight fragment (i = output
+// feature), B' = activation fragment (j = token row) => each lane owns ONE token row and runs of 4
+// consecutive output features: 8/16-byte epilogue vectors.
+// LDS images are written lane-linearly by the DMA; bank-conflict swizzles are applied to the SOURCE
+// address and mirrored on the ds_read_b128 side.
+#include <cstdlib>
+
+#include "ldm_kernels.h"
+
+namespace ldm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+constexpr int RK = 512;          // padded K of the row-stationary operand (halfs)
+constexpr int RKB = RK * 2;      // bytes per weight row = one 1-KiB DMA instruction
+constexpr int W1_STAGE = 32 * RKB;  // 32 weight rows per stage
+
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)l, 16, 0, 0);
+}
+
+// One 32-row weight tile (rows n0..n0+31 of W[.,512]) -> LDS stage: instruction i = row i, lane l
+// fetches logical 16-B chunk (l ^ (i & 15)) so that physical chunk = logical ^ (row & 15).
+__device__ __forceinline__ void issue_w_rows(const __half* W, int row0, char* stage, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = wave + 4 * j;
+    dma16(W + (size_t)(row0 + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
+  }
+}
+
+// A' fragment of weight row (tile row r = lane&31) for k16-step ks: logical chunk 2*ks + hi
+__device__ __forceinline__ f16x8 read_w_frag(const char* stage, int r, int hi, int ks) {
+  return *reinterpret_cast<const f16x8*>(stage + r * RKB + (((2 * ks + hi) ^ (r & 15)) << 4));
+}
+
+struct RowEpi {
+  const float* bias;
+  const float* res;
+  float* C32;
+  __half* C16;
+  int M, N, ldres, ldc32, ldc16, relu;
+};
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K<=512] · W^T + bias);  KS = number of k16 steps actually used (ceil(K/16)).
+// Ordinary global loads inside the tile loop would make hipcc drain the in-flight weight DMA
+// (vmcnt(0) at their first use), so: bias lives in LDS, and the residual of tile nt+1 is loaded
+// during tile nt and "touched" right after the loop-top vmcnt(0) so no later wait is needed.
+template <int KS, int TAG>
+__global__ __launch_bounds__(256, 1) void rowgemm_k(const __half* __restrict__ A, const __half* __restrict__ W, int lda,
+                                                   int n_tiles, RowEpi e) {
+  constexpr int TR = 64;               // weight rows per stage (two 32-row MFMA tiles)
+  constexpr int STAGE = TR * RKB;      // 64 KiB
+  constexpr int PF = 8;                // LDS prefetch depth (fragments in flight ahead of their MFMA)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+  const bool mok = m < e.M;
+
+  for (int i = tid; i < n_tiles * TR; i += 256) sbias[i] = (e.bias && i < e.N) ? e.bias[i] : 0.f;
+  f16x8 xf[KS];
+  {
+    const __half* arow = A + (size_t)m * lda + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
+  }
+  const float* rrow = e.res ? e.res + (size_t)(mok ? m : 0) * e.ldres + hi * 4 : nullptr;
+  float4 rc[8], rn[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    rc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    rn[g] = rc[g];
+    if (rrow && g * 8 + hi * 4 + 3 < e.N) rc[g] = *reinterpret_cast<const float4*>(rrow + g * 8);
+  }
+  auto issue = [&](int nt, char* stage) {
+#pragma unroll
+    for (int j = 0; j < TR / 4; ++j) {
+      const int i = wave + 4 * j;
+      dma16(W + (size_t)(nt * TR + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
+    }
+  };
+  issue(0, smem);
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(rc[g].x), "+v"(rc[g].y), "+v"(rc[g].z), "+v"(rc[g].w));
+    if (nt + 1 < n_tiles) {
+      issue(nt + 1, smem + ((nt + 1) & 1) * STAGE);
+      if (rrow) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+          if ((nt + 1) * TR + g * 8 + hi * 4 + 3 < e.N)
+            rn[g] = *reinterpret_cast<const float4*>(rrow + (nt + 1) * TR + g * 8);
+      }
+    }
+    const char* st = smem + (nt & 1) * STAGE;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // item it = (ks, t): fragment of weight row t*32 + r, k16-step ks; two independent MFMA chains
+    f16x8 q[PF];
+#pragma unroll
+    for (int it = 0; it < PF; ++it) q[it] = read_w_frag(st + (it & 1) * 32 * RKB, r, hi, it >> 1);
+#pragma unroll
+    for (int it = 0; it < 2 * KS; ++it) {
+      const f16x8 cur = q[it % PF];
+      if (it + PF < 2 * KS) q[it % PF] = read_w_frag(st + ((it + PF) & 1) * 32 * RKB, r, hi, (it + PF) >> 1);
+      acc[it & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[it >> 1], acc[it & 1], 0, 0, 0);
+    }
+    if (mok) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int n = nt * TR + g * 8 + hi * 4;
+        if (n + 3 < e.N) {
+          const float4 b = *reinterpret_cast<const float4*>(sbias + n);
+          const int t = g >> 2, rq = g & 3;
+          float v0 = acc[t][rq * 4 + 0] + b.x, v1 = acc[t][rq * 4 + 1] + b.y, v2 = acc[t][rq * 4 + 2] + b.z,
+                v3 = acc[t][rq * 4 + 3] + b.w;
+          if (e.relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          v0 += rc[g].x; v1 += rc[g].y; v2 += rc[g].z; v3 += rc[g].w;
+          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v0, v1, v2, v3);
+          if (e.C16) {
+            const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, v3);
+            uint2 pk;
+            pk.x = *reinterpret_cast<const unsigned*>(&h0);
+            pk.y = *reinterpret_cast<const unsigned*>(&h1);
+            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = pk;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) rc[g] = rn[g];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused FFN.  Per 32-wide hidden chunk c:   hT = W1[c] · H^T (30 MFMAs) ; relu/bias/cast in-lane ;
+//   accT[n-tile] += W2p[n-tile][c] · hT (NT2 x 2 MFMAs).   LDS stage = [W1 chunk 32 x 1 KiB | W2
+//   chunk (NT2*32) x 64 B].
+template <int KS, int NT2>
+__global__ __launch_bounds__(256, 1) void ffn_fused_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
+                                                     const float* __restrict__ b1, const __half* __restrict__ W2p,
+                                                     int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
+                                                     float* __restrict__ out, int ldo, int M, int N, int n_chunks) {
+  constexpr int W2_ROWS = NT2 * 32;
+  constexpr int W2_INST = W2_ROWS / 16;             // 16 rows of 64 B per 1-KiB DMA instruction
+  constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
+  constexpr int NINST = 32 + W2_INST;
+  constexpr int IPW = (NINST + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+
+  for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
+  f16x8 xf[KS];
+  {
+    const __half* hrow = H + (size_t)m * ldh + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(hrow + ks * 16);
+  }
+  f32x16 acc[NT2];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  auto issue = [&](int c, char* stage) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int i = wave + 4 * j;  // wave < 4  =>  (i < 32) == (j < 8): role is known at compile time
+      if (j < 8) {
+        dma16(W1 + (size_t)(c * 32 + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
+      } else if (4 * j + 3 < NINST || i < NINST) {
+        const int row = (i - 32) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        dma16(W2p + (size_t)row * ldw2 + c * 32 + chunk * 8, stage + W1_STAGE + (i - 32) * 1024);
+      }
+    }
+  };
+  issue(0, smem);
+  const int w2sw = (r >> 2) & 3;
+  for (int c = 0; c < n_chunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (c + 1 < n_chunks) issue(c + 1, smem + ((c + 1) & 1) * STAGE);
+    const char* st = smem + (c & 1) * STAGE;
+    // One unified stream of fragments: items [0,KS) = W1 chunk (k16 steps), items [KS, KS+2*NT2) =
+    // W2 chunk (n-tile t, k-step s).  Every item is one ds_read_b128 feeding one MFMA; reads are
+    // issued PF items ahead of their MFMA (one wave per SIMD => nothing else hides LDS latency).
+    constexpr int PF = 8;
+    constexpr int NIT = KS + 2 * NT2;
+    const char* w2 = st + W1_STAGE;
+    auto read_item = [&](int it) -> f16x8 {
+      if (it < KS) return read_w_frag(st, r, hi, it);
+      const int t = (it - KS) >> 1, sx = (it - KS) & 1;
+      return *reinterpret_cast<const f16x8*>(w2 + (t * 32 + r) * 64 + (((2 * sx + hi) ^ w2sw) << 4));
+    };
+    f16x8 q[PF];
+#pragma unroll
+    for (int it = 0; it < PF; ++it) q[it] = read_item(it);
+    f32x16 ha;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ha[i] = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const f16x8 cur = q[it % PF];
+      if (it + PF < NIT) q[it % PF] = read_item(it + PF);
+      if (it < KS) {
+        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[it], ha, 0, 0, 0);
+        if (it == KS - 1) {
+          // bias + ReLU + cast: accumulator reg q <-> hidden f = c*32 + (q&3) + 8*(q>>2) + 4*hi
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const float4 b = *reinterpret_cast<const float4*>(sb1 + c * 32 + rq * 8 + hi * 4);
+            pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + b.x, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + b.y, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + b.z, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + b.w, 0.f);
+          }
+        }
+      } else {
+        const int t = (it - KS) >> 1, sx = (it - KS) & 1;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (m >= M) return;
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n = t * 32 + rq * 8 + hi * 4;
+      if (n + 3 < N) {
+        const float4 b = *reinterpret_cast<const float4*>(b2 + n);
+        const float4 q = *reinterpret_cast<const float4*>(res + (size_t)m * ldo + n);
+        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) =
+            make_float4(acc[t][rq * 4 + 0] + b.x + q.x, acc[t][rq * 4 + 1] + b.y + q.y,
+                        acc[t][rq * 4 + 2] + b.z + q.z, acc[t][rq * 4 + 3] + b.w + q.w);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused FFN, hand-pipelined LDS reads.  hipcc sinks C++-level ds_reads next to their MFMA (read,
+// lgkmcnt(0), MFMA — no overlap with ONE wave per SIMD), so every LDS read of the chunk loop is an
+// inline-asm ds_read_b128 issued PF items ahead, retired by a counted s_waitcnt lgkmcnt(N) and a
+// sched_barrier (cdna guide §5.7, rule 18).  LDS completes in order, so the counts are exact.
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+template <int OFF>
+__device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void dsr128f(float4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KS, int NT2, int PF>
+struct FfnPipe {
+  static constexpr int NIT = KS + 2 * NT2;
+  f16x8 q[PF];
+  unsigned aW1[8], aW2[2];  // per-lane LDS byte addresses inside the current stage
+  const f16x8* xf;
+  f32x16 ha;  // (a two-chain even/odd split was measured slower: +32 accumulator registers push the
+              //  activation fragments into AGPRs and add ~250 v_accvgpr copies per chunk)
+  f32x16* acc;
+  f16x8 pf[2];
+  float4 bb[4];
+  // next chunk's weight DMA, issued one 1-KiB instruction every DMA_EVERY MFMAs (hidden in MFMA shadow)
+  static constexpr int DMA_EVERY = 2;
+  static constexpr int NINST = 32 + NT2 * 2;
+  static constexpr int IPW = (NINST + 3) / 4;
+  const char* gW1;      // W1 + next chunk (uniform)
+  const char* gW2;      // W2p + next chunk (uniform)
+  char* nstage;         // LDS stage of the next chunk (uniform)
+  unsigned lo1[4], lo2; // per-lane byte offsets
+  int wave, ldw2b;
+  bool has_next;
+
+  template <int J>
+  __device__ __forceinline__ void dma_slot() {
+    if constexpr (J < IPW) {
+      if (has_next) {
+        const int i = wave + 4 * J;
+        if constexpr (J < 8) {
+          dma16(gW1 + i * RKB + lo1[J & 3], nstage + i * RKB);
+        } else {
+          if (4 * J + 3 < NINST || i < NINST)
+            dma16(gW2 + (size_t)(i - 32) * 16 * ldw2b + lo2, nstage + W1_STAGE + (i - 32) * 1024);
+        }
+      }
+    }
+  }
+
+  template <int IT>
+  __device__ __forceinline__ void read_item() {
+    if constexpr (IT < KS) {
+      dsr128<256 * (IT >> 3)>(q[IT % PF], aW1[IT & 7]);
+    } else {
+      constexpr int sx = (IT - KS) / NT2, t = (IT - KS) % NT2;  // s-major: acc[t] is reused NT2 items later
+      dsr128<W1_STAGE + t * 2048>(q[IT % PF], aW2[sx]);
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void step() {
+    if constexpr (IT < NIT) {
+      const f16x8 cur_dummy = q[0];
+      (void)cur_dummy;
+      constexpr int after = (NIT - 1 - IT) < (PF - 1) ? (NIT - 1 - IT) : (PF - 1);  // reads younger than item IT
+      wait_lgkm<after>();
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 cur = q[IT % PF];
+      if constexpr (IT < KS) {
+        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], ha, 0, 0, 0);
+      } else {
+        constexpr int sx = (IT - KS) / NT2, t = (IT - KS) % NT2;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT + PF < NIT) read_item<IT + PF>();  // refill the slot just consumed
+      if constexpr (IT % DMA_EVERY == DMA_EVERY - 1) dma_slot<IT / DMA_EVERY>();
+      if constexpr (IT == KS - 1) {
+        // bias + ReLU + cast: accumulator reg <-> hidden f = (q&3) + 8*(q>>2) + 4*hi of this chunk
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + bb[rq].x, 0.f);
+          pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + bb[rq].y, 0.f);
+          pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + bb[rq].z, 0.f);
+          pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + bb[rq].w, 0.f);
+        }
+      }
+      step<IT + 1>();
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_all() {
+    if constexpr (J < IPW) {
+      dma_slot<J>();
+      dma_all<J + 1>();
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void prologue() {
+    if constexpr (IT < PF - 1) {
+      read_item<IT>();
+      prologue<IT + 1>();
+    }
+  }
+};
+
+// ABL: timing ablations only (1 = no weight DMA after the first chunk, 2 = no LDS reads / MFMAs)
+template <int KS, int NT2, int ABL>
+__global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
+                                                      const float* __restrict__ b1, const __half* __restrict__ W2p,
+                                                      int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
+                                                      float* __restrict__ out, int ldo, int M, int N, int n_chunks) {
+  constexpr int W2_ROWS = NT2 * 32;
+  constexpr int W2_INST = W2_ROWS / 16;
+  constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
+  constexpr int NINST = 32 + W2_INST;
+  constexpr int IPW = (NINST + 3) / 4;
+  constexpr int PF = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+
+  for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
+  f16x8 xf[KS];
+  {
+    const __half* hrow = H + (size_t)m * ldh + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(hrow + ks * 16);
+  }
+  f32x16 acc[NT2];
+#pragma unroll
+  for (int t = 0; t < NT2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  auto issue = [&](int c, char* stage) {
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+      const int i = wave + 4 * j;
+      if (j < 8) {
+        dma16(W1 + (size_t)(c * 32 + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
+      } else if (4 * j + 3 < NINST || i < NINST) {
+        const int row = (i - 32) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        dma16(W2p + (size_t)row * ldw2 + c * 32 + chunk * 8, stage + W1_STAGE + (i - 32) * 1024);
+      }
+    }
+  };
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned relW1[8], relW2[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) relW1[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+#pragma unroll
+  for (int sx = 0; sx < 2; ++sx) relW2[sx] = r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);
+  const unsigned relB = lds0 + 2 * STAGE + hi * 16;
+
+  FfnPipe<KS, NT2, PF> P;
+  P.xf = xf;
+  P.acc = acc;
+  P.wave = wave;
+  P.ldw2b = ldw2 * 2;
+#pragma unroll
+  for (int jm = 0; jm < 4; ++jm) P.lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
+  P.lo2 = (unsigned)((lane >> 2) * ldw2 * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+  issue(0, smem);
+  for (int c = 0; c < n_chunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    P.has_next = (ABL != 1) && (c + 1 < n_chunks);
+    P.gW1 = reinterpret_cast<const char*>(W1 + (size_t)(c + 1) * 32 * RK);
+    P.gW2 = reinterpret_cast<const char*>(W2p + (size_t)(c + 1) * 32);
+    P.nstage = smem + ((c + 1) & 1) * STAGE;
+    const unsigned sbase = lds0 + (c & 1) * STAGE;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.aW1[k] = sbase + relW1[k];
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) P.aW2[sx] = sbase + relW2[sx];
+    const unsigned ab = relB + c * 128;  // b1[c*32 + rq*8 + hi*4 ..]
+    dsr128f<0>(P.bb[0], ab);
+    dsr128f<32>(P.bb[1], ab);
+    dsr128f<64>(P.bb[2], ab);
+    dsr128f<96>(P.bb[3], ab);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P.ha[i] = 0.f;
+    if constexpr (ABL == 2) {
+      P.template dma_all<0>();
+    } else {
+      P.template prologue<0>();
+      // queue holds items 0..PF-2; step<IT> waits for item IT, runs its MFMA, then issues item IT+PF
+      P.template read_item<PF - 1>();
+      P.template step<0>();
+    }
+  }
+  if (m >= M) return;
+#pragma unroll
+  for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n = t * 32 + rq * 8 + hi * 4;
+      if (n + 3 < N) {
+        const float4 b = *reinterpret_cast<const float4*>(b2 + n);
+        const float4 qv = *reinterpret_cast<const float4*>(res + (size_t)m * ldo + n);
+        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) =
+            make_float4(acc[t][rq * 4 + 0] + b.x + qv.x, acc[t][rq * 4 + 1] + b.y + qv.y,
+                        acc[t][rq * 4 + 2] + b.z + qv.z, acc[t][rq * 4 + 3] + b.w + qv.w);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int KS, int TAG>
+static void launch_rowgemm_t(const GemmArgs& g, hipStream_t st) {
+  RowEpi e{g.bias, g.res, g.C32, g.C16, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  const int n_tiles = (g.N + 63) / 64;
+  const int lds = 2 * 64 * RKB + n_tiles * 64 * 4;
+  auto kern = rowgemm_k<KS, TAG>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W, g.lda,
+                     n_tiles, e);
+}
+
+// A: [>=ceil(M/128)*128 rows, lda] fp16 with K zero-padded to a multiple of 16 (<=512);
+// W: [>=ceil(N/64)*64 rows, 512] fp16.  N must be a multiple of 4.
+void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st) {
+  const bool k29 = g.K <= 464;
+  switch (tag) {
+    case 0: k29 ? launch_rowgemm_t<29, 0>(g, st) : launch_rowgemm_t<32, 0>(g, st); break;
+    case 1: k29 ? launch_rowgemm_t<29, 1>(g, st) : launch_rowgemm_t<32, 1>(g, st); break;
+    case 2: k29 ? launch_rowgemm_t<29, 2>(g, st) : launch_rowgemm_t<32, 2>(g, st); break;
+    default: k29 ? launch_rowgemm_t<29, 4>(g, st) : launch_rowgemm_t<32, 4>(g, st); break;
+  }
+}
+
+void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
+                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, hipStream_t st) {
+  constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
+  const int lds = 2 * (W1_STAGE + NT2 * 32 * 64) + F * 4;
+  static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
+  auto kern = dbg == 1 ? ffn_fused2_k<KS, NT2, 1> : dbg == 2 ? ffn_fused2_k<KS, NT2, 2> : ffn_fused2_k<KS, NT2, 0>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, W1, b1, W2p, ldw2, b2, res, out, ldo, M,
+                     N, F / 32);
+}
+
+}  // namespace ldm

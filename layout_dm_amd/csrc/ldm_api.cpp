@@ -109,8 +109,10 @@ struct ldm_handle {
   // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64
   int Dq = 0, HD = 0, Fq = 0, Mpad = 0;
   int gemm_cfg[5] = {0, 0, 0, 0, 0};  // qkv, attn_out, ffn1, ffn2, head
+  int row_impl = 0x6;  // bit0 QKV, bit1 out-proj, bit2 fused FFN, bit3 head use the row-stationary kernels
+                       // (measured: tile GEMM is faster for QKV, equal for the head)
   struct FastLayer {
-    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr;
+    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr;
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
@@ -284,6 +286,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     int defaults[5] = {5, 5, 5, 5, 5};
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
+    if (const char* ri = getenv("LDM_ROW_IMPL")) h->row_impl = atoi(ri);
+    if (h->D > 464 || h->HD > 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
   } else {
     A(&h->a16, Mc * h->Dp);
     A(&h->att16, Mc * h->Dp);
@@ -437,6 +441,14 @@ static int build_fast_weights(ldm_handle* h) {
     if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_col, &f.w_out))) return rc;
     if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, id, &f.w1))) return rc;
     if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, id, &f.w2))) return rc;
+    // fused FFN: K axis of W2 in MFMA k-slot order inside every 32-wide hidden chunk:
+    // position 16s + 8g + e  <-  hidden 16s + 8(e>>2) + 4g + (e&3)   (kernels_rowgemm.hip)
+    auto kslot = [](int k) {
+      const int c = k & ~31, f = k & 31;
+      const int s2 = f >> 4, e_hi = (f >> 3) & 1, g = (f >> 2) & 1, e_lo = f & 3;
+      return c + 16 * s2 + 8 * g + 4 * e_hi + e_lo;
+    };
+    if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &f.w2p))) return rc;
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
     for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
@@ -530,14 +542,19 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
-                  double flops, double bytes) {
+                  double flops, double bytes, bool row) {
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.relu = relu; g.res = res; g.ldres = D;
     g.C32 = C32; g.ldc32 = ldc32; g.C16 = C16; g.ldc16 = ldc16;
     const int cfg = h->gemm_cfg[tag];
     g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg)); g.lda = lda; g.ldw = ldw; g.precision = 1;
     ldm_handle::Scope sc(h, st, name, flops, bytes);
-    launch_gemm16(g, cfg, tag, st);
+    if (row) {
+      g.K = K;
+      launch_rowgemm(g, tag, st);
+    } else {
+      launch_gemm16(g, cfg, tag, st);
+    }
   };
   for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
@@ -552,13 +569,13 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
       launch_layernorm(a, st);
     }
     gemm("gemm_qkv", 0, h->a16, Dq, D, f.w_in, Dq, 3 * HD, f.b_in, 0, nullptr, nullptr, 0, h->qkv16,
-         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2));
+         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2), (h->row_impl & 1) != 0);
     {
       ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
       launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
     }
     gemm("gemm_attn_out", 1, h->att16, HD, HD, f.w_out, HD, D, w.b_out, 0, h->P, h->Q, D, nullptr, 0,
-         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
+         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8), (h->row_impl & 2) != 0);
     {
       LnArgs a{};
       a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2; a.y16 = h->h16;
@@ -566,10 +583,15 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
       ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * 6);
       launch_layernorm(a, st);
     }
-    gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
-         gemm_flops(M, F, D), (double)M * (D * 2 + F * 2));
-    gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
-         gemm_flops(M, D, F), (double)M * (F * 2 + D * 8));
+    if (h->row_impl & 4) {
+      ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 2 + D * 8));
+      launch_ffn_fused(h->h16, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, st);
+    } else {
+      gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
+           gemm_flops(M, F, D), (double)M * (D * 2 + F * 2), false);
+      gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
+           gemm_flops(M, D, F), (double)M * (F * 2 + D * 8), false);
+    }
   }
   {
     LnArgs a{};
@@ -579,7 +601,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     launch_layernorm(a, st);
   }
   gemm("gemm_head", 4, h->h16, Dq, D, h->fast_head, Dq, h->Cp, nullptr, 0, nullptr, h->logits, h->Cp,
-       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4));
+       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4), (h->row_impl & 8) != 0);
   return 0;
 }
 
@@ -1014,9 +1036,38 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) launch_gemm16(g, cfg, 2, 0);
+  float *res = nullptr, *out32 = nullptr, *bias1 = nullptr;
+  __half *W1b = nullptr, *W2b = nullptr;
+  if (cfg == 101) {
+    std::vector<uint16_t> h1((size_t)2048 * 512), h2((size_t)512 * 1856);
+    for (auto& x : h1) x = f2h_bits(rnd() * 0.05f);
+    for (auto& x : h2) x = f2h_bits(rnd() * 0.05f);
+    hipMalloc((void**)&W1b, h1.size() * 2);
+    hipMalloc((void**)&W2b, h2.size() * 2);
+    hipMalloc((void**)&bias1, 2048 * 4);
+    hipMemcpy(W1b, h1.data(), h1.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(W2b, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(bias1, 0, 2048 * 4);
+  }
+  auto run = [&]() {
+    if (cfg == 100) {
+      GemmArgs r = g;
+      r.K = K;
+      launch_rowgemm(r, 2, 0);
+    } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
+      launch_ffn_fused(A, Kp, W1b, bias1, W2b, 1856, bias, res, out32, N, M, N, 1856, 0);
+    } else {
+      launch_gemm16(g, cfg, 2, 0);
+    }
+  };
+  if (cfg == 101) {
+    hipMalloc((void**)&res, (size_t)Mp * N * 4);
+    hipMalloc((void**)&out32, (size_t)Mp * N * 4);
+    hipMemset(res, 0, (size_t)Mp * N * 4);
+  }
+  for (int i = 0; i < 3; ++i) run();
   hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) launch_gemm16(g, cfg, 2, 0);
+  for (int i = 0; i < iters; ++i) run();
   hipEventRecord(b, 0);
   hipEventSynchronize(b);
   float ms = 0;
@@ -1029,5 +1080,10 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
   hipFree(W);
   hipFree(Cc);
   hipFree(bias);
+  if (res) hipFree(res);
+  if (out32) hipFree(out32);
+  if (W1b) hipFree(W1b);
+  if (W2b) hipFree(W2b);
+  if (bias1) hipFree(bias1);
   return e == hipSuccess ? 0 : -2;
 }

@@ -48,6 +48,10 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);
+// row-stationary kernels (kernels_rowgemm.hip)
+void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st);
+void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
+                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
 
