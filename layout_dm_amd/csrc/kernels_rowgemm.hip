@@ -501,6 +501,140 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hand-pipelined row-stationary GEMM with fp16 output (QKV projection): C16[M,N] = A·W^T + bias.
+// 64 weight rows per LDS stage = two 32-row MFMA tiles = two independent accumulator chains; LDS reads
+// by inline asm PF items ahead; the next tile's DMA is interleaved (one 1-KiB instruction every 2
+// MFMAs); the tile's 8 stores stay in flight across the barrier (loop-top wait is vmcnt(8): DMA is
+// older than the stores in the in-order vmcnt queue).  Rows >= M are written too (buffers are padded).
+template <int KS, int PF>
+struct RowPipe {
+  static constexpr int NIT = 2 * KS;
+  f16x8 q[PF];
+  unsigned aW[8];
+  const f16x8* xf;
+  f32x16 acc0, acc1;
+  const char* gW;   // next tile's weight rows (uniform)
+  char* nstage;     // LDS stage of the next tile (uniform)
+  unsigned lo1[4];
+  int wave;
+  bool has_next;
+
+  template <int IT>
+  __device__ __forceinline__ void read_item() {
+    constexpr int t = IT & 1, ks = IT >> 1;
+    dsr128<t * 32 * RKB + 256 * (ks >> 3)>(q[IT % PF], aW[ks & 7]);
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_slot() {
+    if constexpr (J < 16) {
+      if (has_next) {
+        const int i = wave + 4 * J;
+        dma16(gW + i * RKB + lo1[J & 3], nstage + i * RKB);
+      }
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void step() {
+    if constexpr (IT < NIT) {
+      constexpr int after = (NIT - 1 - IT) < (PF - 1) ? (NIT - 1 - IT) : (PF - 1);
+      wait_lgkm<after>();
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 cur = q[IT % PF];
+      if constexpr (IT & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT >> 1], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT >> 1], acc0, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT + PF < NIT) read_item<IT + PF>();
+      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
+      step<IT + 1>();
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void prologue() {
+    if constexpr (IT < PF) {
+      read_item<IT>();
+      prologue<IT + 1>();
+    }
+  }
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__ A, const __half* __restrict__ W, int lda,
+                                                     int n_tiles, const float* __restrict__ bias, __half* __restrict__ C16,
+                                                     int ldc, int N) {
+  constexpr int TR = 64;
+  constexpr int STAGE = TR * RKB;
+  constexpr int PF = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+
+  for (int i = tid; i < n_tiles * TR; i += 256) sbias[i] = (bias && i < N) ? bias[i] : 0.f;
+  f16x8 xf[KS];
+  {
+    const __half* arow = A + (size_t)m * lda + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned relW[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) relW[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+  RowPipe<KS, PF> P;
+  P.xf = xf;
+  P.wave = wave;
+#pragma unroll
+  for (int jm = 0; jm < 4; ++jm) P.lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
+  {  // first tile: burst
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = wave + 4 * j;
+      dma16(W + (size_t)i * RK + ((lane ^ (i & 15)) << 3), smem + i * RKB);
+    }
+  }
+  __half* crow = C16 + (size_t)m * ldc + hi * 4;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    // outstanding VMEM, oldest first: [DMA of this tile x16] [stores of the previous tile x8]
+    if (nt > 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    P.has_next = nt + 1 < n_tiles;
+    P.gW = reinterpret_cast<const char*>(W + (size_t)(nt + 1) * TR * RK);
+    P.nstage = smem + ((nt + 1) & 1) * STAGE;
+    const unsigned sbase = lds0 + (nt & 1) * STAGE;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.aW[k] = sbase + relW[k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      P.acc0[i] = 0.f;
+      P.acc1[i] = 0.f;
+    }
+    P.template prologue<0>();
+    P.template step<0>();
+    // epilogue: bias + cast, 8-byte stores (always issued: exactly 8 VMEM ops per tile per wave)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int n = nt * TR + g * 8 + hi * 4;
+      const float4 b = *reinterpret_cast<const float4*>(sbias + n);
+      const int rq = g & 3;
+      const float v0 = (g < 4 ? P.acc0[rq * 4 + 0] : P.acc1[rq * 4 + 0]) + b.x;
+      const float v1 = (g < 4 ? P.acc0[rq * 4 + 1] : P.acc1[rq * 4 + 1]) + b.y;
+      const float v2 = (g < 4 ? P.acc0[rq * 4 + 2] : P.acc1[rq * 4 + 2]) + b.z;
+      const float v3 = (g < 4 ? P.acc0[rq * 4 + 3] : P.acc1[rq * 4 + 3]) + b.w;
+      const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, v3);
+      uint2 pk;
+      pk.x = *reinterpret_cast<const unsigned*>(&h0);
+      pk.y = *reinterpret_cast<const unsigned*>(&h1);
+      *reinterpret_cast<uint2*>(crow + nt * TR + g * 8) = pk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int KS, int TAG>
 static void launch_rowgemm_t(const GemmArgs& g, hipStream_t st) {
   RowEpi e{g.bias, g.res, g.C32, g.C16, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
@@ -520,6 +654,20 @@ static void launch_rowgemm_t(const GemmArgs& g, hipStream_t st) {
 // W: [>=ceil(N/64)*64 rows, 512] fp16.  N must be a multiple of 4.
 void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st) {
   const bool k29 = g.K <= 464;
+  if (tag == 0 && k29 && g.C16 && !g.C32 && !g.res && !g.relu && g.N % 64 == 0 && !getenv("LDM_ROWGEMM_V1")) {
+    constexpr int KS = 29;
+    const int n_tiles = g.N / 64;
+    const int lds = 2 * 64 * RKB + g.N * 4;
+    auto kern = rowgemm16_k<KS>;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W,
+                       g.lda, n_tiles, g.bias, g.C16, g.ldc16, g.N);
+    return;
+  }
   switch (tag) {
     case 0: k29 ? launch_rowgemm_t<29, 0>(g, st) : launch_rowgemm_t<32, 0>(g, st); break;
     case 1: k29 ? launch_rowgemm_t<29, 1>(g, st) : launch_rowgemm_t<32, 1>(g, st); break;

@@ -109,8 +109,8 @@ struct ldm_handle {
   // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64
   int Dq = 0, HD = 0, Fq = 0, Mpad = 0;
   int gemm_cfg[5] = {0, 0, 0, 0, 0};  // qkv, attn_out, ffn1, ffn2, head
-  int row_impl = 0x6;  // bit0 QKV, bit1 out-proj, bit2 fused FFN, bit3 head use the row-stationary kernels
-                       // (measured: tile GEMM is faster for QKV, equal for the head)
+  int row_impl = 0x7;  // bit0 QKV, bit1 out-proj, bit2 fused FFN, bit3 head use the row-stationary kernels
+                       // (measured: row kernels win for QKV, out-proj, FFN; equal for the head)
   struct FastLayer {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr;
     float* b_in = nullptr;
@@ -1053,7 +1053,8 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
     if (cfg == 100) {
       GemmArgs r = g;
       r.K = K;
-      launch_rowgemm(r, 2, 0);
+      r.relu = 0;
+      launch_rowgemm(r, 0, 0);
     } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
       launch_ffn_fused(A, Kp, W1b, bias1, W2b, 1856, bias, res, out32, N, M, N, 1856, 0);
     } else {
