@@ -64,6 +64,15 @@ __global__ __launch_bounds__(256) void ln_rows(LnArgs a) {
   }
   const float var = wave_sum(q) * inv_d;  // biased variance
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  if (a.stats_out && lane == 0) a.stats_out[row] = make_float2(mean, rstd);
+  if (a.raw) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 64 + lane;
+      if (c < nvec) reinterpret_cast<float4*>(a.y32 + (size_t)row * a.D)[c] = v[i];
+    }
+    return;
+  }
   const float4* p0 = reinterpret_cast<const float4*>(a.p0);
   const float4* p1 = reinterpret_cast<const float4*>(a.p1);
 #pragma unroll

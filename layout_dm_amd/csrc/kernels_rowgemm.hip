@@ -62,6 +62,49 @@ struct RowEpi {
   int M, N, ldres, ldc32, ldc16, relu;
 };
 
+// ---- deferred normalisation helpers -------------------------------------------------------------
+// LDS parameter image: sp[0..D) = multiplier (1+scale for AdaLN, gamma for LayerNorm), sp[Dp..Dp+D) = shift/beta
+constexpr int LN_DP = 512;
+__device__ __forceinline__ void stage_ln_params(float* sp, const LnLoad& ln, int tid) {
+  for (int i = tid; i < ln.D; i += 256) {
+    sp[i] = ln.ada ? 1.0f + ln.p0[i] : ln.p0[i];
+    sp[LN_DP + i] = ln.p1[i];
+  }
+}
+// Builds the register-resident fp16 fragments of token row m from the fp32 row + (mean, rstd):
+// y = (x - mean) * rstd * mult + shift   (AdaLayerNorm transformer_utils.py:79-83 / nn.LayerNorm)
+template <int KS>
+__device__ __forceinline__ void load_xf_ln(f16x8 (&xf)[KS], const LnLoad& ln, int m, int hi, const float* sp) {
+  const float2 st = ln.stats[m];
+  const float* xr = ln.x + (size_t)m * ln.ldx + hi * 8;
+  const float* mp = sp + hi * 8;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + ks * 16);
+    const float4 b = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+    const float4 ga = *reinterpret_cast<const float4*>(mp + ks * 16);
+    const float4 gb = *reinterpret_cast<const float4*>(mp + ks * 16 + 4);
+    const float4 sa = *reinterpret_cast<const float4*>(mp + LN_DP + ks * 16);
+    const float4 sb = *reinterpret_cast<const float4*>(mp + LN_DP + ks * 16 + 4);
+    xf[ks][0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
+    xf[ks][1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
+    xf[ks][2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
+    xf[ks][3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
+    xf[ks][4] = (_Float16)fmaf((b.x - st.x) * st.y, gb.x, sb.x);
+    xf[ks][5] = (_Float16)fmaf((b.y - st.x) * st.y, gb.y, sb.y);
+    xf[ks][6] = (_Float16)fmaf((b.z - st.x) * st.y, gb.z, sb.z);
+    xf[ks][7] = (_Float16)fmaf((b.w - st.x) * st.y, gb.w, sb.w);
+  }
+}
+// finish per-row statistics: each lane summed its half of the row, lane^32 holds the other half
+__device__ __forceinline__ void store_row_stats(float2* out, int m, int M, int hi, float s1, float s2, int N) {
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float mean = s1 / (float)N;
+  const float var = fmaxf(s2 / (float)N - mean * mean, 0.f);
+  if (hi == 0 && m < M) out[m] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+}
+
 // ------------------------------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K<=512] · W^T + bias);  KS = number of k16 steps actually used (ceil(K/16)).
 // Ordinary global loads inside the tile loop would make hipcc drain the in-flight weight DMA
@@ -69,12 +112,14 @@ struct RowEpi {
 // during tile nt and "touched" right after the loop-top vmcnt(0) so no later wait is needed.
 template <int KS, int TAG>
 __global__ __launch_bounds__(256, 1) void rowgemm_k(const __half* __restrict__ A, const __half* __restrict__ W, int lda,
-                                                   int n_tiles, RowEpi e) {
+                                                   int n_tiles, RowEpi e, RowExtra ex) {
   constexpr int TR = 64;               // weight rows per stage (two 32-row MFMA tiles)
   constexpr int STAGE = TR * RKB;      // 64 KiB
   constexpr int PF = 8;                // LDS prefetch depth (fragments in flight ahead of their MFMA)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* sp_in = sbias + n_tiles * TR;  // LN-on-load parameters of the A operand
+  float* sp_res = sp_in + 2 * LN_DP;   // parameters of the on-the-fly normalised residual
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,12 +128,20 @@ __global__ __launch_bounds__(256, 1) void rowgemm_k(const __half* __restrict__ A
   const bool mok = m < e.M;
 
   for (int i = tid; i < n_tiles * TR; i += 256) sbias[i] = (e.bias && i < e.N) ? e.bias[i] : 0.f;
+  if (ex.in.x) stage_ln_params(sp_in, ex.in, tid);
+  if (ex.res.x) stage_ln_params(sp_res, ex.res, tid);
   f16x8 xf[KS];
-  {
+  if (ex.in.x) {
+    __syncthreads();
+    load_xf_ln<KS>(xf, ex.in, mok ? m : e.M - 1, hi, sp_in);
+  } else {
     const __half* arow = A + (size_t)m * lda + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
   }
+  float2 rst = make_float2(0.f, 1.f);
+  if (ex.res.x) rst = ex.res.stats[mok ? m : e.M - 1];
+  float s1 = 0.f, s2 = 0.f;
   const float* rrow = e.res ? e.res + (size_t)(mok ? m : 0) * e.ldres + hi * 4 : nullptr;
   float4 rc[8], rn[8];
 #pragma unroll
@@ -147,7 +200,18 @@ __global__ __launch_bounds__(256, 1) void rowgemm_k(const __half* __restrict__ A
           if (e.relu) {
             v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
           }
-          v0 += rc[g].x; v1 += rc[g].y; v2 += rc[g].z; v3 += rc[g].w;
+          if (ex.res.x) {  // residual = AdaLN(layer input) recomputed from the raw row + (mean, rstd)
+            const float4 gm = *reinterpret_cast<const float4*>(sp_res + n);
+            const float4 gs = *reinterpret_cast<const float4*>(sp_res + LN_DP + n);
+            v0 += fmaf((rc[g].x - rst.x) * rst.y, gm.x, gs.x);
+            v1 += fmaf((rc[g].y - rst.x) * rst.y, gm.y, gs.y);
+            v2 += fmaf((rc[g].z - rst.x) * rst.y, gm.z, gs.z);
+            v3 += fmaf((rc[g].w - rst.x) * rst.y, gm.w, gs.w);
+          } else {
+            v0 += rc[g].x; v1 += rc[g].y; v2 += rc[g].z; v3 += rc[g].w;
+          }
+          s1 += (v0 + v1) + (v2 + v3);
+          s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
           if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v0, v1, v2, v3);
           if (e.C16) {
             const __half2 h0 = __floats2half2_rn(v0, v1), h1 = __floats2half2_rn(v2, v3);
@@ -162,120 +226,7 @@ __global__ __launch_bounds__(256, 1) void rowgemm_k(const __half* __restrict__ A
 #pragma unroll
     for (int g = 0; g < 8; ++g) rc[g] = rn[g];
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// fused FFN.  Per 32-wide hidden chunk c:   hT = W1[c] · H^T (30 MFMAs) ; relu/bias/cast in-lane ;
-//   accT[n-tile] += W2p[n-tile][c] · hT (NT2 x 2 MFMAs).   LDS stage = [W1 chunk 32 x 1 KiB | W2
-//   chunk (NT2*32) x 64 B].
-template <int KS, int NT2>
-__global__ __launch_bounds__(256, 1) void ffn_fused_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
-                                                     const float* __restrict__ b1, const __half* __restrict__ W2p,
-                                                     int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
-                                                     float* __restrict__ out, int ldo, int M, int N, int n_chunks) {
-  constexpr int W2_ROWS = NT2 * 32;
-  constexpr int W2_INST = W2_ROWS / 16;             // 16 rows of 64 B per 1-KiB DMA instruction
-  constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
-  constexpr int NINST = 32 + W2_INST;
-  constexpr int IPW = (NINST + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hi = lane >> 5;
-  const int m = blockIdx.x * 128 + wave * 32 + r;
-
-  for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
-  f16x8 xf[KS];
-  {
-    const __half* hrow = H + (size_t)m * ldh + hi * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(hrow + ks * 16);
-  }
-  f32x16 acc[NT2];
-#pragma unroll
-  for (int t = 0; t < NT2; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  auto issue = [&](int c, char* stage) {
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int i = wave + 4 * j;  // wave < 4  =>  (i < 32) == (j < 8): role is known at compile time
-      if (j < 8) {
-        dma16(W1 + (size_t)(c * 32 + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
-      } else if (4 * j + 3 < NINST || i < NINST) {
-        const int row = (i - 32) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        dma16(W2p + (size_t)row * ldw2 + c * 32 + chunk * 8, stage + W1_STAGE + (i - 32) * 1024);
-      }
-    }
-  };
-  issue(0, smem);
-  const int w2sw = (r >> 2) & 3;
-  for (int c = 0; c < n_chunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (c + 1 < n_chunks) issue(c + 1, smem + ((c + 1) & 1) * STAGE);
-    const char* st = smem + (c & 1) * STAGE;
-    // One unified stream of fragments: items [0,KS) = W1 chunk (k16 steps), items [KS, KS+2*NT2) =
-    // W2 chunk (n-tile t, k-step s).  Every item is one ds_read_b128 feeding one MFMA; reads are
-    // issued PF items ahead of their MFMA (one wave per SIMD => nothing else hides LDS latency).
-    constexpr int PF = 8;
-    constexpr int NIT = KS + 2 * NT2;
-    const char* w2 = st + W1_STAGE;
-    auto read_item = [&](int it) -> f16x8 {
-      if (it < KS) return read_w_frag(st, r, hi, it);
-      const int t = (it - KS) >> 1, sx = (it - KS) & 1;
-      return *reinterpret_cast<const f16x8*>(w2 + (t * 32 + r) * 64 + (((2 * sx + hi) ^ w2sw) << 4));
-    };
-    f16x8 q[PF];
-#pragma unroll
-    for (int it = 0; it < PF; ++it) q[it] = read_item(it);
-    f32x16 ha;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ha[i] = 0.f;
-    f16x8 pf[2];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const f16x8 cur = q[it % PF];
-      if (it + PF < NIT) q[it % PF] = read_item(it + PF);
-      if (it < KS) {
-        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[it], ha, 0, 0, 0);
-        if (it == KS - 1) {
-          // bias + ReLU + cast: accumulator reg q <-> hidden f = c*32 + (q&3) + 8*(q>>2) + 4*hi
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            const float4 b = *reinterpret_cast<const float4*>(sb1 + c * 32 + rq * 8 + hi * 4);
-            pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + b.x, 0.f);
-            pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + b.y, 0.f);
-            pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + b.z, 0.f);
-            pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + b.w, 0.f);
-          }
-        }
-      } else {
-        const int t = (it - KS) >> 1, sx = (it - KS) & 1;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
-      }
-    }
-  }
-  if (m >= M) return;
-#pragma unroll
-  for (int t = 0; t < NT2; ++t) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int n = t * 32 + rq * 8 + hi * 4;
-      if (n + 3 < N) {
-        const float4 b = *reinterpret_cast<const float4*>(b2 + n);
-        const float4 q = *reinterpret_cast<const float4*>(res + (size_t)m * ldo + n);
-        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) =
-            make_float4(acc[t][rq * 4 + 0] + b.x + q.x, acc[t][rq * 4 + 1] + b.y + q.y,
-                        acc[t][rq * 4 + 2] + b.z + q.z, acc[t][rq * 4 + 3] + b.w + q.w);
-      }
-    }
-  }
+  if (ex.stats_out) store_row_stats(ex.stats_out, m, e.M, hi, s1, s2, e.N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,7 +347,8 @@ template <int KS, int NT2, int ABL>
 __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
                                                       const float* __restrict__ b1, const __half* __restrict__ W2p,
                                                       int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
-                                                      float* __restrict__ out, int ldo, int M, int N, int n_chunks) {
+                                                      float* __restrict__ out, int ldo, int M, int N, int n_chunks,
+                                                      LnLoad ln, float2* __restrict__ stats_out) {
   constexpr int W2_ROWS = NT2 * 32;
   constexpr int W2_INST = W2_ROWS / 16;
   constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
@@ -405,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* sp_in = sb1 + n_chunks * 32;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,7 +366,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
 
   for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
   f16x8 xf[KS];
-  {
+  if (ln.x) {
+    stage_ln_params(sp_in, ln, tid);
+    __syncthreads();
+    load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
+  } else {
     const __half* hrow = H + (size_t)m * ldh + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(hrow + ks * 16);
@@ -483,20 +440,26 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
       P.template step<0>();
     }
   }
-  if (m >= M) return;
+  {
+    const int mr = m < M ? m : M - 1;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT2; ++t) {
+    for (int t = 0; t < NT2; ++t) {
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int n = t * 32 + rq * 8 + hi * 4;
-      if (n + 3 < N) {
-        const float4 b = *reinterpret_cast<const float4*>(b2 + n);
-        const float4 qv = *reinterpret_cast<const float4*>(res + (size_t)m * ldo + n);
-        *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) =
-            make_float4(acc[t][rq * 4 + 0] + b.x + qv.x, acc[t][rq * 4 + 1] + b.y + qv.y,
-                        acc[t][rq * 4 + 2] + b.z + qv.z, acc[t][rq * 4 + 3] + b.w + qv.w);
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = t * 32 + rq * 8 + hi * 4;
+        if (n + 3 < N) {
+          const float4 b = *reinterpret_cast<const float4*>(b2 + n);
+          const float4 qv = *reinterpret_cast<const float4*>(res + (size_t)mr * ldo + n);
+          const float v0 = acc[t][rq * 4 + 0] + b.x + qv.x, v1 = acc[t][rq * 4 + 1] + b.y + qv.y;
+          const float v2 = acc[t][rq * 4 + 2] + b.z + qv.z, v3 = acc[t][rq * 4 + 3] + b.w + qv.w;
+          s1 += (v0 + v1) + (v2 + v3);
+          s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          if (m < M) *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(v0, v1, v2, v3);
+        }
       }
     }
+    if (stats_out) store_row_stats(stats_out, m, M, hi, s1, s2, N);
   }
 }
 
@@ -560,12 +523,13 @@ struct RowPipe {
 template <int KS>
 __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__ A, const __half* __restrict__ W, int lda,
                                                      int n_tiles, const float* __restrict__ bias, __half* __restrict__ C16,
-                                                     int ldc, int N) {
+                                                     int ldc, int N, int M, LnLoad ln) {
   constexpr int TR = 64;
   constexpr int STAGE = TR * RKB;
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* sp_in = sbias + n_tiles * TR;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -574,7 +538,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
 
   for (int i = tid; i < n_tiles * TR; i += 256) sbias[i] = (bias && i < N) ? bias[i] : 0.f;
   f16x8 xf[KS];
-  {
+  if (ln.x) {
+    stage_ln_params(sp_in, ln, tid);
+    __syncthreads();
+    load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
+  } else {
     const __half* arow = A + (size_t)m * lda + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
@@ -636,10 +604,10 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 template <int KS, int TAG>
-static void launch_rowgemm_t(const GemmArgs& g, hipStream_t st) {
+static void launch_rowgemm_t(const GemmArgs& g, const RowExtra& ex, hipStream_t st) {
   RowEpi e{g.bias, g.res, g.C32, g.C16, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
   const int n_tiles = (g.N + 63) / 64;
-  const int lds = 2 * 64 * RKB + n_tiles * 64 * 4;
+  const int lds = 2 * 64 * RKB + n_tiles * 64 * 4 + 4 * LN_DP * 4;
   auto kern = rowgemm_k<KS, TAG>;
   static bool attr = false;
   if (!attr) {
@@ -647,17 +615,20 @@ static void launch_rowgemm_t(const GemmArgs& g, hipStream_t st) {
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W, g.lda,
-                     n_tiles, e);
+                     n_tiles, e, ex);
 }
 
 // A: [>=ceil(M/128)*128 rows, lda] fp16 with K zero-padded to a multiple of 16 (<=512);
 // W: [>=ceil(N/64)*64 rows, 512] fp16.  N must be a multiple of 4.
-void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st) {
+void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t st) {
   const bool k29 = g.K <= 464;
-  if (tag == 0 && k29 && g.C16 && !g.C32 && !g.res && !g.relu && g.N % 64 == 0 && !getenv("LDM_ROWGEMM_V1")) {
+  RowExtra ex{};
+  if (exp) ex = *exp;
+  if (tag == 0 && k29 && g.C16 && !g.C32 && !g.res && !g.relu && g.N % 64 == 0 && !ex.res.x && !ex.stats_out &&
+      !getenv("LDM_ROWGEMM_V1")) {
     constexpr int KS = 29;
     const int n_tiles = g.N / 64;
-    const int lds = 2 * 64 * RKB + g.N * 4;
+    const int lds = 2 * 64 * RKB + g.N * 4 + 2 * LN_DP * 4;
     auto kern = rowgemm16_k<KS>;
     static bool attr = false;
     if (!attr) {
@@ -665,21 +636,24 @@ void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st) {
       attr = true;
     }
     hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W,
-                       g.lda, n_tiles, g.bias, g.C16, g.ldc16, g.N);
+                       g.lda, n_tiles, g.bias, g.C16, g.ldc16, g.N, g.M, ex.in);
     return;
   }
   switch (tag) {
-    case 0: k29 ? launch_rowgemm_t<29, 0>(g, st) : launch_rowgemm_t<32, 0>(g, st); break;
-    case 1: k29 ? launch_rowgemm_t<29, 1>(g, st) : launch_rowgemm_t<32, 1>(g, st); break;
-    case 2: k29 ? launch_rowgemm_t<29, 2>(g, st) : launch_rowgemm_t<32, 2>(g, st); break;
-    default: k29 ? launch_rowgemm_t<29, 4>(g, st) : launch_rowgemm_t<32, 4>(g, st); break;
+    case 0: k29 ? launch_rowgemm_t<29, 0>(g, ex, st) : launch_rowgemm_t<32, 0>(g, ex, st); break;
+    case 1: k29 ? launch_rowgemm_t<29, 1>(g, ex, st) : launch_rowgemm_t<32, 1>(g, ex, st); break;
+    case 2: k29 ? launch_rowgemm_t<29, 2>(g, ex, st) : launch_rowgemm_t<32, 2>(g, ex, st); break;
+    default: k29 ? launch_rowgemm_t<29, 4>(g, ex, st) : launch_rowgemm_t<32, 4>(g, ex, st); break;
   }
 }
 
 void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
-                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, hipStream_t st) {
+                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, const LnLoad* lnp,
+                      float2* stats_out, hipStream_t st) {
+  LnLoad ln{};
+  if (lnp) ln = *lnp;
   constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
-  const int lds = 2 * (W1_STAGE + NT2 * 32 * 64) + F * 4;
+  const int lds = 2 * (W1_STAGE + NT2 * 32 * 64) + F * 4 + 2 * LN_DP * 4;
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
   auto kern = dbg == 1 ? ffn_fused2_k<KS, NT2, 1> : dbg == 2 ? ffn_fused2_k<KS, NT2, 2> : ffn_fused2_k<KS, NT2, 0>;
   static bool attr = false;
@@ -688,7 +662,7 @@ void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, W1, b1, W2p, ldw2, b2, res, out, ldo, M,
-                     N, F / 32);
+                     N, F / 32, ln, stats_out);
 }
 
 }  // namespace ldm

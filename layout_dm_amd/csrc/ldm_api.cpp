@@ -117,6 +117,8 @@ struct ldm_handle {
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
+  float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
+  int defer_ln = 1;
   int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
   uint64_t* rng = nullptr;                      // device {seed, first_layout}
   // profiling
@@ -282,12 +284,16 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     A(&h->att16, Mp * h->HD);
     A(&h->hid16, Mp * h->Fq);
     A(&h->qkv16, Mp * 3 * h->HD);
+    A(&h->stats_a, Mp);
+    A(&h->stats_b, Mp);
     const char* env = getenv("LDM_GEMM_CFG");  // "q,o,1,2,h" tile-config ids (tuning override)
     int defaults[5] = {5, 5, 5, 5, 5};
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
     if (const char* ri = getenv("LDM_ROW_IMPL")) h->row_impl = atoi(ri);
     if (h->D > 464 || h->HD > 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
+    if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
+    if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
   } else {
     A(&h->a16, Mc * h->Dp);
     A(&h->att16, Mc * h->Dp);
@@ -537,8 +543,68 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
 // ------------------------------------------------------------------------------------------ one pass
 static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 
+// fast mode with DEFERRED NORMALISATION: no LayerNorm kernel, no LN output tensor.  Producers (embedding,
+// out-proj, fused FFN) emit per-row (mean, rstd) next to their fp32 output; consumers (QKV, FFN, head)
+// normalise while loading their register-resident fragments; the out-proj recomputes its residual
+// AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
+static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+  const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
+  {  // x0 = emb[token] + pos -> P (raw) + stats_a
+    LnArgs a{};
+    a.tokens = d_tokens; a.emb = h->emb; a.pos = h->pos; a.y32 = h->P; a.stats_out = h->stats_a; a.raw = 1;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq;
+    ldm_handle::Scope sc(h, st, "embed_stats", 0, (double)M * D * 8);
+    launch_layernorm(a, st);
+  }
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const ldm_handle::FastLayer& f = h->fast[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
+    {  // QKV = AdaLN(x)·Win^T + b   (AdaLN applied while loading the fragments)
+      GemmArgs g{};
+      g.W = f.w_in; g.bias = f.b_in; g.C16 = h->qkv16; g.ldc16 = 3 * HD;
+      g.M = M; g.N = 3 * HD; g.K = D; g.lda = Dq; g.ldw = Dq; g.precision = 1;
+      RowExtra ex{};
+      ex.in = ada;
+      ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * (D * 4 + 3 * HD * 2));
+      launch_rowgemm(g, 0, &ex, st);
+    }
+    {
+      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
+      launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
+    }
+    {  // x1 = AdaLN(x) + att·Wo^T + bo -> Q (+ stats_b)
+      GemmArgs g{};
+      g.A = h->att16; g.W = f.w_out; g.bias = w.b_out; g.res = h->P; g.ldres = D; g.C32 = h->Q; g.ldc32 = D;
+      g.M = M; g.N = D; g.K = HD; g.lda = HD; g.ldw = HD; g.precision = 1;
+      RowExtra ex{};
+      ex.res = ada;
+      ex.stats_out = h->stats_b;
+      ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
+      launch_rowgemm(g, 1, &ex, st);
+    }
+    {  // x2 = x1 + FFN(LN2(x1)) -> P (+ stats_a)
+      const LnLoad ln2{h->Q, h->stats_b, w.g2, w.be2, D, D, 0};
+      ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 4 + D * 8));
+      launch_ffn_fused(nullptr, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
+    }
+  }
+  {  // logits = LN_head(x)·Wh^T
+    GemmArgs g{};
+    g.W = h->fast_head; g.C32 = h->logits; g.ldc32 = h->Cp;
+    g.M = M; g.N = h->Cp; g.K = D; g.lda = Dq; g.ldw = Dq; g.precision = 1;
+    RowExtra ex{};
+    ex.in = LnLoad{h->P, h->stats_a, h->head_g, h->head_b, D, D, 0};
+    ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, h->C, D), (double)M * (D * 4 + h->C * 4));
+    launch_rowgemm(g, 4, &ex, st);
+  }
+  return 0;
+}
+
 // fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
 static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
@@ -551,7 +617,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     ldm_handle::Scope sc(h, st, name, flops, bytes);
     if (row) {
       g.K = K;
-      launch_rowgemm(g, tag, st);
+      launch_rowgemm(g, tag, nullptr, st);
     } else {
       launch_gemm16(g, cfg, tag, st);
     }
@@ -585,7 +651,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     }
     if (h->row_impl & 4) {
       ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 2 + D * 8));
-      launch_ffn_fused(h->h16, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, st);
+      launch_ffn_fused(h->h16, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
     } else {
       gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
            gemm_flops(M, F, D), (double)M * (D * 2 + F * 2), false);
@@ -1054,9 +1120,9 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
       GemmArgs r = g;
       r.K = K;
       r.relu = 0;
-      launch_rowgemm(r, 0, 0);
+      launch_rowgemm(r, 0, nullptr, 0);
     } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
-      launch_ffn_fused(A, Kp, W1b, bias1, W2b, 1856, bias, res, out32, N, M, N, 1856, 0);
+      launch_ffn_fused(A, Kp, W1b, bias1, W2b, 1856, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
     } else {
       launch_gemm16(g, cfg, 2, 0);
     }

@@ -24,7 +24,9 @@ struct LnArgs {
   float* y32;             // [M, D] or nullptr
   __half* y16;            // [M, ld16] or nullptr   (GEMM A operand, fp16 modes)
   __half* y16lo;          // [M, ld16] or nullptr   (split mode: residual x - fp16(x), scaled by 2^11)
+  float2* stats_out;      // [M] (mean, rstd) or nullptr   (deferred normalisation, fast mode)
   int M, D, S, ld16, ada;
+  int raw;                // 1: y32 receives the UN-normalised x (embedding only), stats_out the statistics
 };
 void launch_layernorm(const LnArgs& a, hipStream_t st);
 
@@ -49,9 +51,24 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);
 // row-stationary kernels (kernels_rowgemm.hip)
-void launch_rowgemm(const GemmArgs& g, int tag, hipStream_t st);
+// Deferred normalisation (fast mode): instead of materialising LayerNorm outputs, producers emit per-row
+// (mean, rstd) and consumers normalise while loading their register-resident activation fragments.
+struct LnLoad {
+  const float* x;       // [M, ldx] fp32 un-normalised rows (nullptr: operand is already fp16 in GemmArgs.A)
+  const float2* stats;  // [M] (mean, rstd)
+  const float* p0;      // scale (ada) / gamma   [D]
+  const float* p1;      // shift (ada) / beta    [D]
+  int ldx, D, ada;
+};
+struct RowExtra {
+  LnLoad in;            // LN-on-load of the A operand
+  LnLoad res;           // residual = LN(res.x) recomputed on the fly (out-proj: AdaLN of the layer input)
+  float2* stats_out;    // [M] row statistics of the fp32 output, or nullptr
+};
+void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* ex, hipStream_t st);
 void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
-                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, hipStream_t st);
+                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F,
+                      const LnLoad* ln, float2* stats_out, hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
 
