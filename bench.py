@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="layouts per GPU per step")
     ap.add_argument("--dataset", default="rico25", choices=["rico25", "publaynet"])
     ap.add_argument("--timesteps", type=int, default=100)
-    ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "exact"),
+    ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "fast"),
                     choices=["exact", "fast", "split"])
     ap.add_argument("--sampling", default="random", choices=["random", "deterministic", "top_p", "gumbel"])
     ap.add_argument("--chunk", type=int, default=0)
