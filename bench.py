@@ -163,7 +163,7 @@ def main():
         "dtype": DTYPE[a.precision],
         "data": "synthetic (random-init weights with the reference's init distributions, all-[MASK] start)",
         "config": {"workload": f"{a.dataset} cond=unconditional T={a.timesteps} batch={B}/GPU sampling={a.sampling}",
-                   "precision_mode": a.precision, "hipgraph": not a.no_graph, "chunk_layouts": min(eng.cfg.chunk or 256, B),
+                   "precision_mode": a.precision, "hipgraph": not a.no_graph, "chunk_layouts": min(eng.cfg.chunk or 512, B),
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
         "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
     }

@@ -469,9 +469,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
 // by inline asm PF items ahead; the next tile's DMA is interleaved (one 1-KiB instruction every 2
 // MFMAs); the tile's 8 stores stay in flight across the barrier (loop-top wait is vmcnt(8): DMA is
 // older than the stores in the in-order vmcnt queue).  Rows >= M are written too (buffers are padded).
-template <int KS, int PF>
+template <int KS, int PF, int NT = 2>
 struct RowPipe {
-  static constexpr int NIT = 2 * KS;
+  static constexpr int NIT = NT * KS;
   f16x8 q[PF];
   unsigned aW[8];
   const f16x8* xf;
@@ -484,12 +484,12 @@ struct RowPipe {
 
   template <int IT>
   __device__ __forceinline__ void read_item() {
-    constexpr int t = IT & 1, ks = IT >> 1;
+    constexpr int t = IT % NT, ks = IT / NT;
     dsr128<t * 32 * RKB + 256 * (ks >> 3)>(q[IT % PF], aW[ks & 7]);
   }
   template <int J>
   __device__ __forceinline__ void dma_slot() {
-    if constexpr (J < 16) {
+    if constexpr (J < 8 * NT) {
       if (has_next) {
         const int i = wave + 4 * J;
         dma16(gW + i * RKB + lo1[J & 3], nstage + i * RKB);
@@ -503,8 +503,8 @@ struct RowPipe {
       wait_lgkm<after>();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
-      if constexpr (IT & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT >> 1], acc1, 0, 0, 0);
-      else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT >> 1], acc0, 0, 0, 0);
+      if constexpr (IT % NT == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT / NT], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT / NT], acc0, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT + PF < NIT) read_item<IT + PF>();
       if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
@@ -520,11 +520,11 @@ struct RowPipe {
   }
 };
 
-template <int KS>
+template <int KS, int TR>
 __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__ A, const __half* __restrict__ W, int lda,
                                                      int n_tiles, const float* __restrict__ bias, __half* __restrict__ C16,
                                                      int ldc, int N, int M, LnLoad ln) {
-  constexpr int TR = 64;
+  constexpr int NT = TR / 32;
   constexpr int STAGE = TR * RKB;
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -551,14 +551,14 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
   unsigned relW[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) relW[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
-  RowPipe<KS, PF> P;
+  RowPipe<KS, PF, NT> P;
   P.xf = xf;
   P.wave = wave;
 #pragma unroll
   for (int jm = 0; jm < 4; ++jm) P.lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
   {  // first tile: burst
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 8 * NT; ++j) {
       const int i = wave + 4 * j;
       dma16(W + (size_t)i * RK + ((lane ^ (i & 15)) << 3), smem + i * RKB);
     }
@@ -566,8 +566,11 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
   __half* crow = C16 + (size_t)m * ldc + hi * 4;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   for (int nt = 0; nt < n_tiles; ++nt) {
-    // outstanding VMEM, oldest first: [DMA of this tile x16] [stores of the previous tile x8]
-    if (nt > 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    // outstanding VMEM, oldest first: [DMA of this tile] [stores of the previous tile x 4*NT]
+    if (nt > 0) {
+      if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     P.has_next = nt + 1 < n_tiles;
@@ -583,9 +586,9 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
     }
     P.template prologue<0>();
     P.template step<0>();
-    // epilogue: bias + cast, 8-byte stores (always issued: exactly 8 VMEM ops per tile per wave)
+    // epilogue: bias + cast, 8-byte stores (always issued: exactly 4*NT VMEM ops per tile per wave)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 4 * NT; ++g) {
       const int n = nt * TR + g * 8 + hi * 4;
       const float4 b = *reinterpret_cast<const float4*>(sbias + n);
       const int rq = g & 3;
@@ -600,6 +603,106 @@ __global__ __launch_bounds__(256, 1) void rowgemm16_k(const __half* __restrict__
       *reinterpret_cast<uint2*>(crow + nt * TR + g * 8) = pk;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hand-pipelined row-stationary GEMM with fp32 output + residual + row statistics (attention
+// out-projection):  C32 = A·W^T + bias + LN(res) ; stats_out = (mean, rstd) of every output row.
+// Same pipeline as rowgemm16_k; the tile's residual rows are fetched right after the barrier (ordinary
+// loads, fenced by a sched_barrier so they are not sunk) and have the whole MFMA phase to land.
+template <int KS, int TR>
+__global__ __launch_bounds__(256, 1) void rowgemm32_k(const __half* __restrict__ A, int lda, const __half* __restrict__ W,
+                                                     int n_tiles, const float* __restrict__ bias, float* __restrict__ C32,
+                                                     int ldc, int N, int M, LnLoad rs, float2* __restrict__ stats_out) {
+  constexpr int NT = TR / 32;
+  constexpr int STAGE = TR * RKB;
+  constexpr int PF = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* sp_res = sbias + n_tiles * TR;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+  const int mr = m < M ? m : M - 1;
+
+  for (int i = tid; i < n_tiles * TR; i += 256) sbias[i] = (bias && i < N) ? bias[i] : 0.f;
+  stage_ln_params(sp_res, rs, tid);
+  f16x8 xf[KS];
+  {
+    const __half* arow = A + (size_t)m * lda + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
+  }
+  const float2 rst = rs.stats[mr];
+  const float* rrow = rs.x + (size_t)mr * rs.ldx + hi * 4;
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned relW[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) relW[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+  RowPipe<KS, PF, NT> P;
+  P.xf = xf;
+  P.wave = wave;
+#pragma unroll
+  for (int jm = 0; jm < 4; ++jm) P.lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
+#pragma unroll
+  for (int j = 0; j < 8 * NT; ++j) {
+    const int i = wave + 4 * j;
+    dma16(W + (size_t)i * RK + ((lane ^ (i & 15)) << 3), smem + i * RKB);
+  }
+  float* crow = C32 + (size_t)m * ldc + hi * 4;
+  float s1 = 0.f, s2 = 0.f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (int nt = 0; nt < n_tiles; ++nt) {
+    // outstanding VMEM, oldest first: [DMA of this tile] [stores of the previous tile x 4*NT]
+    if (nt > 0) {
+      if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float4 rv[4 * NT];
+#pragma unroll
+    for (int g = 0; g < 4 * NT; ++g) {
+      const int n = nt * TR + g * 8 + hi * 4;
+      rv[g] = (n + 3 < N) ? *reinterpret_cast<const float4*>(rrow + nt * TR + g * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    P.has_next = nt + 1 < n_tiles;
+    P.gW = reinterpret_cast<const char*>(W + (size_t)(nt + 1) * TR * RK);
+    P.nstage = smem + ((nt + 1) & 1) * STAGE;
+    const unsigned sbase = lds0 + (nt & 1) * STAGE;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.aW[k] = sbase + relW[k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      P.acc0[i] = 0.f;
+      P.acc1[i] = 0.f;
+    }
+    P.template prologue<0>();
+    P.template step<0>();
+#pragma unroll
+    for (int g = 0; g < 4 * NT; ++g) {
+      const int n = nt * TR + g * 8 + hi * 4;
+      const bool ok = n + 3 < N;
+      const float4 b = *reinterpret_cast<const float4*>(sbias + n);
+      const float4 gm = *reinterpret_cast<const float4*>(sp_res + (ok ? n : 0));
+      const float4 gs = *reinterpret_cast<const float4*>(sp_res + LN_DP + (ok ? n : 0));
+      const int rq = g & 3;
+      float v0 = (g < 4 ? P.acc0[rq * 4 + 0] : P.acc1[rq * 4 + 0]) + b.x + fmaf((rv[g].x - rst.x) * rst.y, gm.x, gs.x);
+      float v1 = (g < 4 ? P.acc0[rq * 4 + 1] : P.acc1[rq * 4 + 1]) + b.y + fmaf((rv[g].y - rst.x) * rst.y, gm.y, gs.y);
+      float v2 = (g < 4 ? P.acc0[rq * 4 + 2] : P.acc1[rq * 4 + 2]) + b.z + fmaf((rv[g].z - rst.x) * rst.y, gm.z, gs.z);
+      float v3 = (g < 4 ? P.acc0[rq * 4 + 3] : P.acc1[rq * 4 + 3]) + b.w + fmaf((rv[g].w - rst.x) * rst.y, gm.w, gs.w);
+      if (!ok) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+      s1 += (v0 + v1) + (v2 + v3);
+      s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      // a column group is invalid for ALL lanes or none and only in the LAST tile, so every tile that is
+      // followed by a loop-top vmcnt wait issues exactly 4*NT store instructions per wave
+      if (ok) *reinterpret_cast<float4*>(crow + nt * TR + g * 8) = make_float4(v0, v1, v2, v3);
+    }
+  }
+  if (stats_out) store_row_stats(stats_out, m, M, hi, s1, s2, N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,16 +730,35 @@ void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t
   if (tag == 0 && k29 && g.C16 && !g.C32 && !g.res && !g.relu && g.N % 64 == 0 && !ex.res.x && !ex.stats_out &&
       !getenv("LDM_ROWGEMM_V1")) {
     constexpr int KS = 29;
-    const int n_tiles = g.N / 64;
-    const int lds = 2 * 64 * RKB + g.N * 4 + 2 * LN_DP * 4;
-    auto kern = rowgemm16_k<KS>;
+    static const int tr = getenv("LDM_ROW_TR") ? atoi(getenv("LDM_ROW_TR")) : 32;
+    const int n_tiles = g.N / tr;
+    const int lds = 2 * tr * RKB + g.N * 4 + 2 * LN_DP * 4;
+    auto kern = tr == 32 ? rowgemm16_k<KS, 32> : rowgemm16_k<KS, 64>;
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)rowgemm16_k<KS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)rowgemm16_k<KS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
     hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W,
                        g.lda, n_tiles, g.bias, g.C16, g.ldc16, g.N, g.M, ex.in);
+    return;
+  }
+  if (tag == 1 && !k29 && g.K <= 512 && g.C32 && !g.C16 && !g.relu && ex.res.x && !ex.in.x && g.ldc32 % 4 == 0 &&
+      g.N % 8 == 0 && !getenv("LDM_ROWGEMM_V1")) {
+    constexpr int KS = 32;
+    static const int tr = getenv("LDM_ROW_TR") ? atoi(getenv("LDM_ROW_TR")) : 32;
+    const int n_tiles = (g.N + tr - 1) / tr;
+    const int lds = 2 * tr * RKB + n_tiles * tr * 4 + 2 * LN_DP * 4;
+    auto kern = tr == 32 ? rowgemm32_k<KS, 32> : rowgemm32_k<KS, 64>;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)rowgemm32_k<KS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)rowgemm32_k<KS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, g.lda, (const __half*)g.W,
+                       n_tiles, g.bias, g.C32, g.ldc32, g.N, g.M, ex.res, ex.stats_out);
     return;
   }
   switch (tag) {

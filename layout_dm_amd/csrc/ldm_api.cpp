@@ -256,7 +256,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
-  if (chunk <= 0) chunk = 256;
+  if (chunk <= 0) chunk = 512;
   chunk = std::min(chunk, cfg->max_batch);
   h->chunk = chunk;
 
