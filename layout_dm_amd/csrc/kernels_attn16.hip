@@ -17,6 +17,8 @@
 //       D[i = d][j = query] gives each lane 4 consecutive d of its query: 8-byte stores.
 // K is staged in LDS with the XOR-swizzled 128-B-row image (conflict-free ds_read_b128), V is staged
 // transposed ([d][key], row stride 132 halfs -> conflict-free ds_read_b64).
+#include <cstdlib>
+
 #include "ldm_kernels.h"
 
 namespace ldm {
@@ -27,9 +29,12 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
 constexpr int VT_LD = 132;  // halfs per V^T row
 
+// ABL (timing ablations only): 0 = full kernel, 1 = no global loads, 2 = loads + QK^T only, 3 = no PV
+template <int ABL>
 __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qkv, __half* __restrict__ out, int S,
                                                    int H, int ldq, int ldo, float scale_log2e) {
   __shared__ __attribute__((aligned(16))) __half Ks[128 * 64];
+  __shared__ __attribute__((aligned(16))) __half Qs[128 * 64];
   __shared__ __attribute__((aligned(16))) __half Vt[64 * VT_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -41,49 +46,39 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
   const __half* vbase = qbase + (size_t)2 * H * 64;
   const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 
-  {  // K -> LDS (swizzled rows): thread = (row, half-row), 4 x 16 B
-    const int row = tid >> 1, hr = tid & 1;
-    const int sw = (row >> 1) & 7;
+  {  // Q, K, V -> LDS with FULL-LINE loads: 8 consecutive lanes fetch the 8 16-B chunks of one 128-B head
+     // row (one request per line instead of 4-8), 32 rows per pass.  Q/K keep the XOR-swizzled row image,
+     // V is transposed on the way in (ds_write_b16).
+    const int c = tid & 7;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int chunk = hr * 4 + c;
-      const uint4 v = (row < S) ? *reinterpret_cast<const uint4*>(kbase + (size_t)row * ldq + chunk * 8) : z4;
-      *reinterpret_cast<uint4*>(&Ks[row * 64 + ((chunk ^ sw) << 3)]) = v;
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const bool ok = ABL != 1 && row < S;
+      const size_t go = (size_t)row * ldq + c * 8;
+      const uint4 kv = ok ? *reinterpret_cast<const uint4*>(kbase + go) : z4;
+      const uint4 qv = ok ? *reinterpret_cast<const uint4*>(qbase + go) : z4;
+      const uint4 vv = ok ? *reinterpret_cast<const uint4*>(vbase + go) : z4;
+      const int so = row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
+      *reinterpret_cast<uint4*>(&Ks[so]) = kv;
+      *reinterpret_cast<uint4*>(&Qs[so]) = qv;
+      const unsigned short* pv = reinterpret_cast<const unsigned short*>(&vv);
+      unsigned short* vt = reinterpret_cast<unsigned short*>(Vt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt[(c * 8 + e) * VT_LD + row] = pv[e];
     }
   }
-  {  // V -> LDS transposed: thread = (key pair, 16-wide d chunk); packs (key, key+1) into one dword
-    const int kp = tid & 63, dc = tid >> 6;
-    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-    uint4 a[2], c[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i] = (k0 < S) ? *reinterpret_cast<const uint4*>(vbase + (size_t)k0 * ldq + dc * 16 + i * 8) : z4;
-      c[i] = (k1 < S) ? *reinterpret_cast<const uint4*>(vbase + (size_t)k1 * ldq + dc * 16 + i * 8) : z4;
-    }
-    const unsigned short* pa = reinterpret_cast<const unsigned short*>(a);
-    const unsigned short* pc = reinterpret_cast<const unsigned short*>(c);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const unsigned w = (unsigned)pa[e] | ((unsigned)pc[e] << 16);
-      *reinterpret_cast<unsigned*>(&Vt[(dc * 16 + e) * VT_LD + k0]) = w;
-    }
-  }
-
   const int j = lane & 31;  // this lane's query (within the wave's 32) / fragment row
   const int hi = lane >> 5;
   const int q = wave * 32 + j;
-  f16x8 qf[4];
-  {
-    const int qr = q < S ? q : S - 1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      qf[ks] = *reinterpret_cast<const f16x8*>(qbase + (size_t)qr * ldq + ks * 16 + hi * 8);
-  }
+  const int ksw = (j >> 1) & 7;
   __syncthreads();
+  f16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const f16x8*>(&Qs[q * 64 + (((ks * 2 + hi) ^ ksw) << 3)]);
 
   // ---- scores^T: 4 key tiles x 4 k-steps
   f32x16 sc[4];
-  const int ksw = (j >> 1) & 7;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
@@ -93,6 +88,15 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
       const f16x8 kf = *reinterpret_cast<const f16x8*>(&Ks[(kt * 32 + j) * 64 + (((ks * 2 + hi) ^ ksw) << 3)]);
       sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[kt], 0, 0, 0);
     }
+  }
+  if (ABL == 2) {
+    float t = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sc[kt][r];
+    if (q < S) out[(row0 + q) * ldo + (size_t)h * 64 + hi] = __float2half(t);
+    return;
   }
   // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32).  VALU-lean: only the last key
   // tile can hold padded keys; exp(scale*(s-max)) is one v_fma + one raw v_exp_f32 per score.
@@ -120,6 +124,10 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
 
+  if (ABL == 3) {
+    if (q < S) out[(row0 + q) * ldo + (size_t)h * 64 + hi] = __float2half(inv + (float)sc[1][3]);
+    return;
+  }
   // ---- O^T = V^T · P^T: 2 d-tiles x 8 k-steps (k-slot e of group hi <-> accumulator reg 8*half+e)
   f32x16 o[2];
 #pragma unroll
@@ -165,7 +173,9 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
 
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st) {
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  hipLaunchKernelGGL(attn_mfma_k, dim3(B * H), dim3(256), 0, st, qkv, out, S, H, ldq, ldo, scale_log2e);
+  static const int abl = getenv("LDM_ATTN_ABL") ? atoi(getenv("LDM_ATTN_ABL")) : 0;
+  auto kern = abl == 1 ? attn_mfma_k<1> : abl == 2 ? attn_mfma_k<2> : abl == 3 ? attn_mfma_k<3> : attn_mfma_k<0>;
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), 0, st, qkv, out, S, H, ldq, ldo, scale_log2e);
 }
 
 }  // namespace ldm

@@ -1154,3 +1154,35 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
   if (bias1) hipFree(bias1);
   return e == hipSuccess ? 0 : -2;
 }
+
+// attention micro-benchmark (dev tool): B layouts x 8 heads on random fp16 qkv
+extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
+  const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;
+  const size_t rows = (size_t)B * S + 256;
+  std::vector<uint16_t> hq(rows * ldq);
+  uint32_t s = 777u;
+  for (auto& x : hq) {
+    s = s * 1664525u + 1013904223u;
+    x = f2h_bits(((float)(s >> 8) / 8388608.0f) - 1.0f);
+  }
+  __half *q = nullptr, *o = nullptr;
+  if (hipMalloc((void**)&q, hq.size() * 2) != hipSuccess || hipMalloc((void**)&o, rows * ldo * 2) != hipSuccess) return -3;
+  hipMemcpy(q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) launch_attention16(q, o, B, S, H, 58, ldq, ldo, 0);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) launch_attention16(q, o, B, S, H, 58, ldq, ldo, 0);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  *ms_out = ms / iters;
+  const hipError_t e = hipGetLastError();
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  hipFree(q);
+  hipFree(o);
+  return e == hipSuccess ? 0 : -2;
+}
