@@ -249,7 +249,7 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int NT2, int PF>
+template <int KS, int NT2, int PF, int DE = 2>
 struct FfnPipe {
   static constexpr int NIT = KS + 2 * NT2;
   f16x8 q[PF];
@@ -261,7 +261,7 @@ struct FfnPipe {
   f16x8 pf[2];
   float4 bb[4];
   // next chunk's weight DMA, issued one 1-KiB instruction every DMA_EVERY MFMAs (hidden in MFMA shadow)
-  static constexpr int DMA_EVERY = 2;
+  static constexpr int DMA_EVERY = DE;
   static constexpr int NINST = 32 + NT2 * 2;
   static constexpr int IPW = (NINST + 3) / 4;
   const char* gW1;      // W1 + next chunk (uniform)
@@ -304,7 +304,10 @@ struct FfnPipe {
       wait_lgkm<after>();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
-      if constexpr (IT < KS) {
+      if constexpr (IT == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[0], zero, 0, 0, 0);  // C = inline constant 0
+      } else if constexpr (IT < KS) {
         ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], ha, 0, 0, 0);
       } else {
         constexpr int sx = (IT - KS) / NT2, t = (IT - KS) % NT2;
@@ -343,7 +346,7 @@ struct FfnPipe {
 };
 
 // ABL: timing ablations only (1 = no weight DMA after the first chunk, 2 = no LDS reads / MFMAs)
-template <int KS, int NT2, int ABL>
+template <int KS, int NT2, int ABL, int PF = 8, int DE = 2>
 __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
                                                       const float* __restrict__ b1, const __half* __restrict__ W2p,
                                                       int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
@@ -354,7 +357,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
   constexpr int NINST = 32 + W2_INST;
   constexpr int IPW = (NINST + 3) / 4;
-  constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
   float* sp_in = sb1 + n_chunks * 32;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   for (int sx = 0; sx < 2; ++sx) relW2[sx] = r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);
   const unsigned relB = lds0 + 2 * STAGE + hi * 16;
 
-  FfnPipe<KS, NT2, PF> P;
+  FfnPipe<KS, NT2, PF, DE> P;
   P.xf = xf;
   P.acc = acc;
   P.wave = wave;
@@ -429,8 +431,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     dsr128f<32>(P.bb[1], ab);
     dsr128f<64>(P.bb[2], ab);
     dsr128f<96>(P.bb[3], ab);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) P.ha[i] = 0.f;
     if constexpr (ABL == 2) {
       P.template dma_all<0>();
     } else {
@@ -777,7 +777,14 @@ void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b
   constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
   const int lds = 2 * (W1_STAGE + NT2 * 32 * 64) + F * 4 + 2 * LN_DP * 4;
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
-  auto kern = dbg == 1 ? ffn_fused2_k<KS, NT2, 1> : dbg == 2 ? ffn_fused2_k<KS, NT2, 2> : ffn_fused2_k<KS, NT2, 0>;
+  static const int var = getenv("LDM_FFN_VAR") ? atoi(getenv("LDM_FFN_VAR")) : 0;
+  auto kern = dbg == 1   ? ffn_fused2_k<KS, NT2, 1>
+              : dbg == 2 ? ffn_fused2_k<KS, NT2, 2>
+              : var == 1 ? ffn_fused2_k<KS, NT2, 0, 6, 2>
+              : var == 2 ? ffn_fused2_k<KS, NT2, 0, 10, 2>
+              : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 1>
+              : var == 4 ? ffn_fused2_k<KS, NT2, 0, 8, 3>
+                         : ffn_fused2_k<KS, NT2, 0>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
