@@ -110,20 +110,36 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
       mx = fmaxf(mx, xv[j]);
     }
     mx = wmax(mx);
-    double se = 0.0;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C - 1) se += exp((double)xv[j] - (double)mx);
-    }
-    se = wsumd(se);
-    const double lse0 = log(se);
     float l0[NJ];
+    if (p.f32_lse) {  // fast numerics mode: ~1e-7 relative, far inside its 1e-3 logits budget
+      float se = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int c = lane + 64 * j;
-      float v = (c < C - 1) ? (float)(((double)xv[j] - (double)mx) - lse0) : -70.0f;
-      l0[j] = fminf(fmaxf(v, -70.0f), 0.0f);
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C - 1) se += expf(xv[j] - mx);
+      }
+      const float lse0 = logf(wsum(se));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        const float v = (c < C - 1) ? (xv[j] - mx) - lse0 : -70.0f;
+        l0[j] = fminf(fmaxf(v, -70.0f), 0.0f);
+      }
+    } else {
+      double se = 0.0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C - 1) se += exp((double)xv[j] - (double)mx);
+      }
+      se = wsumd(se);
+      const double lse0 = log(se);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = lane + 64 * j;
+        float v = (c < C - 1) ? (float)(((double)xv[j] - (double)mx) - lse0) : -70.0f;
+        l0[j] = fminf(fmaxf(v, -70.0f), 0.0f);
+      }
     }
     // ---- constrained posterior in this token's attribute sub-vocabulary
     const int T1 = p.T + 1;
@@ -270,7 +286,13 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
       __builtin_amdgcn_wave_barrier();
       float cum[NJ] = {0.f, 0.f, 0.f};
       int rank[NJ] = {0, 0, 0};
-      for (int o = 0; o < C; ++o) {
+      // Only classes of this token's sub-vocabulary can carry mass (every other class sits at
+      // log(1e-30), layout_tokenizer.py:544): walk body + PAD + MASK instead of all C classes.  With a
+      // full-vocabulary logp_in (ldm_sample_tokens hook) every class is a candidate.
+      const int a_start = p.v.start[attr], a_cnt = p.v.count[attr];
+      const int n_cand = p.logp_in ? C : a_cnt + 2;
+      for (int oi = 0; oi < n_cand; ++oi) {
+        const int o = p.logp_in ? oi : (oi < a_cnt ? a_start + oi : (oi == a_cnt ? pad_id : mask_id));
         const float ol = sh_lg[wave][o];
         const float op = sh_pr[wave][o];
 #pragma unroll

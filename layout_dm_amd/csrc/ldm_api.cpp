@@ -800,6 +800,7 @@ static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, 
 static void fill_post(ldm_handle* h, PostArgs& p, const ldm_cond* cond, const ldm_sampler* s, size_t layout_off,
                       int Bc) {
   p.sched = h->sched;
+  p.f32_lse = h->cfg.precision == LDM_PREC_FAST_F16 ? 1 : 0;
   p.T = h->T;
   p.B = Bc;
   p.S = h->S;

@@ -107,6 +107,7 @@ struct PostArgs {
   float temperature, top_p;
   int top_k;
   const uint64_t* rng;     // device {seed, first_layout}
+  int f32_lse;             // 1: fp32 log-softmax (fast numerics mode); 0: float64 like the reference (base.py:137)
   int layout_off;          // + offset of this launch's first layout inside the call's batch
   int step;                // reverse-loop index (RNG counter word)
   int B, S;
