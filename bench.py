@@ -195,6 +195,17 @@ def main():
                     "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "share_of_step": round(dom["ms"] / tot, 3)}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the
+        # value comes from the committed rocprofv3 --pmc pass (profiles/r01_traffic.json), scaled to this
+        # launch's row count; null when no measurement exists for the kernel.
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(dom["name"])
+            if tr and a.precision == "fast":
+                rows_per_launch = min(eng.cfg.chunk or 512, B) * eng.S
+                roof["traffic"] = int((tr["fetch_kb"] + tr["write_kb"]) * 1024 * rows_per_launch / tr["M"])
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw)"
+        except Exception:
+            pass
         out["roofline"] = roof
         out["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
         gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(("gemm", "ffn")))

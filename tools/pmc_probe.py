@@ -1,9 +1,12 @@
-"""Dev tool: launch the fused FFN a few times (for rocprofv3 --pmc passes)."""
-import ctypes as C, os, sys
+"""Dev tool: one short fast-mode loop (for rocprofv3 --pmc passes over the production kernels)."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from layout_dm_amd.binding import load_library
-lib = load_library()
-lib.ldm_dev_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
-ms = C.c_float()
-lib.ldm_dev_bench_gemm(32000, 464, 464, 101, 3, C.byref(ms))
-print(ms.value)
+import torch
+from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion
+from layout_dm_amd import synthetic as SP
+spec = SP.RICO25
+m = HipMaskAndReplaceDiffusion(n_category=25, precision="fast", max_batch=512, use_graph=False)
+m.load_state_dict(SP.synth_state_dict(spec, seed=0))
+out = m.sample(batch_size=512, sampling_cfg={"name": "random", "temperature": 1.0, "num_timesteps": 4}, seed=1)
+torch.cuda.synchronize()
+print(out.shape)
