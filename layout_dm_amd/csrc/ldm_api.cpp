@@ -119,6 +119,10 @@ struct ldm_handle {
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
+  // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
+  int32_t* st_cond_seq = nullptr;
+  uint8_t* st_strong = nullptr;
+  float* st_weak = nullptr;
   int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
   uint64_t* rng = nullptr;                      // device {seed, first_layout}
   // profiling
@@ -309,6 +313,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   A(&h->tok_a, (size_t)cfg->max_batch * h->S);
   A(&h->tok_b, (size_t)cfg->max_batch * h->S);
+  A(&h->st_cond_seq, (size_t)cfg->max_batch * h->S);
+  A(&h->st_strong, (size_t)cfg->max_batch * h->S);
   A(&h->rng, 2);
   A(&h->sched, (size_t)kNumSched * cfg->n_attr * (h->T + 1));
   if (rc != 0) {
@@ -985,6 +991,27 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
   HIP_OK(h, hipMemcpyAsync(h->tok_a, d_tokens_inout, nbytes, hipMemcpyDeviceToDevice, st));
   if (use_graph && !h->profiling) {
+    // copy the constraints into handle-owned staging buffers: the captured graph then only ever sees
+    // fixed addresses and is reused across batches whose cond tensors live elsewhere
+    ldm_cond staged{};
+    if (cond) {
+      const size_t nS = (size_t)B * h->S;
+      staged.pad_disable = cond->pad_disable;
+      if (cond->d_cond_seq) {
+        HIP_OK(h, hipMemcpyAsync(h->st_cond_seq, cond->d_cond_seq, nS * 4, hipMemcpyDeviceToDevice, st));
+        staged.d_cond_seq = h->st_cond_seq;
+      }
+      if (cond->d_strong_mask) {
+        HIP_OK(h, hipMemcpyAsync(h->st_strong, cond->d_strong_mask, nS, hipMemcpyDeviceToDevice, st));
+        staged.d_strong_mask = h->st_strong;
+      }
+      if (cond->d_weak_logits) {
+        if (!h->st_weak && (rc = h->dalloc(&h->st_weak, (size_t)h->cfg.max_batch * h->C * h->S, false))) return rc;
+        HIP_OK(h, hipMemcpyAsync(h->st_weak, cond->d_weak_logits, nS * h->C * 4, hipMemcpyDeviceToDevice, st));
+        staged.d_weak_logits = h->st_weak;
+      }
+      cond = &staged;
+    }
     GraphKey key{};
     key.B = B; key.n_steps = n_steps; key.kind = s->kind; key.top_k = s->top_k;
     key.temperature = s->temperature; key.top_p = s->top_p;

@@ -401,3 +401,29 @@ def test_relation_split_step_equals_fused_with_identity_update(cuda):
     split = sample_with_relation(m, 4, rel, cfg, _MockTokenizer(spec), update_fn=ident, seed=77)
     assert torch.equal(fused, split)
     assert (split[cond["mask"]] == cond["seq"][cond["mask"]]).all()
+
+
+def test_loop_time_difference_and_cond_graph_reuse(cuda):
+    """(a) time_difference > 0 (base.py:218-225) through the host schedule == oracle; (b) conditional
+    loops replayed from ONE captured graph stay correct when the caller's cond tensors move."""
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion
+
+    spec, W = weights("publaynet")
+    m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, precision="exact", max_batch=4)
+    m.load_state_dict(synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True))
+    cfg = {"name": "deterministic", "num_timesteps": 20, "time_difference": 0.1}
+    out = m.sample(batch_size=3, sampling_cfg=cfg)
+    ref = R.sample_loop(W, spec, 3, cfg)
+    assert torch.equal(out, ref)
+    cfg = {"name": "deterministic", "num_timesteps": 10}
+    outs = []
+    for seed in (0, 1, 2):
+        c = synth.synth_cond_c(spec, 4, seed=seed)
+        cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": "c"}
+        junk = torch.empty(1000 * (seed + 1), device="cuda")  # perturb the allocator between calls
+        got = m.sample(batch_size=4, cond=cond, sampling_cfg=cfg)
+        want = R.sample_loop(W, spec, 4, cfg, cond={"seq": c["seq"], "mask": c["mask"], "type": "c"})
+        assert torch.equal(got, want), seed
+        del junk
+        outs.append(got)
+    assert not torch.equal(outs[0], outs[1])
