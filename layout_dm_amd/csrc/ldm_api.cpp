@@ -283,13 +283,6 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->Fq = round_up(h->F, 64);
     h->Mpad = round_up((int)Mc, 256);
     const size_t Mp = h->Mpad;
-    A(&h->a16, Mp * h->Dq);
-    A(&h->h16, Mp * h->Dq);
-    A(&h->att16, Mp * h->HD);
-    A(&h->hid16, Mp * h->Fq);
-    A(&h->qkv16, Mp * 3 * h->HD);
-    A(&h->stats_a, Mp);
-    A(&h->stats_b, Mp);
     const char* env = getenv("LDM_GEMM_CFG");  // "q,o,1,2,h" tile-config ids (tuning override)
     int defaults[5] = {5, 5, 5, 5, 5};
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
@@ -298,6 +291,15 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (h->D > 464 || h->HD > 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
     if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
+    A(&h->att16, Mp * h->HD);
+    A(&h->qkv16, Mp * 3 * h->HD);
+    A(&h->stats_a, Mp);
+    A(&h->stats_b, Mp);
+    if (!h->defer_ln) {  // LayerNorm outputs only exist on the non-deferred path
+      A(&h->a16, Mp * h->Dq);
+      A(&h->h16, Mp * h->Dq);
+    }
+    if (!(h->row_impl & 4)) A(&h->hid16, Mp * h->Fq);  // FFN hidden only without the fused FFN kernel
   } else {
     A(&h->a16, Mc * h->Dp);
     A(&h->att16, Mc * h->Dp);
