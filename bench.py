@@ -208,8 +208,8 @@ def main():
             pass
         out["roofline"] = roof
         out["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
-        gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(("gemm", "ffn")))
-        gemm_fl = sum(r["flops"] for r in rows if r["name"].startswith(("gemm", "ffn")))
+        gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(("gemm", "ffn", "qkv")))
+        gemm_fl = sum(r["flops"] for r in rows if r["name"].startswith(("gemm", "ffn", "qkv")))
         if gemm_ms > 0:
             out["gemm_mfma_utilisation"] = round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision], 4)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

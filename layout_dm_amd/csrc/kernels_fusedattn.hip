@@ -1,0 +1,348 @@
+// Fused QKV projection + self-attention, one workgroup per LAYOUT (125 tokens = 4 waves x 32 rows).
+//
+// The unfused fast path writes qkv ([M, 3*8*64] fp16, 197 MB per 512-layout chunk) and reads it back
+// in the attention kernel: ~40 us of the attention launch and the whole store phase of the QKV GEMM
+// are that round trip.  Here q/k/v of a layout never leave the CU:
+//   * each wave keeps its 32 AdaLN-normalised token rows as MFMA operand fragments in registers
+//     (normalised while loading: deferred normalisation, see kernels_rowgemm.hip);
+//   * per head the six 32-row weight tiles (k0 k1 v0 v1 q0 q1) stream through the LDS-DMA ring;
+//       K tile : D[i=d][j=key]   = W·X^T   -> +bias, fp16, written to Ks[key][d] in MFMA k-slot order
+//       V tile : D[i=key][j=d]   = X·W^T   (operands swapped) -> V^T fragments, written to Vs[d][key-slot]
+//       Q tile : D[i=d][j=query] = W·X^T   -> +bias, fp16: IS the B operand of S^T = K·Q^T (stays in VGPRs)
+//   * then the attention core of kernels_attn16.hip (one 128x128 score tile, in-register softmax, P fed
+//     to PV straight from the accumulators) runs on Ks/Vs (double-buffered by head parity, so the only
+//     synchronisation is the ring's own per-tile barrier);
+//   * output: the head-padded attention rows att[M, 8*64] fp16, exactly what attn_mfma_k produces.
+// Reference semantics: torch.nn.MultiheadAttention in/out of trainer/models/transformer_utils.py:140-142,
+// 197-204 with AdaLayerNorm (l.72-83) applied to the input.
+#include <cstdlib>
+
+#include "ldm_kernels.h"
+
+namespace ldm {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+constexpr int RK = 512;
+constexpr int RKB = RK * 2;
+constexpr int STAGE = 32 * RKB;  // one 32-row weight tile
+constexpr int LN_DP = 512;
+constexpr int KV_BYTES = 128 * 128;  // Ks: 128 keys x 64 halfs ; Vs: 64 d x 128 key-slots (both 16 KiB)
+
+__device__ __forceinline__ void dma16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)l, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 29 (KS) dependent-free reads/MFMAs of one weight tile; SWAP = false: acc = W·X^T, true: acc = X·W^T
+template <int KS, int PF>
+struct TilePipe {
+  f16x8 q[PF];
+  unsigned aW[8];
+  const f16x8* xf;
+  f32x16 acc;
+  const char* gW;
+  char* nstage;
+  unsigned lo1[4];
+  int wave;
+  bool has_next;
+
+  template <int IT>
+  __device__ __forceinline__ void read_item() {
+    dsr128<256 * (IT >> 3)>(q[IT % PF], aW[IT & 7]);
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_slot() {
+    if constexpr (J < 8) {
+      if (has_next) {
+        const int i = wave + 4 * J;
+        dma16(gW + i * RKB + lo1[J & 3], nstage + i * RKB);
+      }
+    }
+  }
+  template <int IT, bool SWAP>
+  __device__ __forceinline__ void step() {
+    if constexpr (IT < KS) {
+      constexpr int after = (KS - 1 - IT) < (PF - 1) ? (KS - 1 - IT) : (PF - 1);
+      wait_lgkm<after>();
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 cur = q[IT % PF];
+      if constexpr (IT == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[0], cur, zero, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[0], zero, 0, 0, 0);
+      } else {
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[IT], cur, acc, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT + PF < KS) read_item<IT + PF>();
+      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
+      step<IT + 1, SWAP>();
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void prologue() {
+    if constexpr (IT < PF) {
+      read_item<IT>();
+      prologue<IT + 1>();
+    }
+  }
+  template <bool SWAP>
+  __device__ __forceinline__ void run() {
+    prologue<0>();
+    step<0, SWAP>();
+  }
+};
+
+template <int S8>
+__device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const float4& b1) {
+  f16x8 o;
+  o[0] = (_Float16)(a[S8 + 0] + b0.x); o[1] = (_Float16)(a[S8 + 1] + b0.y);
+  o[2] = (_Float16)(a[S8 + 2] + b0.z); o[3] = (_Float16)(a[S8 + 3] + b0.w);
+  o[4] = (_Float16)(a[S8 + 4] + b1.x); o[5] = (_Float16)(a[S8 + 5] + b1.y);
+  o[6] = (_Float16)(a[S8 + 6] + b1.z); o[7] = (_Float16)(a[S8 + 7] + b1.w);
+  return o;
+}
+
+}  // namespace
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ Win, const float* __restrict__ bias,
+                                                    LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
+                                                    int M, float scale_log2e) {
+  constexpr int PF = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;                       // 2 x 32 KiB weight tiles
+  char* kvbuf = smem + 2 * STAGE;          // [2 parities][Ks 16 KiB | Vs 16 KiB]
+  float* sbias = reinterpret_cast<float*>(kvbuf + 4 * KV_BYTES);  // [3*H*64]
+  float* sp = sbias + 3 * H * 64;          // AdaLN multiplier / shift (2 x LN_DP)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x;
+  const int row_in = wave * 32 + r;          // token index inside the layout (>= S: padding)
+  const bool valid = row_in < S;
+  const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
+
+  for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias[i];
+  for (int i = tid; i < ln.D; i += 256) {
+    sp[i] = ln.ada ? 1.0f + ln.p0[i] : ln.p0[i];
+    sp[LN_DP + i] = ln.p1[i];
+  }
+  __syncthreads();
+  f16x8 xf[KS];
+  {
+    const float2 st = ln.stats[m];
+    const float* xr = ln.x + m * ln.ldx + hi * 8;
+    const float* mp = sp + hi * 8;
+    unsigned opq = 0;  // always 0, but opaque to the optimiser
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // every 2 k-steps an (always zero) offset is made opaque AND data-dependent on the previous fragment: hipcc
+      // otherwise issues all 58 row loads + 116 parameter reads up front (~700 live VGPRs -> scratch spills)
+      if (ks % 2 == 0 && ks > 0) asm volatile("" : "+v"(opq) : "v"(xf[ks - 1]));
+      const float4 a = *reinterpret_cast<const float4*>(xr + opq + ks * 16);
+      const float4 c = *reinterpret_cast<const float4*>(xr + opq + ks * 16 + 4);
+      const float4 ga = *reinterpret_cast<const float4*>(mp + opq + ks * 16);
+      const float4 gb = *reinterpret_cast<const float4*>(mp + opq + ks * 16 + 4);
+      const float4 sa = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16);
+      const float4 sb = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16 + 4);
+      xf[ks][0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
+      xf[ks][1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
+      xf[ks][2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
+      xf[ks][3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
+      xf[ks][4] = (_Float16)fmaf((c.x - st.x) * st.y, gb.x, sb.x);
+      xf[ks][5] = (_Float16)fmaf((c.y - st.x) * st.y, gb.y, sb.y);
+      xf[ks][6] = (_Float16)fmaf((c.z - st.x) * st.y, gb.z, sb.z);
+      xf[ks][7] = (_Float16)fmaf((c.w - st.x) * st.y, gb.w, sb.w);
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned relW[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) relW[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+  unsigned lo1[4];
+#pragma unroll
+  for (int jm = 0; jm < 4; ++jm) lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
+
+  // tile sequence: ti = h*6 + j ; j -> (which, t): k0 k1 v0 v1 q0 q1
+  auto tile_row = [&](int ti) {
+    const int h = ti / 6, j = ti % 6;
+    const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
+    return (which * H + h) * 64 + (j & 1) * 32;
+  };
+  const int n_tiles = H * 6;
+  {
+    const __half* w0 = Win + (size_t)tile_row(0) * RK;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = wave + 4 * j;
+      dma16(w0 + (size_t)i * RK + ((lane ^ (i & 15)) << 3), ring + i * RKB);
+    }
+  }
+  f16x8 qf[4];
+  const int ksw = (r >> 1) & 7;
+  TilePipe<KS, PF> P;
+  P.xf = xf;
+  P.wave = wave;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P.lo1[k] = lo1[k];
+
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int h = ti / 6, j = ti % 6;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool has_next = ti + 1 < n_tiles;
+    const char* gW = reinterpret_cast<const char*>(Win + (size_t)tile_row(has_next ? ti + 1 : ti) * RK);
+    char* nstage = ring + ((ti + 1) & 1) * STAGE;
+    const unsigned sbase = lds0 + (ti & 1) * STAGE;
+    char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
+    char* Vs = Ks + KV_BYTES;
+    P.has_next = has_next;
+    P.gW = gW;
+    P.nstage = nstage;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) P.aW[k] = sbase + relW[k];
+    if (j == 2 || j == 3) P.template run<true>();
+    else P.template run<false>();
+    const f32x16& acc = P.acc;
+    const int t = j & 1;
+    if (j < 2) {
+      // K tile: lane (key = row_in, hi) holds d = 32t + 8*rq + 4*hi + i ; k-slot chunk c = 4t + 2s + hi
+      const float* bk = sbias + (H + h) * 64 + t * 32 + hi * 4;
+      {
+        const f16x8 v0 = cvt8<0>(acc, *reinterpret_cast<const float4*>(bk), *reinterpret_cast<const float4*>(bk + 8));
+        const f16x8 v1 = cvt8<8>(acc, *reinterpret_cast<const float4*>(bk + 16), *reinterpret_cast<const float4*>(bk + 24));
+        const int sw = (row_in >> 1) & 7;
+        *reinterpret_cast<f16x8*>(Ks + row_in * 128 + (((4 * t + hi) ^ sw) << 4)) = v0;
+        *reinterpret_cast<f16x8*>(Ks + row_in * 128 + (((4 * t + 2 + hi) ^ sw) << 4)) = v1;
+      }
+    } else if (j < 4) {
+      // V tile (swapped operands): lane (d = 32t + r, hi) holds keys 32*wave + 8*rq + 4*hi + i
+      const float bv = sbias[(2 * H + h) * 64 + t * 32 + r];
+      const float4 b4 = make_float4(bv, bv, bv, bv);
+      const int d = t * 32 + r;
+      {
+        const f16x8 v0 = cvt8<0>(acc, b4, b4);
+        const f16x8 v1 = cvt8<8>(acc, b4, b4);
+        *reinterpret_cast<f16x8*>(Vs + d * 256 + (((wave * 4 + hi) ^ (d & 15)) << 4)) = v0;
+        *reinterpret_cast<f16x8*>(Vs + d * 256 + (((wave * 4 + 2 + hi) ^ (d & 15)) << 4)) = v1;
+      }
+    } else {
+      // Q tile: stays in registers as the B operand of S^T (k-slot order = accumulator order)
+      const float* bq = sbias + h * 64 + t * 32 + hi * 4;
+      {
+        const f16x8 v0 = cvt8<0>(acc, *reinterpret_cast<const float4*>(bq), *reinterpret_cast<const float4*>(bq + 8));
+        const f16x8 v1 = cvt8<8>(acc, *reinterpret_cast<const float4*>(bq + 16), *reinterpret_cast<const float4*>(bq + 24));
+        if (t == 0) { qf[0] = v0; qf[1] = v1; } else { qf[2] = v0; qf[3] = v1; }
+      }
+    }
+    if (j != 5) continue;
+
+    // ------------------------------------------------------------------ attention for head h
+    // every wave wrote its K/V parts before the barriers of tiles j=4,5 => Ks/Vs are complete here
+    f32x16 sc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {  // ks = 2t + s ; chunk c = 4t + 2s + hi = 2*ks + hi
+        const f16x8 kf =
+            *reinterpret_cast<const f16x8*>(Ks + (kt * 32 + r) * 128 + (((2 * ks + hi) ^ ksw) << 4));
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[kt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = 96 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+      if (key >= S) sc[3][i] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nmxs = -mx * scale_log2e;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][i], scale_log2e, nmxs));
+        sc[kt][i] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (_Float16)sc[kt][hf * 8 + e];
+        const int c = kt * 4 + hf * 2 + hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d = dt * 32 + r;
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + d * 256 + ((c ^ (d & 15)) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (valid) {
+      __half* orow = att + m * ldo + (size_t)h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d = dt * 32 + rq * 8 + hi * 4;
+          const __half2 h0 = __floats2half2_rn(o[dt][rq * 4 + 0] * inv, o[dt][rq * 4 + 1] * inv);
+          const __half2 h1 = __floats2half2_rn(o[dt][rq * 4 + 2] * inv, o[dt][rq * 4 + 3] * inv);
+          uint2 pk;
+          pk.x = *reinterpret_cast<const unsigned*>(&h0);
+          pk.y = *reinterpret_cast<const unsigned*>(&h1);
+          *reinterpret_cast<uint2*>(orow + d) = pk;
+        }
+    }
+  }
+}
+
+// Win: head-padded in_proj image [3*H*64 rows][512] (q | k | v blocks of H*64 rows), bias [3*H*64].
+void launch_qkv_attention(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
+                          int H, int dh, hipStream_t st) {
+  constexpr int KS = 29;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4;
+  auto kern = qkv_attn_k<KS>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e);
+}
+
+}  // namespace ldm

@@ -119,6 +119,7 @@ struct ldm_handle {
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
+  int fused_attn = 1;  // QKV + attention in one per-layout kernel (qkv never leaves the CU)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -291,6 +292,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (h->D > 464 || h->HD > 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
     if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
+    if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
+    if (!h->defer_ln || h->S > 128 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
@@ -569,17 +572,22 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
     const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
-    {  // QKV = AdaLN(x)·Win^T + b   (AdaLN applied while loading the fragments)
+    if (h->fused_attn) {
+      ldm_handle::Scope sc(h, st, "qkv_attention", gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
+                           (double)M * (D * 4 + HD * 2));
+      launch_qkv_attention(f.w_in, f.b_in, ada, h->att16, HD, Bc, h->S, h->H, h->dh, st);
+    } else {
+      // QKV = AdaLN(x)·Win^T + b   (AdaLN applied while loading the fragments)
       GemmArgs g{};
       g.W = f.w_in; g.bias = f.b_in; g.C16 = h->qkv16; g.ldc16 = 3 * HD;
       g.M = M; g.N = 3 * HD; g.K = D; g.lda = Dq; g.ldw = Dq; g.precision = 1;
       RowExtra ex{};
       ex.in = ada;
-      ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * (D * 4 + 3 * HD * 2));
-      launch_rowgemm(g, 0, &ex, st);
-    }
-    {
-      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
+      {
+        ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * (D * 4 + 3 * HD * 2));
+        launch_rowgemm(g, 0, &ex, st);
+      }
+      ldm_handle::Scope sc2(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
       launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
     }
     {  // x1 = AdaLN(x) + att·Wo^T + bo -> Q (+ stats_b)
