@@ -119,16 +119,27 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 
 }  // namespace
 
-template <int KS>
+// FUSE_OUT: additionally run the attention out-projection + residual (+ row statistics) in the same
+// workgroup: att rows are written in MFMA k-slot order and read back by the SAME lanes as the B operand.
+struct OutProj {
+  const __half* W;     // [>=480 rows][512] out_proj weight, K axis = head-padded + k-slot order
+  const float* bias;   // [N]
+  float* C32;          // [M, ldc] x1 = AdaLN(x) + att·Wo^T + bo
+  float2* stats_out;   // [M]
+  int ldc, N;
+};
+
+template <int KS, bool FUSE_OUT>
 __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ Win, const float* __restrict__ bias,
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
-                                                    int M, float scale_log2e) {
+                                                    int M, float scale_log2e, OutProj op) {
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                       // 2 x 32 KiB weight tiles
   char* kvbuf = smem + 2 * STAGE;          // [2 parities][Ks 16 KiB | Vs 16 KiB]
   float* sbias = reinterpret_cast<float*>(kvbuf + 4 * KV_BYTES);  // [3*H*64]
   float* sp = sbias + 3 * H * 64;          // AdaLN multiplier / shift (2 x LN_DP)
+  float* sbo = sp + 2 * LN_DP;             // out-proj bias (FUSE_OUT)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,6 +150,8 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
   const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
 
   for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias[i];
+  if (FUSE_OUT)
+    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? op.bias[i] : 0.f;
   for (int i = tid; i < ln.D; i += 256) {
     sp[i] = ln.ada ? 1.0f + ln.p0[i] : ln.p0[i];
     sp[LN_DP + i] = ln.p1[i];
@@ -207,8 +220,9 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool has_next = ti + 1 < n_tiles;
-    const char* gW = reinterpret_cast<const char*>(Win + (size_t)tile_row(has_next ? ti + 1 : ti) * RK);
+    const bool has_next = FUSE_OUT || ti + 1 < n_tiles;
+    const char* gW = (ti + 1 < n_tiles) ? reinterpret_cast<const char*>(Win + (size_t)tile_row(ti + 1) * RK)
+                                        : reinterpret_cast<const char*>(op.W);  // first out-proj tile
     char* nstage = ring + ((ti + 1) & 1) * STAGE;
     const unsigned sbase = lds0 + (ti & 1) * STAGE;
     char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
@@ -312,7 +326,22 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
         }
       }
     }
-    if (valid) {
+    if (FUSE_OUT) {
+      // k-slot order: fragment (dt, s) of this lane = accumulator regs 8s..8s+7 -> 16 B at
+      // [row][h*64 + dt*32 + s*16 + hi*8]; read back below by the same lane
+      if (valid) {
+        __half* orow = att + m * ldo + (size_t)h * 64 + hi * 8;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)(o[dt][s2 * 8 + e] * inv);
+            *reinterpret_cast<f16x8*>(orow + dt * 32 + s2 * 16) = v;
+          }
+      }
+    } else if (valid) {
       __half* orow = att + m * ldo + (size_t)h * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -328,6 +357,76 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
         }
     }
   }
+  if constexpr (FUSE_OUT) {
+    // ------------------------------------------------------------------ out-projection phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own att stores are performed before reading back
+    f16x8 of[32];
+    {
+      const __half* arow = att + m * ldo + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) of[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
+    }
+    const float2 rst = ln.stats[m];
+    const float* rrow = ln.x + m * ln.ldx + hi * 4;
+    float* crow = op.C32 + m * op.ldc + hi * 4;
+    TilePipe<32, PF> Q2;
+    Q2.xf = of;
+    Q2.wave = wave;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Q2.lo1[k] = lo1[k];
+    const int n_out = (op.N + 31) / 32;
+    float s1 = 0.f, s2 = 0.f;
+    for (int ot = 0; ot < n_out; ++ot) {
+      const int ti = n_tiles + ot;
+      // oldest first: [DMA of this tile x8] [stores of the previous out tile x4]
+      if (ot == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      float4 rv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ot * 32 + g * 8 + hi * 4;
+        rv[g] = (n + 3 < op.N) ? *reinterpret_cast<const float4*>(rrow + ot * 32 + g * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      Q2.has_next = ot + 1 < n_out;
+      Q2.gW = reinterpret_cast<const char*>(op.W + (size_t)(ot + 1) * 32 * RK);
+      Q2.nstage = ring + ((ti + 1) & 1) * STAGE;
+      const unsigned sbase = lds0 + (ti & 1) * STAGE;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Q2.aW[k] = sbase + relW[k];
+      Q2.template run<false>();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ot * 32 + g * 8 + hi * 4;
+        const bool ok = n + 3 < op.N;
+        const float4 bb = *reinterpret_cast<const float4*>(sbo + n);
+        const float4 gm = *reinterpret_cast<const float4*>(sp + (ok ? n : 0));
+        const float4 gs = *reinterpret_cast<const float4*>(sp + LN_DP + (ok ? n : 0));
+        float v0 = Q2.acc[g * 4 + 0] + bb.x + fmaf((rv[g].x - rst.x) * rst.y, gm.x, gs.x);
+        float v1 = Q2.acc[g * 4 + 1] + bb.y + fmaf((rv[g].y - rst.x) * rst.y, gm.y, gs.y);
+        float v2 = Q2.acc[g * 4 + 2] + bb.z + fmaf((rv[g].z - rst.x) * rst.y, gm.z, gs.z);
+        float v3 = Q2.acc[g * 4 + 3] + bb.w + fmaf((rv[g].w - rst.x) * rst.y, gm.w, gs.w);
+        if (!ok) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+        s1 += (v0 + v1) + (v2 + v3);
+        s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        // invalid column groups occur only in the LAST tile and for all lanes alike; padding rows of the
+        // layout (row_in >= S) are redirected to the lane's own valid row with identical data? No: they
+        // simply skip the store — the count below (vmcnt(4)) stays exact because exec-masked stores of a
+        // partially active wave are still issued, and a fully inactive wave cannot occur (32 rows/wave,
+        // S > 96).
+        if (ok && valid) *reinterpret_cast<float4*>(crow + ot * 32 + g * 8) = make_float4(v0, v1, v2, v3);
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (valid && hi == 0 && op.stats_out) {
+      const float mean = s1 / (float)op.N;
+      const float var = fmaxf(s2 / (float)op.N - mean * mean, 0.f);
+      op.stats_out[m] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+    }
+  }
 }
 
 // Win: head-padded in_proj image [3*H*64 rows][512] (q | k | v blocks of H*64 rows), bias [3*H*64].
@@ -335,14 +434,32 @@ void launch_qkv_attention(const __half* Win, const float* bias, const LnLoad& ln
                           int H, int dh, hipStream_t st) {
   constexpr int KS = 29;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4;
-  auto kern = qkv_attn_k<KS>;
+  const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
+  auto kern = qkv_attn_k<KS, false>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e);
+  OutProj op{};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+}
+
+// same + out-projection: Wout_ks = out_proj weight with head-padded, k-slot-ordered K axis
+void launch_attention_block(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo,
+                            const __half* Wout_ks, const float* b_out, float* C32, int ldc, float2* stats_out, int N,
+                            int B, int S, int H, int dh, hipStream_t st) {
+  constexpr int KS = 29;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
+  auto kern = qkv_attn_k<KS, true>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  OutProj op{Wout_ks, b_out, C32, stats_out, ldc, N};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
 }
 
 }  // namespace ldm

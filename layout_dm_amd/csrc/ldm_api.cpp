@@ -112,14 +112,14 @@ struct ldm_handle {
   int row_impl = 0x7;  // bit0 QKV, bit1 out-proj, bit2 fused FFN, bit3 head use the row-stationary kernels
                        // (measured: row kernels win for QKV, out-proj, FFN; equal for the head)
   struct FastLayer {
-    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr;
+    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 1;  // QKV + attention in one per-layout kernel (qkv never leaves the CU)
+  int fused_attn = 2;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -466,6 +466,9 @@ static int build_fast_weights(ldm_handle* h) {
       return c + 16 * s2 + 8 * g + 4 * e_hi + e_lo;
     };
     if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &f.w2p))) return rc;
+    // fused attention block: the attention rows come back in accumulator (k-slot) order per head d-tile
+    auto head_kslot = [=](int k) { return kslot(head_col(k)); };
+    if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_kslot, &f.w_out_ks))) return rc;
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
     for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
@@ -572,7 +575,14 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
     const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
-    if (h->fused_attn) {
+    if (h->fused_attn == 2) {
+      // whole attention block: x1 = AdaLN(x) + MHA(AdaLN(x)) -> Q (+ stats_b)
+      ldm_handle::Scope sc(h, st, "qkv_attention_out",
+                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D),
+                           (double)M * (D * 8 + D * 4));
+      launch_attention_block(f.w_in, f.b_in, ada, h->att16, HD, f.w_out_ks, w.b_out, h->Q, D, h->stats_b, D, Bc, h->S,
+                             h->H, h->dh, st);
+    } else if (h->fused_attn) {
       ldm_handle::Scope sc(h, st, "qkv_attention", gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
                            (double)M * (D * 4 + HD * 2));
       launch_qkv_attention(f.w_in, f.b_in, ada, h->att16, HD, Bc, h->S, h->H, h->dh, st);
@@ -590,7 +600,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
       ldm_handle::Scope sc2(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
       launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
     }
-    {  // x1 = AdaLN(x) + att·Wo^T + bo -> Q (+ stats_b)
+    if (h->fused_attn != 2) {  // x1 = AdaLN(x) + att·Wo^T + bo -> Q (+ stats_b)
       GemmArgs g{};
       g.A = h->att16; g.W = f.w_out; g.bias = w.b_out; g.res = h->P; g.ldres = D; g.C32 = h->Q; g.ldc32 = D;
       g.M = M; g.N = D; g.K = HD; g.lda = HD; g.ldw = HD; g.precision = 1;
