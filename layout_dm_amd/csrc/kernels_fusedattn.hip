@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "ldm_kernels.h"
+#include "ldm_dma.h"
 
 namespace ldm {
 namespace {
@@ -34,11 +35,12 @@ constexpr int STAGE = 32 * RKB;  // one 32-row weight tile
 constexpr int LN_DP = 512;
 constexpr int KV_BYTES = 128 * 128;  // Ks: 128 keys x 64 halfs ; Vs: 64 d x 128 key-slots (both 16 KiB)
 
-__device__ __forceinline__ void dma16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)l, 16, 0, 0);
-}
 template <int OFF>
 __device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void dsr128f(float4& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 template <int N>
@@ -53,24 +55,23 @@ struct TilePipe {
   unsigned aW[8];
   const f16x8* xf;
   f32x16 acc;
-  const char* gW;
-  char* nstage;
-  unsigned lo1[4];
-  int wave;
-  bool has_next;
+  const char* gnext;  // image of the next tile + wave*8 KiB (uniform)
+  unsigned mnext;     // LDS byte address of the next stage + wave*8 KiB (uniform)
+  unsigned voff;      // lane*16
 
   template <int IT>
   __device__ __forceinline__ void read_item() {
     dsr128<256 * (IT >> 3)>(q[IT % PF], aW[IT & 7]);
   }
+  // next tile's DMA (linear 32-KiB image per tile, 8 KiB per wave): 1 instruction per slot, M0 rewritten one
+  // step ahead of every 4th
+  template <int J>
+  __device__ __forceinline__ void dma_m0() {
+    if constexpr (J < 8 && (J & 3) == 0) dma_set_m0(mnext + (J >> 2) * 4096);
+  }
   template <int J>
   __device__ __forceinline__ void dma_slot() {
-    if constexpr (J < 8) {
-      if (has_next) {
-        const int i = wave + 4 * J;
-        dma16(gW + i * RKB + lo1[J & 3], nstage + i * RKB);
-      }
-    }
+    if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
   }
   template <int IT, bool SWAP>
   __device__ __forceinline__ void step() {
@@ -90,6 +91,7 @@ struct TilePipe {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT + PF < KS) read_item<IT + PF>();
       if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
+      else dma_m0<IT / 2>();
       step<IT + 1, SWAP>();
     }
   }
@@ -122,15 +124,18 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 // FUSE_OUT: additionally run the attention out-projection + residual (+ row statistics) in the same
 // workgroup: att rows are written in MFMA k-slot order and read back by the SAME lanes as the B operand.
 struct OutProj {
-  const __half* W;     // [>=480 rows][512] out_proj weight, K axis = head-padded + k-slot order
   const float* bias;   // [N]
   float* C32;          // [M, ldc] x1 = AdaLN(x) + att·Wo^T + bo
   float2* stats_out;   // [M]
   int ldc, N;
 };
 
-template <int KS, bool FUSE_OUT>
-__global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ Win, const float* __restrict__ bias,
+// phase-timing instrumentation (dev hook only, LDM_ATTN_TM=1): s_memtime sums over blocks
+__device__ unsigned long long g_attn_phase[16];
+#define LDM_TM_NOW() __builtin_amdgcn_s_memtime()
+
+template <int KS, bool FUSE_OUT, bool TM = false>
+__global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ img, const float* __restrict__ bias,
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
                                                     int M, float scale_log2e, OutProj op) {
   constexpr int PF = 8;
@@ -149,107 +154,141 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
   const bool valid = row_in < S;
   const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
 
+  unsigned long long t_start = 0, t_real0 = 0, s_wait = 0, s_run = 0, s_epi = 0, s_att = 0, s_w2 = 0, s_r2 = 0, s_e2 = 0;
+  if constexpr (TM) {
+    t_start = LDM_TM_NOW();
+    t_real0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  const unsigned voff = lane * 16;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) dma_lin4(voff, img + wave * 8192 + a * 4096, lds0 + wave * 8192 + a * 4096);  // tile 0
   for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias[i];
+  // sbo = out-proj bias + AdaLN shift (the residual AdaLN(x) is recomputed in the out-proj epilogue); both
+  // tables are zero beyond N / D so that padded output columns come out as exact zeros without masks
   if (FUSE_OUT)
-    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? op.bias[i] : 0.f;
-  for (int i = tid; i < ln.D; i += 256) {
-    sp[i] = ln.ada ? 1.0f + ln.p0[i] : ln.p0[i];
-    sp[LN_DP + i] = ln.p1[i];
+    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? op.bias[i] + ln.p1[i] : 0.f;
+  for (int i = tid; i < LN_DP; i += 256) {
+    sp[i] = i < ln.D ? (ln.ada ? 1.0f + ln.p0[i] : ln.p0[i]) : 0.f;
+    sp[LN_DP + i] = i < ln.D ? ln.p1[i] : 0.f;
   }
   __syncthreads();
   f16x8 xf[KS];
   {
+    // AdaLN-on-load in groups of G k-steps, raw row loads double buffered one group ahead.  The (always zero)
+    // offset is made opaque AND data-dependent on the previous group's last fragment: hipcc otherwise issues
+    // all 58 row loads + 116 parameter reads up front (~700 live VGPRs -> scratch spills).
+    constexpr int G = 2, NG = (KS + G - 1) / G;
     const float2 st = ln.stats[m];
     const float* xr = ln.x + m * ln.ldx + hi * 8;
     const float* mp = sp + hi * 8;
-    unsigned opq = 0;  // always 0, but opaque to the optimiser
+    unsigned opq = 0;
+    float4 raw[2][G][2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      // every 2 k-steps an (always zero) offset is made opaque AND data-dependent on the previous fragment: hipcc
-      // otherwise issues all 58 row loads + 116 parameter reads up front (~700 live VGPRs -> scratch spills)
-      if (ks % 2 == 0 && ks > 0) asm volatile("" : "+v"(opq) : "v"(xf[ks - 1]));
-      const float4 a = *reinterpret_cast<const float4*>(xr + opq + ks * 16);
-      const float4 c = *reinterpret_cast<const float4*>(xr + opq + ks * 16 + 4);
-      const float4 ga = *reinterpret_cast<const float4*>(mp + opq + ks * 16);
-      const float4 gb = *reinterpret_cast<const float4*>(mp + opq + ks * 16 + 4);
-      const float4 sa = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16);
-      const float4 sb = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16 + 4);
-      xf[ks][0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
-      xf[ks][1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
-      xf[ks][2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
-      xf[ks][3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
-      xf[ks][4] = (_Float16)fmaf((c.x - st.x) * st.y, gb.x, sb.x);
-      xf[ks][5] = (_Float16)fmaf((c.y - st.x) * st.y, gb.y, sb.y);
-      xf[ks][6] = (_Float16)fmaf((c.z - st.x) * st.y, gb.z, sb.z);
-      xf[ks][7] = (_Float16)fmaf((c.w - st.x) * st.y, gb.w, sb.w);
+    for (int i = 0; i < G; ++i) {
+      raw[0][i][0] = *reinterpret_cast<const float4*>(xr + i * 16);
+      raw[0][i][1] = *reinterpret_cast<const float4*>(xr + i * 16 + 4);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g >= 1) asm volatile("" : "+v"(opq) : "v"(xf[g * G - 1]));
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int ks = (g + 1) * G + i;
+          if (ks < KS) {
+            raw[(g + 1) & 1][i][0] = *reinterpret_cast<const float4*>(xr + opq + ks * 16);
+            raw[(g + 1) & 1][i][1] = *reinterpret_cast<const float4*>(xr + opq + ks * 16 + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int ks = g * G + i;
+        if (ks < KS) {
+          const float4 a = raw[g & 1][i][0], c = raw[g & 1][i][1];
+          const float4 ga = *reinterpret_cast<const float4*>(mp + opq + ks * 16);
+          const float4 gb = *reinterpret_cast<const float4*>(mp + opq + ks * 16 + 4);
+          const float4 sa = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16);
+          const float4 sb = *reinterpret_cast<const float4*>(mp + opq + LN_DP + ks * 16 + 4);
+          xf[ks][0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
+          xf[ks][1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
+          xf[ks][2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
+          xf[ks][3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
+          xf[ks][4] = (_Float16)fmaf((c.x - st.x) * st.y, gb.x, sb.x);
+          xf[ks][5] = (_Float16)fmaf((c.y - st.x) * st.y, gb.y, sb.y);
+          xf[ks][6] = (_Float16)fmaf((c.z - st.x) * st.y, gb.z, sb.z);
+          xf[ks][7] = (_Float16)fmaf((c.w - st.x) * st.y, gb.w, sb.w);
+        }
+      }
     }
   }
-  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
   unsigned relW[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) relW[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
-  unsigned lo1[4];
-#pragma unroll
-  for (int jm = 0; jm < 4; ++jm) lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
-
-  // tile sequence: ti = h*6 + j ; j -> (which, t): k0 k1 v0 v1 q0 q1
-  auto tile_row = [&](int ti) {
-    const int h = ti / 6, j = ti % 6;
-    const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
-    return (which * H + h) * 64 + (j & 1) * 32;
-  };
+  // weight stream: img = 32-KiB LDS images of the tiles in consumption order (ldm_api.cpp pack_attn_image):
+  //   tile h*6 + j, j = k0 k1 v0 v1 q0 q1 (32 in_proj rows of head h each), then 15 out_proj tiles (K axis
+  //   head-padded + k-slot ordered) and one zero tile so that the last prefetch needs no branch.
+  // Row i of a tile is 1 KiB, 16-B chunk L stored at physical chunk L ^ (i & 15).
   const int n_tiles = H * 6;
-  {
-    const __half* w0 = Win + (size_t)tile_row(0) * RK;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int i = wave + 4 * j;
-      dma16(w0 + (size_t)i * RK + ((lane ^ (i & 15)) << 3), ring + i * RKB);
-    }
-  }
   f16x8 qf[4];
   const int ksw = (r >> 1) & 7;
+  const unsigned a_bias = lds0 + (unsigned)(reinterpret_cast<char*>(sbias) - smem);
   TilePipe<KS, PF> P;
   P.xf = xf;
-  P.wave = wave;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) P.lo1[k] = lo1[k];
+  P.voff = voff;
 
+  unsigned long long t_pro = 0;
+  if constexpr (TM) t_pro = LDM_TM_NOW();
   for (int ti = 0; ti < n_tiles; ++ti) {
     const int h = ti / 6, j = ti % 6;
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+    if constexpr (TM) tA = LDM_TM_NOW();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool has_next = FUSE_OUT || ti + 1 < n_tiles;
-    const char* gW = (ti + 1 < n_tiles) ? reinterpret_cast<const char*>(Win + (size_t)tile_row(ti + 1) * RK)
-                                        : reinterpret_cast<const char*>(op.W);  // first out-proj tile
-    char* nstage = ring + ((ti + 1) & 1) * STAGE;
+    if constexpr (TM) {
+      tB = LDM_TM_NOW();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    P.gnext = img + (size_t)(ti + 1) * STAGE + wave * 8192;  // (tile n_tiles = first out-proj tile)
+    P.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
     const unsigned sbase = lds0 + (ti & 1) * STAGE;
     char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
     char* Vs = Ks + KV_BYTES;
-    P.has_next = has_next;
-    P.gW = gW;
-    P.nstage = nstage;
 #pragma unroll
     for (int k = 0; k < 8; ++k) P.aW[k] = sbase + relW[k];
-    if (j == 2 || j == 3) P.template run<true>();
-    else P.template run<false>();
-    const f32x16& acc = P.acc;
+    // this tile's bias: read ahead of the weight fragments (older in the LDS queue than everything the pipe
+    // waits on), so the epilogue does not start with an exposed LDS round trip
     const int t = j & 1;
+    float4 bpre[4];
+    float bvs = 0.f;
+    if (j == 2 || j == 3) {
+      const unsigned ab = a_bias + (unsigned)(((2 * H + h) * 64 + t * 32 + r) * 4);
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bvs) : "v"(ab) : "memory");
+      P.template run<true>();
+    } else {
+      const unsigned ab = a_bias + (unsigned)(((j < 2 ? H + h : h) * 64 + t * 32 + hi * 4) * 4);
+      dsr128f<0>(bpre[0], ab);
+      dsr128f<32>(bpre[1], ab);
+      dsr128f<64>(bpre[2], ab);
+      dsr128f<96>(bpre[3], ab);
+      P.template run<false>();
+    }
+    const f32x16& acc = P.acc;
+    if constexpr (TM) tC = LDM_TM_NOW();
     if (j < 2) {
       // K tile: lane (key = row_in, hi) holds d = 32t + 8*rq + 4*hi + i ; k-slot chunk c = 4t + 2s + hi
-      const float* bk = sbias + (H + h) * 64 + t * 32 + hi * 4;
       {
-        const f16x8 v0 = cvt8<0>(acc, *reinterpret_cast<const float4*>(bk), *reinterpret_cast<const float4*>(bk + 8));
-        const f16x8 v1 = cvt8<8>(acc, *reinterpret_cast<const float4*>(bk + 16), *reinterpret_cast<const float4*>(bk + 24));
+        const f16x8 v0 = cvt8<0>(acc, bpre[0], bpre[1]);
+        const f16x8 v1 = cvt8<8>(acc, bpre[2], bpre[3]);
         const int sw = (row_in >> 1) & 7;
         *reinterpret_cast<f16x8*>(Ks + row_in * 128 + (((4 * t + hi) ^ sw) << 4)) = v0;
         *reinterpret_cast<f16x8*>(Ks + row_in * 128 + (((4 * t + 2 + hi) ^ sw) << 4)) = v1;
       }
     } else if (j < 4) {
       // V tile (swapped operands): lane (d = 32t + r, hi) holds keys 32*wave + 8*rq + 4*hi + i
-      const float bv = sbias[(2 * H + h) * 64 + t * 32 + r];
-      const float4 b4 = make_float4(bv, bv, bv, bv);
+      const float4 b4 = make_float4(bvs, bvs, bvs, bvs);
       const int d = t * 32 + r;
       {
         const f16x8 v0 = cvt8<0>(acc, b4, b4);
@@ -259,12 +298,17 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
       }
     } else {
       // Q tile: stays in registers as the B operand of S^T (k-slot order = accumulator order)
-      const float* bq = sbias + h * 64 + t * 32 + hi * 4;
       {
-        const f16x8 v0 = cvt8<0>(acc, *reinterpret_cast<const float4*>(bq), *reinterpret_cast<const float4*>(bq + 8));
-        const f16x8 v1 = cvt8<8>(acc, *reinterpret_cast<const float4*>(bq + 16), *reinterpret_cast<const float4*>(bq + 24));
+        const f16x8 v0 = cvt8<0>(acc, bpre[0], bpre[1]);
+        const f16x8 v1 = cvt8<8>(acc, bpre[2], bpre[3]);
         if (t == 0) { qf[0] = v0; qf[1] = v1; } else { qf[2] = v0; qf[3] = v1; }
       }
+    }
+    if constexpr (TM) {
+      tD = LDM_TM_NOW();
+      s_wait += tB - tA;
+      s_run += tC - tB;
+      s_epi += tD - tC;
     }
     if (j != 5) continue;
 
@@ -356,7 +400,10 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
           *reinterpret_cast<uint2*>(orow + d) = pk;
         }
     }
+    if constexpr (TM) s_att += LDM_TM_NOW() - tD;
   }
+  unsigned long long t_qkv_end = 0;
+  if constexpr (TM) t_qkv_end = LDM_TM_NOW();
   if constexpr (FUSE_OUT) {
     // ------------------------------------------------------------------ out-projection phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own att stores are performed before reading back
@@ -365,59 +412,95 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
       const __half* arow = att + m * ldo + hi * 8;
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) of[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
+      // consume the loads here (hipcc would otherwise put an s_waitcnt vmcnt(n) before every MFMA below)
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(of[ks]));
     }
     const float2 rst = ln.stats[m];
-    const float* rrow = ln.x + m * ln.ldx + hi * 4;
+    const float ra = rst.y, rb = -rst.x * rst.y;  // xn = x * ra + rb
+    const float* rrow = ln.x + m * ln.ldx;
     float* crow = op.C32 + m * op.ldc + hi * 4;
     TilePipe<32, PF> Q2;
     Q2.xf = of;
-    Q2.wave = wave;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) Q2.lo1[k] = lo1[k];
+    Q2.voff = voff;
     const int n_out = (op.N + 31) / 32;
+    // residual row pieces (raw x) of tile ot+1 are loaded during tile ot; columns >= N are clamped to a
+    // valid address (their AdaLN multiplier is 0)
+    auto load_res = [&](int ot, float4(&dst)[4]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int n = ot * 32 + g * 8 + hi * 4;
+        n = n + 3 < op.N ? n : op.N - 4;
+        dst[g] = *reinterpret_cast<const float4*>(rrow + n);
+      }
+    };
+    float4 res_a[4], res_b[4];  // ping-pong (loop unrolled by two: no loop-carried register copies)
+    load_res(0, res_a);
+    const unsigned a_tb = lds0 + (unsigned)(reinterpret_cast<char*>(sbo) - smem) + hi * 16;
+    const unsigned a_gm = lds0 + (unsigned)(reinterpret_cast<char*>(sp) - smem) + hi * 16;
     float s1 = 0.f, s2 = 0.f;
-    for (int ot = 0; ot < n_out; ++ot) {
+    auto out_tile = [&](int ot, float4(&rc)[4], float4(&rn)[4]) {
       const int ti = n_tiles + ot;
-      // oldest first: [DMA of this tile x8] [stores of the previous out tile x4]
+      unsigned long long tA = 0, tB = 0, tC = 0;
+      if constexpr (TM) tA = LDM_TM_NOW();
+      // oldest first: [residual of this tile x4] [DMA of this tile x8] [stores of the previous out tile x4]
       if (ot == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      float4 rv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ot * 32 + g * 8 + hi * 4;
-        rv[g] = (n + 3 < op.N) ? *reinterpret_cast<const float4*>(rrow + ot * 32 + g * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (TM) {
+        tB = LDM_TM_NOW();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      load_res(ot + 1 < n_out ? ot + 1 : ot, rn);  // (unconditional: a branch here makes hipcc copy the fresh registers)
       __builtin_amdgcn_sched_barrier(0);
-      Q2.has_next = ot + 1 < n_out;
-      Q2.gW = reinterpret_cast<const char*>(op.W + (size_t)(ot + 1) * 32 * RK);
-      Q2.nstage = ring + ((ti + 1) & 1) * STAGE;
+      // bias+shift and multiplier of this tile's 16 columns: read ahead of the weight fragments (older in the
+      // LDS queue than everything the pipe waits on)
+      float4 tbv[4], gmv[4];
+      dsr128f<0>(tbv[0], a_tb + ot * 128);
+      dsr128f<32>(tbv[1], a_tb + ot * 128);
+      dsr128f<64>(tbv[2], a_tb + ot * 128);
+      dsr128f<96>(tbv[3], a_tb + ot * 128);
+      dsr128f<0>(gmv[0], a_gm + ot * 128);
+      dsr128f<32>(gmv[1], a_gm + ot * 128);
+      dsr128f<64>(gmv[2], a_gm + ot * 128);
+      dsr128f<96>(gmv[3], a_gm + ot * 128);
+      Q2.gnext = img + (size_t)(ti + 1) * STAGE + wave * 8192;  // (the tile after the last one is zero padding)
+      Q2.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
       const unsigned sbase = lds0 + (ti & 1) * STAGE;
 #pragma unroll
       for (int k = 0; k < 8; ++k) Q2.aW[k] = sbase + relW[k];
       Q2.template run<false>();
+      if constexpr (TM) tC = LDM_TM_NOW();
+      // take delivery of the next tile's residual HERE (issued a whole MFMA run ago): hipcc's wait for it then sits
+      // in front of this tile's stores, and the loop-top wait can leave those stores in flight
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(rn[g].x), "+v"(rn[g].y), "+v"(rn[g].z), "+v"(rn[g].w));
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = ot * 32 + g * 8 + hi * 4;
-        const bool ok = n + 3 < op.N;
-        const float4 bb = *reinterpret_cast<const float4*>(sbo + n);
-        const float4 gm = *reinterpret_cast<const float4*>(sp + (ok ? n : 0));
-        const float4 gs = *reinterpret_cast<const float4*>(sp + LN_DP + (ok ? n : 0));
-        float v0 = Q2.acc[g * 4 + 0] + bb.x + fmaf((rv[g].x - rst.x) * rst.y, gm.x, gs.x);
-        float v1 = Q2.acc[g * 4 + 1] + bb.y + fmaf((rv[g].y - rst.x) * rst.y, gm.y, gs.y);
-        float v2 = Q2.acc[g * 4 + 2] + bb.z + fmaf((rv[g].z - rst.x) * rst.y, gm.z, gs.z);
-        float v3 = Q2.acc[g * 4 + 3] + bb.w + fmaf((rv[g].w - rst.x) * rst.y, gm.w, gs.w);
-        if (!ok) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+        // x1 = att·Wo^T + (bo + shift) + xn * mult ; padded columns: 0 + 0 + xn * 0
+        const float v0 = fmaf(fmaf(rc[g].x, ra, rb), gmv[g].x, Q2.acc[g * 4 + 0] + tbv[g].x);
+        const float v1 = fmaf(fmaf(rc[g].y, ra, rb), gmv[g].y, Q2.acc[g * 4 + 1] + tbv[g].y);
+        const float v2 = fmaf(fmaf(rc[g].z, ra, rb), gmv[g].z, Q2.acc[g * 4 + 2] + tbv[g].z);
+        const float v3 = fmaf(fmaf(rc[g].w, ra, rb), gmv[g].w, Q2.acc[g * 4 + 3] + tbv[g].w);
         s1 += (v0 + v1) + (v2 + v3);
         s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        // invalid column groups occur only in the LAST tile and for all lanes alike; padding rows of the
-        // layout (row_in >= S) are redirected to the lane's own valid row with identical data? No: they
-        // simply skip the store — the count below (vmcnt(4)) stays exact because exec-masked stores of a
-        // partially active wave are still issued, and a fully inactive wave cannot occur (32 rows/wave,
-        // S > 96).
-        if (ok && valid) *reinterpret_cast<float4*>(crow + ot * 32 + g * 8) = make_float4(v0, v1, v2, v3);
+        // (N % 8 == 0: a column group is entirely inside or outside for both lane halves.)  Padding rows of the
+        // layout skip the store by exec mask: the instruction is still issued, so the vmcnt(4) above stays exact
+        // (a fully inactive wave cannot occur: 32 rows/wave, S > 96); incomplete groups exist only in the last tile.
+        if (ot * 32 + g * 8 + 8 <= op.N) {
+          if (valid) *reinterpret_cast<float4*>(crow + ot * 32 + g * 8) = make_float4(v0, v1, v2, v3);
+        }
       }
+      if constexpr (TM) {
+        s_w2 += tB - tA;
+        s_r2 += tC - tB;
+        s_e2 += LDM_TM_NOW() - tC;
+      }
+    };
+    for (int ot = 0; ot < n_out; ot += 2) {
+      out_tile(ot, res_a, res_b);
+      if (ot + 1 < n_out) out_tile(ot + 1, res_b, res_a);
     }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
@@ -427,10 +510,29 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const __half* __restrict__ 
       op.stats_out[m] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (padding) tile prefetch must land before the LDS is released
+  if constexpr (TM) {
+    const unsigned long long t_end = LDM_TM_NOW();
+    const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      atomicAdd(&g_attn_phase[0], 1ull);
+      atomicAdd(&g_attn_phase[1], t_end - t_start);
+      atomicAdd(&g_attn_phase[2], t_real1 - t_real0);
+      atomicAdd(&g_attn_phase[3], t_pro - t_start);
+      atomicAdd(&g_attn_phase[4], s_wait);
+      atomicAdd(&g_attn_phase[5], s_run);
+      atomicAdd(&g_attn_phase[6], s_epi);
+      atomicAdd(&g_attn_phase[7], s_att);
+      atomicAdd(&g_attn_phase[8], t_end - t_qkv_end);
+      atomicAdd(&g_attn_phase[9], s_w2);
+      atomicAdd(&g_attn_phase[10], s_r2);
+      atomicAdd(&g_attn_phase[11], s_e2);
+    }
+  }
 }
 
-// Win: head-padded in_proj image [3*H*64 rows][512] (q | k | v blocks of H*64 rows), bias [3*H*64].
-void launch_qkv_attention(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
+// img: tile-ordered LDS image of the layer's attention weights (see the kernel), bias: head-padded [3*H*64].
+void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
                           int H, int dh, hipStream_t st) {
   constexpr int KS = 29;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
@@ -442,24 +544,32 @@ void launch_qkv_attention(const __half* Win, const float* bias, const LnLoad& ln
     attr = true;
   }
   OutProj op{};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
 }
 
-// same + out-projection: Wout_ks = out_proj weight with head-padded, k-slot-ordered K axis
-void launch_attention_block(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo,
-                            const __half* Wout_ks, const float* b_out, float* C32, int ldc, float2* stats_out, int N,
+// same + out-projection (tiles n_tiles.. of the image)
+void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
+                            const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st) {
   constexpr int KS = 29;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
-  auto kern = qkv_attn_k<KS, true>;
+  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
+  auto kern = tm ? qkv_attn_k<KS, true, true> : qkv_attn_k<KS, true, false>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  OutProj op{Wout_ks, b_out, C32, stats_out, ldc, N};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, Win, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+  OutProj op{b_out, C32, stats_out, ldc, N};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+}
+
+void attn_phase_read(unsigned long long* out16) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_phase), 16 * sizeof(unsigned long long));
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_phase), z, sizeof(z));
 }
 
 }  // namespace ldm

@@ -21,8 +21,10 @@
 // LDS images are written lane-linearly by the DMA; bank-conflict swizzles are applied to the SOURCE
 // address and mirrored on the ds_read_b128 side.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ldm_kernels.h"
+#include "ldm_dma.h"
 
 namespace ldm {
 
@@ -249,9 +251,13 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int NT2, int PF, int DE = 2>
+// phase-timing instrumentation (LDM_FFN_DBG=3, dev hook only): sums over chunks of s_memtime deltas
+__device__ unsigned long long g_ffn_phase[8];
+
+template <int KS, int NT2, int PF, int DE = 2, bool TM = false>
 struct FfnPipe {
   static constexpr int NIT = KS + 2 * NT2;
+  unsigned long long tC, tD;
   f16x8 q[PF];
   unsigned aW1[8], aW2[2];  // per-lane LDS byte addresses inside the current stage
   const f16x8* xf;
@@ -260,30 +266,21 @@ struct FfnPipe {
   f32x16* acc;
   f16x8 pf[2];
   float4 bb[4];
-  // next chunk's weight DMA, issued one 1-KiB instruction every DMA_EVERY MFMAs (hidden in MFMA shadow)
+  // next chunk's weight DMA (linear 64-KiB image per chunk, 16 KiB per wave): one 1-KiB instruction every
+  // DMA_EVERY MFMAs in the MFMA shadow; M0 is rewritten one step before every 4th instruction
   static constexpr int DMA_EVERY = DE;
-  static constexpr int NINST = 32 + NT2 * 2;
-  static constexpr int IPW = (NINST + 3) / 4;
-  const char* gW1;      // W1 + next chunk (uniform)
-  const char* gW2;      // W2p + next chunk (uniform)
-  char* nstage;         // LDS stage of the next chunk (uniform)
-  unsigned lo1[4], lo2; // per-lane byte offsets
-  int wave, ldw2b;
-  bool has_next;
+  static constexpr int IPW = 16;
+  const char* gnext;    // image of the next chunk + wave*16 KiB (uniform)
+  unsigned mnext;       // LDS byte address of the next stage + wave*16 KiB (uniform)
+  unsigned voff;        // lane*16
 
   template <int J>
+  __device__ __forceinline__ void dma_m0() {
+    if constexpr (J < IPW && (J & 3) == 0) dma_set_m0(mnext + (J >> 2) * 4096);
+  }
+  template <int J>
   __device__ __forceinline__ void dma_slot() {
-    if constexpr (J < IPW) {
-      if (has_next) {
-        const int i = wave + 4 * J;
-        if constexpr (J < 8) {
-          dma16(gW1 + i * RKB + lo1[J & 3], nstage + i * RKB);
-        } else {
-          if (4 * J + 3 < NINST || i < NINST)
-            dma16(gW2 + (size_t)(i - 32) * 16 * ldw2b + lo2, nstage + W1_STAGE + (i - 32) * 1024);
-        }
-      }
-    }
+    if constexpr (J < IPW) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
   }
 
   template <int IT>
@@ -295,7 +292,7 @@ struct FfnPipe {
       dsr128<W1_STAGE + t * 2048>(q[IT % PF], aW2[sx]);
     }
   }
-  template <int IT>
+  template <int IT, bool DMA>
   __device__ __forceinline__ void step() {
     if constexpr (IT < NIT) {
       const f16x8 cur_dummy = q[0];
@@ -305,17 +302,25 @@ struct FfnPipe {
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
       if constexpr (IT == 0) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[0], zero, 0, 0, 0);  // C = inline constant 0
+        // GEMM1 accumulates in ARCH VGPRs through inline asm: with the builtin hipcc puts `ha` into the AGPR range
+        // that the 15 GEMM2 accumulator tiles fill completely and then moves one tile out and back every chunk
+        // (32 v_accvgpr copies) plus 16 v_accvgpr_read in the ReLU.  The dependent-MFMA spacing is the same as in
+        // the compiler's own code (>= 1 instruction between), the VALU read after the last one gets its wait
+        // states from the explicit s_nop below (gfx950: 8 passes + 4 = 12 required).
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ha) : "v"(cur), "v"(xf[0]));
       } else if constexpr (IT < KS) {
-        ha = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], ha, 0, 0, 0);
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[IT]));
+        if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");
       } else {
         constexpr int sx = (IT - KS) / NT2, t = (IT - KS) % NT2;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TM && IT == KS - 1) tC = __builtin_amdgcn_s_memtime();
+      if constexpr (TM && IT == KS) tD = __builtin_amdgcn_s_memtime();
       if constexpr (IT + PF < NIT) read_item<IT + PF>();  // refill the slot just consumed
-      if constexpr (IT % DMA_EVERY == DMA_EVERY - 1) dma_slot<IT / DMA_EVERY>();
+      if constexpr (DMA && IT % DMA_EVERY == DMA_EVERY - 1) dma_slot<IT / DMA_EVERY>();
+      else if constexpr (DMA && IT % DMA_EVERY == 0) dma_m0<IT / DMA_EVERY>();
       if constexpr (IT == KS - 1) {
         // bias + ReLU + cast: accumulator reg <-> hidden f = (q&3) + 8*(q>>2) + 4*hi of this chunk
 #pragma unroll
@@ -326,14 +331,7 @@ struct FfnPipe {
           pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + bb[rq].w, 0.f);
         }
       }
-      step<IT + 1>();
-    }
-  }
-  template <int J>
-  __device__ __forceinline__ void dma_all() {
-    if constexpr (J < IPW) {
-      dma_slot<J>();
-      dma_all<J + 1>();
+      step<IT + 1, DMA>();
     }
   }
   template <int IT>
@@ -345,18 +343,20 @@ struct FfnPipe {
   }
 };
 
-// ABL: timing ablations only (1 = no weight DMA after the first chunk, 2 = no LDS reads / MFMAs)
+// ABL: timing ablations only (1 = no weight DMA after the first chunk, 2 = no LDS reads / MFMAs, 3 = phase timing)
+// img: per 32-wide hidden chunk c one 64-KiB LDS image (ldm_api.cpp pack_ffn_image):
+//   [0, 32 KiB)   W1 rows c*32 .. c*32+31, 1 KiB each, 16-B chunk L of row i at physical chunk L ^ (i & 15)
+//   [32, 62 KiB)  W2 (k-slot ordered K axis) columns c*32..+31 of output rows 0..479, 64 B each, chunk L of row n
+//                 at physical chunk L ^ ((n >> 2) & 3);   last 2 KiB padding
+constexpr int FFN_STAGE = 65536;
 template <int KS, int NT2, int ABL, int PF = 8, int DE = 2>
-__global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const __half* __restrict__ W1,
-                                                      const float* __restrict__ b1, const __half* __restrict__ W2p,
-                                                      int ldw2, const float* __restrict__ b2, const float* __restrict__ res,
-                                                      float* __restrict__ out, int ldo, int M, int N, int n_chunks,
-                                                      LnLoad ln, float2* __restrict__ stats_out) {
-  constexpr int W2_ROWS = NT2 * 32;
-  constexpr int W2_INST = W2_ROWS / 16;
-  constexpr int STAGE = W1_STAGE + W2_ROWS * 64;
-  constexpr int NINST = 32 + W2_INST;
-  constexpr int IPW = (NINST + 3) / 4;
+__global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const char* __restrict__ img,
+                                                      const float* __restrict__ b1, const float* __restrict__ b2,
+                                                      const float* __restrict__ res, float* __restrict__ out, int ldo,
+                                                      int M, int N, int n_chunks, LnLoad ln,
+                                                      float2* __restrict__ stats_out) {
+  constexpr int STAGE = FFN_STAGE;
+  static_assert(W1_STAGE + NT2 * 32 * 64 <= STAGE, "chunk image exceeds its stage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
   float* sp_in = sb1 + n_chunks * 32;
@@ -366,6 +366,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   const int r = lane & 31, hi = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + r;
 
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  const unsigned voff = lane * 16;
+  {  // chunk 0 -> stage 0 (this wave's 16 KiB)
+    const char* g0 = img + wave * 16384;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) dma_lin4(voff, g0 + a * 4096, lds0 + wave * 16384 + a * 4096);
+  }
   for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
   f16x8 xf[KS];
   if (ln.x) {
@@ -376,6 +383,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     const __half* hrow = H + (size_t)m * ldh + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const f16x8*>(hrow + ks * 16);
+    // consume the loads here: otherwise hipcc carries "xf may still be in flight" into the chunk loop and puts
+    // an s_waitcnt vmcnt(n) in front of every MFMA (it cannot see the explicit waits in the asm statements)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
   }
   f32x16 acc[NT2];
 #pragma unroll
@@ -383,20 +394,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  auto issue = [&](int c, char* stage) {
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-      const int i = wave + 4 * j;
-      if (j < 8) {
-        dma16(W1 + (size_t)(c * 32 + i) * RK + ((lane ^ (i & 15)) << 3), stage + i * RKB);
-      } else if (4 * j + 3 < NINST || i < NINST) {
-        const int row = (i - 32) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        dma16(W2p + (size_t)row * ldw2 + c * 32 + chunk * 8, stage + W1_STAGE + (i - 32) * 1024);
-      }
-    }
-  };
-  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
   unsigned relW1[8], relW2[2];
 #pragma unroll
   for (int k = 0; k < 8; ++k) relW1[k] = r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
@@ -404,23 +401,29 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   for (int sx = 0; sx < 2; ++sx) relW2[sx] = r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);
   const unsigned relB = lds0 + 2 * STAGE + hi * 16;
 
-  FfnPipe<KS, NT2, PF, DE> P;
+  constexpr bool TM = ABL == 3;
+  unsigned long long t_start = 0, t_real0 = 0, s_wait = 0, s_g1 = 0, s_bub = 0, s_g2 = 0;
+  if constexpr (TM) {
+    t_start = __builtin_amdgcn_s_memtime();
+    t_real0 = __builtin_amdgcn_s_memrealtime();
+  }
+  FfnPipe<KS, NT2, PF, DE, TM> P;
   P.xf = xf;
   P.acc = acc;
-  P.wave = wave;
-  P.ldw2b = ldw2 * 2;
-#pragma unroll
-  for (int jm = 0; jm < 4; ++jm) P.lo1[jm] = (unsigned)((lane ^ ((wave + 4 * jm) & 15)) << 4);
-  P.lo2 = (unsigned)((lane >> 2) * ldw2 * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
-  issue(0, smem);
-  for (int c = 0; c < n_chunks; ++c) {
+  P.voff = voff;
+  auto chunk = [&](int c, auto dma_tag) {
+    constexpr bool DMA = decltype(dma_tag)::value;
+    unsigned long long tA = 0, tB = 0;
+    if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    P.has_next = (ABL != 1) && (c + 1 < n_chunks);
-    P.gW1 = reinterpret_cast<const char*>(W1 + (size_t)(c + 1) * 32 * RK);
-    P.gW2 = reinterpret_cast<const char*>(W2p + (size_t)(c + 1) * 32);
-    P.nstage = smem + ((c + 1) & 1) * STAGE;
+    if constexpr (TM) {
+      tB = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    P.gnext = img + (size_t)((ABL == 1 || c + 1 == n_chunks) ? 0 : c + 1) * STAGE + wave * 16384;
+    P.mnext = lds0 + ((c + 1) & 1) * STAGE + wave * 16384;
     const unsigned sbase = lds0 + (c & 1) * STAGE;
 #pragma unroll
     for (int k = 0; k < 8; ++k) P.aW1[k] = sbase + relW1[k];
@@ -432,30 +435,66 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     dsr128f<64>(P.bb[2], ab);
     dsr128f<96>(P.bb[3], ab);
     if constexpr (ABL == 2) {
-      P.template dma_all<0>();
+      if constexpr (DMA) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dma_lin4(voff, P.gnext + a * 4096, P.mnext + a * 4096);
+      }
     } else {
       P.template prologue<0>();
       // queue holds items 0..PF-2; step<IT> waits for item IT, runs its MFMA, then issues item IT+PF
       P.template read_item<PF - 1>();
-      P.template step<0>();
+      P.template step<0, DMA>();
+    }
+    if constexpr (TM) {
+      const unsigned long long tE = __builtin_amdgcn_s_memtime();
+      s_wait += tB - tA;
+      s_g1 += P.tC - tB;
+      s_bub += P.tD - P.tC;
+      s_g2 += tE - P.tD;
+    }
+  };
+  // (a peeled DMA-free last chunk made hipcc spill MFMA operands in the peeled copy: the last chunk simply
+  //  prefetches chunk 0 again into the idle stage — 1/58 extra L2 reads, drained below)
+  for (int c = 0; c < n_chunks; ++c) chunk(c, std::true_type{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TM) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      atomicAdd(&g_ffn_phase[0], 1ull);
+      atomicAdd(&g_ffn_phase[1], t_end - t_start);
+      atomicAdd(&g_ffn_phase[2], t_real1 - t_real0);
+      atomicAdd(&g_ffn_phase[3], s_wait);
+      atomicAdd(&g_ffn_phase[4], s_g1);
+      atomicAdd(&g_ffn_phase[5], s_bub);
+      atomicAdd(&g_ffn_phase[6], s_g2);
     }
   }
   {
-    const int mr = m < M ? m : M - 1;
+    // row / lane-half re-materialised behind an opaque asm: hipcc otherwise hoists the 60 epilogue addresses and
+    // masks above the last chunk and spills MFMA operands to scratch there
+    int me = m, hie = hi;
+    asm volatile("" : "+v"(me), "+v"(hie));
+    const int mr = me < M ? me : M - 1;
+    const float* rrow = res + (size_t)mr * ldo + hie * 4;
+    float* orow = out + (size_t)mr * ldo + hie * 4;
+    const float* brow = b2 + hie * 4;
+    const bool mok = me < M;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const int n = t * 32 + rq * 8 + hi * 4;
-        if (n + 3 < N) {
-          const float4 b = *reinterpret_cast<const float4*>(b2 + n);
-          const float4 qv = *reinterpret_cast<const float4*>(res + (size_t)mr * ldo + n);
+        const int n0 = t * 32 + rq * 8;  // N % 8 == 0: the group is inside or outside for both lane halves
+        if (n0 + 8 <= N) {
+          const float4 b = *reinterpret_cast<const float4*>(brow + n0);
+          const float4 qv = *reinterpret_cast<const float4*>(rrow + n0);
           const float v0 = acc[t][rq * 4 + 0] + b.x + qv.x, v1 = acc[t][rq * 4 + 1] + b.y + qv.y;
           const float v2 = acc[t][rq * 4 + 2] + b.z + qv.z, v3 = acc[t][rq * 4 + 3] + b.w + qv.w;
           s1 += (v0 + v1) + (v2 + v3);
           s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-          if (m < M) *reinterpret_cast<float4*>(out + (size_t)m * ldo + n) = make_float4(v0, v1, v2, v3);
+          if (mok) *reinterpret_cast<float4*>(orow + n0) = make_float4(v0, v1, v2, v3);
         }
       }
     }
@@ -769,29 +808,35 @@ void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t
   }
 }
 
-void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
-                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F, const LnLoad* lnp,
-                      float2* stats_out, hipStream_t st) {
+void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1, const float* b2, const float* res,
+                      float* out, int ldo, int M, int N, int F, const LnLoad* lnp, float2* stats_out, hipStream_t st) {
   LnLoad ln{};
   if (lnp) ln = *lnp;
   constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
-  const int lds = 2 * (W1_STAGE + NT2 * 32 * 64) + F * 4 + 2 * LN_DP * 4;
+  const int lds = 2 * FFN_STAGE + F * 4 + 2 * LN_DP * 4;
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
   static const int var = getenv("LDM_FFN_VAR") ? atoi(getenv("LDM_FFN_VAR")) : 0;
   auto kern = dbg == 1   ? ffn_fused2_k<KS, NT2, 1>
               : dbg == 2 ? ffn_fused2_k<KS, NT2, 2>
+              : dbg == 3 ? ffn_fused2_k<KS, NT2, 3>
               : var == 1 ? ffn_fused2_k<KS, NT2, 0, 6, 2>
               : var == 2 ? ffn_fused2_k<KS, NT2, 0, 10, 2>
-              : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 1>
-              : var == 4 ? ffn_fused2_k<KS, NT2, 0, 8, 3>
                          : ffn_fused2_k<KS, NT2, 0>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, W1, b1, W2p, ldw2, b2, res, out, ldo, M,
-                     N, F / 32, ln, stats_out);
+  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)img, b1, b2, res, out, ldo,
+                     M, N, F / 32, ln, stats_out);
+}
+
+// dev hook: read + reset the phase sums {blocks, cycles, realtime ticks, wait, gemm1, bubble, gemm2, -}
+void ffn_phase_read(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ffn_phase), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_phase), z, sizeof(z));
 }
 
 }  // namespace ldm

@@ -113,6 +113,7 @@ struct ldm_handle {
                        // (measured: row kernels win for QKV, out-proj, FFN; equal for the head)
   struct FastLayer {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
+    void *ffn_img = nullptr, *attn_img = nullptr;  // LDS-image ordered weight streams of the fused kernels
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
@@ -289,7 +290,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
     if (const char* ri = getenv("LDM_ROW_IMPL")) h->row_impl = atoi(ri);
-    if (h->D > 464 || h->HD > 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
+    if (h->D > 464 || h->Dq != 512 || h->HD != 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
     if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
     if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
@@ -442,6 +443,71 @@ static int pack_w16(ldm_handle* h, const float* d_src, int N, int K, int Np, int
   return 0;
 }
 
+// ---- LDS-image weight streams (kernels_rowgemm.hip ffn_fused2_k / kernels_fusedattn.hip qkv_attn_k): the fused
+// kernels copy their weights global -> LDS with linear 1-KiB DMA instructions, so the global copy is stored in
+// consumption order with the LDS bank swizzle already applied.
+static std::vector<uint16_t> download16(ldm_handle* h, const __half* d, size_t n, int* rc) {
+  std::vector<uint16_t> v(n);
+  *rc = 0;
+  if (hipMemcpy(v.data(), d, n * 2, hipMemcpyDeviceToHost) != hipSuccess) {
+    h->err = "hipMemcpy (weight image) failed";
+    *rc = -2;
+  }
+  return v;
+}
+static int upload_image(ldm_handle* h, const std::vector<uint16_t>& img, void** out) {
+  __half* d = nullptr;
+  int rc = h->dalloc(&d, img.size(), false);
+  if (rc) return rc;
+  HIP_OK(h, hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+// one 32-row x 512-half tile: row i = src row (or zeros), 16-B chunk L -> physical chunk L ^ (i & 15)
+static void put_tile_1k(uint16_t* dst, const uint16_t* src_rows[32]) {
+  for (int i = 0; i < 32; ++i) {
+    if (!src_rows[i]) continue;
+    for (int L = 0; L < 64; ++L) memcpy(dst + i * 512 + ((L ^ (i & 15)) << 3), src_rows[i] + L * 8, 16);
+  }
+}
+// w1: [>=F rows][512] fp16 (row = hidden unit), w2p: [>=480 rows][ldw2] fp16 with the k-slot ordered K axis.
+// Per 32-wide hidden chunk: 64 KiB = 32 KiB W1 tile | 30 KiB W2 slab (480 rows x 64 B, chunk L of row n at
+// L ^ ((n >> 2) & 3)) | 2 KiB padding.
+static std::vector<uint16_t> pack_ffn_image(const uint16_t* w1, const uint16_t* w2p, int ldw2, int F, int n_rows2) {
+  const int nc = F / 32;
+  std::vector<uint16_t> img((size_t)nc * 32768, 0);
+  for (int c = 0; c < nc; ++c) {
+    uint16_t* t = img.data() + (size_t)c * 32768;
+    const uint16_t* rows[32];
+    for (int i = 0; i < 32; ++i) rows[i] = w1 + (size_t)(c * 32 + i) * 512;
+    put_tile_1k(t, rows);
+    uint16_t* t2 = t + 16384;
+    for (int n = 0; n < n_rows2; ++n)
+      for (int L = 0; L < 4; ++L)
+        memcpy(t2 + n * 32 + ((L ^ ((n >> 2) & 3)) << 3), w2p + (size_t)n * ldw2 + c * 32 + L * 8, 16);
+  }
+  return img;
+}
+// w_in: [3*H*64][512] head-padded in_proj (q | k | v), w_out_ks: [>=480][512] out_proj with head-padded k-slot K.
+// Tiles: h*6 + {k0 k1 v0 v1 q0 q1}, then 15 out_proj tiles, then one zero tile.
+static std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_t* w_out_ks, int H, int n_out_tiles) {
+  const int nt = H * 6 + n_out_tiles + 1;
+  std::vector<uint16_t> img((size_t)nt * 16384, 0);
+  const uint16_t* rows[32];
+  for (int hh = 0; hh < H; ++hh)
+    for (int j = 0; j < 6; ++j) {
+      const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
+      const int row0 = (which * H + hh) * 64 + (j & 1) * 32;
+      for (int i = 0; i < 32; ++i) rows[i] = w_in + (size_t)(row0 + i) * 512;
+      put_tile_1k(img.data() + (size_t)(hh * 6 + j) * 16384, rows);
+    }
+  for (int t = 0; t < n_out_tiles; ++t) {
+    for (int i = 0; i < 32; ++i) rows[i] = w_out_ks + (size_t)(t * 32 + i) * 512;
+    put_tile_1k(img.data() + (size_t)(H * 6 + t) * 16384, rows);
+  }
+  return img;
+}
+
 static int build_fast_weights(ldm_handle* h) {
   const int D = h->D, F = h->F, C = h->C, H = h->H, dh = h->dh, HD = h->HD, Dq = h->Dq, Fq = h->Fq;
   auto id = [](int x) { return x; };
@@ -469,6 +535,18 @@ static int build_fast_weights(ldm_handle* h) {
     // fused attention block: the attention rows come back in accumulator (k-slot) order per head d-tile
     auto head_kslot = [=](int k) { return kslot(head_col(k)); };
     if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_kslot, &f.w_out_ks))) return rc;
+    if (Dq == 512 && HD == 512 && F % 32 == 0 && D <= 480) {  // geometry of the fused kernels
+      const std::vector<uint16_t> h1 = download16(h, f.w1, (size_t)F * Dq, &rc);
+      if (rc) return rc;
+      const std::vector<uint16_t> h2 = download16(h, f.w2p, (size_t)round_up(D, 256) * Fq, &rc);
+      if (rc) return rc;
+      if ((rc = upload_image(h, pack_ffn_image(h1.data(), h2.data(), Fq, F, 480), &f.ffn_img))) return rc;
+      const std::vector<uint16_t> hin = download16(h, f.w_in, (size_t)3 * HD * Dq, &rc);
+      if (rc) return rc;
+      const std::vector<uint16_t> hout = download16(h, f.w_out_ks, (size_t)round_up(D, 256) * HD, &rc);
+      if (rc) return rc;
+      if ((rc = upload_image(h, pack_attn_image(hin.data(), hout.data(), H, 15), &f.attn_img))) return rc;
+    }
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
     for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
@@ -580,12 +658,12 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
       ldm_handle::Scope sc(h, st, "qkv_attention_out",
                            gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D),
                            (double)M * (D * 8 + D * 4));
-      launch_attention_block(f.w_in, f.b_in, ada, h->att16, HD, f.w_out_ks, w.b_out, h->Q, D, h->stats_b, D, Bc, h->S,
+      launch_attention_block(f.attn_img, f.b_in, ada, h->att16, HD, w.b_out, h->Q, D, h->stats_b, D, Bc, h->S,
                              h->H, h->dh, st);
     } else if (h->fused_attn) {
       ldm_handle::Scope sc(h, st, "qkv_attention", gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
                            (double)M * (D * 4 + HD * 2));
-      launch_qkv_attention(f.w_in, f.b_in, ada, h->att16, HD, Bc, h->S, h->H, h->dh, st);
+      launch_qkv_attention(f.attn_img, f.b_in, ada, h->att16, HD, Bc, h->S, h->H, h->dh, st);
     } else {
       // QKV = AdaLN(x)·Win^T + b   (AdaLN applied while loading the fragments)
       GemmArgs g{};
@@ -613,7 +691,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     {  // x2 = x1 + FFN(LN2(x1)) -> P (+ stats_a)
       const LnLoad ln2{h->Q, h->stats_b, w.g2, w.be2, D, D, 0};
       ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 4 + D * 8));
-      launch_ffn_fused(nullptr, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
+      launch_ffn_fused(nullptr, Dq, f.ffn_img, w.b1, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
     }
   }
   {  // logits = LN_head(x)·Wh^T
@@ -677,7 +755,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     }
     if (h->row_impl & 4) {
       ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 2 + D * 8));
-      launch_ffn_fused(h->h16, Dq, f.w1, w.b1, f.w2p, Fq, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
+      launch_ffn_fused(h->h16, Dq, f.ffn_img, w.b1, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
     } else {
       gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
            gemm_flops(M, F, D), (double)M * (D * 2 + F * 2), false);
@@ -1156,11 +1234,10 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
     std::vector<uint16_t> h1((size_t)2048 * 512), h2((size_t)512 * 1856);
     for (auto& x : h1) x = f2h_bits(rnd() * 0.05f);
     for (auto& x : h2) x = f2h_bits(rnd() * 0.05f);
-    hipMalloc((void**)&W1b, h1.size() * 2);
-    hipMalloc((void**)&W2b, h2.size() * 2);
+    const std::vector<uint16_t> img = pack_ffn_image(h1.data(), h2.data(), 1856, 1856, 480);
+    hipMalloc((void**)&W1b, img.size() * 2);
     hipMalloc((void**)&bias1, 2048 * 4);
-    hipMemcpy(W1b, h1.data(), h1.size() * 2, hipMemcpyHostToDevice);
-    hipMemcpy(W2b, h2.data(), h2.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(W1b, img.data(), img.size() * 2, hipMemcpyHostToDevice);
     hipMemset(bias1, 0, 2048 * 4);
   }
   auto run = [&]() {
@@ -1170,7 +1247,7 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
       r.relu = 0;
       launch_rowgemm(r, 0, nullptr, 0);
     } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
-      launch_ffn_fused(A, Kp, W1b, bias1, W2b, 1856, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
+      launch_ffn_fused(A, Kp, W1b, bias1, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
     } else {
       launch_gemm16(g, cfg, 2, 0);
     }
@@ -1204,6 +1281,14 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
 }
 
 // attention micro-benchmark (dev tool): B layouts x 8 heads on random fp16 qkv
+namespace ldm {
+void ffn_phase_read(unsigned long long* out8);
+void attn_phase_read(unsigned long long* out16);
+}  // namespace ldm
+// dev hooks: s_memtime phase sums of the instrumented kernel variants (LDM_FFN_DBG=3 / LDM_ATTN_TM=1)
+extern "C" void ldm_dev_ffn_phases(unsigned long long* out8) { ldm::ffn_phase_read(out8); }
+extern "C" void ldm_dev_attn_phases(unsigned long long* out16) { ldm::attn_phase_read(out16); }
+
 extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
   const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;
   const size_t rows = (size_t)B * S + 256;

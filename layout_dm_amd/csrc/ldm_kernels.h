@@ -66,15 +66,15 @@ struct RowExtra {
   float2* stats_out;    // [M] row statistics of the fp32 output, or nullptr
 };
 void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* ex, hipStream_t st);
-void launch_ffn_fused(const __half* H, int ldh, const __half* W1, const float* b1, const __half* W2p, int ldw2,
-                      const float* b2, const float* res, float* out, int ldo, int M, int N, int F,
-                      const LnLoad* ln, float2* stats_out, hipStream_t st);
+// img: per-chunk LDS image of W1 | W2 (ldm_api.cpp pack_ffn_image)
+void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1, const float* b2, const float* res,
+                      float* out, int ldo, int M, int N, int F, const LnLoad* ln, float2* stats_out, hipStream_t st);
 // fused QKV projection + attention, one workgroup per layout (kernels_fusedattn.hip)
-void launch_qkv_attention(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
+void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
                           int H, int dh, hipStream_t st);
 // same + out-projection, AdaLN residual and row statistics (Wout_ks: K axis head-padded + k-slot order)
-void launch_attention_block(const __half* Win, const float* bias, const LnLoad& ln, __half* att, int ldo,
-                            const __half* Wout_ks, const float* b_out, float* C32, int ldc, float2* stats_out, int N,
+void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
+                            const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
