@@ -120,6 +120,18 @@ int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond
                     const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
                     uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream);
 
+/* ---- result packaging ----------------------------------------------------------------- */
+/* ids -> {bbox, label, mask}: LayoutSequenceTokenizer.decode (helpers/layout_tokenizer.py:255-266) +
+ * BboxTokenizer.decode (helpers/bbox_tokenizer.py:117-168) for var_order c-x-y-w-h with the stacked
+ * x-y-w-h bbox vocabulary and no bos/eos (the LayoutDM configuration), which LayoutDM.sample
+ * (models/layoutdm.py:77-88) runs on the host inside the reference's timed region (test.py:194-203).
+ * d_tokens: (B,S) int32.  d_centres: NULL for bbox_quantization=linear, else the (4,n_bin) float64
+ * cluster centres in x,y,w,h order (kmeans / percentile).  box_f64: 0 -> d_bbox is (B,E,4) float32
+ * (what the reference returns for linear), 1 -> float64 (what it returns for kmeans/percentile).
+ * d_label: (B,E) int64, d_mask: (B,E) uint8 (bool). */
+int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B, const double* d_centres, int box_f64,
+                       void* d_bbox, int64_t* d_label, uint8_t* d_mask, void* stream);
+
 /* ---- introspection ------------------------------------------------------------------- */
 /* average device time (ms) of the most recent ldm_sample_loop, measured with HIP events on the
  * stream it ran on; blocks until that loop has finished. */

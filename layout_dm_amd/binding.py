@@ -25,6 +25,7 @@ SAMPLERS = {"deterministic": 0, "random": 1, "top_p": 2, "top_k": 3, "gumbel": 4
 EXPORTS = (
     "ldm_create", "ldm_destroy", "ldm_last_error", "ldm_load_weight", "ldm_finalize_weights",
     "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
+    "ldm_decode_layouts",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
     "ldm_abi_version",
 )
@@ -75,6 +76,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                     i32, i32, vp]
     lib.ldm_sample_loop.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
                                     C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
+    lib.ldm_decode_layouts.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldm_set_profiling.argtypes = [vp, i32]
     lib.ldm_profile_count.argtypes = [vp]
@@ -121,6 +123,7 @@ class Engine:
         self.cfg = LdmConfig(ABI_VERSION, n_category, n_bin, max_elem, n_attr, d_model, n_head, d_ff, n_layer,
                              n_step, prec, max_batch, chunk)
         self.S = max_elem * n_attr
+        self.n_attr, self.n_bin, self.n_category = n_attr, n_bin, n_category
         self.C = n_category + 4 * n_bin + 2
         self.T = n_step
         self.pad_id, self.mask_id = self.C - 2, self.C - 1
@@ -256,6 +259,29 @@ class Engine:
         if keep and lc_keep is None:
             torch.cuda.current_stream(self.device).synchronize()
         return tokens, inter
+
+    # ------------------------------------------------------------------ result packaging
+    def decode(self, tokens: torch.Tensor, centres: Optional[torch.Tensor] = None):
+        """ids (B,S) -> {"bbox" (B,E,4), "label" (B,E) int64, "mask" (B,E) bool} on the device
+        (LayoutSequenceTokenizer.decode + BboxTokenizer.decode, layout_tokenizer.py:255-266 /
+        bbox_tokenizer.py:117-168).  centres: None = linear bins (float32 boxes); (4,n_bin) float64
+        cluster centres in x,y,w,h order = kmeans/percentile (float64 boxes, like the reference)."""
+        tokens = self._tok(tokens)
+        B = tokens.shape[0]
+        E = self.S // self.n_attr
+        f64 = centres is not None
+        if f64:
+            centres = torch.as_tensor(centres, dtype=torch.float64).to(self.device).contiguous()
+            assert centres.numel() == 4 * self.n_bin, "centres must be (4, n_bin)"
+        bbox = torch.empty((B, E, 4), dtype=torch.float64 if f64 else torch.float32, device=self.device)
+        label = torch.empty((B, E), dtype=torch.int64, device=self.device)
+        mask = torch.empty((B, E), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ldm_decode_layouts(self._h, tokens.data_ptr(), B, centres.data_ptr() if f64 else None,
+                                                1 if f64 else 0, bbox.data_ptr(), label.data_ptr(),
+                                                mask.data_ptr(), _stream_ptr(self.device)), "ldm_decode_layouts")
+        if f64:
+            torch.cuda.current_stream(self.device).synchronize()  # `centres` must outlive the kernel
+        return {"bbox": bbox, "label": label, "mask": mask.bool()}
 
     # ------------------------------------------------------------------ introspection
     def last_loop_ms(self) -> float:

@@ -1026,6 +1026,20 @@ extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_s
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ decode
+extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B, const double* d_centres, int box_f64,
+                                  void* d_bbox, int64_t* d_label, uint8_t* d_mask, void* stream) {
+  if (!h) return -1;
+  if (B < 0) return h->fail(-1, "negative batch");
+  if (B == 0) return 0;
+  if (!d_tokens || !d_bbox || !d_label || !d_mask) return h->fail(-1, "null argument");
+  HIP_OK(h, hipSetDevice(h->device));  // (n_attr == 5, i.e. c-x-y-w-h, is enforced by ldm_create)
+  launch_decode_layouts(d_tokens, B, h->cfg.max_elem, h->cfg.n_attr, h->cfg.n_category, h->cfg.n_bin, d_centres,
+                        box_f64, d_bbox, d_label, d_mask, (hipStream_t)stream);
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ hot path
 extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
                                int t_post, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,

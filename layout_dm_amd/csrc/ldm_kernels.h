@@ -76,6 +76,10 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
 void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
                             const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st);
+// ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
+void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
+                           const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,
+                           hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
 

@@ -179,8 +179,46 @@ class LayoutDM:
         return inner.sample(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg,
                             get_intermediate_results=get_intermediate_results, **kwargs)
 
+    def _device_decode_centres(self):
+        """Returns (ok, centres): whether ids -> {bbox,label,mask} can run in kernels_decode.hip for this
+        tokenizer (c-x-y-w-h, stacked x-y-w-h bbox vocabulary, no bos/eos) and the (4,n_bin) float64 cluster
+        centres for kmeans/percentile quantisation (None for linear bins)."""
+        if getattr(self, "_decode_plan", None) is not None:
+            return self._decode_plan
+        tok = self.tokenizer
+        plan = (False, None)
+        try:
+            bbt = tok.bbox_tokenizer
+            special = list(tok.special_tokens)
+            ok = ("bos" not in special and "eos" not in special and list(tok.var_names) == ["c", "x", "y", "w", "h"]
+                  and bbt.shared_bbox_vocab == "x-y-w-h" and list(bbt.var_names) == ["x", "y", "w", "h"]
+                  and list(getattr(bbt, "_var_order", ["x", "y", "w", "h"])) == ["x", "y", "w", "h"])
+            if ok and bbt.bbox_quantization == "linear":
+                plan = (True, None)
+            elif ok and bbt.bbox_quantization in ("kmeans", "percentile"):
+                import numpy as np
+
+                N = tok.N_bbox_per_var
+                cs = [np.asarray(bbt.clustering_models[f"{k}-{N}"].cluster_centers_, dtype=np.float64).reshape(-1)
+                      for k in ("x", "y", "w", "h")]
+                if all(c.shape == (N,) for c in cs):
+                    plan = (True, torch.from_numpy(np.stack(cs)))
+        except AttributeError:
+            plan = (False, None)
+        self._decode_plan = plan
+        return plan
+
     def sample(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None, **kwargs):
-        """layoutdm.py:77-88: ids -> CPU -> tokenizer.decode -> {"bbox","label","mask"}."""
+        """layoutdm.py:77-88: ids -> tokenizer.decode -> {"bbox","label","mask"} (CPU tensors).  The decode runs on
+        the GPU (Engine.decode) when the tokenizer is the LayoutDM one; any other tokenizer configuration falls back
+        to the caller's own `tokenizer.decode` on the host, exactly like the reference."""
         kwargs.pop("get_intermediate_results", None)
+        ok, centres = self._device_decode_centres()
+        cond_is_relation = bool(cond) and cond.get("type", None) == "relation"
+        if ok and not cond_is_relation:
+            ids = self._sample_tokens(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg,
+                                      return_device_tensor=True, **kwargs)
+            out = self.model.module.engine.decode(ids, centres)
+            return {k: v.cpu() for k, v in out.items()}
         ids = self._sample_tokens(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg, **kwargs).cpu()
         return self.tokenizer.decode(ids)

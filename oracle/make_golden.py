@@ -125,8 +125,51 @@ def capture_probs(m, spec, tokens, t, cfg, cond=None):
     return captured["p"].view(B, S, spec.n_class).permute(0, 2, 1).contiguous()  # (B,C,S)
 
 
+def decode_cases(tok, spec, B=16, seed=11):
+    """ids -> {bbox,label,mask} through the reference's own LayoutSequenceTokenizer.decode: valid layouts plus
+    every corruption the range filter sees (pad / mask tokens, labels in bbox slots, bbox ids in the label slot,
+    bbox ids of ANOTHER attribute's sub-vocabulary, which pass the filter and are clamped by BboxTokenizer.decode).
+    Both bbox_quantization=linear and the cluster-centre path (kmeans/percentile code path driven with synthetic
+    float64 centres through the reference's DummyClusteringModel, bbox_tokenizer.py:23-25)."""
+    from trainer.helpers.bbox_tokenizer import DummyClusteringModel
+
+    g = torch.Generator().manual_seed(seed)
+    tokens = random_valid_tokens(spec, B, 0.0, g)
+    noise = torch.randint(0, spec.n_class, tokens.shape, generator=g)
+    corrupt = torch.rand(tokens.shape, generator=g) < 0.15
+    corrupt[0] = False                     # one fully valid layout
+    tokens = torch.where(corrupt, noise, tokens)
+    tokens[1] = spec.mask_id               # all [MASK]
+    tokens[2] = spec.pad_id                # all [PAD]
+    out = {"tokens": tokens.numpy()}
+    dec = tok.decode(tokens.clone())
+    out["linear_bbox"], out["linear_label"], out["linear_mask"] = (dec["bbox"].numpy(), dec["label"].numpy(),
+                                                                   dec["mask"].numpy())
+    bbt = tok.bbox_tokenizer
+    saved = (bbt._bbox_quantization, bbt._clustering_models)
+    rng = np.random.default_rng(seed)
+    centres = np.sort(rng.uniform(-0.05, 1.05, size=(4, spec.n_bin)), axis=1)   # some outside [0,1]: clamp path
+    bbt._bbox_quantization = "kmeans"
+    bbt._clustering_models = {f"{k}-{spec.n_bin}": DummyClusteringModel(centres[i].reshape(-1, 1))
+                              for i, k in enumerate(["x", "y", "w", "h"])}
+    try:
+        dec = tok.decode(tokens.clone())
+    finally:
+        bbt._bbox_quantization, bbt._clustering_models = saved
+    out["centres"] = centres
+    out["kmeans_bbox"], out["kmeans_label"], out["kmeans_mask"] = (dec["bbox"].numpy(), dec["label"].numpy(),
+                                                                   dec["mask"].numpy())
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "decode":
+        for ds in ("rico25", "publaynet"):
+            _, tok = rh.build_reference_model(ds, seed=0)
+            np.savez_compressed(os.path.join(OUT, f"{ds}_decode.npz"), **decode_cases(tok, SP.SPECS[ds]))
+        return
     for ds in ("rico25", "publaynet"):
         spec = SP.SPECS[ds]
         m, tok = rh.build_reference_model(ds, seed=0)
@@ -139,6 +182,7 @@ def main():
         with open(os.path.join(OUT, f"{ds}_state_dict_manifest.txt"), "w") as f:
             for k, v in rh.state_dict_layoutdm_keys(m).items():
                 f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+        np.savez_compressed(os.path.join(OUT, f"{ds}_decode.npz"), **decode_cases(tok, spec))
         load_synth(m, spec)
         np.savez_compressed(os.path.join(OUT, f"{ds}_step_cases.npz"), **step_cases(m, spec, [99, 60, 20, 1, 0]))
 

@@ -364,3 +364,32 @@ def sample_loop(W, spec: ModelSpec, batch_size: int, cfg: dict, cond: Optional[d
         if get_intermediate_results:
             inter.append(tokens.clone())
     return inter if get_intermediate_results else tokens
+
+
+# ------------------------------------------------------------------------------------------------
+# result packaging: ids -> {bbox, label, mask}
+def decode_layouts(spec: ModelSpec, tokens, centres=None) -> Dict[str, torch.Tensor]:
+    """LayoutSequenceTokenizer.decode (helpers/layout_tokenizer.py:255-266) with
+    _filter_invalid_labels_and_bboxes (l.106-114; no bos/eos => _filter_eos is all-False, l.116-121) and
+    BboxTokenizer.decode (helpers/bbox_tokenizer.py:117-168) for var_order c-x-y-w-h / shared_bbox_vocab
+    x-y-w-h.  centres: None -> bbox_quantization=linear (float32 boxes, l.141-146); (4,n_bin) float64 ->
+    kmeans/percentile (float64 boxes clamped to [0,1], l.148-166)."""
+    ids = torch.as_tensor(tokens).long().view(-1, spec.max_elem, spec.n_attr)
+    label = ids[..., 0].clone()
+    bbox = ids[..., 1:] - spec.n_category
+    n_bbox = 4 * spec.n_bin
+    valid = (label >= 0) & (label < spec.n_category) & ((bbox >= 0) & (bbox < n_bbox)).all(dim=-1)
+    arr = bbox - torch.arange(4) * spec.n_bin           # KEY_MULT_DICT["x-y-w-h"]: y 1, w 2, h 3
+    arr = arr.clamp(0, spec.n_bin - 1)
+    if centres is None:
+        d = 1 / spec.n_bin
+        out = torch.zeros(arr.shape, dtype=torch.float32)
+        out[..., :2] = arr[..., :2].float() * d
+        out[..., 2:] = (arr[..., 2:] + 1).float() * d
+    else:
+        c = torch.as_tensor(centres, dtype=torch.float64).view(4, spec.n_bin)
+        out = torch.stack([c[j][arr[..., j]] for j in range(4)], dim=-1).clamp(0.0, 1.0)
+    invalid = ~valid
+    label[invalid] = 0
+    out[invalid] = 0.0
+    return {"bbox": out, "label": label, "mask": valid}

@@ -383,6 +383,64 @@ def test_dropin_layoutdm_class(cuda, golden_dir):
         m.train()
 
 
+# ----------------------------------------------------------------------------- result packaging (decode)
+@pytest.mark.parametrize("ds", ["rico25", "publaynet"])
+def test_decode_vs_reference_tokenizer_golden(cuda, golden_dir, ds):
+    """kernels_decode.hip == the reference's LayoutSequenceTokenizer.decode (bit-exact boxes, labels, masks)."""
+    spec = SP.SPECS[ds]
+    e = engine(ds, "exact")
+    g = np.load(os.path.join(golden_dir, f"{ds}_decode.npz"))
+    tokens = torch.from_numpy(g["tokens"]).int()
+    lin = e.decode(tokens)
+    assert lin["bbox"].dtype == torch.float32 and lin["label"].dtype == torch.int64 and lin["mask"].dtype == torch.bool
+    assert np.array_equal(lin["bbox"].cpu().numpy(), g["linear_bbox"])
+    assert np.array_equal(lin["label"].cpu().numpy(), g["linear_label"])
+    assert np.array_equal(lin["mask"].cpu().numpy(), g["linear_mask"])
+    km = e.decode(tokens, centres=torch.from_numpy(g["centres"]))
+    assert km["bbox"].dtype == torch.float64
+    assert np.array_equal(km["bbox"].cpu().numpy(), g["kmeans_bbox"])
+    assert np.array_equal(km["label"].cpu().numpy(), g["kmeans_label"])
+    assert np.array_equal(km["mask"].cpu().numpy(), g["kmeans_mask"])
+    # larger ragged batch vs the oracle restatement, incl. out-of-vocabulary / negative ids and an empty batch
+    gen = torch.Generator().manual_seed(3)
+    big = torch.randint(-3, spec.n_class + 3, (777, spec.seq_len), generator=gen).int()
+    big[::3, 0::5] = torch.randint(0, spec.n_category, big[::3, 0::5].shape, generator=gen).int()
+    for a in range(1, 5):
+        ids = torch.as_tensor(spec.full_ids(a)[:-2])
+        big[::3, a::5] = ids[torch.randint(0, len(ids), big[::3, a::5].shape, generator=gen)].int()
+    ref = R.decode_layouts(spec, big)
+    out = e.decode(big)
+    assert torch.equal(out["bbox"].cpu(), ref["bbox"]) and torch.equal(out["label"].cpu(), ref["label"])
+    assert torch.equal(out["mask"].cpu(), ref["mask"]) and 0.2 < ref["mask"].float().mean() < 0.5
+    empty = e.decode(torch.empty((0, spec.seq_len), dtype=torch.int32))
+    assert empty["bbox"].shape == (0, spec.max_elem, 4) and empty["mask"].shape == (0, spec.max_elem)
+
+
+class _LinearBboxTokenizer:
+    """The attributes of the reference's BboxTokenizer (helpers/bbox_tokenizer.py:28-83) that the drop-in inspects."""
+    shared_bbox_vocab, bbox_quantization = "x-y-w-h", "linear"
+    var_names = ["x", "y", "w", "h"]
+    _var_order = ["x", "y", "w", "h"]
+
+
+def test_dropin_sample_decodes_on_device(cuda, golden_dir):
+    """LayoutDM.sample -> {"bbox","label","mask"} CPU tensors (layoutdm.py:77-88) with the decode on the GPU."""
+    from layout_dm_amd.layoutdm import LayoutDM
+
+    spec, _ = weights("rico25")
+    tok = _MockTokenizer(spec)
+    tok.bbox_tokenizer = _LinearBboxTokenizer()
+    m = LayoutDM(backbone_cfg=BACKBONE_CFG, tokenizer=tok, q_type="constrained", precision="exact", max_batch=8)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True).items()})
+    out = m.sample(batch_size=4, cond=None, sampling_cfg={"name": "deterministic", "num_timesteps": 100})
+    g = np.load(os.path.join(golden_dir, "rico25_uncond_greedy_loop.npz"))
+    ref = R.decode_layouts(spec, g["states_after"][-1])
+    assert set(out) == {"bbox", "label", "mask"} and all(not v.is_cuda for v in out.values())
+    assert out["bbox"].shape == (4, 25, 4) and out["bbox"].dtype == torch.float32
+    assert torch.equal(out["bbox"], ref["bbox"]) and torch.equal(out["label"], ref["label"])
+    assert torch.equal(out["mask"], ref["mask"])
+
+
 def test_relation_split_step_equals_fused_with_identity_update(cuda):
     """cond=relation split-step path (denoise -> posterior -> update_fn -> draw) with an identity
     update_fn must reproduce the fused kernel path of cond=c (same strong mask + PAD disable)."""
