@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 1
+#define LDM_ABI_VERSION 2
 
 typedef struct ldm_handle ldm_handle;
 
@@ -32,6 +32,14 @@ enum {
   LDM_PREC_EXACT_F32 = 0, /* v_mfma_f32_32x32x2_f32: exact fp32 (== fmaf chain) */
   LDM_PREC_FAST_F16 = 1,  /* fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) */
   LDM_PREC_SPLIT_F16 = 2  /* fp16 hi+lo split operands, 3 MFMA passes, ~fp32 accuracy */
+};
+
+/* transition-matrix family == Q_TYPES of the reference (models/layoutdm.py:20-23) */
+enum {
+  LDM_Q_CONSTRAINED = 0, /* ConstrainedMaskAndReplaceDiffusion: one sub-vocabulary per attribute
+                            (categorical_diffusion/constrained.py) — the LayoutDM default */
+  LDM_Q_VANILLA = 1      /* VanillaMaskAndReplaceDiffusion: one vocabulary of all C classes, MASK last,
+                            un-prefixed schedule buffers (categorical_diffusion/vanilla.py) */
 };
 
 /* sampler kinds: trainer/helpers/sampling.py:13-59,81-130 */
@@ -61,6 +69,7 @@ typedef struct {
   int32_t max_batch;   /* largest B any call will use (workspace is sized for it) */
   int32_t chunk;       /* layouts processed per pass through the network (0 = auto) so that the
                           activation working set stays inside the 256 MiB Infinity Cache */
+  int32_t q_type;      /* LDM_Q_* (ABI 2) */
 } ldm_config;
 
 /* sampling_cfg of the reference (helpers/sampling.py dataclasses) */

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16 = 0, 1, 2
 PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16,
@@ -34,7 +34,10 @@ EXPORTS = (
 class LdmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "n_category", "n_bin", "max_elem", "n_attr", "d_model", "n_head", "d_ff",
-        "n_layer", "n_step", "precision", "max_batch", "chunk")]
+        "n_layer", "n_step", "precision", "max_batch", "chunk", "q_type")]
+
+
+Q_TYPES = {"constrained": 0, "vanilla": 1}  # models/layoutdm.py:20-23
 
 
 class LdmSampler(C.Structure):
@@ -113,7 +116,10 @@ class Engine:
 
     def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
                  d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4, n_step: int = 100,
-                 precision="exact", max_batch: int = 512, chunk: int = 0, device: Optional[int] = None):
+                 precision="exact", max_batch: int = 512, chunk: int = 0, device: Optional[int] = None,
+                 q_type: str = "constrained"):
+        if q_type not in Q_TYPES:
+            raise NotImplementedError(f"q_type={q_type}: one of {sorted(Q_TYPES)}")
         if not torch.cuda.is_available():
             raise RuntimeError("layout_dm_amd needs a ROCm GPU (MI355X); there is no CPU path")
         self.lib = load_library()
@@ -121,7 +127,8 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         self.cfg = LdmConfig(ABI_VERSION, n_category, n_bin, max_elem, n_attr, d_model, n_head, d_ff, n_layer,
-                             n_step, prec, max_batch, chunk)
+                             n_step, prec, max_batch, chunk, Q_TYPES[q_type])
+        self.q_type = q_type
         self.S = max_elem * n_attr
         self.n_attr, self.n_bin, self.n_category = n_attr, n_bin, n_category
         self.C = n_category + 4 * n_bin + 2

@@ -256,9 +256,18 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   h->vocab.n_attr = cfg->n_attr;
   h->vocab.pad_id = h->C - 2;
   h->vocab.mask_id = h->C - 1;
+  if (cfg->q_type != LDM_Q_CONSTRAINED && cfg->q_type != LDM_Q_VANILLA) {
+    delete h;
+    return bad("unknown q_type");
+  }
   for (int a = 0; a < cfg->n_attr; ++a) {
-    h->vocab.start[a] = (a == 0) ? 0 : cfg->n_category + (a - 1) * cfg->n_bin;
-    h->vocab.count[a] = (a == 0) ? cfg->n_category : cfg->n_bin;
+    if (cfg->q_type == LDM_Q_VANILLA) {  // one vocabulary: every class is live at every position (vanilla.py)
+      h->vocab.start[a] = 0;
+      h->vocab.count[a] = h->C - 2;
+    } else {
+      h->vocab.start[a] = (a == 0) ? 0 : cfg->n_category + (a - 1) * cfg->n_bin;
+      h->vocab.count[a] = (a == 0) ? cfg->n_category : cfg->n_bin;
+    }
   }
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
@@ -612,7 +621,8 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   for (int k = 0; k < kNumSched; ++k) {
     const bool cum = (k == kLogCumAt || k == kLogCumBt || k == kLogCumCt || k == kLog1mCumCt);
     for (int a = 0; a < h->cfg.n_attr; ++a) {
-      const std::string key = std::string(keys[a]) + "_" + names[k];
+      // vanilla.py:66-73 registers ONE un-prefixed set; it is replicated into every attribute's row
+      const std::string key = h->cfg.q_type == LDM_Q_VANILLA ? std::string(names[k]) : std::string(keys[a]) + "_" + names[k];
       const float* d = nullptr;
       if ((rc = need(h, key, {cum ? T + 1 : T}, &d))) return rc;
       HIP_OK(h, hipMemcpy(&host[((size_t)k * h->cfg.n_attr + a) * (T + 1)], d, (cum ? T + 1 : T) * sizeof(float),

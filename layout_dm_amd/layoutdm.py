@@ -58,8 +58,9 @@ class LayoutDM:
                  num_timesteps: int = 100, auxiliary_loss_weight: float = 1e-1, q_type: str = "single",
                  seq_type: str = "poset", precision: str = "fast", max_batch: int = 512, device: Optional[int] = None,
                  **kwargs) -> None:
-        if q_type != "constrained":
-            raise NotImplementedError("only q_type=constrained (LayoutDM default, experiment/layoutdm.yaml:18)")
+        if q_type not in ("constrained", "vanilla"):  # Q_TYPES, layoutdm.py:20-23
+            raise NotImplementedError(f"q_type={q_type}: constrained (LayoutDM default, experiment/layoutdm.yaml:18) "
+                                      "or vanilla")
         if transformer_type != "flattened" or pos_emb != "elem_attr":
             raise NotImplementedError("only transformer_type=flattened / pos_emb=elem_attr")
         assert seq_type in ["set", "poset"]
@@ -81,7 +82,7 @@ class LayoutDM:
         inner = HipMaskAndReplaceDiffusion(
             n_category=tokenizer.N_category, n_bin=tokenizer.N_bbox_per_var, max_elem=tokenizer.max_seq_length,
             n_attr=tokenizer.N_var_per_element, d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer,
-            num_timesteps=num_timesteps, precision=precision, max_batch=max_batch, device=device)
+            num_timesteps=num_timesteps, precision=precision, max_batch=max_batch, device=device, q_type=q_type)
         assert inner.num_classes == tokenizer.N_total and inner.max_token_length == tokenizer.max_token_length
         self.model = _ModuleShim(inner, self)
         self._refine_table = None

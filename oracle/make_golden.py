@@ -162,9 +162,41 @@ def decode_cases(tok, spec, B=16, seed=11):
     return out
 
 
+def vanilla_cases(spec, B=2):
+    """q_type=vanilla (models/layoutdm.py:20-23 -> categorical_diffusion/vanilla.py): teacher-forced step pieces on
+    states whose tokens are NOT restricted to their attribute's sub-vocabulary (the single-vocabulary posterior
+    accepts any class anywhere) and a stochastic reference trajectory with per-state greedy answers."""
+    m, _ = rh.build_reference_model("rico25", seed=0, q_type="vanilla")  # (installs the import stubs)
+    from trainer.models.categorical_diffusion.util import index_to_log_onehot
+
+    ssd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True, prefix="", q_type="vanilla")
+    sched_ref = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("log_")}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+    out = {f"sched_{k}": v.numpy() for k, v in sched_ref.items()}  # the reference's own buffers (pin spec.py)
+    g = torch.Generator().manual_seed(321)
+    ts = [99, 60, 20, 1, 0]
+    out["ts"] = np.array(ts, np.int32)
+    for t in ts:
+        tokens = torch.randint(0, spec.n_class - 1, (B, spec.seq_len), generator=g)
+        tokens[torch.rand(B, spec.seq_len, generator=g) < t / (spec.n_step - 1)] = spec.mask_id
+        tt = torch.full((B,), t, dtype=torch.long)
+        with torch.no_grad():
+            lz = index_to_log_onehot(tokens, spec.n_class)
+            x0 = m.predict_start(lz, tt)
+            post = m.q_posterior(x0, lz, tt)
+        out[f"tokens_{t}"] = tokens.numpy().astype(np.int16)
+        out[f"post_{t}"] = post.numpy()
+    tr = trajectory(m, spec, B, rh.sampling_cfg("random"), None, seed=3)
+    out.update({f"traj_{k}": v for k, v in tr.items()})
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "vanilla":
+        np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(SP.SPECS["rico25"]))
+        return
     if only == "decode":
         for ds in ("rico25", "publaynet"):
             _, tok = rh.build_reference_model(ds, seed=0)
@@ -187,6 +219,7 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"{ds}_step_cases.npz"), **step_cases(m, spec, [99, 60, 20, 1, 0]))
 
         if ds == "rico25":
+            np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(spec))
             tr = trajectory(m, spec, 4, rh.sampling_cfg("random"), None, seed=0)
             np.savez_compressed(os.path.join(OUT, "rico25_uncond_trajectory.npz"), **tr)
             torch.manual_seed(0)

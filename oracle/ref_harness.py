@@ -199,7 +199,8 @@ def make_cfgs(dataset: str = "rico25"):
     return data_cfg, dataset_cfg, backbone_cfg
 
 
-def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool = False):
+def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool = False,
+                          q_type: str = "constrained"):
     """Instantiate the reference diffusion module with the reference's own init.
 
     perturb=True additionally randomises every bias / LayerNorm affine parameter so
@@ -218,7 +219,10 @@ def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool 
     data_cfg, dataset_cfg, backbone_cfg = make_cfgs(dataset)
     torch.manual_seed(seed)
     tok = LayoutSequenceTokenizer(data_cfg, dataset_cfg)
-    m = ConstrainedMaskAndReplaceDiffusion(
+    cls = ConstrainedMaskAndReplaceDiffusion
+    if q_type == "vanilla":  # Q_TYPES, models/layoutdm.py:20-23
+        from trainer.models.categorical_diffusion.vanilla import VanillaMaskAndReplaceDiffusion as cls
+    m = cls(
         backbone_cfg=shrink(backbone_cfg, 29 / 32),
         num_classes=tok.N_total,
         max_token_length=tok.max_token_length,

@@ -134,8 +134,13 @@ def predict_start_from_logits(logits: torch.Tensor) -> torch.Tensor:
     return torch.clamp(log_pred, -70, 0)
 
 
-def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Tensor, t: int) -> torch.Tensor:
-    """ConstrainedMaskAndReplaceDiffusion.q_posterior
+def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Tensor, t: int,
+                q_type: str = "constrained") -> torch.Tensor:
+    """q_type="vanilla": VanillaMaskAndReplaceDiffusion.q_posterior (categorical_diffusion/vanilla.py:112-151 with
+    q_pred 92-110 and q_pred_one_timestep 74-90) — the same recursion over ONE vocabulary of all C classes
+    (MASK last, PAD an ordinary class) with the un-prefixed schedule buffers.  Otherwise:
+
+    ConstrainedMaskAndReplaceDiffusion.q_posterior
     (categorical_diffusion/constrained.py:135-206, helpers q_pred 112-133 and
     q_pred_one_timestep 92-110; Converter gather/scatter helpers/layout_tokenizer.py:540-557).
 
@@ -148,17 +153,19 @@ def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Ten
     assert 0 <= t < T  # constrained.py:139
     u = (t - 1 + (T + 1)) % (T + 1)  # constrained.py:114
     out = torch.full((B, C, S), LOG_EPS, dtype=torch.float32)  # p_to_f_log fill, layout_tokenizer.py:544
-    for a, key in enumerate(VAR_NAMES):
-        full = torch.as_tensor(spec.full_ids(a))  # partial -> full id
+    groups = [(f"{key}_", torch.as_tensor(spec.full_ids(a)), slice(a, None, A)) for a, key in enumerate(VAR_NAMES)]
+    if q_type == "vanilla":
+        groups = [("", torch.arange(C), slice(None))]
+    for prefix, full, pos in groups:  # full: partial -> full id
         K = full.numel()
-        buf = lambda n: W[f"{key}_{n}"].float()
+        buf = lambda n: W[f"{prefix}{n}"].float()
         la, lb, lc = buf("log_at")[t], buf("log_bt")[t], buf("log_ct")[t]
         LA, LB, LC = buf("log_cumprod_at")[t], buf("log_cumprod_bt")[t], buf("log_cumprod_ct")[t]
         LAu, LBu, LCu = buf("log_cumprod_at")[u], buf("log_cumprod_bt")[u], buf("log_cumprod_ct")[u]
         L1Cu = buf("log_1_min_cumprod_ct")[u]
 
-        tok_a = tokens[:, a::A]  # (B,E) full ids
-        lxs = log_x_start[:, :, a::A][:, full, :]  # f_to_p_log: (B,K,E)
+        tok_a = tokens[:, pos]  # (B,E) full ids
+        lxs = log_x_start[:, :, pos][:, full, :]  # f_to_p_log: (B,K,E)
         # one-hot log_x_t in the partial vocabulary (util.py:34-40 then gather)
         part = (tok_a.unsqueeze(1) == full.view(1, K, 1))
         lxt = torch.log(part.float().clamp(min=1e-30))
@@ -183,7 +190,7 @@ def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Ten
         ], dim=1)
         ev = torch.clamp(r + q1 + lse, -70, 0)
         # p_to_f_log scatter + interleave (constrained.py:198-204)
-        sub = out[:, :, a::A]
+        sub = out[:, :, pos]
         sub[:, full, :] = ev
     return out
 
@@ -316,7 +323,7 @@ def timestep_list(T_model: int, T_eval: int):
 
 
 def single_step(W, spec, tokens, t, cfg, cond=None, skip_step: int = 0, uniforms=None, generator=None,
-                dtype=torch.float32, return_all=False):
+                dtype=torch.float32, return_all=False, q_type: str = "constrained"):
     """_sample_single_step (categorical_diffusion/base.py:205-291) in token form."""
     logits = denoiser_logits(W, spec, tokens, t, dtype=dtype).float()
     log_x0 = predict_start_from_logits(logits)
@@ -326,7 +333,7 @@ def single_step(W, spec, tokens, t, cfg, cond=None, skip_step: int = 0, uniforms
         noise_t = min(max(t - int(spec.n_step * td), 0), spec.n_step - 1)
     if skip_step > 0 and noise_t > skip_step:
         noise_t = noise_t - skip_step
-    logp = q_posterior(W, spec, log_x0, tokens, noise_t)
+    logp = q_posterior(W, spec, log_x0, tokens, noise_t, q_type=q_type)
     logp = apply_cond(spec, logp, cond)
     nxt = sample_tokens(logp, cfg, uniforms=uniforms, generator=generator)
     if return_all:
@@ -336,7 +343,7 @@ def single_step(W, spec, tokens, t, cfg, cond=None, skip_step: int = 0, uniforms
 
 def sample_loop(W, spec: ModelSpec, batch_size: int, cfg: dict, cond: Optional[dict] = None,
                 seed: Optional[int] = None, first_layout: int = 0, generator=None,
-                dtype=torch.float32, get_intermediate_results=False):
+                dtype=torch.float32, get_intermediate_results=False, q_type: str = "constrained"):
     """BaseMaskAndReplaceDiffusion.sample (categorical_diffusion/base.py:293-371).
     With `seed` the stochastic draws use the Philox inverse-CDF rule of the HIP kernel
     (keyed by global layout index => independent of batch split); otherwise
@@ -359,7 +366,7 @@ def sample_loop(W, spec: ModelSpec, batch_size: int, cfg: dict, cond: Optional[d
         if seed is not None and cfg["name"] != "deterministic":
             u = token_uniforms(seed, first_layout, batch_size, spec.seq_len, i)[..., 0]
         tokens = single_step(W, spec, tokens, t, cfg, cond, skip_step=prev - t - 1, uniforms=u,
-                             generator=generator, dtype=dtype)
+                             generator=generator, dtype=dtype, q_type=q_type)
         prev = t
         if get_intermediate_results:
             inter.append(tokens.clone())

@@ -95,16 +95,19 @@ SCHEDULE_NAMES = (
 )
 
 
-def schedule_buffers(spec: ModelSpec):
-    """{f"{key}_{name}": float32 array} as registered at constrained.py:56-90.
+def schedule_buffers(spec: ModelSpec, q_type: str = "constrained"):
+    """{f"{key}_{name}": float32 array} as registered at constrained.py:56-90, or — q_type="vanilla" — the
+    un-prefixed single-vocabulary buffers of vanilla.py:42-72 (N = C - 1).
 
     torch.log / log_1_min_a (util.py:15-16) are evaluated in float64 then cast to
     float32, exactly as the reference does (torch.tensor(float64) -> .float()).
     """
     out = {}
+    groups = [(f"{key}_", spec.sub_vocab_size(a) - 1) for a, key in enumerate(VAR_NAMES)]
+    if q_type == "vanilla":
+        groups = [("", spec.n_class - 1)]
     with np.errstate(divide="ignore"):
-        for a, key in enumerate(VAR_NAMES):
-            N = spec.sub_vocab_size(a) - 1
+        for prefix, N in groups:
             at, bt, ct, att, btt, ctt = alpha_schedule(spec.n_step, N)
             log_at, log_bt, log_ct = np.log(at), np.log(bt), np.log(ct)
             l_att, l_btt, l_ctt = np.log(att), np.log(btt), np.log(ctt)
@@ -112,5 +115,5 @@ def schedule_buffers(spec: ModelSpec):
             log_1_min_cumprod_ct = np.log(1 - np.exp(l_ctt) + 1e-40)
             vals = (log_at, log_bt, log_ct, l_att, l_btt, l_ctt, log_1_min_ct, log_1_min_cumprod_ct)
             for n, v in zip(SCHEDULE_NAMES, vals):
-                out[f"{key}_{n}"] = v.astype(np.float32)
+                out[f"{prefix}{n}"] = v.astype(np.float32)
     return out

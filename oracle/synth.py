@@ -18,7 +18,7 @@ PREFIX = "model.module."  # CustomDataParallel wrapper, models/layoutdm.py:52
 
 
 def synth_state_dict(spec: ModelSpec, seed: int = 0, perturb: bool = False, prefix: str = PREFIX,
-                     weight_std: float = 0.02):
+                     weight_std: float = 0.02, q_type: str = "constrained"):
     """Returns {key: np.ndarray(float32)} with the 100 reference keys."""
     rng = np.random.default_rng(seed)
     D, F, C, T = spec.d_model, spec.d_ff, spec.n_class, spec.n_step
@@ -39,7 +39,7 @@ def synth_state_dict(spec: ModelSpec, seed: int = 0, perturb: bool = False, pref
     sd = {}
     sd["Lt_history"] = np.zeros(T, np.float32)
     sd["Lt_count"] = np.zeros(T, np.float32)
-    sd.update(schedule_buffers(spec))
+    sd.update(schedule_buffers(spec, q_type))
     tr = "transformer."
     sd[tr + "cat_emb.weight"] = normal(C, D)
     sd[tr + "pos_emb.elem_emb"] = rng.random((spec.max_elem, D)).astype(np.float32)

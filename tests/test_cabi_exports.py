@@ -37,7 +37,7 @@ def test_header_symbols_exported(lib_path):
 def test_binding_struct_layout_matches_header():
     from layout_dm_amd import binding
 
-    assert ctypes.sizeof(binding.LdmConfig) == 13 * 4
+    assert ctypes.sizeof(binding.LdmConfig) == 14 * 4  # ABI 2: + q_type
     assert ctypes.sizeof(binding.LdmSampler) == 16
     assert ctypes.sizeof(binding.LdmCond) == 3 * 8 + 8  # three pointers + int32 (+pad)
 

@@ -383,6 +383,53 @@ def test_dropin_layoutdm_class(cuda, golden_dir):
         m.train()
 
 
+# ----------------------------------------------------------------------------- q_type = vanilla
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_vanilla_q_type_vs_reference_golden(cuda, golden_dir, precision):
+    """VanillaMaskAndReplaceDiffusion (categorical_diffusion/vanilla.py) through the same kernels: posterior vs the
+    reference's q_posterior on unrestricted token states, greedy step on every state of a reference trajectory, and a
+    seeded stochastic loop vs the oracle with the same Philox uniforms."""
+    from layout_dm_amd.binding import Engine
+
+    spec = SP.RICO25
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True, q_type="vanilla")
+    W = R.as_torch_weights(sd)
+    e = Engine(n_category=spec.n_category, precision=precision, max_batch=8, q_type="vanilla")
+    e.load_state_dict(sd)
+    g = np.load(os.path.join(golden_dir, "rico25_vanilla.npz"))
+    for t in g["ts"]:
+        t = int(t)
+        tokens = torch.from_numpy(g[f"tokens_{t}"].astype(np.int64))
+        ref_post = torch.from_numpy(g[f"post_{t}"])
+        logits = e.denoise_logits(tokens.int(), t)
+        post = e.posterior(logits, tokens.int(), t).cpu()
+        tol = 2e-4 if precision == "exact" else 5e-2  # log-probabilities; logits themselves carry <=1e-3 rel in fast
+        assert (post - ref_post).abs().max().item() <= tol
+    before = torch.from_numpy(g["traj_states_before"].astype(np.int64))
+    ref_next = torch.from_numpy(g["traj_greedy_next"].astype(np.int64))
+    mism = 0
+    for i, t in enumerate(g["traj_steps"]):
+        nxt = e.sample_step(before[i].int(), int(t), {"name": "deterministic"}).cpu().long()
+        mism += int((nxt != ref_next[i]).sum())
+    if precision == "exact":
+        assert mism == 0, f"{mism}/{ref_next.numel()}"
+    else:
+        assert mism <= 0.005 * ref_next.numel(), f"{mism}/{ref_next.numel()}"
+    if precision == "exact":
+        cfg = {"name": "random", "temperature": 1.0, "num_timesteps": 20}
+        tk = torch.full((3, spec.seq_len), spec.mask_id, dtype=torch.int32)
+        from layout_dm_amd.diffusion import timestep_schedule
+
+        tm, tp = timestep_schedule(spec.n_step, 20)
+        out, _ = e.sample_loop(tk, tm, tp, cfg, seed=77, first_layout=5)
+        ref = R.sample_loop(W, spec, 3, cfg, seed=77, first_layout=5, q_type="vanilla")
+        frac = (out.cpu().long() != ref).float().mean().item()
+        assert frac <= 0.02, frac  # inverse-CDF draws can flip only where a uniform lands within fp32 noise of a bin edge
+    e.close()
+    with pytest.raises(NotImplementedError):
+        Engine(n_category=spec.n_category, q_type="single")
+
+
 # ----------------------------------------------------------------------------- result packaging (decode)
 @pytest.mark.parametrize("ds", ["rico25", "publaynet"])
 def test_decode_vs_reference_tokenizer_golden(cuda, golden_dir, ds):
