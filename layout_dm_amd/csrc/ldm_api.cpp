@@ -303,7 +303,9 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
     if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
-    if (!h->defer_ln || h->S > 128 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
+    // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
+    // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
+    if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
