@@ -129,6 +129,27 @@ int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond
                     const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
                     uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream);
 
+/* ---- cond=relation ---------------------------------------------------------------------- */
+/* The logit adjustment the reference applies between the posterior and the draw for cond["type"] ==
+ * "relation" (base.py:261-269 -> update(), categorical_diffusion/logit_adjustment.py:88-126, losses
+ * models/clg/const.py:221-236), relation_mode = "average": `num_update` SGD steps (t >= 10 only) on
+ * the mean relational-constraint loss, with the gradient evaluated analytically.  Call between
+ * ldm_posterior and ldm_sample_tokens.  The graph is cond["batch_w_canvas"] (helpers/task.py:112-114)
+ * re-indexed per layout: node 0 = canvas, node k = k-th element whose conditioned category is not PAD. */
+typedef struct {
+  const int32_t* d_edge_offsets; /* (B+1) CSR offsets into the edge arrays */
+  const int32_t* d_edge_src;     /* (n_edges) node id inside its layout's graph */
+  const int32_t* d_edge_dst;
+  const int32_t* d_edge_attr;    /* 1<<RelSize | 1<<RelLoc bitmasks (trainer/data/util.py:14-27,168) */
+  const float* d_centres;        /* (4, n_bin) cluster centres in x,y,w,h order (float32, as update() casts them) */
+  int32_t canvas_bins[4];        /* bbox_tokenizer.encode([0.5,0.5,1,1]) per coordinate, 0..n_bin-1 */
+  float relation_lambda;         /* sampling_cfg.relation_lambda (SGD learning rate) */
+  int32_t num_update;            /* sampling_cfg.relation_num_update */
+  int32_t n_graph_total;         /* batch size of the whole sampling call: the loss is a mean over 14*B terms */
+} ldm_relation;
+int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int32_t* d_cond_seq, const ldm_relation* rel,
+                        int t, int B, void* stream);
+
 /* ---- result packaging ----------------------------------------------------------------- */
 /* ids -> {bbox, label, mask}: LayoutSequenceTokenizer.decode (helpers/layout_tokenizer.py:255-266) +
  * BboxTokenizer.decode (helpers/bbox_tokenizer.py:117-168) for var_order c-x-y-w-h with the stacked

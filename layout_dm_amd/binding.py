@@ -25,7 +25,7 @@ SAMPLERS = {"deterministic": 0, "random": 1, "top_p": 2, "top_k": 3, "gumbel": 4
 EXPORTS = (
     "ldm_create", "ldm_destroy", "ldm_last_error", "ldm_load_weight", "ldm_finalize_weights",
     "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
-    "ldm_decode_layouts",
+    "ldm_decode_layouts", "ldm_relation_update",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
     "ldm_abi_version",
 )
@@ -38,6 +38,12 @@ class LdmConfig(C.Structure):
 
 
 Q_TYPES = {"constrained": 0, "vanilla": 1}  # models/layoutdm.py:20-23
+
+
+class LdmRelation(C.Structure):  # include/ldm_hip.h: ldm_relation
+    _fields_ = [("d_edge_offsets", C.c_void_p), ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p),
+                ("d_edge_attr", C.c_void_p), ("d_centres", C.c_void_p), ("canvas_bins", C.c_int32 * 4),
+                ("relation_lambda", C.c_float), ("num_update", C.c_int32), ("n_graph_total", C.c_int32)]
 
 
 class LdmSampler(C.Structure):
@@ -80,6 +86,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.ldm_sample_loop.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
                                     C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
     lib.ldm_decode_layouts.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.ldm_relation_update.argtypes = [vp, vp, vp, C.POINTER(LdmRelation), i32, i32, vp]
     lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldm_set_profiling.argtypes = [vp, i32]
     lib.ldm_profile_count.argtypes = [vp]
@@ -266,6 +273,43 @@ class Engine:
         if keep and lc_keep is None:
             torch.cuda.current_stream(self.device).synchronize()
         return tokens, inter
+
+    # ------------------------------------------------------------------ cond=relation
+    def make_relation(self, graph, centres, canvas_bins, relation_lambda: float, num_update: int, n_graph_total: int):
+        """Device-side description of cond["batch_w_canvas"] for ldm_relation_update.  graph: object / dict with
+        y (nodes,), edge_index (2,E) global node ids, edge_attr (E,), batch (nodes,) — torch_geometric DataBatch
+        fields (helpers/task.py:112-114).  Returns (LdmRelation, keep-alive tensors)."""
+        get = (lambda k: graph[k]) if isinstance(graph, dict) else (lambda k: getattr(graph, k))
+        batch = torch.as_tensor(get("batch")).long().cpu()
+        ei = torch.as_tensor(get("edge_index")).long().cpu().view(2, -1)
+        ea = torch.as_tensor(get("edge_attr")).long().cpu().view(-1)
+        B = int(n_graph_total)
+        n_nodes = torch.bincount(batch, minlength=B)
+        first = torch.cat([n_nodes.new_zeros(1), n_nodes.cumsum(0)])[:-1]
+        eg = batch[ei[0]] if ei.numel() else torch.zeros(0, dtype=torch.long)
+        order = torch.argsort(eg, stable=True)
+        eg, src, dst, ea = eg[order], ei[0][order], ei[1][order], ea[order]
+        if ei.numel():
+            assert bool((batch[dst] == eg).all()), "edge crosses two layouts"
+        off = torch.cat([eg.new_zeros(1), torch.bincount(eg, minlength=B).cumsum(0)]).int()
+        dev = self.device
+        keep = [off.to(dev), (src - first[eg]).int().to(dev), (dst - first[eg]).int().to(dev), ea.int().to(dev),
+                torch.as_tensor(centres, dtype=torch.float64).float().reshape(4, self.n_bin).contiguous().to(dev)]
+        rel = LdmRelation(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                          keep[4].data_ptr(), (C.c_int32 * 4)(*[int(x) for x in canvas_bins]),
+                          float(relation_lambda), int(num_update), B)
+        return rel, keep
+
+    def relation_update(self, logp: torch.Tensor, cond_seq: torch.Tensor, rel, t: int, layout_offset: int = 0):
+        """In-place logit adjustment of `logp` (B,C,S) float32 cuda (logit_adjustment.update, l.88-126)."""
+        assert logp.is_cuda and logp.dtype == torch.float32 and logp.is_contiguous()
+        lr, keep = rel
+        cond_seq = self._tok(cond_seq)
+        assert layout_offset == 0, "relation graphs are indexed from the first layout of the call"
+        self._check(self.lib.ldm_relation_update(self._h, logp.data_ptr(), cond_seq.data_ptr(), C.byref(lr), int(t),
+                                                 logp.shape[0], _stream_ptr(self.device)), "ldm_relation_update")
+        torch.cuda.current_stream(self.device).synchronize()  # cond_seq copy / keep-alives may be temporaries
+        return logp
 
     # ------------------------------------------------------------------ result packaging
     def decode(self, tokens: torch.Tensor, centres: Optional[torch.Tensor] = None):

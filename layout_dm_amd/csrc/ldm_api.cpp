@@ -1038,6 +1038,32 @@ extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_s
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ relation
+extern "C" int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int32_t* d_cond_seq,
+                                   const ldm_relation* rel, int t, int B, void* stream) {
+  if (!h) return -1;
+  if (B <= 0) return B == 0 ? 0 : h->fail(-1, "negative batch");
+  if (!d_logp_inout || !d_cond_seq || !rel) return h->fail(-1, "null argument");
+  if (!rel->d_edge_offsets || !rel->d_centres) return h->fail(-1, "ldm_relation: null edge offsets / centres");
+  if (rel->n_graph_total < B) return h->fail(-1, "ldm_relation.n_graph_total smaller than B");
+  if (h->cfg.max_elem > 32 || h->cfg.n_bin > 32) return h->fail(-4, "relation kernel: max_elem and n_bin must be <= 32");
+  for (int x = 0; x < 4; ++x)
+    if (rel->canvas_bins[x] < 0 || rel->canvas_bins[x] >= h->cfg.n_bin) return h->fail(-1, "canvas bin out of range");
+  if (t < 10 || rel->num_update <= 0) return 0;  // logit_adjustment.py:107
+  HIP_OK(h, hipSetDevice(h->device));
+  RelArgs a{};
+  a.logp = d_logp_inout; a.cond_seq = d_cond_seq;
+  a.edge_off = rel->d_edge_offsets; a.edge_src = rel->d_edge_src; a.edge_dst = rel->d_edge_dst;
+  a.edge_attr = rel->d_edge_attr; a.centres = rel->d_centres;
+  for (int x = 0; x < 4; ++x) a.canvas_bins[x] = rel->canvas_bins[x];
+  a.step = rel->relation_lambda / (14.0f * (float)rel->n_graph_total);
+  a.num_update = rel->num_update; a.B = B; a.C = h->C; a.S = h->S; a.A = h->cfg.n_attr;
+  a.n_category = h->cfg.n_category; a.n_bin = h->cfg.n_bin; a.pad_id = h->vocab.pad_id;
+  launch_relation_update(a, (hipStream_t)stream);
+  HIP_OK(h, hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ decode
 extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B, const double* d_centres, int box_f64,
                                   void* d_bbox, int64_t* d_label, uint8_t* d_mask, void* stream) {

@@ -80,6 +80,18 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,
                            hipStream_t st);
+// cond=relation logit adjustment (kernels_relation.hip)
+struct RelArgs {
+  float* logp;              // (B,C,S) log p(x_{t-1}|x_t), updated in place
+  const int32_t* cond_seq;  // (B,S) conditioned sequence: element e is a graph node iff cond_seq[b][e*A] != pad
+  const int32_t* edge_off;  // (B+1) offsets of each layout's edges
+  const int32_t *edge_src, *edge_dst, *edge_attr;  // node ids inside the layout's graph (0 = canvas), bitmasks
+  const float* centres;     // (4, n_bin) cluster centres, x y w h
+  int canvas_bins[4];       // bin of the canvas box (0.5, 0.5, 1, 1) per coordinate
+  float step;               // relation_lambda / (14 * number of graphs in the call)
+  int num_update, B, C, S, A, n_category, n_bin, pad_id;
+};
+void launch_relation_update(const RelArgs& a, hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
 

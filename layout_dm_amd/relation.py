@@ -1,14 +1,15 @@
 """cond=relation through the split-step API.
 
-The reference interleaves an autograd-driven logit adjustment between the posterior and the draw
+The reference interleaves a gradient-descent logit adjustment between the posterior and the draw
 (`update()`, trainer/models/categorical_diffusion/logit_adjustment.py:88-126, called at
-base.py:261-269).  That optimiser stays in PyTorch; the denoiser forward, the posterior + cond
-overrides and the categorical draw still run in libldm_hip.so through the three parity hooks
-(ldm_denoise_logits / ldm_posterior / ldm_sample_tokens), all on device tensors, no host copies.
+base.py:261-269).  Here every stage runs in libldm_hip.so on device tensors:
+ldm_denoise_logits -> ldm_posterior -> ldm_relation_update (analytic gradient of the 14 relational
+losses, kernels_relation.hip) -> ldm_sample_tokens.
 
-`update_fn(t, cond, model_log_prob, tokenizer, sampling_cfg) -> model_log_prob` defaults to the
-reference's own function (the reference package is installed in a drop-in deployment); any callable
-with that signature can be injected.
+The HIP update covers relation_mode="average" (the reference's default; "gumbel" `did not work at all`,
+logit_adjustment.py:25) with the LayoutDM tokenizer (stacked x-y-w-h vocabulary, 1-D cluster centres).
+Anything else — or an explicit `update_fn(t, cond, model_log_prob, tokenizer, sampling_cfg)` — goes
+through that callable instead (default: the reference's own PyTorch function when the package is installed).
 """
 from __future__ import annotations
 
@@ -31,12 +32,40 @@ def _reference_update():
     return update
 
 
+def hip_relation_plan(eng, cond: Dict, sampling_cfg, tokenizer, batch_size: int):
+    """(LdmRelation, keep-alives) when the HIP logit adjustment applies, else None."""
+    try:
+        if str(_cfg_get(sampling_cfg, "relation_mode", "average")) != "average":
+            return None
+        bt = tokenizer.bbox_tokenizer
+        N = tokenizer.N_bbox_per_var
+        if bt.shared_bbox_vocab != "x-y-w-h" or list(bt.var_names) != ["x", "y", "w", "h"] or N > 32:
+            return None
+        import numpy as np
+
+        cs = [np.asarray(bt.clustering_models[f"{k}-{N}"].cluster_centers_, dtype=np.float64).reshape(-1)
+              for k in ("x", "y", "w", "h")]
+        if any(c.shape != (N,) for c in cs):
+            return None
+        canvas = bt.encode(torch.tensor([[[0.5, 0.5, 1.0, 1.0]]])).long().view(-1)  # logit_adjustment.py:38-41
+        bins = [int(canvas[i]) - i * N for i in range(4)]
+        return eng.make_relation(cond["batch_w_canvas"], np.stack(cs), bins,
+                                 float(_cfg_get(sampling_cfg, "relation_lambda", 3e6)),
+                                 int(_cfg_get(sampling_cfg, "relation_num_update", 3)), batch_size)
+    except (AttributeError, KeyError):
+        return None
+
+
 def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, cond: Dict, sampling_cfg, tokenizer,
                          update_fn: Optional[Callable] = None, get_intermediate_results: bool = False,
                          seed: Optional[int] = None, first_layout: int = 0, **_kw):
     """BaseMaskAndReplaceDiffusion.sample for cond["type"] == "relation" (base.py:293-371)."""
     eng = inner.engine
-    update_fn = update_fn or _reference_update()
+    plan = None
+    if update_fn is None:
+        plan = hip_relation_plan(eng, cond, sampling_cfg, tokenizer, int(batch_size))
+        if plan is None:
+            update_fn = _reference_update()
     T = inner.num_timesteps
     t_model, t_post = timestep_schedule(T, int(_cfg_get(sampling_cfg, "num_timesteps", T)),
                                         float(_cfg_get(sampling_cfg, "time_difference", 0.0) or 0.0))
@@ -50,6 +79,7 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
                 v = v.repeat([B] + [1] * (v.dim() - 1))
             cond[k] = v.to(eng.device)
     tokens = cond["seq"].to(dtype=torch.int32).contiguous().clone()
+    tokens_cond = tokens.clone()  # the graph's node set is defined by the CONDITIONED sequence (logit_adjustment.py:44)
     # strong mask + PAD-disable are applied by ldm_posterior exactly as base.py:245-251,272-284 would
     # after update(); update() itself must see the strong-masked log-probs (base.py order), so the
     # hook applies them first and they are re-imposed after the adjustment.
@@ -61,7 +91,10 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
     for i, (tm, tp) in enumerate(zip(t_model, t_post)):
         logits = eng.denoise_logits(tokens, tm)
         logp = eng.posterior(logits, tokens, tp, {"seq": hip_cond["seq"], "mask": hip_cond["mask"], "type": "partial"})
-        logp = update_fn(t=tm, cond=cond, model_log_prob=logp, tokenizer=tokenizer, sampling_cfg=sampling_cfg)
+        if plan is not None:
+            logp = eng.relation_update(logp, tokens_cond, plan, tm)
+        else:
+            logp = update_fn(t=tm, cond=cond, model_log_prob=logp, tokenizer=tokenizer, sampling_cfg=sampling_cfg)
         with torch.no_grad():
             logp = logp.detach().float().contiguous()
             logp[:, eng.pad_id, :] = torch.where(pad_mask, torch.full_like(logp[:, eng.pad_id, :], LOG_EPS),

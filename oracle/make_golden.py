@@ -191,9 +191,60 @@ def vanilla_cases(spec, B=2):
     return out
 
 
+def relation_cases(spec, B=2, seed=7):
+    """cond=relation: the reference's own logit_adjustment.update (SGD on the 14 relational-constraint losses of
+    clg/const.py) applied to posterior-shaped log-probabilities, on graphs produced by the reference's own
+    AddCanvasElement + AddRelationConstraints transforms (data/util.py:111-177) from random layouts."""
+    _, tok = rh.build_reference_model("rico25", seed=0)          # (installs the import stubs)
+    from trainer.data.util import AddCanvasElement, AddRelationConstraints
+    from trainer.models.categorical_diffusion.logit_adjustment import update
+
+    g = torch.Generator().manual_seed(seed)
+    rel = AddRelationConstraints(seed=seed, edge_ratio=0.5)
+    ys, eis, eas, bts, seqs = [], [], [], [], []
+    off = 0
+    for b in range(B):
+        n = int(torch.randint(3, 9, (1,), generator=g))
+        box = torch.rand(n, 4, generator=g) * torch.tensor([0.8, 0.8, 0.5, 0.5]) + torch.tensor([0.1, 0.1, 0.05, 0.05])
+        lab = torch.randint(0, spec.n_category, (n,), generator=g)
+        data = type("Data", (), {})()
+        data.x, data.y, data.attr = box, lab, {"has_canvas_element": torch.tensor([False])}
+        data = rel(AddCanvasElement()(data))
+        ys.append(data.y)
+        eis.append(data.edge_index.view(2, -1) + off)
+        eas.append(data.edge_attr)
+        bts.append(torch.full((n + 1,), b, dtype=torch.long))
+        off += n + 1
+        seq = torch.full((spec.seq_len,), spec.pad_id, dtype=torch.long)
+        seq[: n * spec.n_attr] = spec.mask_id
+        seq[0: n * spec.n_attr: spec.n_attr] = lab                      # categories given, the rest [MASK]
+        seqs.append(seq)
+    graph = rh.GraphBatch(torch.cat(ys), torch.cat(eis, dim=1), torch.cat(eas), torch.cat(bts))
+    cond = {"seq": torch.stack(seqs), "batch_w_canvas": graph, "type": "relation"}
+    logp = torch.log_softmax(2.0 * torch.randn(B, spec.n_class, spec.seq_len, generator=g), dim=1).clamp(-70, 0)
+    cfg = rh.sampling_cfg("random", relation_lambda=3e6, relation_mode="average", relation_tau=1.0,
+                          relation_num_update=3)
+    bt = tok.bbox_tokenizer
+    centres = np.stack([np.asarray(bt.clustering_models[f"{k}-{spec.n_bin}"].cluster_centers_, np.float64).reshape(-1)
+                        for k in ("x", "y", "w", "h")])
+    canvas_ids = bt.encode(torch.tensor([[[0.5, 0.5, 1.0, 1.0]]])).long().view(-1)    # logit_adjustment.py:38
+    canvas_bins = (canvas_ids - torch.arange(4) * spec.n_bin).numpy()
+    out = {"logp_in": logp.numpy(), "cond_seq": cond["seq"].numpy().astype(np.int16), "y": graph.y.numpy(),
+           "edge_index": graph.edge_index.numpy(), "edge_attr": graph.edge_attr.numpy(), "batch": graph.batch.numpy(),
+           "centres": centres, "canvas_bins": canvas_bins.astype(np.int32), "lr": np.float64(3e6),
+           "num_update": np.int32(3)}
+    for t in (50, 5):
+        new = update(t=t, cond=cond, model_log_prob=logp.clone(), tokenizer=tok, sampling_cfg=cfg)
+        out[f"logp_out_t{t}"] = new.numpy()
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "relation":
+        np.savez_compressed(os.path.join(OUT, "rico25_relation.npz"), **relation_cases(SP.SPECS["rico25"]))
+        return
     if only == "vanilla":
         np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(SP.SPECS["rico25"]))
         return
@@ -220,6 +271,7 @@ def main():
 
         if ds == "rico25":
             np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(spec))
+            np.savez_compressed(os.path.join(OUT, "rico25_relation.npz"), **relation_cases(spec))
             tr = trajectory(m, spec, 4, rh.sampling_cfg("random"), None, seed=0)
             np.savez_compressed(os.path.join(OUT, "rico25_uncond_trajectory.npz"), **tr)
             torch.manual_seed(0)

@@ -119,6 +119,59 @@ def _stub(name: str, **attrs):
     return m
 
 
+# --- minimal, faithful stand-ins for the two torch_geometric.utils functions the relational constraint losses
+# call (trainer/models/clg/const.py:5,12,29,76,121,155).  Semantics of PyG 2.x: nodes / edges are grouped by graph
+# in order; duplicate (b, i, j) entries accumulate.
+def to_dense_batch(x, batch=None, fill_value=0.0, max_num_nodes=None, batch_size=None):
+    import torch
+
+    if batch is None:
+        batch = x.new_zeros(x.size(0), dtype=torch.long)
+    B = int(batch.max()) + 1 if batch_size is None else batch_size
+    num = torch.zeros(B, dtype=torch.long, device=x.device).scatter_add_(0, batch, torch.ones_like(batch))
+    cum = torch.cat([num.new_zeros(1), num.cumsum(0)])
+    N = int(num.max()) if max_num_nodes is None else max_num_nodes
+    local = torch.arange(batch.numel(), device=x.device) - cum[batch]
+    out = x.new_full((B, N) + tuple(x.shape[1:]), fill_value)
+    mask = torch.zeros(B, N, dtype=torch.bool, device=x.device)
+    out[batch, local] = x
+    mask[batch, local] = True
+    return out, mask
+
+
+def to_dense_adj(edge_index, batch=None, edge_attr=None, max_num_nodes=None, batch_size=None):
+    import torch
+
+    if batch is None:
+        n = int(edge_index.max()) + 1 if edge_index.numel() > 0 else 0
+        batch = edge_index.new_zeros(n)
+    B = int(batch.max()) + 1 if batch_size is None else batch_size
+    num = torch.zeros(B, dtype=torch.long, device=batch.device).scatter_add_(0, batch, torch.ones_like(batch))
+    cum = torch.cat([num.new_zeros(1), num.cumsum(0)])
+    N = int(num.max()) if max_num_nodes is None else max_num_nodes
+    eb = batch[edge_index[0]]
+    i = edge_index[0] - cum[eb]
+    j = edge_index[1] - cum[eb]
+    if edge_attr is None:
+        edge_attr = torch.ones(edge_index.size(1), device=edge_index.device)
+    adj = edge_attr.new_zeros((B, N, N) + tuple(edge_attr.shape[1:]))
+    flat = adj.view((B * N * N,) + tuple(edge_attr.shape[1:]))
+    flat.index_add_(0, eb * N * N + i * N + j, edge_attr)
+    return adj
+
+
+class GraphBatch:
+    """The attributes of a torch_geometric DataBatch that logit_adjustment.update / clg/const.py read
+    (cond["batch_w_canvas"], helpers/task.py:112-114): y (labels, canvas = 0, others label+1: data/util.py:111-125),
+    edge_index (2,E) global node ids, edge_attr (E,) relation bitmasks (data/util.py:128-177), batch (node -> graph)."""
+
+    def __init__(self, y, edge_index, edge_attr, batch):
+        self.y, self.edge_index, self.edge_attr, self.batch = y, edge_index, edge_attr, batch
+
+    def to(self, *_a, **_k):
+        return self
+
+
 _INSTALLED = False
 
 
@@ -148,7 +201,8 @@ def install_stubs():
         _stub("hydra.core.config_store")
     if need("torch_geometric"):
         _stub("torch_geometric")
-        for sub in ("utils", "data", "loader"):
+        _stub("torch_geometric.utils", to_dense_batch=to_dense_batch, to_dense_adj=to_dense_adj)
+        for sub in ("data", "loader"):
             _stub(f"torch_geometric.{sub}")
         for sub in ("collate", "dataset", "makedirs", "separate"):
             _stub(f"torch_geometric.data.{sub}")

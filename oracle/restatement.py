@@ -400,3 +400,97 @@ def decode_layouts(spec: ModelSpec, tokens, centres=None) -> Dict[str, torch.Ten
     label[invalid] = 0
     out[invalid] = 0.0
     return {"bbox": out, "label": label, "mask": valid}
+
+
+# ------------------------------------------------------------------------------------------------
+# cond=relation: logit adjustment by gradient descent on the relational-constraint losses
+REL_SIZE_ALPHA = 0.1                                   # data/util.py:30
+REL_SIZE = {"unknown": 0, "smaller": 1, "equal": 2, "larger": 3}          # data/util.py:14-18
+REL_LOC = {"unknown": 4, "left": 5, "top": 6, "right": 7, "bottom": 8, "center": 9}   # data/util.py:21-27
+
+
+def relation_expected_boxes(spec: ModelSpec, logp: torch.Tensor, cond_seq: torch.Tensor, centres, canvas_bins):
+    """_stochastic_convert, mode="average" (categorical_diffusion/logit_adjustment.py:16-85): per valid node
+    (canvas first, then every element whose conditioned category is not PAD) the softmax-expectation of the
+    cluster centres over that coordinate's 32-bin sub-vocabulary.  Returns (N_nodes, 4) in x,y,w,h order."""
+    B, C, S = logp.shape
+    A, N = spec.n_attr, spec.n_bin
+    mask = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.as_tensor(cond_seq)[:, ::A] != spec.pad_id], dim=1)
+    per_coord = []
+    for i in range(A - 1):
+        sl = slice(spec.n_category + i * N, spec.n_category + (i + 1) * N)
+        canvas = torch.full((B, N, 1), LOG_EPS, dtype=logp.dtype)   # index_to_log_onehot of the canvas id, util.py:34-40
+        canvas[:, int(canvas_bins[i]), 0] = 0.0
+        per_coord.append(torch.cat([canvas, logp[:, sl, (i + 1)::A]], dim=2))      # (B, N, E+1)
+    logits = torch.stack(per_coord, dim=-1).permute(0, 2, 1, 3)[mask]              # (nodes, N, 4)
+    prob = F.softmax(logits, dim=1)
+    c = torch.as_tensor(centres, dtype=torch.float64).view(4, N).t().unsqueeze(0).to(prob.dtype)   # (1, N, 4)
+    return (prob * c).sum(dim=1)
+
+
+def relation_costs(bbox: torch.Tensor, y, edge_index, edge_attr, batch, n_graph: int) -> torch.Tensor:
+    """The 14 losses of clg/const.py:221-236 (`relation`), each summed per graph -> (n_graph, 14)."""
+    src, dst = edge_index[0], edge_index[1]
+    from_canvas = y[src] == 0
+    relu = torch.relu
+    eps = 1e-8
+
+    def less_equal(a, b):   # const.py:48-49
+        return relu(a - b)
+
+    def less(a, b):         # const.py:52-53
+        return relu(a - b + eps)
+
+    def per_graph(cost, cond):
+        cost = cost.masked_fill(~cond, 0)
+        return torch.zeros(n_graph, dtype=cost.dtype).index_add(0, batch[src], cost)   # to_dense_adj(...).sum((1,2))
+
+    def bit(v):
+        return (edge_attr & (1 << v)) != 0
+
+    out = []
+    area = bbox[:, 2] * bbox[:, 3]
+    a1, a2 = area[src], area[dst]
+    sm, lg = (1 - REL_SIZE_ALPHA) * a1, (1 + REL_SIZE_ALPHA) * a1
+    for rel, cost in ((REL_SIZE["smaller"], less_equal(a2, sm)), (REL_SIZE["equal"], less(sm, a2) + less(a2, lg)),
+                      (REL_SIZE["larger"], less_equal(lg, a2))):          # const.py:56-106
+        for canvas in (False, True):
+            out.append(per_graph(cost, (from_canvas == canvas) & bit(rel)))
+    yc = bbox[:, 1][dst]                                                     # const.py:109-157
+    y_sm, y_lg = 1.0 / 3, 2.0 / 3
+    out.append(per_graph(less_equal(yc, y_sm), from_canvas & bit(REL_LOC["top"])))
+    out.append(per_graph(less(y_sm, yc) + less(yc, y_lg), from_canvas & bit(REL_LOC["center"])))
+    out.append(per_graph(less_equal(y_lg, yc), from_canvas & bit(REL_LOC["bottom"])))
+    xc, ycc, w, h = bbox.t()                                                 # convert_xywh_to_ltrb, helpers/util.py:16-22
+    l, t, r, b = xc - w / 2, ycc - h / 2, xc + w / 2, ycc + h / 2
+    l1, t1, r1, b1, l2, t2, r2, b2 = l[src], t[src], r[src], b[src], l[dst], t[dst], r[dst], b[dst]
+    overlap_y = less(t1, b2) + less(t2, b1)                                  # const.py:176-178
+    not_canvas = ~from_canvas
+    out.append(per_graph(less_equal(b2, t1), not_canvas & bit(REL_LOC["top"])))                       # relation_loc_t
+    out.append(per_graph(less_equal(b1, t2), not_canvas & bit(REL_LOC["bottom"])))                    # relation_loc_b
+    out.append(per_graph(less_equal(r2, l1) + overlap_y, not_canvas & bit(REL_LOC["left"])))          # relation_loc_l
+    out.append(per_graph(less_equal(r1, l2) + overlap_y, not_canvas & bit(REL_LOC["right"])))         # relation_loc_r
+    out.append(per_graph(less(l1, r2) + less(l2, r1) + overlap_y, not_canvas & bit(REL_LOC["center"])))  # relation_loc_c
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13]
+    return torch.stack([out[i] for i in order], dim=-1)
+
+
+def relation_update(spec: ModelSpec, logp: torch.Tensor, cond_seq, graph: dict, centres, canvas_bins, lr: float,
+                    num_update: int, t: int) -> torch.Tensor:
+    """logit_adjustment.update (categorical_diffusion/logit_adjustment.py:88-126): `num_update` plain-SGD steps
+    (lr = relation_lambda) on the mean of the 14 per-graph losses w.r.t. the whole (B,C,S) log-probability tensor;
+    no update for t < 10.  graph: y (nodes,), edge_index (2,E) global node ids, edge_attr (E,), batch (nodes,)."""
+    x = logp.detach().clone().requires_grad_(True)
+    y, ei = torch.as_tensor(graph["y"]), torch.as_tensor(graph["edge_index"]).long()
+    ea, bt = torch.as_tensor(graph["edge_attr"]).long(), torch.as_tensor(graph["batch"]).long()
+    n_graph = logp.shape[0]
+    for _ in range(0 if t < 10 else num_update):
+        x.grad = None
+        bbox = relation_expected_boxes(spec, x, cond_seq, centres, canvas_bins)
+        if ei.numel() == 0:
+            continue
+        loss = relation_costs(bbox, y, ei.view(2, -1), ea, bt, n_graph).mean()
+        loss.backward()
+        with torch.no_grad():
+            x -= lr * x.grad
+    return x.detach()

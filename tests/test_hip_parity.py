@@ -383,6 +383,125 @@ def test_dropin_layoutdm_class(cuda, golden_dir):
         m.train()
 
 
+# ----------------------------------------------------------------------------- cond = relation
+def _random_graph(spec, B, gen, edge_ratio=0.6):
+    """Random relation graphs in the reference's format (data/util.py:128-177): node 0 of every layout = canvas."""
+    ys, eis, eas, bts, seqs, off = [], [], [], [], [], 0
+    for b in range(B):
+        n = int(torch.randint(0 if b == 1 else 2, 12, (1,), generator=gen))   # layout 1 may be empty
+        lab = torch.randint(0, spec.n_category, (n,), generator=gen)
+        ys.append(torch.cat([torch.zeros(1, dtype=torch.long), lab + 1]))
+        for i in range(n + 1):
+            for j in range(i + 1, n + 1):
+                if torch.rand(1, generator=gen).item() < edge_ratio:
+                    size = int(torch.randint(0, 4, (1,), generator=gen))
+                    loc = int(torch.randint(4, 10, (1,), generator=gen))
+                    eis.append((off + i, off + j))
+                    eas.append((1 << size) | (1 << loc))
+        bts.append(torch.full((n + 1,), b, dtype=torch.long))
+        off += n + 1
+        seq = torch.full((spec.seq_len,), spec.pad_id, dtype=torch.long)
+        seq[: n * spec.n_attr] = spec.mask_id
+        seq[0: n * spec.n_attr: spec.n_attr] = lab
+        seqs.append(seq)
+    ei = torch.tensor(eis, dtype=torch.long).t().contiguous() if eis else torch.zeros((2, 0), dtype=torch.long)
+    return {"y": torch.cat(ys), "edge_index": ei, "edge_attr": torch.tensor(eas, dtype=torch.long),
+            "batch": torch.cat(bts)}, torch.stack(seqs)
+
+
+def _rel_close(a, ref, start, rtol):
+    """fp32 agreement of two SGD results: error relative to the size of the update (the steps are O(10..1e4) while the
+    results may cancel back to O(1e-2)); analytic vs autograd gradients measured 3e-7 .. 1.5e-6 on the CPU."""
+    scale = max(1.0, (ref - start).abs().max().item())
+    return (a - ref).abs().max().item() <= rtol * scale
+
+
+def test_relation_update_vs_reference_and_oracle(cuda, golden_dir):
+    """kernels_relation.hip (analytic gradient) == logit_adjustment.update (autograd): reference-produced golden at the
+    default hyper-parameters, then random graphs / moderate step sizes against the oracle restatement."""
+    spec = SP.RICO25
+    e = engine("rico25", "exact")
+    g = np.load(os.path.join(golden_dir, "rico25_relation.npz"))
+    graph = {k: torch.from_numpy(g[k]) for k in ("y", "edge_index", "edge_attr", "batch")}
+    seq = torch.from_numpy(g["cond_seq"].astype(np.int64))
+    B = seq.shape[0]
+    rel = e.make_relation(graph, g["centres"], g["canvas_bins"], float(g["lr"]), int(g["num_update"]), B)
+    for t in (50, 5):
+        out = e.relation_update(torch.from_numpy(g["logp_in"]).to(cuda).contiguous(), seq, rel, t).cpu()
+        assert _rel_close(out, torch.from_numpy(g[f"logp_out_t{t}"]), torch.from_numpy(g["logp_in"]), 1e-5), t
+    # random graphs (one layout without elements), several step sizes, incl. a graph-free batch
+    gen = torch.Generator().manual_seed(17)
+    centres = np.stack([np.linspace(0, 1 - 1 / 32, 32), np.linspace(0, 1 - 1 / 32, 32), np.linspace(1 / 32, 1, 32),
+                        np.linspace(1 / 32, 1, 32)])
+    bins = [16, 16, 31, 31]
+    for B, lr, nup in ((5, 3e4, 3), (3, 5e3, 1), (4, 2e5, 4)):
+        graph, seq = _random_graph(spec, B, gen)
+        logp = torch.log_softmax(1.5 * torch.randn(B, spec.n_class, spec.seq_len, generator=gen), dim=1).clamp(-70, 0)
+        ref = R.relation_update(spec, logp, seq, graph, centres, bins, lr, nup, 40)
+        rel = e.make_relation(graph, centres, bins, lr, nup, B)
+        out = e.relation_update(logp.to(cuda).contiguous(), seq, rel, 40).cpu()
+        assert (ref != logp).any()
+        assert _rel_close(out, ref, logp, 1e-5), (B, lr, nup, (out - ref).abs().max().item())
+    empty = {"y": graph["y"], "edge_index": torch.zeros((2, 0), dtype=torch.long), "edge_attr": torch.zeros(0, dtype=torch.long),
+             "batch": graph["batch"]}
+    rel = e.make_relation(empty, centres, bins, 3e6, 3, B)
+    out = e.relation_update(logp.to(cuda).contiguous(), seq, rel, 40).cpu()
+    assert torch.equal(out, logp)
+
+
+class _RelBboxTokenizer:
+    """BboxTokenizer attributes used by the relation plan (bbox_tokenizer.py:28-115): linear bins."""
+    shared_bbox_vocab, bbox_quantization = "x-y-w-h", "linear"
+    var_names = ["x", "y", "w", "h"]
+
+    def __init__(self, n_bin):
+        d = 1.0 / n_bin
+        mk = lambda a: type("M", (), {"cluster_centers_": a.reshape(-1, 1)})()
+        self.clustering_models = {f"x-{n_bin}": mk(np.linspace(0, 1 - d, n_bin)), f"y-{n_bin}": mk(np.linspace(0, 1 - d, n_bin)),
+                                  f"w-{n_bin}": mk(np.linspace(d, 1, n_bin)), f"h-{n_bin}": mk(np.linspace(d, 1, n_bin))}
+        self.n_bin = n_bin
+
+    def encode(self, bbox):  # bbox_tokenizer.py:84-115, linear
+        d = 1.0 / self.n_bin
+        q = torch.zeros_like(bbox)
+        q[..., :2] = torch.clamp(bbox[..., :2], 0.0, 1.0 - d)
+        q[..., 2:] = torch.clamp(bbox[..., 2:], d, 1.0) - d
+        idx = (self.n_bin * q).round().long()
+        return idx + torch.arange(4) * self.n_bin
+
+
+def test_relation_sampling_loop_hip_update_equals_oracle_update(cuda):
+    """sample_with_relation end to end: the HIP logit adjustment inside the split-step loop gives the same greedy
+    tokens as the same loop driven by the oracle's autograd update."""
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion
+    from layout_dm_amd.relation import sample_with_relation
+
+    spec = SP.RICO25
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, precision="exact", max_batch=4)
+    m.load_state_dict(sd)
+    tok = _MockTokenizer(spec)
+    tok.bbox_tokenizer = _RelBboxTokenizer(spec.n_bin)
+    gen = torch.Generator().manual_seed(23)
+    B = 3
+    graph, seq = _random_graph(spec, B, gen)
+    gb = type("G", (), dict(graph, to=lambda self, *_a, **_k: self))()
+    cond = {"seq": seq, "mask": seq != spec.mask_id, "type": "relation", "batch_w_canvas": gb}
+    cfg = {"name": "deterministic", "num_timesteps": 12, "relation_lambda": 2e4, "relation_mode": "average",
+           "relation_tau": 1.0, "relation_num_update": 2}
+    centres = np.stack([tok.bbox_tokenizer.clustering_models[f"{k}-32"].cluster_centers_.reshape(-1) for k in "xywh"])
+
+    def oracle_update(t, cond, model_log_prob, tokenizer, sampling_cfg):
+        out = R.relation_update(spec, model_log_prob.detach().cpu(), seq, graph, centres, [16, 16, 31, 31],
+                                cfg["relation_lambda"], cfg["relation_num_update"], t)
+        return out.to(model_log_prob.device)
+
+    a = sample_with_relation(m, B, cond, cfg, tok, seed=1)
+    b = sample_with_relation(m, B, cond, cfg, tok, update_fn=oracle_update, seed=1)
+    assert (a != b).float().mean().item() <= 0.01
+    assert (a[:, 0::5] == seq[:, 0::5]).all()  # conditioned categories survive
+
+
 # ----------------------------------------------------------------------------- q_type = vanilla
 @pytest.mark.parametrize("precision", ["exact", "fast"])
 def test_vanilla_q_type_vs_reference_golden(cuda, golden_dir, precision):
