@@ -94,7 +94,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # LDM_BENCH_FORCE_DIST=1 (dev): take the RCCL code path (init, all_gather, barrier, all_reduce) with ONE rank, so
+    # the multi-GPU plumbing can be smoke-tested on a single-GPU box under torch.distributed.run --nproc-per-node 1
+    force_dist = world == 1 and os.environ.get("LDM_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -117,17 +120,17 @@ def main():
     dev = eng.device
     init = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=dev)
     tokens = torch.empty_like(init)
-    gathered = torch.empty((world * B, eng.S), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, eng.S), dtype=torch.int32, device=dev) if dist is not None else None
 
     def one_step(i):
         tokens.copy_(init)  # inputs resident in HBM
         eng.sample_loop(tokens, t_model, t_post, cfg, seed=1000 + i, first_layout=rank * B,
                         use_graph=not a.no_graph)
-        if world > 1:
+        if dist is not None:
             dist.all_gather_into_tensor(gathered, tokens)  # the single RCCL collective of the path
 
     def sync():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,11 +142,11 @@ def main():
         one_step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    final = (gathered if world > 1 else tokens).cpu()
+    final = (gathered if dist is not None else tokens).cpu()
     assert (final != eng.mask_id).all(), "sampling left [MASK] tokens"
 
     layouts = world * B * a.steps
@@ -229,7 +232,7 @@ def main():
                          "layouts_per_s_incl_decode": round(world * B / ((step_ms + dec_ms) * 1e-3), 2)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, sd, a.timesteps, a.sampling, a.cpu_batch)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
