@@ -1,4 +1,6 @@
-"""Dev tool (GPU box): numerics of each precision mode vs the oracle on teacher-forced states."""
+"""Checker script (GPU box, not collected by pytest): numerics of each precision mode vs the oracle on teacher-forced
+states -> gpurun_out/precision_report.json (committed copy: profiles/r01_precision_report.json).  Lives under tests/
+because it imports the oracle."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
