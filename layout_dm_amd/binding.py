@@ -279,21 +279,12 @@ class Engine:
         """Device-side description of cond["batch_w_canvas"] for ldm_relation_update.  graph: object / dict with
         y (nodes,), edge_index (2,E) global node ids, edge_attr (E,), batch (nodes,) — torch_geometric DataBatch
         fields (helpers/task.py:112-114).  Returns (LdmRelation, keep-alive tensors)."""
-        get = (lambda k: graph[k]) if isinstance(graph, dict) else (lambda k: getattr(graph, k))
-        batch = torch.as_tensor(get("batch")).long().cpu()
-        ei = torch.as_tensor(get("edge_index")).long().cpu().view(2, -1)
-        ea = torch.as_tensor(get("edge_attr")).long().cpu().view(-1)
+        from .relation import graph_to_csr
+
         B = int(n_graph_total)
-        n_nodes = torch.bincount(batch, minlength=B)
-        first = torch.cat([n_nodes.new_zeros(1), n_nodes.cumsum(0)])[:-1]
-        eg = batch[ei[0]] if ei.numel() else torch.zeros(0, dtype=torch.long)
-        order = torch.argsort(eg, stable=True)
-        eg, src, dst, ea = eg[order], ei[0][order], ei[1][order], ea[order]
-        if ei.numel():
-            assert bool((batch[dst] == eg).all()), "edge crosses two layouts"
-        off = torch.cat([eg.new_zeros(1), torch.bincount(eg, minlength=B).cumsum(0)]).int()
+        off, src_l, dst_l, ea = graph_to_csr(graph, B)
         dev = self.device
-        keep = [off.to(dev), (src - first[eg]).int().to(dev), (dst - first[eg]).int().to(dev), ea.int().to(dev),
+        keep = [off.to(dev), src_l.to(dev), dst_l.to(dev), ea.to(dev),
                 torch.as_tensor(centres, dtype=torch.float64).float().reshape(4, self.n_bin).contiguous().to(dev)]
         rel = LdmRelation(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
                           keep[4].data_ptr(), (C.c_int32 * 4)(*[int(x) for x in canvas_bins]),

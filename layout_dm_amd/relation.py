@@ -32,6 +32,30 @@ def _reference_update():
     return update
 
 
+def graph_to_csr(graph, n_graph: int):
+    """cond["batch_w_canvas"] (torch_geometric DataBatch fields: batch (nodes,), edge_index (2,E) GLOBAL node ids,
+    edge_attr (E,); helpers/task.py:112-114, data/util.py:128-177) -> per-layout CSR with LOCAL node ids, the form
+    ldm_relation_update takes: (offsets int32 (n_graph+1,), src int32 (E,), dst int32 (E,), attr int32 (E,)), edges
+    of a layout kept in their original order."""
+    get = (lambda k: graph[k]) if isinstance(graph, dict) else (lambda k: getattr(graph, k))
+    batch = torch.as_tensor(get("batch")).long().cpu()
+    ei = torch.as_tensor(get("edge_index")).long().cpu().reshape(2, -1)
+    ea = torch.as_tensor(get("edge_attr")).long().cpu().reshape(-1)
+    if batch.numel() and int(batch.max()) >= n_graph:
+        raise ValueError("graph batch index exceeds the number of layouts")
+    if ei.shape[1] != ea.numel():
+        raise ValueError("edge_index / edge_attr length mismatch")
+    n_nodes = torch.bincount(batch, minlength=n_graph)
+    first = torch.cat([n_nodes.new_zeros(1), n_nodes.cumsum(0)])[:-1]
+    eg = batch[ei[0]] if ei.numel() else torch.zeros(0, dtype=torch.long)
+    if ei.numel() and not bool((batch[ei[1]] == eg).all()):
+        raise ValueError("an edge connects nodes of two different layouts")
+    order = torch.argsort(eg, stable=True)
+    eg, src, dst, ea = eg[order], ei[0][order], ei[1][order], ea[order]
+    off = torch.cat([eg.new_zeros(1), torch.bincount(eg, minlength=n_graph).cumsum(0)])
+    return off.int(), (src - first[eg]).int(), (dst - first[eg]).int(), ea.int()
+
+
 def hip_relation_plan(eng, cond: Dict, sampling_cfg, tokenizer, batch_size: int):
     """(LdmRelation, keep-alives) when the HIP logit adjustment applies, else None."""
     try:

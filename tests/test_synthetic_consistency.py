@@ -31,3 +31,44 @@ def test_timestep_schedule_matches_oracle():
             skip = prev - t - 1
             assert p == (t - skip if (skip > 0 and t > skip) else t)
             prev = t
+
+
+def test_relation_graph_to_csr_roundtrip():
+    """Host logic of cond=relation: DataBatch-style global edge lists -> per-layout CSR with local node ids."""
+    import pytest
+    import torch
+
+    from layout_dm_amd.relation import graph_to_csr
+
+    g = torch.Generator().manual_seed(0)
+    B = 6
+    n_nodes = [1, 4, 1, 7, 3, 2]                      # canvas only / several elements
+    batch = torch.cat([torch.full((n,), b, dtype=torch.long) for b, n in enumerate(n_nodes)])
+    first = [0]
+    for n in n_nodes[:-1]:
+        first.append(first[-1] + n)
+    edges = []
+    for b, n in enumerate(n_nodes):
+        for i in range(n):
+            for j in range(i + 1, n):
+                if torch.rand(1, generator=g).item() < 0.7:
+                    edges.append((first[b] + i, first[b] + j, int(torch.randint(1, 1024, (1,), generator=g))))
+    perm = torch.randperm(len(edges), generator=g).tolist()   # DataBatch order is not required to be grouped
+    edges = [edges[k] for k in perm]
+    ei = torch.tensor([[e[0] for e in edges], [e[1] for e in edges]])
+    ea = torch.tensor([e[2] for e in edges])
+    off, src, dst, attr = graph_to_csr({"batch": batch, "edge_index": ei, "edge_attr": ea}, B)
+    assert off.dtype == torch.int32 and off.tolist()[0] == 0 and off.tolist()[-1] == len(edges)
+    rebuilt = []
+    for b in range(B):
+        for k in range(int(off[b]), int(off[b + 1])):
+            assert 0 <= int(src[k]) < n_nodes[b] and 0 <= int(dst[k]) < n_nodes[b]
+            rebuilt.append((first[b] + int(src[k]), first[b] + int(dst[k]), int(attr[k])))
+    assert sorted(rebuilt) == sorted(edges)
+    per_layout_order = [e for e in edges if batch[e[0]] == 3]          # original order inside a layout is kept
+    assert rebuilt[int(off[3]):int(off[4])] == per_layout_order
+    e_off, e_src, _, _ = graph_to_csr({"batch": batch, "edge_index": torch.zeros((2, 0), dtype=torch.long),
+                                      "edge_attr": torch.zeros(0, dtype=torch.long)}, B)
+    assert e_off.tolist() == [0] * (B + 1) and e_src.numel() == 0
+    with pytest.raises(ValueError):
+        graph_to_csr({"batch": batch, "edge_index": torch.tensor([[0], [1]]), "edge_attr": torch.tensor([3])}, B)
