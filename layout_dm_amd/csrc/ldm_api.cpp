@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ldm_kernels.h"
+#include "ldm_pack.h"
 
 using namespace ldm;
 
@@ -474,58 +475,17 @@ static int upload_image(ldm_handle* h, const std::vector<uint16_t>& img, void** 
   *out = d;
   return 0;
 }
-// one 32-row x 512-half tile: row i = src row (or zeros), 16-B chunk L -> physical chunk L ^ (i & 15)
-static void put_tile_1k(uint16_t* dst, const uint16_t* src_rows[32]) {
-  for (int i = 0; i < 32; ++i) {
-    if (!src_rows[i]) continue;
-    for (int L = 0; L < 64; ++L) memcpy(dst + i * 512 + ((L ^ (i & 15)) << 3), src_rows[i] + L * 8, 16);
-  }
-}
-// w1: [>=F rows][512] fp16 (row = hidden unit), w2p: [>=480 rows][ldw2] fp16 with the k-slot ordered K axis.
-// Per 32-wide hidden chunk: 64 KiB = 32 KiB W1 tile | 30 KiB W2 slab (480 rows x 64 B, chunk L of row n at
-// L ^ ((n >> 2) & 3)) | 2 KiB padding.
-static std::vector<uint16_t> pack_ffn_image(const uint16_t* w1, const uint16_t* w2p, int ldw2, int F, int n_rows2) {
-  const int nc = F / 32;
-  std::vector<uint16_t> img((size_t)nc * 32768, 0);
-  for (int c = 0; c < nc; ++c) {
-    uint16_t* t = img.data() + (size_t)c * 32768;
-    const uint16_t* rows[32];
-    for (int i = 0; i < 32; ++i) rows[i] = w1 + (size_t)(c * 32 + i) * 512;
-    put_tile_1k(t, rows);
-    uint16_t* t2 = t + 16384;
-    for (int n = 0; n < n_rows2; ++n)
-      for (int L = 0; L < 4; ++L)
-        memcpy(t2 + n * 32 + ((L ^ ((n >> 2) & 3)) << 3), w2p + (size_t)n * ldw2 + c * 32 + L * 8, 16);
-  }
-  return img;
-}
-// w_in: [3*H*64][512] head-padded in_proj (q | k | v), w_out_ks: [>=480][512] out_proj with head-padded k-slot K.
-// Tiles: h*6 + {k0 k1 v0 v1 q0 q1}, then 15 out_proj tiles, then one zero tile.
-static std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_t* w_out_ks, int H, int n_out_tiles) {
-  const int nt = H * 6 + n_out_tiles + 1;
-  std::vector<uint16_t> img((size_t)nt * 16384, 0);
-  const uint16_t* rows[32];
-  for (int hh = 0; hh < H; ++hh)
-    for (int j = 0; j < 6; ++j) {
-      const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
-      const int row0 = (which * H + hh) * 64 + (j & 1) * 32;
-      for (int i = 0; i < 32; ++i) rows[i] = w_in + (size_t)(row0 + i) * 512;
-      put_tile_1k(img.data() + (size_t)(hh * 6 + j) * 16384, rows);
-    }
-  for (int t = 0; t < n_out_tiles; ++t) {
-    for (int i = 0; i < 32; ++i) rows[i] = w_out_ks + (size_t)(t * 32 + i) * 512;
-    put_tile_1k(img.data() + (size_t)(H * 6 + t) * 16384, rows);
-  }
-  return img;
-}
+// (index maps and image packers: ldm_pack.h — pure C++, unit-tested on the CPU by tests/cpu_pack_check.cpp)
+using ldm_pack::pack_attn_image;
+using ldm_pack::pack_ffn_image;
 
 static int build_fast_weights(ldm_handle* h) {
   const int D = h->D, F = h->F, C = h->C, H = h->H, dh = h->dh, HD = h->HD, Dq = h->Dq, Fq = h->Fq;
   auto id = [](int x) { return x; };
   // in_proj row n = which*D + head*dh + d  ->  (which*H + head)*64 + d   (head slices padded to 64)
-  auto qkv_row = [=](int n) { return ((n / D) * H + (n % D) / dh) * 64 + (n % D) % dh; };
+  auto qkv_row = [=](int n) { return ldm_pack::qkv_row(n, D, H, dh); };
   // out_proj column k = head*dh + d -> head*64 + d (matches the attention kernel's output layout)
-  auto head_col = [=](int k) { return (k / dh) * 64 + k % dh; };
+  auto head_col = [=](int k) { return ldm_pack::head_col(k, dh); };
   h->fast.assign(h->L, ldm_handle::FastLayer{});
   int rc;
   for (int i = 0; i < h->L; ++i) {
@@ -537,11 +497,7 @@ static int build_fast_weights(ldm_handle* h) {
     if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, id, &f.w2))) return rc;
     // fused FFN: K axis of W2 in MFMA k-slot order inside every 32-wide hidden chunk:
     // position 16s + 8g + e  <-  hidden 16s + 8(e>>2) + 4g + (e&3)   (kernels_rowgemm.hip)
-    auto kslot = [](int k) {
-      const int c = k & ~31, f = k & 31;
-      const int s2 = f >> 4, e_hi = (f >> 3) & 1, g = (f >> 2) & 1, e_lo = f & 3;
-      return c + 16 * s2 + 8 * g + 4 * e_hi + e_lo;
-    };
+    auto kslot = [](int k) { return ldm_pack::kslot(k); };
     if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &f.w2p))) return rc;
     // fused attention block: the attention rows come back in accumulator (k-slot) order per head d-tile
     auto head_kslot = [=](int k) { return kslot(head_col(k)); };

@@ -1,0 +1,74 @@
+// Host-side weight repacking for the fused fast-mode kernels — pure C++ (no HIP), so the index maps and the
+// LDS-image packers can be unit-tested on a CPU (tests/cpu_pack_check.cpp) against the kernels' read formulas.
+//
+// Index maps (destination position <- logical weight index):
+//   qkv_row    in_proj row  n = which*D + head*dh + d  ->  (which*H + head)*64 + d      (head slices padded to 64)
+//   head_col   out_proj col k = head*dh + d            ->  head*64 + d
+//   kslot      MFMA k-slot order inside every 32-wide K chunk: position 16s + 8g + e holds logical 16s + 8(e>>2) + 4g + (e&3),
+//              i.e. the accumulator layout of v_mfma_f32_32x32x16_f16 (lane half g, register 8s + e) IS the B operand
+//              of the next MFMA (kernels_rowgemm.hip fused FFN GEMM2, kernels_fusedattn.hip out-projection)
+// LDS images: global memory holds exactly what the kernels want in LDS (tiles in consumption order, bank swizzle
+// applied), so the weight stream is a linear copy.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace ldm_pack {
+
+inline int qkv_row(int n, int D, int H, int dh) { return ((n / D) * H + (n % D) / dh) * 64 + (n % D) % dh; }
+inline int head_col(int k, int dh) { return (k / dh) * 64 + k % dh; }
+inline int kslot(int k) {
+  const int c = k & ~31, f = k & 31;
+  const int s2 = f >> 4, e_hi = (f >> 3) & 1, g = (f >> 2) & 1, e_lo = f & 3;
+  return c + 16 * s2 + 8 * g + 4 * e_hi + e_lo;
+}
+
+// one 32-row x 512-half tile: row i = src row (or zeros), 16-B chunk L -> physical chunk L ^ (i & 15)
+inline void put_tile_1k(uint16_t* dst, const uint16_t* const src_rows[32]) {
+  for (int i = 0; i < 32; ++i) {
+    if (!src_rows[i]) continue;
+    for (int L = 0; L < 64; ++L) memcpy(dst + i * 512 + ((L ^ (i & 15)) << 3), src_rows[i] + L * 8, 16);
+  }
+}
+
+// w1: [>=F rows][512] fp16 (row = hidden unit), w2p: [>=n_rows2 rows][ldw2] fp16 with the k-slot ordered K axis.
+// Per 32-wide hidden chunk: 64 KiB = 32 KiB W1 tile | 30 KiB W2 slab (480 rows x 64 B, chunk L of row n at
+// L ^ ((n >> 2) & 3)) | 2 KiB padding.
+inline std::vector<uint16_t> pack_ffn_image(const uint16_t* w1, const uint16_t* w2p, int ldw2, int F, int n_rows2) {
+  const int nc = F / 32;
+  std::vector<uint16_t> img((size_t)nc * 32768, 0);
+  for (int c = 0; c < nc; ++c) {
+    uint16_t* t = img.data() + (size_t)c * 32768;
+    const uint16_t* rows[32];
+    for (int i = 0; i < 32; ++i) rows[i] = w1 + (size_t)(c * 32 + i) * 512;
+    put_tile_1k(t, rows);
+    uint16_t* t2 = t + 16384;
+    for (int n = 0; n < n_rows2; ++n)
+      for (int L = 0; L < 4; ++L)
+        memcpy(t2 + n * 32 + ((L ^ ((n >> 2) & 3)) << 3), w2p + (size_t)n * ldw2 + c * 32 + L * 8, 16);
+  }
+  return img;
+}
+
+// w_in: [3*H*64][512] head-padded in_proj (q | k | v), w_out_ks: [>=32*n_out_tiles][512] out_proj with head-padded
+// k-slot K.  Tiles: h*6 + {k0 k1 v0 v1 q0 q1}, then the out_proj tiles, then one zero tile.
+inline std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_t* w_out_ks, int H, int n_out_tiles) {
+  const int nt = H * 6 + n_out_tiles + 1;
+  std::vector<uint16_t> img((size_t)nt * 16384, 0);
+  const uint16_t* rows[32];
+  for (int hh = 0; hh < H; ++hh)
+    for (int j = 0; j < 6; ++j) {
+      const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
+      const int row0 = (which * H + hh) * 64 + (j & 1) * 32;
+      for (int i = 0; i < 32; ++i) rows[i] = w_in + (size_t)(row0 + i) * 512;
+      put_tile_1k(img.data() + (size_t)(hh * 6 + j) * 16384, rows);
+    }
+  for (int t = 0; t < n_out_tiles; ++t) {
+    for (int i = 0; i < 32; ++i) rows[i] = w_out_ks + (size_t)(t * 32 + i) * 512;
+    put_tile_1k(img.data() + (size_t)(H * 6 + t) * 16384, rows);
+  }
+  return img;
+}
+
+}  // namespace ldm_pack

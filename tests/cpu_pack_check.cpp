@@ -1,0 +1,105 @@
+// CPU unit test of the weight repacking (layout_dm_amd/csrc/ldm_pack.h) against the read formulas of the fused
+// kernels (kernels_rowgemm.hip ffn_fused2_k, kernels_fusedattn.hip qkv_attn_k).  Compiled with plain g++ by
+// tests/test_pack_images.py.  Weights are filled with unique 16-bit ids so every fetched element can be identified.
+//
+// What the kernels do (restated here):
+//   * a tile / chunk image is copied linearly into an LDS stage (global_load_lds, lane-linear);
+//   * MFMA A-operand read of k16-step ks by lane (r = lane&31, hi = lane>>5) from a 1-KiB-row tile:
+//       byte  r*1024 + 256*(ks>>3) + ((((ks&7)<<1 | hi) ^ (r&15)) << 4)        -> 8 halfs  W[row r][16*ks + 8*hi + e]
+//   * FFN GEMM2 A-operand read (slab at +32 KiB, output tile t, k-step sx):
+//       byte  32768 + t*2048 + r*64 + (((2*sx+hi) ^ ((r>>2)&3)) << 4)          -> 8 halfs  W2[32t+r][chunk*32 + f(sx,hi,e)]
+//     with f(s,g,e) = 16s + 8(e>>2) + 4g + (e&3): the accumulator layout of the GEMM1 MFMA that produced the B operand;
+//   * out-projection B operand of k-step ks = 4h + 2dt + s: attention output d = 32dt + f(s,hi,e) - 32dt... of head h.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../layout_dm_amd/csrc/ldm_pack.h"
+
+static int fails = 0;
+#define CHECK(cond, ...)                  \
+  do {                                    \
+    if (!(cond)) {                        \
+      if (fails < 10) { printf(__VA_ARGS__); printf("\n"); } \
+      ++fails;                            \
+    }                                     \
+  } while (0)
+
+static inline int f_slot(int s, int g, int e) { return 16 * s + 8 * (e >> 2) + 4 * g + (e & 3); }
+
+int main() {
+  const int D = 464, F = 1856, H = 8, dh = 58, HD = 512, Dq = 512, Fq = 1856;
+  // ---------------- logical weights with identifiable values (never 0: 0 marks padding)
+  auto id16 = [](int a, int b) { return (uint16_t)(1 + ((a * 2654435761u + b * 40503u) % 65535u)); };
+  std::vector<uint16_t> w_in((size_t)3 * D * D), w_out((size_t)D * D), w1((size_t)F * D), w2((size_t)D * F);
+  for (int n = 0; n < 3 * D; ++n) for (int k = 0; k < D; ++k) w_in[(size_t)n * D + k] = id16(n, k);
+  for (int n = 0; n < D; ++n) for (int k = 0; k < D; ++k) w_out[(size_t)n * D + k] = id16(n + 5000, k);
+  for (int n = 0; n < F; ++n) for (int k = 0; k < D; ++k) w1[(size_t)n * D + k] = id16(n + 9000, k);
+  for (int n = 0; n < D; ++n) for (int k = 0; k < F; ++k) w2[(size_t)n * F + k] = id16(n + 20000, k);
+  // ---------------- pack_w16 equivalents (dst[rmap(n)][cmap(k)] = src[n][k], zero padded)
+  std::vector<uint16_t> p_in((size_t)1536 * Dq, 0), p_out_ks((size_t)512 * HD, 0), p_w1((size_t)2048 * Dq, 0),
+      p_w2p((size_t)512 * Fq, 0);
+  for (int n = 0; n < 3 * D; ++n) for (int k = 0; k < D; ++k)
+    p_in[(size_t)ldm_pack::qkv_row(n, D, H, dh) * Dq + k] = w_in[(size_t)n * D + k];
+  for (int n = 0; n < D; ++n) for (int k = 0; k < D; ++k)
+    p_out_ks[(size_t)n * HD + ldm_pack::kslot(ldm_pack::head_col(k, dh))] = w_out[(size_t)n * D + k];
+  for (int n = 0; n < F; ++n) for (int k = 0; k < D; ++k) p_w1[(size_t)n * Dq + k] = w1[(size_t)n * D + k];
+  for (int n = 0; n < D; ++n) for (int k = 0; k < F; ++k) p_w2p[(size_t)n * Fq + ldm_pack::kslot(k)] = w2[(size_t)n * F + k];
+  const std::vector<uint16_t> ffn = ldm_pack::pack_ffn_image(p_w1.data(), p_w2p.data(), Fq, F, 480);
+  const std::vector<uint16_t> att = ldm_pack::pack_attn_image(p_in.data(), p_out_ks.data(), H, 15);
+  CHECK(ffn.size() == (size_t)58 * 32768, "ffn image size");
+  CHECK(att.size() == (size_t)64 * 16384, "attention image size");
+
+  auto tile_read = [](const uint16_t* stage, int r, int hi, int ks) {  // 1-KiB-row tile, returns pointer to 8 halfs
+    const int byte = r * 1024 + 256 * (ks >> 3) + (((((ks & 7) << 1) | hi) ^ (r & 15)) << 4);
+    return stage + byte / 2;
+  };
+  // ---------------- fused FFN
+  for (int c = 0; c < F / 32; ++c) {
+    const uint16_t* stage = ffn.data() + (size_t)c * 32768;  // linear DMA: LDS stage == image chunk
+    for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) {
+      for (int ks = 0; ks < 29; ++ks) {  // GEMM1: hidden unit c*32+r, K slice 16ks+8hi..
+        const uint16_t* p = tile_read(stage, r, hi, ks);
+        for (int e = 0; e < 8; ++e)
+          CHECK(p[e] == w1[(size_t)(c * 32 + r) * D + ks * 16 + hi * 8 + e], "W1 c=%d r=%d hi=%d ks=%d e=%d", c, r, hi, ks, e);
+      }
+      for (int t = 0; t < 15; ++t) for (int sx = 0; sx < 2; ++sx) {  // GEMM2: output feature 32t+r, hidden in k-slot order
+        const int byte = 32768 + t * 2048 + r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);
+        const uint16_t* p = stage + byte / 2;
+        const int n = t * 32 + r;
+        for (int e = 0; e < 8; ++e) {
+          const uint16_t want = n < D ? w2[(size_t)n * F + c * 32 + f_slot(sx, hi, e)] : 0;
+          CHECK(p[e] == want, "W2 c=%d t=%d r=%d hi=%d sx=%d e=%d", c, t, r, hi, sx, e);
+        }
+      }
+    }
+  }
+  // ---------------- attention block
+  for (int h = 0; h < H; ++h) for (int j = 0; j < 6; ++j) {
+    const uint16_t* stage = att.data() + (size_t)(h * 6 + j) * 16384;
+    const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);  // k0 k1 v0 v1 q0 q1
+    for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 29; ++ks) {
+      const uint16_t* p = tile_read(stage, r, hi, ks);
+      const int d = (j & 1) * 32 + r;
+      for (int e = 0; e < 8; ++e) {
+        const uint16_t want = d < dh ? w_in[(size_t)(which * D + h * dh + d) * D + ks * 16 + hi * 8 + e] : 0;
+        CHECK(p[e] == want, "Win h=%d j=%d r=%d hi=%d ks=%d e=%d", h, j, r, hi, ks, e);
+      }
+    }
+  }
+  for (int ot = 0; ot < 15; ++ot) {
+    const uint16_t* stage = att.data() + (size_t)(H * 6 + ot) * 16384;
+    for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 32; ++ks) {
+      const uint16_t* p = tile_read(stage, r, hi, ks);
+      const int n = ot * 32 + r, h = ks >> 2, dt = (ks >> 1) & 1, s = ks & 1;
+      for (int e = 0; e < 8; ++e) {
+        const int d = dt * 32 + f_slot(s, hi, e);  // attention-output feature this k-slot carries (B operand layout)
+        const uint16_t want = (n < D && d < dh) ? w_out[(size_t)n * D + h * dh + d] : 0;
+        CHECK(p[e] == want, "Wout ot=%d r=%d hi=%d ks=%d e=%d", ot, r, hi, ks, e);
+      }
+    }
+  }
+  for (size_t i = (size_t)63 * 16384; i < att.size(); ++i) CHECK(att[i] == 0, "padding tile not zero");
+  if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
+  printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
+  return 0;
+}
