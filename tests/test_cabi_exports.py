@@ -40,6 +40,9 @@ def test_binding_struct_layout_matches_header():
     assert ctypes.sizeof(binding.LdmConfig) == 14 * 4  # ABI 2: + q_type
     assert ctypes.sizeof(binding.LdmSampler) == 16
     assert ctypes.sizeof(binding.LdmCond) == 3 * 8 + 8  # three pointers + int32 (+pad)
+    # ldm_relation: 5 pointers, int32[4], float, 2 x int32 (+4 pad)
+    assert ctypes.sizeof(binding.LdmRelation) == 5 * 8 + 16 + 4 + 4 + 4 + 4
+    assert binding.LdmRelation.canvas_bins.offset == 40 and binding.LdmRelation.relation_lambda.offset == 56
 
 
 def test_no_gpu_fails_loudly(lib_path):
