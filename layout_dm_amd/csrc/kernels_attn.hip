@@ -121,11 +121,7 @@ static void launch_rows(const AttnArgs& a, hipStream_t st) {
 #define LDM_ATTN_CASE(DHP)                                                                                      \
   {                                                                                                             \
     const size_t sh = (size_t)2 * a.S * DHP * sizeof(float);                                                    \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      hipFuncSetAttribute((const void*)attn_rows<TIn, DHP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    allow_big_lds((const void*)attn_rows<TIn, DHP>);                                                            \
     hipLaunchKernelGGL((attn_rows<TIn, DHP>), grid, block, sh, st, (const TIn*)a.qkv, o32, o16, o16lo, a.S, a.H, \
                        a.dh, a.D, a.ld, a.ldo32, a.ldo16, scale);                                                          \
   }

@@ -134,10 +134,14 @@ struct OutProj {
 __device__ unsigned long long g_attn_phase[16];
 #define LDM_TM_NOW() __builtin_amdgcn_s_memtime()
 
-template <int KS, bool FUSE_OUT, bool TM = false>
+// V bit 0: batched prologue (row loads in 3 batches instead of 15 dependent double-buffered groups);
+// V bit 1: the per-head attention outputs stay in REGISTERS until the out-projection (they already are its B
+//          operand fragments): no scratch tensor, no reload phase.  Needs FUSE_OUT and H == 8.
+template <int KS, bool FUSE_OUT, bool TM = false, int V = 0>
 __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ img, const float* __restrict__ bias,
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
-                                                    int M, float scale_log2e, OutProj op) {
+                                                    int M, float scale_log2e, OutProj op, int skew) {
+  constexpr bool REG_OF = FUSE_OUT && (V & 2);
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                       // 2 x 32 KiB weight tiles
@@ -174,7 +178,9 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   }
   __syncthreads();
   f16x8 xf[KS];
-  {
+  if constexpr (V & 1) {
+    load_xf_ln_batched<KS, 8>(xf, ln, (int)m, hi, sp);
+  } else {
     // AdaLN-on-load in groups of G k-steps, raw row loads double buffered one group ahead.  The (always zero)
     // offset is made opaque AND data-dependent on the previous group's last fragment: hipcc otherwise issues
     // all 58 row loads + 116 parameter reads up front (~700 live VGPRs -> scratch spills).
@@ -237,6 +243,14 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   TilePipe<KS, PF> P;
   P.xf = xf;
   P.voff = voff;
+  f16x8 of[32];  // (REG_OF) B-operand fragments of the out-projection: head h -> of[4h .. 4h+3]
+  if constexpr (REG_OF) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) of[i][e] = (_Float16)0.f;
+  }
+  const int nskew = wave * skew;
 
   unsigned long long t_pro = 0;
   if constexpr (TM) t_pro = LDM_TM_NOW();
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    for (int i = 0; i < nskew; ++i) asm volatile("s_nop 7");
     if constexpr (TM) {
       tB = LDM_TM_NOW();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -370,7 +385,25 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         }
       }
     }
-    if (FUSE_OUT) {
+    if constexpr (REG_OF) {
+      // k-slot order: fragment (dt, s) of this lane = accumulator regs 8s..8s+7 IS the out-projection's B operand
+      // for k16-step 4h + 2dt + s.  A switch with constant indices per case keeps of[] in registers.
+      f16x8 nf[4];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) nf[dt * 2 + s2][e] = (_Float16)(o[dt][s2 * 8 + e] * inv);
+#define LDM_OF_CASE(HH) \
+  case HH: of[4 * HH] = nf[0]; of[4 * HH + 1] = nf[1]; of[4 * HH + 2] = nf[2]; of[4 * HH + 3] = nf[3]; break;
+      switch (h) {
+        LDM_OF_CASE(0) LDM_OF_CASE(1) LDM_OF_CASE(2) LDM_OF_CASE(3)
+        LDM_OF_CASE(4) LDM_OF_CASE(5) LDM_OF_CASE(6) LDM_OF_CASE(7)
+        default: break;
+      }
+#undef LDM_OF_CASE
+    } else if (FUSE_OUT) {
       // k-slot order: fragment (dt, s) of this lane = accumulator regs 8s..8s+7 -> 16 B at
       // [row][h*64 + dt*32 + s*16 + hi*8]; read back below by the same lane
       if (valid) {
@@ -406,9 +439,8 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   if constexpr (TM) t_qkv_end = LDM_TM_NOW();
   if constexpr (FUSE_OUT) {
     // ------------------------------------------------------------------ out-projection phase
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own att stores are performed before reading back
-    f16x8 of[32];
-    {
+    if constexpr (!REG_OF) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own att stores are performed before reading back
       const __half* arow = att + m * ldo + hi * 8;
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) of[ks] = *reinterpret_cast<const f16x8*>(arow + ks * 16);
@@ -448,6 +480,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      for (int i = 0; i < nskew; ++i) asm volatile("s_nop 7");
       if constexpr (TM) {
         tB = LDM_TM_NOW();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -538,16 +571,13 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
   auto kern = qkv_attn_k<KS, false>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  allow_big_lds((const void*)kern);
   OutProj op{};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op, 0);
 }
 
-// same + out-projection (tiles n_tiles.. of the image)
+// same + out-projection (tiles n_tiles.. of the image).  LDM_ATTN_V: bit 0 batched prologue, bit 1 attention outputs
+// exchanged through registers (default 3); LDM_ATTN_V=0 = the r01 kernel for A/B timing.
 void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
                             const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st) {
@@ -555,14 +585,21 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = tm ? qkv_attn_k<KS, true, true> : qkv_attn_k<KS, true, false>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
+  static const int skew = getenv("LDM_ATTN_SKEW") ? atoi(getenv("LDM_ATTN_SKEW")) : 0;
+  static const int ver_env = getenv("LDM_ATTN_V") ? atoi(getenv("LDM_ATTN_V")) : 3;
+  const int ver = (H == 8) ? ver_env : (ver_env & 1);
+  using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int);
+  K kern;
+  switch (ver & 3) {
+    case 0: kern = tm ? qkv_attn_k<KS, true, true, 0> : qkv_attn_k<KS, true, false, 0>; break;
+    case 1: kern = tm ? qkv_attn_k<KS, true, true, 1> : qkv_attn_k<KS, true, false, 1>; break;
+    case 2: kern = tm ? qkv_attn_k<KS, true, true, 2> : qkv_attn_k<KS, true, false, 2>; break;
+    default: kern = tm ? qkv_attn_k<KS, true, true, 3> : qkv_attn_k<KS, true, false, 3>; break;
   }
+  allow_big_lds((const void*)kern);
   OutProj op{b_out, C32, stats_out, ldc, N};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op,
+                     skew);
 }
 
 void attn_phase_read(unsigned long long* out16) {

@@ -247,11 +247,7 @@ static void launch_cfg(const GemmArgs& g, hipStream_t st) {
   Epi16 e{g.bias, g.res, g.C32, g.C16, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
   auto kern = gemm16_k<BM, BN, BK, NSTAGE, WM, WN, TAG>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr = true;
-  }
+  allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A,
                      (const __half*)g.W, g.lda, g.ldw, g.K, tiles_n, e);
 }

@@ -252,7 +252,7 @@ __device__ __forceinline__ void wait_lgkm() {
 }
 
 // phase-timing instrumentation (LDM_FFN_DBG=3, dev hook only): sums over chunks of s_memtime deltas
-__device__ unsigned long long g_ffn_phase[8];
+__device__ unsigned long long g_ffn_phase[12];
 
 template <int KS, int NT2, int PF, int DE = 2, bool TM = false>
 struct FfnPipe {
@@ -344,27 +344,34 @@ struct FfnPipe {
 };
 
 // ABL: timing ablations only (1 = no weight DMA after the first chunk, 2 = no LDS reads / MFMAs, 3 = phase timing)
+// V  : 0 = r01 prologue / epilogue (loads sunk to their uses: ~6 + 60 dependent memory round trips per block),
+//      1 = batched prologue (2 round trips), b2 in LDS, epilogue with the residual loaded 30 column groups at a time
+//          (2 round trips), rows >= M written into the padding of `out` (no exec-masked stores); N must be 464.
 // img: per 32-wide hidden chunk c one 64-KiB LDS image (ldm_api.cpp pack_ffn_image):
 //   [0, 32 KiB)   W1 rows c*32 .. c*32+31, 1 KiB each, 16-B chunk L of row i at physical chunk L ^ (i & 15)
 //   [32, 62 KiB)  W2 (k-slot ordered K axis) columns c*32..+31 of output rows 0..479, 64 B each, chunk L of row n
 //                 at physical chunk L ^ ((n >> 2) & 3);   last 2 KiB padding
 constexpr int FFN_STAGE = 65536;
-template <int KS, int NT2, int ABL, int PF = 8, int DE = 2>
+template <int KS, int NT2, int ABL, int PF = 8, int DE = 2, int V = 0>
 __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const char* __restrict__ img,
                                                       const float* __restrict__ b1, const float* __restrict__ b2,
                                                       const float* __restrict__ res, float* __restrict__ out, int ldo,
                                                       int M, int N, int n_chunks, LnLoad ln,
-                                                      float2* __restrict__ stats_out) {
+                                                      float2* __restrict__ stats_out, int skew) {
   constexpr int STAGE = FFN_STAGE;
   static_assert(W1_STAGE + NT2 * 32 * 64 <= STAGE, "chunk image exceeds its stage");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * STAGE);
   float* sp_in = sb1 + n_chunks * 32;
+  float* sb2 = sp_in + 2 * LN_DP;  // (V == 1) linear2 bias, zero beyond N
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hi = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + r;
+  constexpr bool TM = ABL == 3;
+  unsigned long long t_entry = 0;
+  if constexpr (TM) t_entry = __builtin_amdgcn_s_memtime();
 
   const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
   const unsigned voff = lane * 16;
@@ -374,11 +381,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     for (int a = 0; a < 4; ++a) dma_lin4(voff, g0 + a * 4096, lds0 + wave * 16384 + a * 4096);
   }
   for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
+  if constexpr (V == 1)
+    for (int i = tid; i < 512; i += 256) sb2[i] = i < N ? b2[i] : 0.f;
   f16x8 xf[KS];
   if (ln.x) {
     stage_ln_params(sp_in, ln, tid);
     __syncthreads();
-    load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
+    if constexpr (V == 1) load_xf_ln_batched<KS, 15>(xf, ln, m < M ? m : M - 1, hi, sp_in);
+    else load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
   } else {
     const __half* hrow = H + (size_t)m * ldh + hi * 8;
 #pragma unroll
@@ -400,8 +410,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
 #pragma unroll
   for (int sx = 0; sx < 2; ++sx) relW2[sx] = r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);
   const unsigned relB = lds0 + 2 * STAGE + hi * 16;
+  // wave skew (experiment): wave w starts every chunk w*skew s_nop-8 later, so that the four waves' 1-KiB DMA
+  // instructions do not reach the CU's vector-memory issue port in the same cycle
+  const int nskew = wave * skew;
 
-  constexpr bool TM = ABL == 3;
   unsigned long long t_start = 0, t_real0 = 0, s_wait = 0, s_g1 = 0, s_bub = 0, s_g2 = 0;
   if constexpr (TM) {
     t_start = __builtin_amdgcn_s_memtime();
@@ -418,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    for (int i = 0; i < nskew; ++i) asm volatile("s_nop 7");
     if constexpr (TM) {
       tB = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -458,20 +471,48 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   for (int c = 0; c < n_chunks; ++c) chunk(c, std::true_type{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t_end = 0, t_real1 = 0;
   if constexpr (TM) {
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
-      atomicAdd(&g_ffn_phase[0], 1ull);
-      atomicAdd(&g_ffn_phase[1], t_end - t_start);
-      atomicAdd(&g_ffn_phase[2], t_real1 - t_real0);
-      atomicAdd(&g_ffn_phase[3], s_wait);
-      atomicAdd(&g_ffn_phase[4], s_g1);
-      atomicAdd(&g_ffn_phase[5], s_bub);
-      atomicAdd(&g_ffn_phase[6], s_g2);
-    }
+    t_end = __builtin_amdgcn_s_memtime();
+    t_real1 = __builtin_amdgcn_s_memrealtime();
   }
-  {
+  if constexpr (V == 1) {
+    // residual + bias + row statistics, the residual row pieces fetched GB column groups at a time (the chunk
+    // loop's 116 fragment registers are dead here).  The row / lane-half are re-materialised behind an opaque
+    // asm so that hipcc cannot hoist the addresses (and then the loads) above the last chunk.
+    int me = m, hie = hi;
+    asm volatile("" : "+v"(me), "+v"(hie));
+    const int mr = me < M ? me : M - 1;
+    const float* rrow = res + (size_t)mr * ldo + hie * 4;
+    float* orow = out + (size_t)me * ldo + hie * 4;  // rows >= M: padding rows of `out` (allocated by the host)
+    const float* brow = sb2 + hie * 4;
+    constexpr int NGV = 58;  // valid 8-column groups: N = 464 (checked by the launcher)
+    constexpr int GB = 30;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      float4 rv[GB];
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+        if (h2 * GB + g < NGV) rv[g] = *reinterpret_cast<const float4*>(rrow + (h2 * GB + g) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const int gg = h2 * GB + g;
+        if (gg < NGV) {
+          const int t = gg >> 2, rq = gg & 3;
+          const float4 b = *reinterpret_cast<const float4*>(brow + gg * 8);
+          const float v0 = acc[t][rq * 4 + 0] + b.x + rv[g].x, v1 = acc[t][rq * 4 + 1] + b.y + rv[g].y;
+          const float v2 = acc[t][rq * 4 + 2] + b.z + rv[g].z, v3 = acc[t][rq * 4 + 3] + b.w + rv[g].w;
+          s1 += (v0 + v1) + (v2 + v3);
+          s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (stats_out) store_row_stats(stats_out, m, M, hi, s1, s2, N);
+  } else {
     // row / lane-half re-materialised behind an opaque asm: hipcc otherwise hoists the 60 epilogue addresses and
     // masks above the last chunk and spills MFMA operands to scratch there
     int me = m, hie = hi;
@@ -499,6 +540,21 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
       }
     }
     if (stats_out) store_row_stats(stats_out, m, M, hi, s1, s2, N);
+  }
+  if constexpr (TM) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue time includes the drain of its stores
+    const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      atomicAdd(&g_ffn_phase[0], 1ull);
+      atomicAdd(&g_ffn_phase[1], t_end - t_start);
+      atomicAdd(&g_ffn_phase[2], t_real1 - t_real0);
+      atomicAdd(&g_ffn_phase[3], s_wait);
+      atomicAdd(&g_ffn_phase[4], s_g1);
+      atomicAdd(&g_ffn_phase[5], s_bub);
+      atomicAdd(&g_ffn_phase[6], s_g2);
+      atomicAdd(&g_ffn_phase[7], t_start - t_entry);  // prologue: LN parameters, row loads, fragments
+      atomicAdd(&g_ffn_phase[8], t_exit - t_end);     // epilogue: residual, bias, statistics, stores
+    }
   }
 }
 
@@ -751,11 +807,7 @@ static void launch_rowgemm_t(const GemmArgs& g, const RowExtra& ex, hipStream_t 
   const int n_tiles = (g.N + 63) / 64;
   const int lds = 2 * 64 * RKB + n_tiles * 64 * 4 + 4 * LN_DP * 4;
   auto kern = rowgemm_k<KS, TAG>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W, g.lda,
                      n_tiles, e, ex);
 }
@@ -773,12 +825,7 @@ void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t
     const int n_tiles = g.N / tr;
     const int lds = 2 * tr * RKB + g.N * 4 + 2 * LN_DP * 4;
     auto kern = tr == 32 ? rowgemm16_k<KS, 32> : rowgemm16_k<KS, 64>;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)rowgemm16_k<KS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)rowgemm16_k<KS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
+    allow_big_lds((const void*)kern);
     hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, (const __half*)g.W,
                        g.lda, n_tiles, g.bias, g.C16, g.ldc16, g.N, g.M, ex.in);
     return;
@@ -790,12 +837,7 @@ void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t
     const int n_tiles = (g.N + tr - 1) / tr;
     const int lds = 2 * tr * RKB + n_tiles * tr * 4 + 2 * LN_DP * 4;
     auto kern = tr == 32 ? rowgemm32_k<KS, 32> : rowgemm32_k<KS, 64>;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)rowgemm32_k<KS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)rowgemm32_k<KS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
+    allow_big_lds((const void*)kern);
     hipLaunchKernelGGL(kern, dim3((g.M + 127) / 128), dim3(256), lds, st, (const __half*)g.A, g.lda, (const __half*)g.W,
                        n_tiles, g.bias, g.C32, g.ldc32, g.N, g.M, ex.res, ex.stats_out);
     return;
@@ -813,29 +855,36 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1
   LnLoad ln{};
   if (lnp) ln = *lnp;
   constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
-  const int lds = 2 * FFN_STAGE + F * 4 + 2 * LN_DP * 4;
+  const int lds = 2 * FFN_STAGE + F * 4 + 2 * LN_DP * 4 + 512 * 4;
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
   static const int var = getenv("LDM_FFN_VAR") ? atoi(getenv("LDM_FFN_VAR")) : 0;
-  auto kern = dbg == 1   ? ffn_fused2_k<KS, NT2, 1>
-              : dbg == 2 ? ffn_fused2_k<KS, NT2, 2>
-              : dbg == 3 ? ffn_fused2_k<KS, NT2, 3>
-              : var == 1 ? ffn_fused2_k<KS, NT2, 0, 6, 2>
-              : var == 2 ? ffn_fused2_k<KS, NT2, 0, 10, 2>
-                         : ffn_fused2_k<KS, NT2, 0>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static const int skew = getenv("LDM_FFN_SKEW") ? atoi(getenv("LDM_FFN_SKEW")) : 0;
+  // V = 1 (batched prologue / epilogue) needs N == 464 and `out` padded to a multiple of 128 rows (the engine's
+  // workspace is); LDM_FFN_V=0 selects the r01 prologue / epilogue for A/B timing
+  static const int ver_env = getenv("LDM_FFN_V") ? atoi(getenv("LDM_FFN_V")) : 1;
+  const int ver = (N == 464) ? ver_env : 0;
+  using K = void (*)(const __half*, int, const char*, const float*, const float*, const float*, float*, int, int, int,
+                     int, LnLoad, float2*, int);
+  K kern;
+  if (ver == 0)
+    kern = dbg == 1   ? ffn_fused2_k<KS, NT2, 1>
+           : dbg == 2 ? ffn_fused2_k<KS, NT2, 2>
+           : dbg == 3 ? ffn_fused2_k<KS, NT2, 3>
+                      : ffn_fused2_k<KS, NT2, 0>;
+  else
+    kern = dbg == 3   ? ffn_fused2_k<KS, NT2, 3, 8, 2, 1>
+           : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 3, 1>
+                      : ffn_fused2_k<KS, NT2, 0, 8, 2, 1>;
+  allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)img, b1, b2, res, out, ldo,
-                     M, N, F / 32, ln, stats_out);
+                     M, N, F / 32, ln, stats_out, skew);
 }
 
 // dev hook: read + reset the phase sums {blocks, cycles, realtime ticks, wait, gemm1, bubble, gemm2, -}
-void ffn_phase_read(unsigned long long* out8) {
+void ffn_phase_read(unsigned long long* out12) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ffn_phase), 8 * sizeof(unsigned long long));
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_ffn_phase), 12 * sizeof(unsigned long long));
+  unsigned long long z[12] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_phase), z, sizeof(z));
 }
 

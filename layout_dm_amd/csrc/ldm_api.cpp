@@ -281,8 +281,11 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   auto A = [&](auto** p, size_t n) {
     if (rc == 0) rc = h->dalloc(p, n);
   };
-  A(&h->P, Mc * h->D);
-  A(&h->Q, Mc * h->D);
+  // P / Q carry padding rows up to the next multiple of 256: the row-stationary kernels write whole 128-row
+  // blocks (rows >= M land in the padding instead of being exec-masked)
+  const size_t Mrows = (size_t)round_up((int)Mc, 256);
+  A(&h->P, Mrows * h->D);
+  A(&h->Q, Mrows * h->D);
   A(&h->logits, Mc * h->Cp);
   if (cfg->precision == LDM_PREC_EXACT_F32) {
     A(&h->qkv32, Mc * 3 * h->D);
@@ -1290,11 +1293,11 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
 
 // attention micro-benchmark (dev tool): B layouts x 8 heads on random fp16 qkv
 namespace ldm {
-void ffn_phase_read(unsigned long long* out8);
+void ffn_phase_read(unsigned long long* out12);
 void attn_phase_read(unsigned long long* out16);
 }  // namespace ldm
 // dev hooks: s_memtime phase sums of the instrumented kernel variants (LDM_FFN_DBG=3 / LDM_ATTN_TM=1)
-extern "C" void ldm_dev_ffn_phases(unsigned long long* out8) { ldm::ffn_phase_read(out8); }
+extern "C" void ldm_dev_ffn_phases(unsigned long long* out12) { ldm::ffn_phase_read(out12); }
 extern "C" void ldm_dev_attn_phases(unsigned long long* out16) { ldm::attn_phase_read(out16); }
 
 extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {

@@ -5,7 +5,28 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <mutex>
+#include <set>
+#include <utility>
+
 namespace ldm {
+
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once
+// per (device, kernel): the attribute is per device, so a process-wide "done" flag is wrong as soon as a second
+// handle lives on another GPU.  Thread-safe; a failure is reported once on stderr (the launch then fails loudly).
+inline void allow_big_lds(const void* kern) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (!done.insert({dev, kern}).second) return;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess)
+    fprintf(stderr, "libldm_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s\n", dev,
+            hipGetErrorString(e));
+}
 
 constexpr float kLogEps = -69.07755278982137f;  // log(1e-30): categorical_diffusion/util.py:8
 constexpr int kMaxAttr = 8;

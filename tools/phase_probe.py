@@ -19,7 +19,7 @@ tokens = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32)
 for _ in range(2):
     e.denoise_logits(tokens, 50)
 torch.cuda.synchronize()
-f8 = (C.c_ulonglong * 8)()
+f8 = (C.c_ulonglong * 12)()
 a16 = (C.c_ulonglong * 16)()
 lib.ldm_dev_ffn_phases(f8)
 lib.ldm_dev_attn_phases(a16)  # reset after warm-up
@@ -38,6 +38,11 @@ if f[0]:
     for name, v in zip(("wait(top)", "gemm1", "bubble", "gemm2"), f[3:7]):
         print(f"   {name:10s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per chunk {v/n/58:7.1f}")
     print(f"   ideal MFMA cycles/block = {58*59*32}  ({100*58*59*32/tot:.1f}% of block)")
+    # outside the chunk loop (the r01 probe did not see these): prologue = LN parameters + row loads + fragments,
+    # epilogue = residual / bias / statistics / stores (incl. the drain of the stores)
+    print(f"   prologue   {f[7]/n:9.0f} cyc/block  = {100*f[7]/n/tot:5.1f}% of the chunk loop    ({f[7]/n/clk:.1f} us)")
+    print(f"   epilogue   {f[8]/n:9.0f} cyc/block  = {100*f[8]/n/tot:5.1f}% of the chunk loop    ({f[8]/n/clk:.1f} us)")
+    print(f"   whole block = {(f[1]+f[7]+f[8])/n/clk:.1f} us")
 if a[0]:
     n = a[0]
     clk = a[1] / max(a[2], 1) * 100.0
