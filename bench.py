@@ -1,21 +1,34 @@
 #!/usr/bin/env python
 """bench.py — layouts/sec of the LayoutDM sampling hot path on MI355X.
 
-One "step" = one full pass of the hot path over one batch: the T=100-step reverse loop
-(denoiser forward + posterior + categorical draw per step) for `--batch` Rico25-shaped layouts per
-GPU, starting from the all-[MASK] state resident in HBM and ending with the final int32 tokens
-(gathered to every rank with ONE RCCL all_gather when N>1).  Workload = BASELINE.json configs[1]
-(Rico25, cond=unconditional, T=100, batch=512 per GPU, random-init synthetic weights).
+One "step" = one full pass of the hot path over one batch: the T-step reverse loop (denoiser forward + posterior +
+categorical draw per step) for `batch` layouts per GPU, starting from a state resident in HBM (all-[MASK] or the
+conditioned sequence) and ending with the final int32 tokens on the device (gathered to every rank with ONE RCCL
+all_gather when N>1, through layout_dm_amd.distributed.sample_sharded).
 
-Contract: `python bench.py --gpus N --steps K --warmup W` ; for N>1 launched under
-torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+Workloads (BASELINE.json configs), selected with --config:
+  2  Rico25    cond=unconditional  T=100  512 layouts/GPU   sampling=random    (default at --gpus 1; the config the
+                                                                                 metric is quoted on)
+  3  PubLayNet cond=c              T=100  1024 layouts/GPU  sampling=top_p 0.9 (cond built as helpers/task.py:94-110)
+  4  Rico25    cond=unconditional  T=100  1024 layouts/GPU  sampling=random    (default at --gpus N>1: 8 GPUs = 8192)
+Random-init synthetic weights with the reference's init distributions (no checkpoints offline).
+
+The ONE JSON line carries the headline numerics mode (--precision, default `fast`) at top level and, at N=1, every
+numerics mode under "modes" (exact = fp32 MFMA, the mode of the bit-exact token tests; split = fp16x3; fast = fp16
+operands / fp32 accumulate), each with its own roofline fraction against its own peak.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run (one rank
+per GPU).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -26,8 +39,15 @@ FLOP_PER_TOKEN_STEP = {  # 4 x [QKV + attn + out-proj + FFN] + he
     "rico25": 21_740_256,
     "publaynet": 21_721_696,
 }
-PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0}  # MI355X_MICROARCH.md (dense MFMA)
+# MI355X_MICROARCH.md dense MFMA peaks; split = 3 fp16 MFMA passes per product (divide by the passes)
+PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3}
 DTYPE = {"exact": "f32", "fast": "f16 (f32 accumulate)", "split": "f16x3 split (f32 accumulate)"}
+CONFIGS = {
+    2: dict(dataset="rico25", cond="unconditional", batch=512, sampling="random"),
+    3: dict(dataset="publaynet", cond="c", batch=1024, sampling="top_p"),
+    4: dict(dataset="rico25", cond="unconditional", batch=1024, sampling="random"),
+}
+GEMM_CLASSES = ("gemm", "ffn", "qkv")
 
 
 def parse():
@@ -35,48 +55,227 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="layouts per GPU per step")
-    ap.add_argument("--dataset", default="rico25", choices=["rico25", "publaynet"])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4], help="BASELINE config (0 = 2 at N=1, 4 at N>1)")
+    ap.add_argument("--batch", type=int, default=0, help="layouts per GPU per step (0 = the config's)")
+    ap.add_argument("--dataset", default=None, choices=["rico25", "publaynet"])
+    ap.add_argument("--cond", default=None, choices=["unconditional", "c"])
+    ap.add_argument("--sampling", default=None, choices=["random", "deterministic", "top_p", "top_k", "gumbel"])
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "fast"),
                     choices=["exact", "fast", "split"])
-    ap.add_argument("--sampling", default="random", choices=["random", "deterministic", "top_p", "gumbel"])
+    ap.add_argument("--modes", default=None,
+                    help="comma list of numerics modes reported under 'modes' (default: all three at N=1, none at N>1)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="layouts in the bounded CPU-baseline sample")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes")
+    ap.add_argument("--cpu-budget", type=float, default=22.0, help="seconds of CPU work for the cpu_baseline leg")
     return ap.parse_args()
 
 
-def cpu_baseline(spec, sd, T, sampling, batch, budget_s=20.0, max_threads=32):
-    """The oracle restatement of the reference's CPU path (kind = "port"), timed on this host on a
-    BOUNDED sample of the same workload: `batch` layouts taken through as many of the T reverse
-    steps as fit in ~budget_s seconds (every step costs the same: one denoiser forward + posterior
-    + draw), fp32, torch CPU.  layouts/s = batch / (mean step time x T)."""
+# ----------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(spec, sd, T, sampling, cond_np, budget_s=22.0):
+    """The oracle restatement of the reference's CPU path (kind = "port"), timed on this host on a BOUNDED sample of
+    the same workload.  (batch, threads) is swept first — small-batch CPU inference degrades with too many threads —
+    then the best configuration runs as many of the T reverse steps as fit in the remaining budget (every step costs
+    the same: one denoiser forward + posterior + draw), fp32, torch CPU.  layouts/s = batch / (mean step time x T)."""
     import torch
 
     from oracle import restatement as R
 
     W = R.as_torch_weights(sd)
-    cores = min(os.cpu_count() or 1, max_threads)  # small-batch CPU inference degrades beyond ~32 threads
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     cfg = {"name": sampling, "temperature": 1.0, "top_p": 0.9}
     steps = R.timestep_list(spec.n_step, T)
-    tokens = torch.full((batch, spec.seq_len), spec.mask_id, dtype=torch.long)
-    R.single_step(W, spec, tokens[:1], steps[0], cfg, uniforms=R.token_uniforms(0, 0, 1, spec.seq_len, 0)[..., 0])
-    done, t0 = 0, time.time()
-    for i, t in enumerate(steps):
-        u = R.token_uniforms(0, 0, batch, spec.seq_len, i)[..., 0] if sampling != "deterministic" else None
-        tokens = R.single_step(W, spec, tokens, t, cfg, uniforms=u)
-        done += 1
-        if time.time() - t0 > budget_s:
+
+    def make(batch):
+        if cond_np is None:
+            return torch.full((batch, spec.seq_len), spec.mask_id, dtype=torch.long), None
+        c = {"seq": torch.from_numpy(cond_np["seq"][:batch]), "mask": torch.from_numpy(cond_np["mask"][:batch]),
+             "type": "c"}
+        return c["seq"].clone(), c
+
+    def run(batch, threads, n_steps, budget):
+        torch.set_num_threads(threads)
+        tokens, cond = make(batch)
+        t0, done = time.time(), 0
+        for i, t in enumerate(steps[:n_steps]):
+            u = R.token_uniforms(0, 0, batch, spec.seq_len, i)[..., 0] if sampling != "deterministic" else None
+            tokens = R.single_step(W, spec, tokens, t, cfg, uniforms=u, cond=cond)
+            done += 1
+            if time.time() - t0 > budget:
+                break
+        return (time.time() - t0) / done, done
+
+    t_all = time.time()
+    cands = [(16, min(ncpu, 32)), (64, min(ncpu, 32)), (64, min(ncpu, 64)), (64, min(ncpu, 128))]
+    seen, best = set(), None
+    for batch, threads in cands:
+        if (batch, threads) in seen:
+            continue
+        seen.add((batch, threads))
+        run(batch, threads, 1, 5.0)  # warm-up (thread pool, allocator)
+        per_step, _ = run(batch, threads, 2, 4.0)
+        rate = batch / per_step
+        if best is None or rate > best[0]:
+            best = (rate, batch, threads)
+        if time.time() - t_all > 0.45 * budget_s:
             break
-    dt = time.time() - t0
-    per_step = dt / done
-    return {"value": round(batch / (per_step * T), 3), "unit": "layouts/s", "cores": cores, "kind": "port",
-            "sample": f"{batch} layouts x {done} of T={T} reverse steps ({dt:.1f} s; per-step cost is uniform), "
-                      f"oracle/restatement.py, torch CPU fp32, {cores} threads"}
+    _, batch, threads = best
+    remaining = max(4.0, budget_s - (time.time() - t_all))
+    per_step, done = run(batch, threads, T, remaining)
+    return {"value": round(batch / (per_step * T), 3), "unit": "layouts/s", "cores": threads, "kind": "port",
+            "host_logical_cpus": ncpu,
+            "sample": f"{batch} layouts x {done} of T={T} reverse steps ({per_step * done:.1f} s; per-step cost is "
+                      f"uniform), best of a (batch, threads) sweep {sorted(seen)}, oracle/restatement.py, torch CPU "
+                      f"fp32, {threads} threads"}
+
+
+# ----------------------------------------------------------------------------------------- HBM traffic (PMC)
+def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s: int = 170):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected live: two separate counter
+    passes (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2 — MI355X_MICROARCH.md) over tools/pmc_probe.py (a
+    4-step loop with the bench's launch shapes).  Returns (dict | None, note)."""
+    exe = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp", PMC_DATASET=dataset, PMC_PRECISION=precision)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix=f"ldm_pmc_{counter}_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "run", "--",
+               sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                               timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        if p.returncode != 0:
+            return None, f"rocprofv3 --pmc {counter} failed rc={p.returncode}: {p.stdout[-300:]}"
+        import csv
+
+        acc = []
+        for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    acc.append(float(row["Counter_Value"]))
+        subprocess.run(["rm", "-rf", out_dir])
+        if not acc:
+            return None, f"no {counter} rows for kernel '{kernel_substr}'"
+        vals[counter] = sum(acc) / len(acc)  # KB per launch
+    return vals, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), KB per launch"
+
+
+KERNEL_SYMBOL = {"ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
+                 "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
+                 "attention": "attn_"}
+
+
+# ----------------------------------------------------------------------------------------- one numerics mode
+def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, local_rank, dist, with_roofline):
+    """Times `steps` passes of the workload in one numerics mode; returns (result dict, engine, last tokens)."""
+    import torch
+
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion, timestep_schedule
+    from layout_dm_amd.distributed import sample_sharded
+
+    model = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
+                                       d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
+                                       num_timesteps=spec.n_step, precision=precision, max_batch=B, chunk=a.chunk,
+                                       device=local_rank, use_graph=not a.no_graph)
+    model.load_state_dict(sd)
+    eng = model.engine
+    cfg = {"name": a.sampling, "temperature": 1.0, "top_p": 0.9, "top_k": 5, "num_timesteps": a.timesteps}
+    t_model, t_post = timestep_schedule(spec.n_step, a.timesteps)
+    dev = eng.device
+    if cond_local is None:
+        init = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=dev)
+        lc_keep = None
+    else:
+        init = torch.from_numpy(cond_local["seq"]).to(device=dev, dtype=torch.int32).contiguous()
+        lc_keep = eng.make_cond({"seq": init, "mask": torch.from_numpy(cond_local["mask"]).to(dev), "type": "c"}, B)
+    tokens = torch.empty_like(init)
+    seed_box = [0]
+
+    def sample_fn(first_layout, count):  # this rank's shard: `count` layouts starting at global index `first_layout`
+        assert count == B
+        tokens.copy_(init)  # inputs resident in HBM
+        eng.sample_loop(tokens, t_model, t_post, cfg, seed=seed_box[0], first_layout=first_layout,
+                        use_graph=not a.no_graph, lc_keep=lc_keep)
+        return tokens
+
+    def one_step(i):
+        seed_box[0] = 1000 + i
+        return sample_sharded(sample_fn, world * B)  # world == 1: no collective; else ONE all_gather of the tokens
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    final = None
+    for i in range(warmup):
+        final = one_step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        final = one_step(warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fin = final.cpu()
+    assert fin.shape[0] == world * B
+    assert (fin != eng.mask_id).all(), "sampling left [MASK] tokens"
+    if cond_local is not None:  # conditioned categories survive (strong mask)
+        m = torch.from_numpy(cond_local["mask"])
+        mine = fin[rank * B:(rank + 1) * B]
+        assert (mine[m] == torch.from_numpy(cond_local["seq"])[m].int()).all(), "strong-masked tokens changed"
+
+    value = world * B * steps / dt
+    flop_layout = FLOP_PER_TOKEN_STEP[a.dataset] * spec.seq_len * a.timesteps
+    res = {"value": round(value, 2), "unit": "layouts/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 3), "dtype": DTYPE[precision],
+           "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
+           "frac_of_mfma_peak_whole_job": round(value * flop_layout / 1e12 / (world * PEAK_TFLOPS[precision]), 4)}
+    if with_roofline and rank == 0:
+        # per-kernel durations: HIP events around every launch, on the stream the kernels run on, over one more step of
+        # the same workload (eager launches — events cannot bracket graph nodes)
+        eng.set_profiling(True)
+        tokens.copy_(init)
+        eng.sample_loop(tokens, t_model, t_post, cfg, seed=999, first_layout=0, use_graph=False, lc_keep=lc_keep)
+        torch.cuda.synchronize()
+        rows = eng.profile(reset=True)
+        eng.set_profiling(False)
+        tot = sum(r["ms"] for r in rows) or 1.0
+        rows.sort(key=lambda r: -r["ms"])
+        dom = rows[0]
+        avg_ms = dom["ms"] / max(dom["launches"], 1)
+        if dom["flops"] > 0:
+            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[precision]
+            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None}
+        else:
+            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None}
+        roof.update({"avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                     "share_of_step": round(dom["ms"] / tot, 3),
+                     "algorithmic_per_launch": dom["flops"] / dom["launches"] if dom["flops"] > 0
+                     else dom["bytes"] / dom["launches"]})
+        res["roofline"] = roof
+        res["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
+        gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(GEMM_CLASSES))
+        gemm_fl = sum(r["flops"] for r in rows if r["name"].startswith(GEMM_CLASSES))
+        if gemm_ms > 0:
+            res["gemm_mfma_utilisation"] = round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_TFLOPS[precision], 4)
+    return res, eng, tokens
 
 
 def main():
@@ -102,119 +301,53 @@ def main():
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion, timestep_schedule
     from layout_dm_amd import synthetic as SP
-    synth = SP
+    from layout_dm_amd.distributed import shard_range
 
+    config = a.config or (2 if world == 1 else 4)
+    base = CONFIGS[config]
+    a.dataset = a.dataset or base["dataset"]
+    a.cond = a.cond or base["cond"]
+    a.sampling = a.sampling or base["sampling"]
+    B = a.batch or base["batch"]
     spec = SP.SPECS[a.dataset]
-    sd = synth.synth_state_dict(spec, seed=0, perturb=False)  # the reference's init distributions
-    B = a.batch
-    model = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
-                                       d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff,
-                                       n_layer=spec.n_layer, num_timesteps=spec.n_step, precision=a.precision,
-                                       max_batch=B, chunk=a.chunk, device=local_rank, use_graph=not a.no_graph)
-    model.load_state_dict(sd)
-    eng = model.engine
-    cfg = {"name": a.sampling, "temperature": 1.0, "top_p": 0.9, "num_timesteps": a.timesteps}
-    t_model, t_post = timestep_schedule(spec.n_step, a.timesteps)
-    dev = eng.device
-    init = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=dev)
-    tokens = torch.empty_like(init)
-    gathered = torch.empty((world * B, eng.S), dtype=torch.int32, device=dev) if dist is not None else None
+    sd = SP.synth_state_dict(spec, seed=0, perturb=False)  # the reference's init distributions
+    cond_global = cond_local = None
+    if a.cond == "c":
+        cond_global = SP.synth_cond_c(spec, world * B, seed=0)
+        lo, hi = shard_range(world * B, rank, world)
+        cond_local = {k: cond_global[k][lo:hi] for k in ("seq", "mask")}
 
-    def one_step(i):
-        tokens.copy_(init)  # inputs resident in HBM
-        eng.sample_loop(tokens, t_model, t_post, cfg, seed=1000 + i, first_layout=rank * B,
-                        use_graph=not a.no_graph)
-        if dist is not None:
-            dist.all_gather_into_tensor(gathered, tokens)  # the single RCCL collective of the path
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        one_step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        one_step(a.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    final = (gathered if dist is not None else tokens).cpu()
-    assert (final != eng.mask_id).all(), "sampling left [MASK] tokens"
-
-    layouts = world * B * a.steps
-    value = layouts / dt
-    flop_layout = FLOP_PER_TOKEN_STEP[a.dataset] * spec.seq_len * a.timesteps
+    res, eng, tokens = run_mode(a, spec, sd, a.precision, B, a.steps, a.warmup, cond_local, rank, world, local_rank,
+                                dist, with_roofline=not a.no_roofline)
+    workload = (f"BASELINE config {config}: {a.dataset} cond={a.cond} T={a.timesteps} batch={B}/GPU "
+                f"sampling={a.sampling}" + (" top_p=0.9" if a.sampling == "top_p" else ""))
+    dsname = {"rico25": "Rico25", "publaynet": "PubLayNet"}[a.dataset]
+    cname = {"unconditional": "uncond", "c": "cond=c"}[a.cond]
     out = {
-        "metric": "layouts/sec (whole node), Rico25 uncond T=100",
-        "value": round(value, 2),
+        "metric": f"layouts/sec (whole node), {dsname} {cname} T={a.timesteps}",
+        "value": res["value"],
         "unit": "layouts/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": round(1e3 * dt / a.steps, 3),
+        "ms_per_step": res["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPE[a.precision],
-        "data": "synthetic (random-init weights with the reference's init distributions, all-[MASK] start)",
-        "config": {"workload": f"{a.dataset} cond=unconditional T={a.timesteps} batch={B}/GPU sampling={a.sampling}",
-                   "precision_mode": a.precision, "hipgraph": not a.no_graph, "chunk_layouts": min(eng.cfg.chunk or 512, B),
+        "data": "synthetic (random-init weights with the reference's init distributions; "
+                + ("all-[MASK] start)" if a.cond == "unconditional" else
+                   "cond=c sequences built as helpers/task.py:94-110, n~U{1..25} elements per layout)"),
+        "config": {"workload": workload, "precision_mode": a.precision, "hipgraph": not a.no_graph,
+                   "chunk_layouts": min(eng.cfg.chunk or 512, B),
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
-        "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
+        "algorithmic_tflops": res["algorithmic_tflops"],
     }
+    for k in ("roofline", "kernel_breakdown_ms", "gemm_mfma_utilisation"):
+        if k in res:
+            out[k] = res[k]
 
-    if rank == 0 and not a.no_roofline:
-        # per-kernel durations: HIP events around every launch, on the stream the kernels run on,
-        # over one more step of the same workload (eager launches — events cannot bracket graph nodes)
-        eng.set_profiling(True)
-        tokens.copy_(init)
-        eng.sample_loop(tokens, t_model, t_post, cfg, seed=999, first_layout=0, use_graph=False)
-        torch.cuda.synchronize()
-        rows = eng.profile(reset=True)
-        eng.set_profiling(False)
-        tot = sum(r["ms"] for r in rows) or 1.0
-        rows.sort(key=lambda r: -r["ms"])
-        dom = rows[0]
-        is_gemm = dom["flops"] > 0
-        avg_ms = dom["ms"] / max(dom["launches"], 1)
-        if is_gemm:
-            ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[a.precision]
-            roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-                    "share_of_step": round(dom["ms"] / tot, 3)}
-        else:
-            ach = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom["name"], "achieved": round(ach, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
-                    "share_of_step": round(dom["ms"] / tot, 3)}
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the
-        # value comes from the committed rocprofv3 --pmc pass (profiles/r01_traffic.json), scaled to this
-        # launch's row count; null when no measurement exists for the kernel.
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(dom["name"])
-            if tr and a.precision == "fast":
-                rows_per_launch = min(eng.cfg.chunk or 512, B) * eng.S
-                roof["traffic"] = int((tr["fetch_kb"] + tr["write_kb"]) * 1024 * rows_per_launch / tr["M"])
-                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE+WRITE_SIZE, raw)"
-        except Exception:
-            pass
-        out["roofline"] = roof
-        out["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
-        gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(("gemm", "ffn", "qkv")))
-        gemm_fl = sum(r["flops"] for r in rows if r["name"].startswith(("gemm", "ffn", "qkv")))
-        if gemm_ms > 0:
-            out["gemm_mfma_utilisation"] = round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.precision], 4)
     if rank == 0:
         # the reference's own timer (test.py:194-203) also covers ids -> {bbox,label,mask} and the copy to the host:
         # reported beside the headline (which stops at tokens resident in HBM), never folded into `value`
@@ -227,11 +360,44 @@ def main():
         torch.cuda.synchronize()
         dec_ms = 1e3 * (time.perf_counter() - t1) / reps
         assert host["bbox"].shape == (B, spec.max_elem, 4)
-        step_ms = 1e3 * dt / a.steps
         out["decode"] = {"ms_per_batch_incl_d2h": round(dec_ms, 3), "valid_elements": int(host["mask"].sum()),
-                         "layouts_per_s_incl_decode": round(world * B / ((step_ms + dec_ms) * 1e-3), 2)}
+                         "layouts_per_s_incl_decode": round(world * B / ((res["ms_per_step"] + dec_ms) * 1e-3), 2)}
+    eng.close()
+
+    # every numerics mode in the one line (N=1): the bit-exact mode's throughput next to the headline's
+    modes = a.modes if a.modes is not None else ("exact,split,fast" if world == 1 else "")
+    modes = [m for m in modes.split(",") if m and m != "none"]
+    if modes:
+        out["modes"] = {}
+        for m in modes:
+            if m == a.precision:
+                r = dict(res)
+            else:
+                k = a.steps if m == "fast" else min(a.steps, 2)  # exact / split steps take seconds each
+                r, e2, _ = run_mode(a, spec, sd, m, B, k, 1, cond_local, rank, world, local_rank, dist,
+                                    with_roofline=not a.no_roofline)
+                e2.close()
+            r.pop("kernel_breakdown_ms", None)
+            out["modes"][m] = r
+
+    if rank == 0 and world == 1 and not a.no_roofline and not a.no_traffic and "roofline" in out:
+        sym = KERNEL_SYMBOL.get(out["roofline"]["kernel"])
+        if sym:
+            vals, note = measure_traffic(sym, a.dataset, a.precision)
+            if vals:
+                rows_probe = 512 * spec.seq_len  # tools/pmc_probe.py launches M = 64000-row kernels
+                rows_launch = min(eng.cfg.chunk or 512, B) * spec.seq_len
+                scale = rows_launch / rows_probe
+                out["roofline"]["traffic"] = int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 * scale)
+                out["roofline"]["traffic_detail"] = {
+                    "fetch_bytes_raw": int(vals["FETCH_SIZE"] * 1024 * scale),
+                    "write_bytes_raw": int(vals["WRITE_SIZE"] * 1024 * scale),
+                    "source": note + "; raw counter values (the guide's x2 FETCH_SIZE correction applies to 16 B/lane "
+                                     "coalesced streams; see profiles/ for the calibration on this kernel's pattern)"}
+            else:
+                out["roofline"]["traffic_detail"] = {"source": f"live PMC collection unavailable: {note}"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(spec, sd, a.timesteps, a.sampling, a.cpu_batch)
+        out["cpu_baseline"] = cpu_baseline(spec, sd, a.timesteps, a.sampling, cond_global, a.cpu_budget)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

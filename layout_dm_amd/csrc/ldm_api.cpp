@@ -31,6 +31,25 @@ static thread_local std::string g_create_error;
 
 namespace {
 
+// Entry points run on the handle's device but leave the calling thread's current device as they found it
+// (PyTorch tracks its own notion of the current device per thread).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    else if (err == hipSuccess) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define ON_DEVICE(h)                                                                                    \
+  DeviceGuard _dev_guard((h)->device);                                                                  \
+  if (_dev_guard.err != hipSuccess) return (h)->fail(-2, "hipSetDevice(%d) failed: %s", (h)->device,    \
+                                                     hipGetErrorString(_dev_guard.err))
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -66,13 +85,13 @@ struct PendingEvent {
 struct GraphKey {
   int B, n_steps, kind, top_k, has_cond, has_strong, has_weak, pad_disable, has_inter;
   float temperature, top_p;
-  const void *tokens, *cond_seq, *strong, *weak, *inter;
+  const void *tokens, *cond_seq, *strong, *weak;
   std::vector<int32_t> t_model, t_post;
   bool operator==(const GraphKey& o) const {
     return B == o.B && n_steps == o.n_steps && kind == o.kind && top_k == o.top_k && has_cond == o.has_cond &&
            has_strong == o.has_strong && has_weak == o.has_weak && pad_disable == o.pad_disable &&
            has_inter == o.has_inter && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
-           cond_seq == o.cond_seq && strong == o.strong && weak == o.weak && inter == o.inter &&
+           cond_seq == o.cond_seq && strong == o.strong && weak == o.weak &&
            t_model == o.t_model && t_post == o.t_post;
   }
 };
@@ -126,6 +145,7 @@ struct ldm_handle {
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
   float* st_weak = nullptr;
+  int32_t* st_inter = nullptr;  // (n_step, max_batch, S) intermediates of a graph-captured loop
   int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
   uint64_t* rng = nullptr;                      // device {seed, first_layout}
   // profiling
@@ -228,7 +248,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return bad("no HIP device visible: the MI355X path has no CPU fallback");
   if (device < 0 || device >= ndev) return bad("device index out of range");
-  if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed");
+  DeviceGuard create_guard(device);
+  if (create_guard.err != hipSuccess) return bad("hipSetDevice failed");
 
   auto* h = new ldm_handle();
   h->cfg = *cfg;
@@ -351,7 +372,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
 
 extern "C" void ldm_destroy(ldm_handle* h) {
   if (!h) return;
-  hipSetDevice(h->device);
+  DeviceGuard guard(h->device);
   hipDeviceSynchronize();
   h->drain_profile();
   for (auto& g : h->graphs) {
@@ -381,7 +402,7 @@ static std::string strip_prefix(const char* key) {
 
 extern "C" int ldm_load_weight(ldm_handle* h, const char* key, const float* h_data, const int64_t* shape, int ndim) {
   if (!h || !key || !h_data || (ndim > 0 && !shape)) return h ? h->fail(-1, "null argument") : -1;
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   const std::string k = strip_prefix(key);
   Raw r;
   r.shape.assign(shape, shape + ndim);
@@ -528,7 +549,7 @@ static int build_fast_weights(ldm_handle* h) {
 
 extern "C" int ldm_finalize_weights(ldm_handle* h) {
   if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   const int D = h->D, F = h->F, C = h->C, T = h->T, L = h->L;
   const std::string tr = "transformer.";
   int rc;
@@ -942,7 +963,7 @@ extern "C" int ldm_denoise_logits(ldm_handle* h, const int32_t* d_tokens, int t,
   if (rc) return rc;
   if (!d_tokens || !d_logits) return h->fail(-1, "null argument");
   if (t < 0 || t >= h->T) return h->fail(-1, "timestep out of range");
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   for (int off = 0; off < B; off += h->chunk) {
     const int Bc = std::min(h->chunk, B - off);
@@ -960,7 +981,7 @@ extern "C" int ldm_posterior(ldm_handle* h, const float* d_logits, const int32_t
   if (rc) return rc;
   if (!d_logits || !d_tokens || !d_logp) return h->fail(-1, "null argument");
   if (t_post < 0 || t_post >= h->T) return h->fail(-1, "timestep out of range");
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   PostArgs p{};
   fill_post(h, p, cond, nullptr, 0, B);
   p.logits = d_logits;
@@ -984,7 +1005,7 @@ extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_s
   if (rc) return rc;
   if ((rc = check_sampler(h, s))) return rc;
   if (!d_logp || !d_tokens_out) return h->fail(-1, "null argument");
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
   PostArgs p{};
@@ -1009,7 +1030,7 @@ extern "C" int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int
   for (int x = 0; x < 4; ++x)
     if (rel->canvas_bins[x] < 0 || rel->canvas_bins[x] >= h->cfg.n_bin) return h->fail(-1, "canvas bin out of range");
   if (t < 10 || rel->num_update <= 0) return 0;  // logit_adjustment.py:107
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   RelArgs a{};
   a.logp = d_logp_inout; a.cond_seq = d_cond_seq;
   a.edge_off = rel->d_edge_offsets; a.edge_src = rel->d_edge_src; a.edge_dst = rel->d_edge_dst;
@@ -1030,7 +1051,7 @@ extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B,
   if (B < 0) return h->fail(-1, "negative batch");
   if (B == 0) return 0;
   if (!d_tokens || !d_bbox || !d_label || !d_mask) return h->fail(-1, "null argument");
-  HIP_OK(h, hipSetDevice(h->device));  // (n_attr == 5, i.e. c-x-y-w-h, is enforced by ldm_create)
+  ON_DEVICE(h);  // (n_attr == 5, i.e. c-x-y-w-h, is enforced by ldm_create)
   launch_decode_layouts(d_tokens, B, h->cfg.max_elem, h->cfg.n_attr, h->cfg.n_category, h->cfg.n_bin, d_centres,
                         box_f64, d_bbox, d_label, d_mask, (hipStream_t)stream);
   HIP_OK(h, hipGetLastError());
@@ -1045,7 +1066,7 @@ extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_
   if (rc) return rc;
   if ((rc = check_sampler(h, s))) return rc;
   if (!d_tokens_in || !d_tokens_out) return h->fail(-1, "null argument");
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
   if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, s, step, B, 0, st))) return rc;
@@ -1093,7 +1114,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
   for (int i = 0; i < n_steps; ++i)
     if (h_t_model[i] < 0 || h_t_model[i] >= h->T || h_t_post[i] < 0 || h_t_post[i] >= h->T)
       return h->fail(-1, "timestep out of range [0,%d)", h->T);
-  HIP_OK(h, hipSetDevice(h->device));
+  ON_DEVICE(h);
   hipStream_t st = (hipStream_t)stream;
   const size_t nbytes = (size_t)B * h->S * 4;
   HIP_OK(h, hipEventRecord(h->loop_a, st));
@@ -1129,7 +1150,15 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
     key.strong = cond ? cond->d_strong_mask : nullptr;
     key.weak = cond ? cond->d_weak_logits : nullptr;
     key.pad_disable = cond ? cond->pad_disable : 0;
-    key.inter = d_intermediates;
+    // intermediates are captured into a handle-owned buffer (fixed address) and copied out after the launch, so
+    // get_intermediate_results=True replays the same graph instead of re-capturing for every caller pointer
+    int32_t* inter_dst = nullptr;
+    if (d_intermediates) {
+      if (n_steps > h->T) return h->fail(-1, "intermediates: n_steps %d > T %d", n_steps, h->T);
+      if (!h->st_inter && (rc = h->dalloc(&h->st_inter, (size_t)h->T * h->cfg.max_batch * h->S, false))) return rc;
+      inter_dst = h->st_inter;
+    }
+    key.has_inter = inter_dst != nullptr;
     key.t_model.assign(h_t_model, h_t_model + n_steps);
     key.t_post.assign(h_t_post, h_t_post + n_steps);
     GraphEntry* ge = nullptr;
@@ -1145,7 +1174,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       hipStream_t cap = nullptr;
       HIP_OK(h, hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       HIP_OK(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-      rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, d_intermediates, cap);
+      rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, inter_dst, cap);
       hipGraph_t graph = nullptr;
       hipError_t e = hipStreamEndCapture(cap, &graph);
       hipStreamDestroy(cap);
@@ -1162,6 +1191,8 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       ge = &h->graphs.back();
     }
     HIP_OK(h, hipGraphLaunch(ge->exec, st));
+    if (inter_dst)
+      HIP_OK(h, hipMemcpyAsync(d_intermediates, inter_dst, (size_t)n_steps * B * h->S * 4, hipMemcpyDeviceToDevice, st));
   } else {
     if ((rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, d_intermediates, st))) return rc;
   }

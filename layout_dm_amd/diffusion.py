@@ -110,12 +110,19 @@ class HipMaskAndReplaceDiffusion:
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         B = int(batch_size)
+        if B == 0:  # an empty shard (distributed.shard_range with fewer layouts than ranks)
+            empty = torch.empty((0, eng.S), dtype=torch.int32, device=eng.device)
+            if get_intermediate_results:
+                return [empty.long().cpu() for _ in t_model]
+            return empty if return_device_tensor else empty.long().cpu()
         if cond:
             seq = torch.as_tensor(cond["seq"])
             if seq.size(0) == 1 and B > 1:  # duplicate_cond, helpers/task.py:235-248
                 cond = dict(cond)
                 for k, v in list(cond.items()):
-                    if isinstance(v, torch.Tensor):
+                    # only what still has the single-layout batch dimension (a caller may hand over tensors that
+                    # are already per-sample, e.g. a (B,C,S) refinement prior)
+                    if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == 1:
                         cond[k] = v.repeat([B] + [1] * (v.dim() - 1))
                 seq = cond["seq"]
             assert seq.size(0) == B, "cond['seq'] batch does not match batch_size"

@@ -38,6 +38,95 @@ def _find(cfg, key):
     return result
 
 
+# ---- pure host logic (no GPU, no handle): unit-tested on the CPU against the reference's own objects -----------
+def aggregate_sampling_settings(tokenizer, sampling_cfg, args):
+    """base_model.py:124-150 + layoutdm.py:90-97: fold the test-time CLI args into sampling_cfg."""
+    if args.cond == "refinement" and args.refine_lambda > 0.0:
+        sampling_cfg.refine_mode = args.refine_mode
+        sampling_cfg.refine_offset_ratio = args.refine_offset_ratio
+        sampling_cfg.refine_lambda = args.refine_lambda
+    if args.cond == "relation" and args.relation_lambda > 0.0:
+        sampling_cfg.relation_mode = args.relation_mode
+        sampling_cfg.relation_lambda = args.relation_lambda
+        sampling_cfg.relation_tau = args.relation_tau
+        sampling_cfg.relation_num_update = args.relation_num_update
+    if "num_timesteps" not in sampling_cfg:
+        if "eos" in tokenizer.special_tokens:
+            sampling_cfg.num_timesteps = tokenizer.max_token_length
+        else:
+            sampling_cfg.num_timesteps = args.num_timesteps
+    if args.time_difference > 0:
+        sampling_cfg.time_difference = args.time_difference
+    return sampling_cfg
+
+
+def refinement_prior_table(tokenizer, mode: str, ratio: float) -> torch.Tensor:
+    """The (C,C) [token, class] table of `_index_to_smoothed_log_onehot` (helpers/task.py:154-201) before the
+    refine_lambda weight: identity outside the bbox sub-vocabularies, a neighbourhood indicator (uniform / negative)
+    or a negative squared distance (gaussian) between cluster centres inside each of them."""
+    C, N = tokenizer.N_total, tokenizer.N_bbox_per_var
+    bbt = tokenizer.bbox_tokenizer
+    table = torch.zeros((C, C))
+    table.fill_diagonal_(1.0)
+    shared = bbt.shared_bbox_vocab == "xywh"
+    for i, k in enumerate(bbt.var_names):
+        sl = slice(tokenizer.N_category, tokenizer.N_category + N) if shared else \
+            slice(tokenizer.N_category + i * N, tokenizer.N_category + (i + 1) * N)
+        centers = torch.from_numpy(bbt.clustering_models[f"{k}-{N}"].cluster_centers_).view(-1)
+        ii, jj = torch.meshgrid(centers, centers, indexing="ij")
+        if mode == "uniform":
+            table[sl, sl] = (torch.abs(ii - jj) < ratio).float()
+        elif mode == "negative":
+            table[sl, sl] = (torch.abs(ii - jj) >= ratio).float()
+        elif mode == "gaussian":
+            table[sl, sl] = -1.0 * (ii - jj) ** 2
+        else:
+            raise NotImplementedError(mode)
+    return table.float()
+
+
+def refinement_weak_logits(tokenizer, seq_orig: torch.Tensor, sampling_cfg, cache: Optional[dict] = None):
+    """cond["weak_logits"] of set_additional_conditions_for_refinement (helpers/task.py:204-224): (B,C,S)."""
+    mode = _cfg_get(sampling_cfg, "refine_mode", "uniform")
+    ratio = float(_cfg_get(sampling_cfg, "refine_offset_ratio", 0.1))
+    w = float(_cfg_get(sampling_cfg, "refine_lambda", 3.0))
+    if mode == "negative":
+        w *= -1.0
+    key = (mode, ratio)
+    if cache is None or cache.get("key") != key:
+        table = refinement_prior_table(tokenizer, mode, ratio)
+        if cache is not None:
+            cache["key"], cache["table"] = key, table
+    else:
+        table = cache["table"]
+    return (table[seq_orig.cpu().long()].permute(0, 2, 1) * w).contiguous()
+
+
+def device_decode_plan(tokenizer):
+    """(ok, centres): whether ids -> {bbox,label,mask} can run in kernels_decode.hip for this tokenizer (c-x-y-w-h,
+    stacked x-y-w-h bbox vocabulary, no bos/eos) and the (4,n_bin) float64 cluster centres for kmeans / percentile
+    quantisation (None for linear bins, whose decode is closed-form: bbox_tokenizer.py:117-168)."""
+    try:
+        bbt = tokenizer.bbox_tokenizer
+        special = list(tokenizer.special_tokens)
+        ok = ("bos" not in special and "eos" not in special and list(tokenizer.var_names) == ["c", "x", "y", "w", "h"]
+              and bbt.shared_bbox_vocab == "x-y-w-h" and list(bbt.var_names) == ["x", "y", "w", "h"]
+              and list(getattr(bbt, "_var_order", ["x", "y", "w", "h"])) == ["x", "y", "w", "h"])
+        if ok and bbt.bbox_quantization == "linear":
+            return True, None
+        if ok and bbt.bbox_quantization in ("kmeans", "percentile"):
+            import numpy as np
+
+            N = tokenizer.N_bbox_per_var
+            cs = [np.asarray(bbt.clustering_models[f"{k}-{N}"].cluster_centers_, dtype=np.float64).reshape(-1)
+                  for k in ("x", "y", "w", "h")]
+            if all(c.shape == (N,) for c in cs):
+                return True, torch.from_numpy(np.stack(cs))
+    except AttributeError:
+        pass
+    return False, None
+
+
 class _ModuleShim:
     """Gives `model.model.module` / `model.model.sample` the shapes the reference exposes through
     CustomDataParallel (models/common/nn_lib.py:17-23)."""
@@ -110,55 +199,13 @@ class LayoutDM:
 
     # ---- base_model.py:124-150 + layoutdm.py:90-97 -------------------------------------------------
     def aggregate_sampling_settings(self, sampling_cfg, args):
-        if args.cond == "refinement" and args.refine_lambda > 0.0:
-            sampling_cfg.refine_mode = args.refine_mode
-            sampling_cfg.refine_offset_ratio = args.refine_offset_ratio
-            sampling_cfg.refine_lambda = args.refine_lambda
-        if args.cond == "relation" and args.relation_lambda > 0.0:
-            sampling_cfg.relation_mode = args.relation_mode
-            sampling_cfg.relation_lambda = args.relation_lambda
-            sampling_cfg.relation_tau = args.relation_tau
-            sampling_cfg.relation_num_update = args.relation_num_update
-        if "num_timesteps" not in sampling_cfg:
-            if "eos" in self.tokenizer.special_tokens:
-                sampling_cfg.num_timesteps = self.tokenizer.max_token_length
-            else:
-                sampling_cfg.num_timesteps = args.num_timesteps
-        if args.time_difference > 0:
-            sampling_cfg.time_difference = args.time_difference
-        return sampling_cfg
+        return aggregate_sampling_settings(self.tokenizer, sampling_cfg, args)
 
     # ---- refinement prior: helpers/task.py:154-224 --------------------------------------------------
     def _weak_logits(self, seq_orig: torch.Tensor, sampling_cfg) -> torch.Tensor:
-        tok = self.tokenizer
-        mode = _cfg_get(sampling_cfg, "refine_mode", "uniform")
-        ratio = float(_cfg_get(sampling_cfg, "refine_offset_ratio", 0.1))
-        w = float(_cfg_get(sampling_cfg, "refine_lambda", 3.0))
-        if mode == "negative":
-            w *= -1.0
-        key = (mode, ratio)
-        if self._refine_table is None or self._refine_table[0] != key:
-            C, N = tok.N_total, tok.N_bbox_per_var
-            bbt = tok.bbox_tokenizer
-            table = torch.zeros((C, C))
-            table.fill_diagonal_(1.0)
-            shared = bbt.shared_bbox_vocab == "xywh"
-            for i, k in enumerate(bbt.var_names):
-                sl = slice(tok.N_category, tok.N_category + N) if shared else \
-                    slice(tok.N_category + i * N, tok.N_category + (i + 1) * N)
-                centers = torch.from_numpy(bbt.clustering_models[f"{k}-{N}"].cluster_centers_).view(-1)
-                ii, jj = torch.meshgrid(centers, centers, indexing="ij")
-                if mode == "uniform":
-                    table[sl, sl] = (torch.abs(ii - jj) < ratio).float()
-                elif mode == "negative":
-                    table[sl, sl] = (torch.abs(ii - jj) >= ratio).float()
-                elif mode == "gaussian":
-                    table[sl, sl] = -1.0 * (ii - jj) ** 2
-                else:
-                    raise NotImplementedError(mode)
-            self._refine_table = (key, table.float())
-        table = self._refine_table[1]
-        return (table[seq_orig.cpu().long()].permute(0, 2, 1) * w).contiguous()  # (B,C,S)
+        if self._refine_table is None:
+            self._refine_table = {}
+        return refinement_weak_logits(self.tokenizer, seq_orig, sampling_cfg, self._refine_table)
 
     # ---- sampling --------------------------------------------------------------------------------
     def _sample_tokens(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None,
@@ -168,10 +215,9 @@ class LayoutDM:
             cond = dict(cond)  # the reference mutates the caller's dict (base.py:328-336); we do not
             ctype = cond.get("type", None)
             if ctype == "refinement" and "weak_logits" not in cond:
-                seq_orig = cond["seq_orig"]
-                if seq_orig.size(0) == 1 and batch_size > 1:
-                    seq_orig = seq_orig.repeat(batch_size, 1)
-                cond["weak_logits"] = self._weak_logits(seq_orig, sampling_cfg)
+                # set_additional_conditions_for_refinement (helpers/task.py:204-224) runs on the cond as given —
+                # (1,S) for a single conditioning layout — and duplicate_cond repeats the result once, in sample()
+                cond["weak_logits"] = self._weak_logits(cond["seq_orig"], sampling_cfg)
             if ctype == "relation":
                 from .relation import sample_with_relation
 
@@ -181,33 +227,9 @@ class LayoutDM:
                             get_intermediate_results=get_intermediate_results, **kwargs)
 
     def _device_decode_centres(self):
-        """Returns (ok, centres): whether ids -> {bbox,label,mask} can run in kernels_decode.hip for this
-        tokenizer (c-x-y-w-h, stacked x-y-w-h bbox vocabulary, no bos/eos) and the (4,n_bin) float64 cluster
-        centres for kmeans/percentile quantisation (None for linear bins)."""
-        if getattr(self, "_decode_plan", None) is not None:
-            return self._decode_plan
-        tok = self.tokenizer
-        plan = (False, None)
-        try:
-            bbt = tok.bbox_tokenizer
-            special = list(tok.special_tokens)
-            ok = ("bos" not in special and "eos" not in special and list(tok.var_names) == ["c", "x", "y", "w", "h"]
-                  and bbt.shared_bbox_vocab == "x-y-w-h" and list(bbt.var_names) == ["x", "y", "w", "h"]
-                  and list(getattr(bbt, "_var_order", ["x", "y", "w", "h"])) == ["x", "y", "w", "h"])
-            if ok and bbt.bbox_quantization == "linear":
-                plan = (True, None)
-            elif ok and bbt.bbox_quantization in ("kmeans", "percentile"):
-                import numpy as np
-
-                N = tok.N_bbox_per_var
-                cs = [np.asarray(bbt.clustering_models[f"{k}-{N}"].cluster_centers_, dtype=np.float64).reshape(-1)
-                      for k in ("x", "y", "w", "h")]
-                if all(c.shape == (N,) for c in cs):
-                    plan = (True, torch.from_numpy(np.stack(cs)))
-        except AttributeError:
-            plan = (False, None)
-        self._decode_plan = plan
-        return plan
+        if getattr(self, "_decode_plan", None) is None:
+            self._decode_plan = device_decode_plan(self.tokenizer)
+        return self._decode_plan
 
     def sample(self, batch_size: Optional[int] = 1, cond: Optional[Dict] = None, sampling_cfg=None, **kwargs):
         """layoutdm.py:77-88: ids -> tokenizer.decode -> {"bbox","label","mask"} (CPU tensors).  The decode runs on

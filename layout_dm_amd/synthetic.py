@@ -183,3 +183,22 @@ def strip_prefix(sd):
     return out
 
 
+
+
+def synth_cond_c(spec: ModelSpec, batch: int, seed: int = 0):
+    """Synthetic cond=c inputs shaped exactly like helpers/task.py:94-110 output: per layout
+    n ~ U{1..max_elem} elements; categories kept, other attributes of valid elements = mask_id, padded elements =
+    pad_id; mask=True on category slots of valid elements and on every slot of padded elements."""
+    rng = np.random.default_rng(seed + 77)
+    S, A = spec.seq_len, spec.n_attr
+    seq = np.full((batch, S), spec.pad_id, np.int64)
+    mask = np.ones((batch, S), bool)
+    n_elem = rng.integers(1, spec.max_elem + 1, size=batch)
+    for b in range(batch):
+        n = int(n_elem[b])
+        cats = rng.integers(0, spec.n_category, size=n)
+        for e in range(n):
+            seq[b, e * A] = cats[e]
+            seq[b, e * A + 1:(e + 1) * A] = spec.mask_id
+            mask[b, e * A + 1:(e + 1) * A] = False
+    return {"seq": seq, "mask": mask, "type": "c", "num_element": n_elem}

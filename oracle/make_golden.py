@@ -86,19 +86,37 @@ def trajectory(m, spec, B, cfg, cond=None, seed=0):
     for k in cfg:
         if k.startswith("refine") or k.startswith("relation"):
             det[k] = cfg[k]
-    greedy = []
+    greedy, margin = [], []
     steps = [int(i * spec.n_step / T) for i in range(T - 1, -1, -1)]
-    for i, t in enumerate(steps):
-        lz = index_to_log_onehot(prev_states[i], spec.n_class)
-        tt = torch.full((B,), t, dtype=torch.long)
-        cc = copy.deepcopy(c)  # already holds weak_* keys for refinement
-        nz = m._sample_single_step(lz, tt, skip_step=0, sampling_cfg=det, cond=cc)
-        greedy.append(nz.argmax(1))
+    # the log-probabilities the reference hands to sample() (base.py:286-287), captured at the call site: their
+    # top-2 gap says how far a reduced-precision implementation may be off before ITS argmax may legitimately differ
+    import trainer.models.categorical_diffusion.base as ref_base
+
+    orig_sample = ref_base.sample
+    seen = {}
+
+    def spy(logits, sampling_cfg):
+        seen["logp"] = logits.detach().clone()
+        return orig_sample(logits, sampling_cfg)
+
+    ref_base.sample = spy
+    try:
+        for i, t in enumerate(steps):
+            lz = index_to_log_onehot(prev_states[i], spec.n_class)
+            tt = torch.full((B,), t, dtype=torch.long)
+            cc = copy.deepcopy(c)  # already holds weak_* keys for refinement
+            nz = m._sample_single_step(lz, tt, skip_step=0, sampling_cfg=det, cond=cc)
+            greedy.append(nz.argmax(1))
+            top2 = seen["logp"].topk(2, dim=1).values
+            margin.append(top2[:, 0] - top2[:, 1])
+    finally:
+        ref_base.sample = orig_sample
     return {
         "steps": np.array(steps, np.int32),
         "states_before": prev_states.numpy().astype(np.int16),
         "states_after": states.numpy().astype(np.int16),
         "greedy_next": torch.stack(greedy).numpy().astype(np.int16),
+        "greedy_margin": torch.stack(margin).numpy().astype(np.float32),
     }
 
 

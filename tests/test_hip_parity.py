@@ -179,44 +179,84 @@ def test_sampler_statistics_match_reference_distribution(cuda):
 
 
 # ----------------------------------------------------------------------------- fused step / loop
-def _traj_check(e, g, cfg, cond=None, tol_frac=0.0):
-    steps = g["steps"]
-    before = torch.from_numpy(g["states_before"].astype(np.int32))
-    ref_next = torch.from_numpy(g["greedy_next"].astype(np.int32))
-    bad = 0
+# Greedy-token criterion per numerics mode (north star: "token indices bit-exact under greedy/argmax decoding"):
+#   exact : 0 mismatches against the reference's own argmax tokens;
+#   split / fast : a token may differ from the reference ONLY where the reference's own top-2 log-probability gap
+#   (`greedy_margin`, captured at the reference's sample() call site by oracle/make_golden.py) is below the bound
+#   the mode's logits tolerance allows: fast carries <= 1e-3 relative logits error on logits of magnitude <= ~10,
+#   i.e. <= ~1e-2 absolute per class, so two classes closer than 2e-2 are a legitimate tie for it.
+MARGIN_BOUND = {"exact": 0.0, "split": 1e-4, "fast": 2e-2}
+
+
+def _traj_check(e, g, cfg, cond=None, prefix=""):
+    steps = g[prefix + "steps"]
+    before = torch.from_numpy(g[prefix + "states_before"].astype(np.int32))
+    ref_next = torch.from_numpy(g[prefix + "greedy_next"].astype(np.int32))
+    margin = torch.from_numpy(g[prefix + "greedy_margin"])
+    bad, worst = 0, 0.0
     for i, t in enumerate(steps):
         out = e.sample_step(before[i], int(t), cfg, cond=cond, step=i).cpu()
-        bad += (out != ref_next[i]).sum().item()
-    return bad, ref_next.numel()
+        mism = out != ref_next[i]
+        if mism.any():
+            bad += int(mism.sum())
+            worst = max(worst, margin[i][mism].max().item())
+    return bad, ref_next.numel(), worst
 
 
-def test_step_teacher_forced_uncond_all_t(cuda, golden_dir):
-    """Every t in 99..0: fused HIP step (greedy, exact mode) == the reference's own argmax tokens on
-    states visited by a stochastic reference trajectory (bit-exact tokens)."""
-    e = engine("rico25", "exact")
+def _assert_traj(name, precision, bad, n, worst):
+    print(f"[{name}/{precision}] greedy tokens differing from the reference: {bad}/{n}"
+          + (f" (largest reference top-2 margin among them {worst:.3e})" if bad else ""))
+    if precision == "exact":
+        assert bad == 0, f"{bad}/{n} tokens differ"
+    else:
+        assert bad == 0 or worst < MARGIN_BOUND[precision], (bad, worst)
+        assert bad <= 2e-3 * n
+
+
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
+def test_step_teacher_forced_uncond_all_t(cuda, golden_dir, precision):
+    """Every t in 99..0: fused HIP step (greedy) vs the reference's own argmax tokens on the states visited by a
+    stochastic reference trajectory: bit-exact in `exact`, margin-bounded in the fp16 modes (see MARGIN_BOUND)."""
+    e = engine("rico25", precision)
     g = np.load(os.path.join(golden_dir, "rico25_uncond_trajectory.npz"))
-    bad, n = _traj_check(e, g, {"name": "deterministic"})
-    assert bad == 0, f"{bad}/{n} tokens differ"
+    _assert_traj("uncond", precision, *_traj_check(e, g, {"name": "deterministic"}))
 
 
-def test_step_teacher_forced_cond_c(cuda, golden_dir):
-    e = engine("publaynet", "exact")
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
+def test_step_teacher_forced_cond_c(cuda, golden_dir, precision):
+    e = engine("publaynet", precision)
     g = np.load(os.path.join(golden_dir, "publaynet_cond_c_trajectory.npz"))
     cond = {"seq": g["cond_seq"].astype(np.int64), "mask": g["cond_mask"], "type": "c"}
-    bad, n = _traj_check(e, g, {"name": "deterministic"}, cond)
-    assert bad == 0, f"{bad}/{n} tokens differ"
+    _assert_traj("cond=c", precision, *_traj_check(e, g, {"name": "deterministic"}, cond))
 
 
-def test_step_teacher_forced_refinement(cuda, golden_dir):
-    spec = SP.RICO25
-    e = engine("rico25", "exact")
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
+def test_step_teacher_forced_refinement(cuda, golden_dir, precision):
+    e = engine("rico25", precision)
     g = np.load(os.path.join(golden_dir, "rico25_refinement_trajectory.npz"))
     table = torch.from_numpy(g["weak_table"])
     seq_orig = torch.from_numpy(g["seq_orig"].astype(np.int64))
     cond = {"seq": g["cond_seq"].astype(np.int64), "mask": g["cond_mask"], "type": "refinement",
             "weak_logits": table[seq_orig].permute(0, 2, 1).contiguous()}
-    bad, n = _traj_check(e, g, {"name": "deterministic"}, cond)
-    assert bad == 0, f"{bad}/{n} tokens differ"
+    _assert_traj("refinement", precision, *_traj_check(e, g, {"name": "deterministic"}, cond))
+
+
+@pytest.mark.parametrize("ds", ["rico25", "publaynet"])
+def test_posterior_fast_mode_f32_lse_vs_reference_golden(cuda, golden_dir, ds):
+    """The fast mode replaces the reference's float64 log-softmax (base.py:137) by an fp32 one inside the fused step
+    (kernels_post.hip, f32_lse).  ldm_posterior on a fast-mode handle runs that variant: it must reproduce the
+    reference's post_* golden (reference logits in) to the same tolerance as the f64 path, argmax included."""
+    e = engine(ds, "fast")
+    g = np.load(os.path.join(golden_dir, f"{ds}_step_cases.npz"))
+    for t in g["ts"]:
+        t = int(t)
+        tokens = torch.from_numpy(g[f"tokens_{t}"].astype(np.int32))
+        ref = torch.from_numpy(g[f"post_{t}"])
+        out = e.posterior(torch.from_numpy(g[f"logits_{t}"]), tokens, t).cpu()
+        assert (out - ref).abs().max().item() <= 5e-4, t
+        assert torch.equal(out.argmax(1), ref.argmax(1))
+        dead = ref == ref.min()
+        assert torch.equal(out[dead], ref[dead])
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -524,16 +564,8 @@ def test_vanilla_q_type_vs_reference_golden(cuda, golden_dir, precision):
         post = e.posterior(logits, tokens.int(), t).cpu()
         tol = 2e-4 if precision == "exact" else 5e-2  # log-probabilities; logits themselves carry <=1e-3 rel in fast
         assert (post - ref_post).abs().max().item() <= tol
-    before = torch.from_numpy(g["traj_states_before"].astype(np.int64))
-    ref_next = torch.from_numpy(g["traj_greedy_next"].astype(np.int64))
-    mism = 0
-    for i, t in enumerate(g["traj_steps"]):
-        nxt = e.sample_step(before[i].int(), int(t), {"name": "deterministic"}).cpu().long()
-        mism += int((nxt != ref_next[i]).sum())
-    if precision == "exact":
-        assert mism == 0, f"{mism}/{ref_next.numel()}"
-    else:
-        assert mism <= 0.005 * ref_next.numel(), f"{mism}/{ref_next.numel()}"
+    bad, n, worst = _traj_check(e, g, {"name": "deterministic"}, prefix="traj_")
+    _assert_traj("vanilla", precision, bad, n, worst)
     if precision == "exact":
         cfg = {"name": "random", "temperature": 1.0, "num_timesteps": 20}
         tk = torch.full((3, spec.seq_len), spec.mask_id, dtype=torch.int32)

@@ -19,6 +19,13 @@ def test_same_checkpoint(ds):
         assert np.array_equal(P.SPECS[ds].full_ids(at), OS.SPECS[ds].full_ids(at))
 
 
+def test_same_synthetic_cond_c():
+    for ds in ("rico25", "publaynet"):
+        a = P.synth_cond_c(P.SPECS[ds], 37, seed=4)
+        b = O.synth_cond_c(OS.SPECS[ds], 37, seed=4)
+        assert np.array_equal(a["seq"], b["seq"]) and np.array_equal(a["mask"], b["mask"])
+
+
 def test_timestep_schedule_matches_oracle():
     from layout_dm_amd.diffusion import timestep_schedule
     from oracle import restatement as R
