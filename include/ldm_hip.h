@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 2
+#define LDM_ABI_VERSION 3
 
 typedef struct ldm_handle ldm_handle;
 
@@ -88,6 +88,22 @@ typedef struct {
   int32_t pad_disable;          /* cond["type"] in {c,cwh,refinement,relation} (base.py:272-284) */
 } ldm_cond;
 
+/* cond=relation: the graph of cond["batch_w_canvas"] (helpers/task.py:112-114) re-indexed per layout — node 0 =
+ * canvas, node k = k-th element whose conditioned category is not PAD — plus the hyper-parameters of the logit
+ * adjustment the reference applies between the posterior and the draw (base.py:261-269 -> update(),
+ * categorical_diffusion/logit_adjustment.py:88-126, losses models/clg/const.py:221-236), relation_mode = "average". */
+typedef struct {
+  const int32_t* d_edge_offsets; /* (B+1) CSR offsets into the edge arrays */
+  const int32_t* d_edge_src;     /* (n_edges) node id inside its layout's graph */
+  const int32_t* d_edge_dst;
+  const int32_t* d_edge_attr;    /* 1<<RelSize | 1<<RelLoc bitmasks (trainer/data/util.py:14-27,168) */
+  const float* d_centres;        /* (4, n_bin) cluster centres in x,y,w,h order (float32, as update() casts them) */
+  int32_t canvas_bins[4];        /* bbox_tokenizer.encode([0.5,0.5,1,1]) per coordinate, 0..n_bin-1 */
+  float relation_lambda;         /* sampling_cfg.relation_lambda (SGD learning rate) */
+  int32_t num_update;            /* sampling_cfg.relation_num_update */
+  int32_t n_graph_total;         /* batch size of the whole sampling call: the loss is a mean over 14*B terms */
+} ldm_relation;
+
 /* ---- lifecycle ---------------------------------------------------------------------- */
 int ldm_create(const ldm_config* cfg, int device, ldm_handle** out);
 void ldm_destroy(ldm_handle* h);
@@ -110,43 +126,36 @@ int ldm_denoise_logits(ldm_handle* h, const int32_t* d_tokens, int t, int B, flo
  * t_post = the timestep handed to q_posterior (noise_t [- skip_step], base.py:218-240). */
 int ldm_posterior(ldm_handle* h, const float* d_logits, const int32_t* d_tokens, int t_post, int B,
                   const ldm_cond* cond, float* d_logp, void* stream);
-/* helpers/sampling.py:81-130 on a (B,C,S) log-prob tensor -> (B,S) int32 tokens */
-int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_sampler* s, uint64_t seed,
+/* helpers/sampling.py:81-130 on a (B,C,S) log-prob tensor -> (B,S) int32 tokens.  cond (may be NULL): only
+ * d_cond_seq + pad_disable are used — the [PAD] disabling of base.py:272-284, which the reference applies right
+ * before the draw (for cond=relation: after the logit adjustment). */
+int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,
                       uint64_t first_layout, int step, int B, int32_t* d_tokens_out, void* stream);
 
 /* ---- the hot path -------------------------------------------------------------------- */
-/* One reverse step (_sample_single_step, base.py:205-291), fused: tokens (B,S) -> tokens. */
+/* One reverse step (_sample_single_step, base.py:205-291), fused: tokens (B,S) -> tokens.
+ * rel (may be NULL): cond["type"] == "relation" — the step then runs posterior (+ strong mask) -> logit adjustment
+ * (t_model >= 10) -> [PAD] disable -> draw, exactly the reference's order. */
 int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
-                    int t_post, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,
+                    int t_post, const ldm_cond* cond, const ldm_relation* rel, const ldm_sampler* s, uint64_t seed,
                     uint64_t first_layout, int step, int B, void* stream);
 /* The T-step reverse loop (BaseMaskAndReplaceDiffusion.sample, base.py:293-371).
  * d_tokens_inout: initial state (all [MASK] for unconditional, cond["seq"] otherwise) -> final.
  * h_t_model / h_t_post: host arrays of n_steps timesteps (diffusion_list and the posterior's t).
+ * rel: NULL, or the relation graph of the B layouts (cond must then carry d_cond_seq).
  * d_intermediates: optional (n_steps,B,S) int32 (get_intermediate_results=True).
- * use_graph != 0: the whole loop is captured once per (B, schedule, sampler, cond layout) into
- * a hipGraph and replayed (seed / first_layout live in device memory so replays may change them). */
-int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const int32_t* h_t_model,
-                    const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
-                    uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream);
+ * use_graph != 0: the whole loop is captured once per (B, schedule, sampler, cond / relation layout) into
+ * a hipGraph and replayed (seed / first_layout live in device memory so replays may change them; cond tensors,
+ * the relation graph and the intermediates are staged through handle-owned buffers at fixed addresses). */
+int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const ldm_relation* rel,
+                    const int32_t* h_t_model, const int32_t* h_t_post, int n_steps, const ldm_sampler* s,
+                    uint64_t seed, uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph,
+                    void* stream);
 
-/* ---- cond=relation ---------------------------------------------------------------------- */
-/* The logit adjustment the reference applies between the posterior and the draw for cond["type"] ==
- * "relation" (base.py:261-269 -> update(), categorical_diffusion/logit_adjustment.py:88-126, losses
- * models/clg/const.py:221-236), relation_mode = "average": `num_update` SGD steps (t >= 10 only) on
- * the mean relational-constraint loss, with the gradient evaluated analytically.  Call between
- * ldm_posterior and ldm_sample_tokens.  The graph is cond["batch_w_canvas"] (helpers/task.py:112-114)
- * re-indexed per layout: node 0 = canvas, node k = k-th element whose conditioned category is not PAD. */
-typedef struct {
-  const int32_t* d_edge_offsets; /* (B+1) CSR offsets into the edge arrays */
-  const int32_t* d_edge_src;     /* (n_edges) node id inside its layout's graph */
-  const int32_t* d_edge_dst;
-  const int32_t* d_edge_attr;    /* 1<<RelSize | 1<<RelLoc bitmasks (trainer/data/util.py:14-27,168) */
-  const float* d_centres;        /* (4, n_bin) cluster centres in x,y,w,h order (float32, as update() casts them) */
-  int32_t canvas_bins[4];        /* bbox_tokenizer.encode([0.5,0.5,1,1]) per coordinate, 0..n_bin-1 */
-  float relation_lambda;         /* sampling_cfg.relation_lambda (SGD learning rate) */
-  int32_t num_update;            /* sampling_cfg.relation_num_update */
-  int32_t n_graph_total;         /* batch size of the whole sampling call: the loss is a mean over 14*B terms */
-} ldm_relation;
+/* ---- cond=relation, split-step form ------------------------------------------------------- */
+/* The logit adjustment alone (`num_update` SGD steps on the mean relational-constraint loss, analytic gradient;
+ * no-op for t < 10, logit_adjustment.py:107), for callers that drive the step stage by stage: call between
+ * ldm_posterior (cond without pad_disable) and ldm_sample_tokens (cond with pad_disable). */
 int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int32_t* d_cond_seq, const ldm_relation* rel,
                         int t, int B, void* stream);
 

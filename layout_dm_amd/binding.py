@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16 = 0, 1, 2
 PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16,
@@ -80,11 +80,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.ldm_finalize_weights.argtypes = [vp]
     lib.ldm_denoise_logits.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ldm_posterior.argtypes = [vp, vp, vp, i32, i32, C.POINTER(LdmCond), vp, vp]
-    lib.ldm_sample_tokens.argtypes = [vp, vp, C.POINTER(LdmSampler), u64, u64, i32, i32, vp, vp]
-    lib.ldm_sample_step.argtypes = [vp, vp, vp, i32, i32, C.POINTER(LdmCond), C.POINTER(LdmSampler), u64, u64,
-                                    i32, i32, vp]
-    lib.ldm_sample_loop.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
-                                    C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
+    lib.ldm_sample_tokens.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(LdmSampler), u64, u64, i32, i32, vp, vp]
+    lib.ldm_sample_step.argtypes = [vp, vp, vp, i32, i32, C.POINTER(LdmCond), C.POINTER(LdmRelation),
+                                    C.POINTER(LdmSampler), u64, u64, i32, i32, vp]
+    lib.ldm_sample_loop.argtypes = [vp, vp, C.POINTER(LdmCond), C.POINTER(LdmRelation), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int32), i32, C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
     lib.ldm_decode_layouts.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.ldm_relation_update.argtypes = [vp, vp, vp, C.POINTER(LdmRelation), i32, i32, vp]
     lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -226,18 +226,26 @@ class Engine:
         torch.cuda.current_stream(self.device).synchronize() if keep else None
         return out
 
-    def sample_tokens(self, logp: torch.Tensor, sampling_cfg, seed: int = 0, first_layout: int = 0, step: int = 0):
+    def sample_tokens(self, logp: torch.Tensor, sampling_cfg, seed: int = 0, first_layout: int = 0, step: int = 0,
+                      cond: Optional[dict] = None):
+        """helpers/sampling.py:81-130 on (B,C,S) log-probabilities.  cond (optional): {"seq", "type"} — the [PAD]
+        disabling of base.py:272-284 for cond types c / cwh / refinement / relation."""
         logp = logp.to(device=self.device, dtype=torch.float32).contiguous()
         B = logp.shape[0]
         s = make_sampler(sampling_cfg)
+        lc, keep = self.make_cond({"seq": cond["seq"], "type": cond.get("type")}, B) if cond else (None, [])
         out = torch.empty((B, self.S), dtype=torch.int32, device=self.device)
-        self._check(self.lib.ldm_sample_tokens(self._h, logp.data_ptr(), C.byref(s), seed, first_layout, step, B,
-                                               out.data_ptr(), _stream_ptr(self.device)), "ldm_sample_tokens")
+        self._check(self.lib.ldm_sample_tokens(self._h, logp.data_ptr(), C.byref(lc) if lc else None, C.byref(s), seed,
+                                               first_layout, step, B, out.data_ptr(), _stream_ptr(self.device)),
+                    "ldm_sample_tokens")
+        if keep:
+            torch.cuda.current_stream(self.device).synchronize()
         return out
 
     # ------------------------------------------------------------------ hot path
     def sample_step(self, tokens: torch.Tensor, t_model: int, sampling_cfg, t_post: Optional[int] = None,
-                    cond: Optional[dict] = None, seed: int = 0, first_layout: int = 0, step: int = 0):
+                    cond: Optional[dict] = None, seed: int = 0, first_layout: int = 0, step: int = 0, relation=None):
+        """relation: (LdmRelation, keep-alives) from make_relation for cond["type"] == "relation"."""
         tokens = self._tok(tokens)
         B = tokens.shape[0]
         s = make_sampler(sampling_cfg)
@@ -245,7 +253,8 @@ class Engine:
         out = torch.empty_like(tokens)
         self._check(self.lib.ldm_sample_step(self._h, tokens.data_ptr(), out.data_ptr(), int(t_model),
                                              int(t_model if t_post is None else t_post),
-                                             C.byref(lc) if lc else None, C.byref(s), seed, first_layout, step, B,
+                                             C.byref(lc) if lc else None, C.byref(relation[0]) if relation else None,
+                                             C.byref(s), seed, first_layout, step, B,
                                              _stream_ptr(self.device)), "ldm_sample_step")
         if keep:
             torch.cuda.current_stream(self.device).synchronize()
@@ -253,8 +262,10 @@ class Engine:
 
     def sample_loop(self, tokens: torch.Tensor, t_model: Sequence[int], t_post: Sequence[int], sampling_cfg,
                     cond: Optional[dict] = None, seed: int = 0, first_layout: int = 0,
-                    intermediates: bool = False, use_graph: bool = True, lc_keep=None):
-        """In-place T-step loop on `tokens` (B,S) int32 cuda. Returns (tokens, intermediates|None)."""
+                    intermediates: bool = False, use_graph: bool = True, lc_keep=None, relation=None):
+        """In-place T-step loop on `tokens` (B,S) int32 cuda. Returns (tokens, intermediates|None).
+        relation: (LdmRelation, keep-alives) from make_relation — the whole cond=relation loop (posterior ->
+        logit adjustment -> [PAD] disable -> draw per step) then runs inside the same launch sequence / hipGraph."""
         tokens = self._tok(tokens)
         B = tokens.shape[0]
         n = len(t_model)
@@ -266,7 +277,8 @@ class Engine:
         inter = torch.empty((n, B, self.S), dtype=torch.int32, device=self.device) if intermediates else None
         tm = (C.c_int32 * n)(*[int(x) for x in t_model])
         tp = (C.c_int32 * n)(*[int(x) for x in t_post])
-        self._check(self.lib.ldm_sample_loop(self._h, tokens.data_ptr(), C.byref(lc) if lc else None, tm, tp, n,
+        self._check(self.lib.ldm_sample_loop(self._h, tokens.data_ptr(), C.byref(lc) if lc else None,
+                                             C.byref(relation[0]) if relation else None, tm, tp, n,
                                              C.byref(s), seed, first_layout, B,
                                              inter.data_ptr() if inter is not None else None,
                                              1 if use_graph else 0, _stream_ptr(self.device)), "ldm_sample_loop")

@@ -209,8 +209,14 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
       if (c >= C) continue;
       if (strong) lp[j] = (c == cs) ? 0.0f : kLogEps;
       else if (p.weak) lp[j] += p.weak[((size_t)b * C + c) * p.S + s];
-      if (p.pad_disable && p.cond_seq && c == pad_id && attr != 0 && cs != pad_id) lp[j] = kLogEps;
     }
+  }
+  // disable [PAD] where the number of elements is known (base.py:272-284).  Also on the logp_in path: for
+  // cond=relation the reference applies it AFTER the logit adjustment, i.e. between ldm_relation_update and the draw.
+  if (p.pad_disable && p.cond_seq && attr != 0 && p.cond_seq[row] != pad_id) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (lane + 64 * j == pad_id) lp[j] = kLogEps;
   }
   if (p.logp_out) {
 #pragma unroll

@@ -84,13 +84,19 @@ struct PendingEvent {
 
 struct GraphKey {
   int B, n_steps, kind, top_k, has_cond, has_strong, has_weak, pad_disable, has_inter;
+  int has_rel = 0, rel_num_update = 0, rel_n_graph = 0, rel_bins[4] = {0, 0, 0, 0};
+  float rel_lambda = 0.f;
+  const void* rel_edges = nullptr;
   float temperature, top_p;
   const void *tokens, *cond_seq, *strong, *weak;
   std::vector<int32_t> t_model, t_post;
   bool operator==(const GraphKey& o) const {
     return B == o.B && n_steps == o.n_steps && kind == o.kind && top_k == o.top_k && has_cond == o.has_cond &&
            has_strong == o.has_strong && has_weak == o.has_weak && pad_disable == o.pad_disable &&
-           has_inter == o.has_inter && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
+           has_inter == o.has_inter && has_rel == o.has_rel && rel_num_update == o.rel_num_update &&
+           rel_n_graph == o.rel_n_graph && rel_lambda == o.rel_lambda && rel_edges == o.rel_edges &&
+           rel_bins[0] == o.rel_bins[0] && rel_bins[1] == o.rel_bins[1] && rel_bins[2] == o.rel_bins[2] &&
+           rel_bins[3] == o.rel_bins[3] && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
            cond_seq == o.cond_seq && strong == o.strong && weak == o.weak &&
            t_model == o.t_model && t_post == o.t_post;
   }
@@ -146,6 +152,12 @@ struct ldm_handle {
   uint8_t* st_strong = nullptr;
   float* st_weak = nullptr;
   int32_t* st_inter = nullptr;  // (n_step, max_batch, S) intermediates of a graph-captured loop
+  // cond=relation: the adjusted log-probabilities of one chunk + staging of the caller's graph (fixed addresses)
+  float* rel_logp = nullptr;            // (chunk, C, S)
+  int32_t* st_rel_off = nullptr;        // (max_batch + 1)
+  int32_t* st_rel_edges = nullptr;      // 3 x st_rel_cap : src | dst | attr
+  size_t st_rel_cap = 0;
+  float* st_rel_centres = nullptr;      // (4, n_bin)
   int32_t *tok_a = nullptr, *tok_b = nullptr;  // loop state ping-pong (max_batch)
   uint64_t* rng = nullptr;                      // device {seed, first_layout}
   // profiling
@@ -933,9 +945,37 @@ static int check_sampler(ldm_handle* h, const ldm_sampler* s) {
   return 0;
 }
 
-// one fused reverse step over the whole batch, chunk by chunk
+static int check_relation(ldm_handle* h, const ldm_relation* rel, const ldm_cond* cond, int B) {
+  if (!rel) return 0;
+  if (!cond || !cond->d_cond_seq) return h->fail(-1, "cond=relation needs cond->d_cond_seq (the conditioned sequence)");
+  if (!rel->d_edge_offsets || !rel->d_centres) return h->fail(-1, "ldm_relation: null edge offsets / centres");
+  if (rel->n_graph_total < B) return h->fail(-1, "ldm_relation.n_graph_total smaller than B");
+  if (h->cfg.max_elem > 32 || h->cfg.n_bin > 32) return h->fail(-4, "relation kernel: max_elem and n_bin must be <= 32");
+  for (int x = 0; x < 4; ++x)
+    if (rel->canvas_bins[x] < 0 || rel->canvas_bins[x] >= h->cfg.n_bin) return h->fail(-1, "canvas bin out of range");
+  if (!h->rel_logp) {
+    int rc = h->dalloc(&h->rel_logp, (size_t)h->chunk * h->C * h->S, false);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static void fill_rel(ldm_handle* h, RelArgs& a, const ldm_relation* rel, size_t layout_off, int Bc) {
+  a.edge_off = rel->d_edge_offsets + layout_off;  // offsets are absolute positions in the edge arrays
+  a.edge_src = rel->d_edge_src; a.edge_dst = rel->d_edge_dst; a.edge_attr = rel->d_edge_attr;
+  a.centres = rel->d_centres;
+  for (int x = 0; x < 4; ++x) a.canvas_bins[x] = rel->canvas_bins[x];
+  a.step = rel->relation_lambda / (14.0f * (float)rel->n_graph_total);
+  a.num_update = rel->num_update; a.B = Bc; a.C = h->C; a.S = h->S; a.A = h->cfg.n_attr;
+  a.n_category = h->cfg.n_category; a.n_bin = h->cfg.n_bin; a.pad_id = h->vocab.pad_id;
+}
+
+// one fused reverse step over the whole batch, chunk by chunk.  `cond` / `rel` describe layouts 0..B of THIS call
+// (the loop body hands over pointers already advanced to its chunk); rel_layout_off = position of row 0 inside the
+// relation graph's CSR offsets.
 static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_model, int t_post, const ldm_cond* cond,
-                    const ldm_sampler* s, int step, int B, size_t rng_layout_off, hipStream_t st) {
+                    const ldm_relation* rel, size_t rel_layout_off, const ldm_sampler* s, int step, int B,
+                    size_t rng_layout_off, hipStream_t st) {
   if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
     return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
   for (int off = 0; off < B; off += h->chunk) {
@@ -947,12 +987,45 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
     p.logits = h->logits;
     p.ldl = h->Cp;
     p.tokens = tin + (size_t)off * h->S;
-    p.tokens_out = tout + (size_t)off * h->S;
     p.t_post = t_post;
     p.step = step;
     p.layout_off = (int)(rng_layout_off + off);
-    ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
-    launch_posterior_sample(p, st);
+    if (!rel) {
+      p.tokens_out = tout + (size_t)off * h->S;
+      ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
+      launch_posterior_sample(p, st);
+      continue;
+    }
+    // cond=relation (base.py:243-291): posterior + strong mask -> logit adjustment -> [PAD] disable -> draw
+    {
+      PostArgs q = p;
+      q.pad_disable = 0;  // applied after the adjustment, below
+      q.logp_out = h->rel_logp;
+      q.tokens_out = nullptr;
+      ldm_handle::Scope sc(h, st, "posterior", 0, (double)Bc * h->S * (h->Cp * 4 + h->C * 4));
+      launch_posterior_sample(q, st);
+    }
+    if (t_model >= 10 && rel->num_update > 0) {  // logit_adjustment.py:107
+      RelArgs a{};
+      a.logp = h->rel_logp;
+      a.cond_seq = cond->d_cond_seq + (size_t)off * h->S;
+      fill_rel(h, a, rel, rel_layout_off + off, Bc);
+      ldm_handle::Scope sc(h, st, "relation_update", 0, (double)Bc * 4 * h->cfg.n_bin * h->cfg.max_elem * 8);
+      launch_relation_update(a, st);
+    }
+    {
+      PostArgs q{};
+      fill_post(h, q, cond, s, off, Bc);
+      q.strong = nullptr;  // already imposed on rel_logp
+      q.weak = nullptr;
+      q.pad_disable = 1;
+      q.logp_in = h->rel_logp;
+      q.tokens_out = tout + (size_t)off * h->S;
+      q.step = step;
+      q.layout_off = (int)(rng_layout_off + off);
+      ldm_handle::Scope sc(h, st, "pad_disable_sample", 0, (double)Bc * h->S * (h->C * 4 + 8));
+      launch_posterior_sample(q, st);
+    }
   }
   return 0;
 }
@@ -999,8 +1072,9 @@ static int set_rng(ldm_handle* h, uint64_t seed, uint64_t first_layout, hipStrea
   return 0;
 }
 
-extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_sampler* s, uint64_t seed,
-                                 uint64_t first_layout, int step, int B, int32_t* d_tokens_out, void* stream) {
+extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_cond* cond, const ldm_sampler* s,
+                                 uint64_t seed, uint64_t first_layout, int step, int B, int32_t* d_tokens_out,
+                                 void* stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
   if ((rc = check_sampler(h, s))) return rc;
@@ -1010,6 +1084,10 @@ extern "C" int ldm_sample_tokens(ldm_handle* h, const float* d_logp, const ldm_s
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
   PostArgs p{};
   fill_post(h, p, nullptr, s, 0, B);
+  if (cond) {  // only the [PAD] disabling applies at this stage (base.py:272-284)
+    p.cond_seq = cond->d_cond_seq;
+    p.pad_disable = cond->pad_disable;
+  }
   p.logp_in = d_logp;
   p.tokens_out = d_tokens_out;
   p.step = step;
@@ -1032,13 +1110,9 @@ extern "C" int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int
   if (t < 10 || rel->num_update <= 0) return 0;  // logit_adjustment.py:107
   ON_DEVICE(h);
   RelArgs a{};
-  a.logp = d_logp_inout; a.cond_seq = d_cond_seq;
-  a.edge_off = rel->d_edge_offsets; a.edge_src = rel->d_edge_src; a.edge_dst = rel->d_edge_dst;
-  a.edge_attr = rel->d_edge_attr; a.centres = rel->d_centres;
-  for (int x = 0; x < 4; ++x) a.canvas_bins[x] = rel->canvas_bins[x];
-  a.step = rel->relation_lambda / (14.0f * (float)rel->n_graph_total);
-  a.num_update = rel->num_update; a.B = B; a.C = h->C; a.S = h->S; a.A = h->cfg.n_attr;
-  a.n_category = h->cfg.n_category; a.n_bin = h->cfg.n_bin; a.pad_id = h->vocab.pad_id;
+  a.logp = d_logp_inout;
+  a.cond_seq = d_cond_seq;
+  fill_rel(h, a, rel, 0, B);
   launch_relation_update(a, (hipStream_t)stream);
   HIP_OK(h, hipGetLastError());
   return 0;
@@ -1060,22 +1134,24 @@ extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B,
 
 // ------------------------------------------------------------------------------------------ hot path
 extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
-                               int t_post, const ldm_cond* cond, const ldm_sampler* s, uint64_t seed,
-                               uint64_t first_layout, int step, int B, void* stream) {
+                               int t_post, const ldm_cond* cond, const ldm_relation* rel, const ldm_sampler* s,
+                               uint64_t seed, uint64_t first_layout, int step, int B, void* stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
   if ((rc = check_sampler(h, s))) return rc;
   if (!d_tokens_in || !d_tokens_out) return h->fail(-1, "null argument");
   ON_DEVICE(h);
+  if ((rc = check_relation(h, rel, cond, B))) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
-  if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, s, step, B, 0, st))) return rc;
+  if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, rel, 0, s, step, B, 0, st))) return rc;
   HIP_OK(h, hipGetLastError());
   return 0;
 }
 
-static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const int32_t* t_model, const int32_t* t_post,
-                         int n_steps, const ldm_sampler* s, int B, int32_t* d_inter, hipStream_t st) {
+static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation* rel, const int32_t* t_model,
+                         const int32_t* t_post, int n_steps, const ldm_sampler* s, int B, int32_t* d_inter,
+                         hipStream_t st) {
   // state lives in tok_a / tok_b (ping-pong); chunk-major order keeps one chunk's activations and the
   // weights resident in L2 / Infinity Cache for all T steps before moving to the next chunk
   const size_t S = h->S;
@@ -1091,7 +1167,7 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const int32_t* t_m
     int32_t* cur = h->tok_a + off * S;
     int32_t* nxt = h->tok_b + off * S;
     for (int i = 0; i < n_steps; ++i) {
-      int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, s, i, Bc, off, st);
+      int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st);
       if (rc) return rc;
       if (d_inter)
         HIP_OK(h, hipMemcpyAsync(d_inter + ((size_t)i * B + off) * S, nxt, (size_t)Bc * S * 4,
@@ -1104,9 +1180,10 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const int32_t* t_m
   return 0;
 }
 
-extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const int32_t* h_t_model,
-                               const int32_t* h_t_post, int n_steps, const ldm_sampler* s, uint64_t seed,
-                               uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph, void* stream) {
+extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const ldm_relation* rel,
+                               const int32_t* h_t_model, const int32_t* h_t_post, int n_steps, const ldm_sampler* s,
+                               uint64_t seed, uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph,
+                               void* stream) {
   int rc = check_ready(h, B);
   if (rc) return rc;
   if ((rc = check_sampler(h, s))) return rc;
@@ -1115,6 +1192,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
     if (h_t_model[i] < 0 || h_t_model[i] >= h->T || h_t_post[i] < 0 || h_t_post[i] >= h->T)
       return h->fail(-1, "timestep out of range [0,%d)", h->T);
   ON_DEVICE(h);
+  if ((rc = check_relation(h, rel, cond, B))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const size_t nbytes = (size_t)B * h->S * 4;
   HIP_OK(h, hipEventRecord(h->loop_a, st));
@@ -1142,6 +1220,39 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       }
       cond = &staged;
     }
+    // same for the relation graph: CSR offsets are read back once (host) to size the edge staging
+    ldm_relation staged_rel{};
+    if (rel) {
+      staged_rel = *rel;
+      std::vector<int32_t> off(B + 1);
+      HIP_OK(h, hipMemcpyAsync(off.data(), rel->d_edge_offsets, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIP_OK(h, hipStreamSynchronize(st));
+      const int32_t e0 = off[0], ne = off[B] - off[0];
+      if (ne < 0) return h->fail(-1, "ldm_relation: edge offsets are not monotonic");
+      if (!h->st_rel_off && (rc = h->dalloc(&h->st_rel_off, (size_t)h->cfg.max_batch + 1))) return rc;
+      if (!h->st_rel_centres && (rc = h->dalloc(&h->st_rel_centres, (size_t)4 * h->cfg.n_bin))) return rc;
+      if ((size_t)ne > h->st_rel_cap) {  // (a grown buffer has a new address: graphs keyed on the old one miss)
+        const size_t cap = std::max<size_t>(1024, (size_t)ne * 2);
+        if ((rc = h->dalloc(&h->st_rel_edges, 3 * cap))) return rc;
+        h->st_rel_cap = cap;
+      }
+      for (auto& o : off) o -= e0;
+      HIP_OK(h, hipMemcpyAsync(h->st_rel_off, off.data(), (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));
+      HIP_OK(h, hipStreamSynchronize(st));  // `off` is pageable host memory
+      if (ne > 0) {
+        const size_t cap = h->st_rel_cap;
+        HIP_OK(h, hipMemcpyAsync(h->st_rel_edges, rel->d_edge_src + e0, (size_t)ne * 4, hipMemcpyDeviceToDevice, st));
+        HIP_OK(h, hipMemcpyAsync(h->st_rel_edges + cap, rel->d_edge_dst + e0, (size_t)ne * 4, hipMemcpyDeviceToDevice, st));
+        HIP_OK(h, hipMemcpyAsync(h->st_rel_edges + 2 * cap, rel->d_edge_attr + e0, (size_t)ne * 4, hipMemcpyDeviceToDevice, st));
+      }
+      HIP_OK(h, hipMemcpyAsync(h->st_rel_centres, rel->d_centres, (size_t)4 * h->cfg.n_bin * 4, hipMemcpyDeviceToDevice, st));
+      staged_rel.d_edge_offsets = h->st_rel_off;
+      staged_rel.d_edge_src = h->st_rel_edges;
+      staged_rel.d_edge_dst = h->st_rel_edges + h->st_rel_cap;
+      staged_rel.d_edge_attr = h->st_rel_edges + 2 * h->st_rel_cap;
+      staged_rel.d_centres = h->st_rel_centres;
+      rel = &staged_rel;
+    }
     GraphKey key{};
     key.B = B; key.n_steps = n_steps; key.kind = s->kind; key.top_k = s->top_k;
     key.temperature = s->temperature; key.top_p = s->top_p;
@@ -1159,6 +1270,14 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       inter_dst = h->st_inter;
     }
     key.has_inter = inter_dst != nullptr;
+    if (rel) {
+      key.has_rel = 1;
+      key.rel_num_update = rel->num_update;
+      key.rel_n_graph = rel->n_graph_total;
+      key.rel_lambda = rel->relation_lambda;
+      key.rel_edges = rel->d_edge_src;
+      for (int x = 0; x < 4; ++x) key.rel_bins[x] = rel->canvas_bins[x];
+    }
     key.t_model.assign(h_t_model, h_t_model + n_steps);
     key.t_post.assign(h_t_post, h_t_post + n_steps);
     GraphEntry* ge = nullptr;
@@ -1174,7 +1293,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       hipStream_t cap = nullptr;
       HIP_OK(h, hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
       HIP_OK(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-      rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, inter_dst, cap);
+      rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, inter_dst, cap);
       hipGraph_t graph = nullptr;
       hipError_t e = hipStreamEndCapture(cap, &graph);
       hipStreamDestroy(cap);
@@ -1194,7 +1313,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
     if (inter_dst)
       HIP_OK(h, hipMemcpyAsync(d_intermediates, inter_dst, (size_t)n_steps * B * h->S * 4, hipMemcpyDeviceToDevice, st));
   } else {
-    if ((rc = run_loop_body(h, cond, h_t_model, h_t_post, n_steps, s, B, d_intermediates, st))) return rc;
+    if ((rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, d_intermediates, st))) return rc;
   }
   HIP_OK(h, hipMemcpyAsync(d_tokens_inout, h->tok_a, nbytes, hipMemcpyDeviceToDevice, st));
   HIP_OK(h, hipEventRecord(h->loop_b, st));

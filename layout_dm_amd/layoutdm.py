@@ -237,8 +237,7 @@ class LayoutDM:
         to the caller's own `tokenizer.decode` on the host, exactly like the reference."""
         kwargs.pop("get_intermediate_results", None)
         ok, centres = self._device_decode_centres()
-        cond_is_relation = bool(cond) and cond.get("type", None) == "relation"
-        if ok and not cond_is_relation:
+        if ok:
             ids = self._sample_tokens(batch_size=batch_size, cond=cond, sampling_cfg=sampling_cfg,
                                       return_device_tensor=True, **kwargs)
             out = self.model.module.engine.decode(ids, centres)

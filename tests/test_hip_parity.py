@@ -536,10 +536,43 @@ def test_relation_sampling_loop_hip_update_equals_oracle_update(cuda):
                                 cfg["relation_lambda"], cfg["relation_num_update"], t)
         return out.to(model_log_prob.device)
 
-    a = sample_with_relation(m, B, cond, cfg, tok, seed=1)
-    b = sample_with_relation(m, B, cond, cfg, tok, update_fn=oracle_update, seed=1)
+    a = sample_with_relation(m, B, cond, cfg, tok, seed=1)                            # fused: inside the hipGraph
+    b = sample_with_relation(m, B, cond, cfg, tok, update_fn=oracle_update, seed=1)    # split-step, oracle autograd
     assert (a != b).float().mean().item() <= 0.01
     assert (a[:, 0::5] == seq[:, 0::5]).all()  # conditioned categories survive
+
+    # graph path == eager path == split-step path (every stage launched separately through the parity hooks, with the
+    # HIP logit adjustment as the update function): bit-exact tokens, deterministic AND stochastic sampler
+    from layout_dm_amd.relation import hip_relation_plan
+
+    eng = m.engine
+    plan = hip_relation_plan(eng, {"batch_w_canvas": gb}, cfg, tok, B)
+
+    def hip_update(t, cond, model_log_prob, tokenizer, sampling_cfg):
+        return eng.relation_update(model_log_prob.contiguous(), seq, plan, t)
+
+    for scfg in (cfg, dict(cfg, name="random", temperature=1.0), dict(cfg, name="top_p", top_p=0.9, temperature=1.0)):
+        fused = sample_with_relation(m, B, cond, scfg, tok, seed=5)
+        m.use_graph = False
+        eager = sample_with_relation(m, B, cond, scfg, tok, seed=5)
+        m.use_graph = True
+        split = sample_with_relation(m, B, cond, scfg, tok, update_fn=hip_update, seed=5)
+        assert torch.equal(fused, eager), scfg["name"]
+        assert torch.equal(fused, split), scfg["name"]
+    inter = sample_with_relation(m, B, cond, cfg, tok, seed=5, get_intermediate_results=True)
+    assert len(inter) == 12 and torch.equal(inter[-1], sample_with_relation(m, B, cond, cfg, tok, seed=5))
+    # relation_mode="gumbel" has no implementation (and no reference fallback)
+    with pytest.raises(NotImplementedError):
+        sample_with_relation(m, B, cond, dict(cfg, relation_mode="gumbel"), tok, seed=1)
+    # more layouts than max_batch: windows of the same graph (max_batch = 4 here)
+    B2 = 6
+    graph2, seq2 = _random_graph(spec, B2, gen)
+    gb2 = type("G", (), dict(graph2, to=lambda self, *_a, **_k: self))()
+    cond2 = {"seq": seq2, "mask": seq2 != spec.mask_id, "type": "relation", "batch_w_canvas": gb2}
+    big = sample_with_relation(m, B2, cond2, cfg, tok, seed=9)
+    m6 = HipMaskAndReplaceDiffusion(n_category=spec.n_category, precision="exact", max_batch=8)
+    m6.load_state_dict(sd)
+    assert torch.equal(big, sample_with_relation(m6, B2, cond2, cfg, tok, seed=9))
 
 
 # ----------------------------------------------------------------------------- q_type = vanilla
