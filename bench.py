@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--modes", default=None,
                     help="comma list of numerics modes reported under 'modes' (default: all three at N=1, none at N>1)")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent chunk pipelines (0 = library default)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -185,7 +186,7 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, 
     model = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
                                        d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
                                        num_timesteps=spec.n_step, precision=precision, max_batch=B, chunk=a.chunk,
-                                       device=local_rank, use_graph=not a.no_graph)
+                                       device=local_rank, use_graph=not a.no_graph, lanes=a.lanes)
     model.load_state_dict(sd)
     eng = model.engine
     cfg = {"name": a.sampling, "temperature": 1.0, "top_p": 0.9, "top_k": 5, "num_timesteps": a.timesteps}

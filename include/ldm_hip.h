@@ -70,6 +70,8 @@ typedef struct {
   int32_t chunk;       /* layouts processed per pass through the network (0 = auto) so that the
                           activation working set stays inside the 256 MiB Infinity Cache */
   int32_t q_type;      /* LDM_Q_* (ABI 2) */
+  int32_t lanes;       /* chunk pipelines run concurrently, each on its own stream / hipGraph, phase-shifted so that
+                          their HBM-bound phases do not coincide (0 or 1 = one; ABI 3) */
 } ldm_config;
 
 /* sampling_cfg of the reference (helpers/sampling.py dataclasses) */

@@ -34,7 +34,7 @@ EXPORTS = (
 class LdmConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "n_category", "n_bin", "max_elem", "n_attr", "d_model", "n_head", "d_ff",
-        "n_layer", "n_step", "precision", "max_batch", "chunk", "q_type")]
+        "n_layer", "n_step", "precision", "max_batch", "chunk", "q_type", "lanes")]
 
 
 Q_TYPES = {"constrained": 0, "vanilla": 1}  # models/layoutdm.py:20-23
@@ -124,7 +124,7 @@ class Engine:
     def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
                  d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4, n_step: int = 100,
                  precision="exact", max_batch: int = 512, chunk: int = 0, device: Optional[int] = None,
-                 q_type: str = "constrained"):
+                 q_type: str = "constrained", lanes: int = 0):
         if q_type not in Q_TYPES:
             raise NotImplementedError(f"q_type={q_type}: one of {sorted(Q_TYPES)}")
         if not torch.cuda.is_available():
@@ -134,7 +134,7 @@ class Engine:
         self.device = torch.device("cuda", self.device_index)
         prec = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         self.cfg = LdmConfig(ABI_VERSION, n_category, n_bin, max_elem, n_attr, d_model, n_head, d_ff, n_layer,
-                             n_step, prec, max_batch, chunk, Q_TYPES[q_type])
+                             n_step, prec, max_batch, chunk, Q_TYPES[q_type], lanes)
         self.q_type = q_type
         self.S = max_elem * n_attr
         self.n_attr, self.n_bin, self.n_category = n_attr, n_bin, n_category

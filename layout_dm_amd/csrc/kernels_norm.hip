@@ -181,4 +181,13 @@ void launch_pos_table(const float* elem, const float* attr, float* pos, int E, i
   hipLaunchKernelGGL(pos_table_k, dim3((n + 255) / 256), dim3(256), 0, st, elem, attr, pos, E, A, D);
 }
 
+// Lane phase offset: one wave spins for `us` microseconds on the constant 100 MHz s_memrealtime counter.
+__global__ void delay_k(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void launch_delay_us(int us, hipStream_t st) {
+  hipLaunchKernelGGL(delay_k, dim3(1), dim3(64), 0, st, (unsigned long long)us * 100ull);
+}
+
 }  // namespace ldm

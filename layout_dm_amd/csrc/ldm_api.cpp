@@ -104,8 +104,16 @@ struct GraphKey {
 
 struct GraphEntry {
   GraphKey key;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  std::vector<hipGraph_t> graph;      // one per lane
+  std::vector<hipGraphExec_t> exec;
+  void destroy() {
+    for (auto e : exec)
+      if (e) hipGraphExecDestroy(e);
+    for (auto g : graph)
+      if (g) hipGraphDestroy(g);
+    exec.clear();
+    graph.clear();
+  }
 };
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -127,11 +135,40 @@ struct ldm_handle {
   const float *emb = nullptr, *head_g = nullptr, *head_b = nullptr, *head_w = nullptr;
   __half *head_w16 = nullptr, *head_w16lo = nullptr;
   std::vector<void*> owned;  // everything hipMalloc'ed by the handle
-  // workspace (one chunk)
+  // workspace of ONE chunk.  These are the pointers the launch sequences use; with several lanes (below) they are
+  // switched to the lane's own buffers by activate() before its launches are recorded / issued.
   float *P = nullptr, *Q = nullptr, *qkv32 = nullptr, *att32 = nullptr, *h32 = nullptr, *hid32 = nullptr,
         *logits = nullptr;
   __half *a16 = nullptr, *a16lo = nullptr, *qkv16 = nullptr, *att16 = nullptr, *att16lo = nullptr, *h16 = nullptr,
          *h16lo = nullptr, *hid16 = nullptr, *hid16lo = nullptr;
+  // Lanes: chunks c, c + n_lanes, ... form lane (c % n_lanes); every lane has its own workspace, stream and
+  // captured graph, and the lanes run CONCURRENTLY, lane l starting l * lane_offset_us late.  Why: the fused
+  // kernels alternate HBM-bound phases (row loads / stores, ~30 % of a block) with MFMA-bound phases, and with one
+  // kernel on the whole chip every CU hits the memory phase at the same moment (all-CU burst ~4 TB/s, then HBM
+  // idles).  Two half-chip kernels out of phase halve each burst (profiles/r02_call2_phase_vs_blocks.txt).
+  struct Workspace {
+    float *P, *Q, *qkv32, *att32, *h32, *hid32, *logits, *rel_logp;
+    __half *a16, *a16lo, *qkv16, *att16, *att16lo, *h16, *h16lo, *hid16, *hid16lo;
+    float2 *stats_a, *stats_b;
+  };
+  std::vector<Workspace> ws;
+  std::vector<hipStream_t> lane_stream;
+  std::vector<hipEvent_t> lane_done;
+  hipEvent_t fork_ev = nullptr;
+  int n_lanes = 1, lane_offset_us = 0, cur_lane = -1;
+  void save_ws(int l) {
+    ws[l] = Workspace{P, Q, qkv32, att32, h32, hid32, logits, rel_logp, a16, a16lo, qkv16, att16, att16lo,
+                      h16, h16lo, hid16, hid16lo, stats_a, stats_b};
+  }
+  void activate(int l) {
+    if (l == cur_lane) return;
+    if (cur_lane >= 0) ws[cur_lane].rel_logp = rel_logp;  // (allocated lazily)
+    const Workspace& w = ws[l];
+    P = w.P; Q = w.Q; qkv32 = w.qkv32; att32 = w.att32; h32 = w.h32; hid32 = w.hid32; logits = w.logits;
+    rel_logp = w.rel_logp; a16 = w.a16; a16lo = w.a16lo; qkv16 = w.qkv16; att16 = w.att16; att16lo = w.att16lo;
+    h16 = w.h16; h16lo = w.h16lo; hid16 = w.hid16; hid16lo = w.hid16lo; stats_a = w.stats_a; stats_b = w.stats_b;
+    cur_lane = l;
+  }
   // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64
   int Dq = 0, HD = 0, Fq = 0, Mpad = 0;
   int gemm_cfg[5] = {0, 0, 0, 0, 0};  // qkv, attn_out, ffn1, ffn2, head
@@ -305,15 +342,24 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
+  if (const char* ce = getenv("LDM_CHUNK")) chunk = atoi(ce);  // experiments
   if (chunk <= 0) chunk = 512;
   chunk = std::min(chunk, cfg->max_batch);
   h->chunk = chunk;
 
+  // lanes: LDM_LANES / LDM_LANE_OFFSET_US override cfg->lanes (experiments); more lanes than chunks make no sense
+  h->n_lanes = cfg->lanes > 0 ? cfg->lanes : 1;
+  if (const char* le = getenv("LDM_LANES")) h->n_lanes = std::max(1, atoi(le));
+  h->n_lanes = std::min(h->n_lanes, std::max(1, (cfg->max_batch + chunk - 1) / chunk));
+  h->lane_offset_us = 50;
+  if (const char* lo = getenv("LDM_LANE_OFFSET_US")) h->lane_offset_us = std::max(0, atoi(lo));
+  h->ws.resize(h->n_lanes);
   const size_t Mc = (size_t)chunk * h->S;
   int rc = 0;
   auto A = [&](auto** p, size_t n) {
     if (rc == 0) rc = h->dalloc(p, n);
   };
+  for (int lane = 0; lane < h->n_lanes; ++lane) {
   // P / Q carry padding rows up to the next multiple of 256: the row-stationary kernels write whole 128-row
   // blocks (rows >= M land in the padding instead of being exec-masked)
   const size_t Mrows = (size_t)round_up((int)Mc, 256);
@@ -365,6 +411,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
       A(&h->hid16lo, Mc * h->Fp);
     }
   }
+  h->save_ws(lane);
+  }
+  h->cur_lane = h->n_lanes - 1;
+  h->activate(0);
   A(&h->tok_a, (size_t)cfg->max_batch * h->S);
   A(&h->tok_b, (size_t)cfg->max_batch * h->S);
   A(&h->st_cond_seq, (size_t)cfg->max_batch * h->S);
@@ -378,6 +428,17 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   hipEventCreate(&h->loop_a);
   hipEventCreate(&h->loop_b);
+  hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming);
+  h->lane_stream.assign(h->n_lanes, nullptr);
+  h->lane_done.assign(h->n_lanes, nullptr);
+  for (int l = 1; l < h->n_lanes; ++l) {
+    if (hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming) != hipSuccess) {
+      g_create_error = "lane stream / event creation failed";
+      ldm_destroy(h);
+      return -2;
+    }
+  }
   *out = h;
   return 0;
 }
@@ -387,15 +448,17 @@ extern "C" void ldm_destroy(ldm_handle* h) {
   DeviceGuard guard(h->device);
   hipDeviceSynchronize();
   h->drain_profile();
-  for (auto& g : h->graphs) {
-    if (g.exec) hipGraphExecDestroy(g.exec);
-    if (g.graph) hipGraphDestroy(g.graph);
-  }
+  for (auto& g : h->graphs) g.destroy();
   for (auto& kv : h->raw)
     if (kv.second.d) hipFree(kv.second.d);
   for (void* p : h->owned) hipFree(p);
   if (h->loop_a) hipEventDestroy(h->loop_a);
   if (h->loop_b) hipEventDestroy(h->loop_b);
+  if (h->fork_ev) hipEventDestroy(h->fork_ev);
+  for (auto st : h->lane_stream)
+    if (st) hipStreamDestroy(st);
+  for (auto ev : h->lane_done)
+    if (ev) hipEventDestroy(ev);
   delete h;
 }
 
@@ -627,10 +690,7 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   HIP_OK(h, hipDeviceSynchronize());
   HIP_OK(h, hipGetLastError());
   // graphs captured against older weights stay valid (pointers unchanged) but drop them anyway
-  for (auto& g : h->graphs) {
-    if (g.exec) hipGraphExecDestroy(g.exec);
-    if (g.graph) hipGraphDestroy(g.graph);
-  }
+  for (auto& g : h->graphs) g.destroy();
   h->graphs.clear();
   h->finalized = true;
   return 0;
@@ -931,6 +991,7 @@ static void fill_post(ldm_handle* h, PostArgs& p, const ldm_cond* cond, const ld
 
 static int check_ready(ldm_handle* h, int B) {
   if (!h) return -1;
+  h->activate(0);
   if (!h->finalized) return h->fail(-5, "weights not finalized: call ldm_finalize_weights first");
   if (B < 1 || B > h->cfg.max_batch) return h->fail(-1, "batch %d outside [1, max_batch=%d]", B, h->cfg.max_batch);
   return 0;
@@ -953,9 +1014,13 @@ static int check_relation(ldm_handle* h, const ldm_relation* rel, const ldm_cond
   if (h->cfg.max_elem > 32 || h->cfg.n_bin > 32) return h->fail(-4, "relation kernel: max_elem and n_bin must be <= 32");
   for (int x = 0; x < 4; ++x)
     if (rel->canvas_bins[x] < 0 || rel->canvas_bins[x] >= h->cfg.n_bin) return h->fail(-1, "canvas bin out of range");
-  if (!h->rel_logp) {
-    int rc = h->dalloc(&h->rel_logp, (size_t)h->chunk * h->C * h->S, false);
+  for (int l = 0; l < h->n_lanes; ++l) {
+    if (h->ws[l].rel_logp) continue;
+    float* buf = nullptr;
+    int rc = h->dalloc(&buf, (size_t)h->chunk * h->C * h->S, false);
     if (rc) return rc;
+    h->ws[l].rel_logp = buf;
+    if (l == h->cur_lane) h->rel_logp = buf;
   }
   return 0;
 }
@@ -1149,13 +1214,17 @@ extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_
   return 0;
 }
 
+// The T-step loop of the chunks of ONE lane (lane < 0: every chunk, in order, through lane 0's workspace).
 static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation* rel, const int32_t* t_model,
                          const int32_t* t_post, int n_steps, const ldm_sampler* s, int B, int32_t* d_inter,
-                         hipStream_t st) {
+                         int lane, hipStream_t st) {
   // state lives in tok_a / tok_b (ping-pong); chunk-major order keeps one chunk's activations and the
   // weights resident in L2 / Infinity Cache for all T steps before moving to the next chunk
   const size_t S = h->S;
-  for (int off = 0; off < B; off += h->chunk) {
+  const int first = lane < 0 ? 0 : lane * h->chunk;
+  const int stride = lane < 0 ? h->chunk : h->n_lanes * h->chunk;
+  h->activate(lane < 0 ? 0 : lane);
+  for (int off = first; off < B; off += stride) {
     const int Bc = std::min(h->chunk, B - off);
     ldm_cond cc{};
     if (cond) {
@@ -1283,37 +1352,57 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
     GraphEntry* ge = nullptr;
     for (auto& g : h->graphs)
       if (g.key == key) ge = &g;
+    // lanes that actually own a chunk of this call
+    const int n_chunks = (B + h->chunk - 1) / h->chunk;
+    const int lanes = std::min(h->n_lanes, n_chunks);
     if (!ge) {
       if (h->graphs.size() >= 8) {  // small LRU-less cache: drop the oldest
-        if (h->graphs[0].exec) hipGraphExecDestroy(h->graphs[0].exec);
-        if (h->graphs[0].graph) hipGraphDestroy(h->graphs[0].graph);
+        h->graphs[0].destroy();
         h->graphs.erase(h->graphs.begin());
       }
-      // capture on a private stream so the caller's stream state is untouched
-      hipStream_t cap = nullptr;
-      HIP_OK(h, hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-      HIP_OK(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-      rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, inter_dst, cap);
-      hipGraph_t graph = nullptr;
-      hipError_t e = hipStreamEndCapture(cap, &graph);
-      hipStreamDestroy(cap);
-      if (rc) {
-        if (graph) hipGraphDestroy(graph);
-        return rc;
-      }
-      if (e != hipSuccess) return h->fail(-2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
       GraphEntry ne;
       ne.key = key;
-      ne.graph = graph;
-      HIP_OK(h, hipGraphInstantiate(&ne.exec, graph, nullptr, nullptr, 0));
+      for (int lane = 0; lane < lanes; ++lane) {
+        // capture on a private stream so the caller's stream state is untouched; one linear graph per lane
+        hipStream_t cap = nullptr;
+        HIP_OK(h, hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+        HIP_OK(h, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        if (lane > 0 && h->lane_offset_us > 0) launch_delay_us(lane * h->lane_offset_us, cap);
+        rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, inter_dst, lanes > 1 ? lane : -1, cap);
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(cap, &graph);
+        hipStreamDestroy(cap);
+        if (rc || e != hipSuccess) {
+          if (graph) hipGraphDestroy(graph);
+          ne.destroy();
+          if (rc) return rc;
+          return h->fail(-2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        ne.graph.push_back(graph);
+        if (e != hipSuccess) {
+          ne.destroy();
+          return h->fail(-2, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        }
+        ne.exec.push_back(exec);
+      }
       h->graphs.push_back(ne);
       ge = &h->graphs.back();
     }
-    HIP_OK(h, hipGraphLaunch(ge->exec, st));
+    // lane 0 replays on the caller's stream, the others on their own streams between a fork and a join event
+    if (ge->exec.size() > 1) HIP_OK(h, hipEventRecord(h->fork_ev, st));
+    for (size_t lane = 1; lane < ge->exec.size(); ++lane) {
+      HIP_OK(h, hipStreamWaitEvent(h->lane_stream[lane], h->fork_ev, 0));
+      HIP_OK(h, hipGraphLaunch(ge->exec[lane], h->lane_stream[lane]));
+      HIP_OK(h, hipEventRecord(h->lane_done[lane], h->lane_stream[lane]));
+    }
+    HIP_OK(h, hipGraphLaunch(ge->exec[0], st));
+    for (size_t lane = 1; lane < ge->exec.size(); ++lane) HIP_OK(h, hipStreamWaitEvent(st, h->lane_done[lane], 0));
     if (inter_dst)
       HIP_OK(h, hipMemcpyAsync(d_intermediates, inter_dst, (size_t)n_steps * B * h->S * 4, hipMemcpyDeviceToDevice, st));
   } else {
-    if ((rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, d_intermediates, st))) return rc;
+    if ((rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, d_intermediates, -1, st))) return rc;
   }
   HIP_OK(h, hipMemcpyAsync(d_tokens_inout, h->tok_a, nbytes, hipMemcpyDeviceToDevice, st));
   HIP_OK(h, hipEventRecord(h->loop_b, st));

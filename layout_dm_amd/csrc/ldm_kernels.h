@@ -162,6 +162,7 @@ void launch_posterior_sample(const PostArgs& p, hipStream_t st);
 void launch_set_rng(uint64_t* rng, uint64_t seed, uint64_t first_layout, hipStream_t st);
 
 // ---- small utilities ---------------------------------------------------------------------
+void launch_delay_us(int us, hipStream_t st);  // one wave spinning for `us` microseconds (lane phase offset)
 void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st);
 // AdaLN table: out[t][l][2D] = Linear(SiLU(Emb[t])) (transformer_utils.py:67-69,80)
 void launch_adaln_table(const float* emb /*[T,D]*/, const float* w /*[2D,D]*/, const float* b /*[2D]*/,

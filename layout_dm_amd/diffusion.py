@@ -58,11 +58,12 @@ class HipMaskAndReplaceDiffusion:
     def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
                  d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4,
                  num_timesteps: int = 100, precision: str = "exact", max_batch: int = 512, chunk: int = 0,
-                 device: Optional[int] = None, use_graph: bool = True, q_type: str = "constrained"):
+                 device: Optional[int] = None, use_graph: bool = True, q_type: str = "constrained", lanes: int = 0):
         # q_type: Q_TYPES of models/layoutdm.py:20-23 — "constrained" (constrained.py) or "vanilla" (vanilla.py)
         self.engine = Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
                              d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
-                             precision=precision, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type)
+                             precision=precision, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type,
+                             lanes=lanes)
         self.q_type = q_type
         self.num_timesteps = num_timesteps
         self.num_classes = self.engine.C

@@ -257,9 +257,16 @@ def relation_cases(spec, B=2, seed=7):
     return out
 
 
-def main():
+def main(out_dir=None, only=None):
+    """Writes every fixture into out_dir (default tests/golden).  tests/test_oracle_vs_reference.py regenerates them
+    into a temporary directory and compares with the committed files, so the pin is re-checked by CI wherever the
+    reference tree is present."""
+    global OUT
+    if out_dir is not None:
+        OUT = out_dir
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only is None and out_dir is None:
+        only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == "relation":
         np.savez_compressed(os.path.join(OUT, "rico25_relation.npz"), **relation_cases(SP.SPECS["rico25"]))
         return

@@ -34,15 +34,43 @@ def test_header_symbols_exported(lib_path):
     assert lib.ldm_abi_version() == binding.ABI_VERSION
 
 
-def test_binding_struct_layout_matches_header():
+def test_binding_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of every struct of include/ldm_hip.h as gcc lays them out == the ctypes mirrors in
+    layout_dm_amd/binding.py (the header is compiled, not transcribed)."""
+    import subprocess
+
     from layout_dm_amd import binding
 
-    assert ctypes.sizeof(binding.LdmConfig) == 14 * 4  # ABI 2: + q_type
-    assert ctypes.sizeof(binding.LdmSampler) == 16
-    assert ctypes.sizeof(binding.LdmCond) == 3 * 8 + 8  # three pointers + int32 (+pad)
-    # ldm_relation: 5 pointers, int32[4], float, 2 x int32 (+4 pad)
-    assert ctypes.sizeof(binding.LdmRelation) == 5 * 8 + 16 + 4 + 4 + 4 + 4
-    assert binding.LdmRelation.canvas_bins.offset == 40 and binding.LdmRelation.relation_lambda.offset == 56
+    structs = {"ldm_config": binding.LdmConfig, "ldm_sampler": binding.LdmSampler, "ldm_cond": binding.LdmCond,
+               "ldm_relation": binding.LdmRelation}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "ldm_hip.h")}"',
+             'int main(void) {', '  printf("abi %d\\n", LDM_ABI_VERSION);']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout.split("\n")
+    seen = 0
+    for line in filter(None, out):
+        parts = line.split()
+        if parts[0] == "abi":
+            assert int(parts[1]) == binding.ABI_VERSION
+            continue
+        cls = structs[parts[0]]
+        if parts[1] == "size":
+            assert ctypes.sizeof(cls) == int(parts[2]), line
+        else:
+            assert getattr(cls, parts[1]).offset == int(parts[2]), line
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
+    # every field of the header's structs is mirrored (a field added to the header only would shift nothing above)
+    hdr = open(os.path.join(ROOT, "include", "ldm_hip.h")).read()
+    assert hdr.count("int32_t lanes;") == 1 and len(binding.LdmConfig._fields_) == 15
 
 
 def test_no_gpu_fails_loudly(lib_path):
@@ -56,7 +84,7 @@ def test_no_gpu_fails_loudly(lib_path):
         binding.Engine(n_category=25)
     # and the C entry point itself refuses too
     lib = binding.load_library()
-    cfg = binding.LdmConfig(binding.ABI_VERSION, 25, 32, 25, 5, 464, 8, 1856, 4, 100, 0, 4, 0)
+    cfg = binding.LdmConfig(binding.ABI_VERSION, 25, 32, 25, 5, 464, 8, 1856, 4, 100, 0, 4, 0, 0, 0)
     h = ctypes.c_void_p()
     rc = lib.ldm_create(ctypes.byref(cfg), 0, ctypes.byref(h))
     assert rc != 0 and b"no HIP device" in lib.ldm_last_error(None)

@@ -1,0 +1,71 @@
+"""CPU, build container only (skipped where /root/reference is absent, e.g. on the GPU box): the committed golden
+fixtures are exactly what the REAL reference produces today, and the oracle restatement agrees with the live
+reference on fresh inputs.  This is the pin of oracle/restatement.py (the reference ships no tests or
+golden vectors of its own)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_harness as rh
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference tree not present")
+
+
+def test_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
+    """python -m oracle.make_golden into a scratch directory == tests/golden/*.npz, array for array."""
+    from oracle import make_golden
+
+    out = str(tmp_path / "golden")
+    make_golden.main(out_dir=out)
+    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(out) if f.endswith(".npz"))
+    for n in names:
+        a, b = np.load(os.path.join(golden_dir, n)), np.load(os.path.join(out, n))
+        assert sorted(a.keys()) == sorted(b.keys()), n
+        for k in a.keys():
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (n, k)
+    for n in (f for f in os.listdir(golden_dir) if f.endswith(".txt")):
+        assert open(os.path.join(golden_dir, n)).read() == open(os.path.join(out, n)).read(), n
+
+
+def test_restatement_matches_live_reference_on_fresh_states():
+    """Fresh random states (not the committed ones), both datasets: denoiser logits, x0, posterior, greedy step of the
+    oracle == the reference's own modules (transformer forward nn_lib.py:191-237, predict_start base.py:127-146,
+    q_posterior constrained.py:135-206, _sample_single_step base.py:205-291)."""
+    from oracle import restatement as R
+    from oracle import spec as SP
+    from oracle import synth
+
+    for ds in ("rico25", "publaynet"):
+        spec = SP.SPECS[ds]
+        m, _tok = rh.build_reference_model(ds, seed=0)
+        from trainer.models.categorical_diffusion.util import index_to_log_onehot
+
+        ssd = synth.synth_state_dict(spec, seed=7, perturb=True, prefix="")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+        W = R.as_torch_weights(synth.synth_state_dict(spec, seed=7, perturb=True))
+        g = torch.Generator().manual_seed(99)
+        for t in (97, 55, 12, 0):
+            tokens = torch.empty(3, spec.seq_len, dtype=torch.long)
+            for a in range(spec.n_attr):
+                ids = torch.as_tensor(spec.full_ids(a))
+                tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (3, spec.max_elem), generator=g)]
+            tokens[torch.rand(3, spec.seq_len, generator=g) < t / 99] = spec.mask_id
+            tt = torch.full((3,), t, dtype=torch.long)
+            with torch.no_grad():
+                ref_logits = m.transformer(tokens, timestep=tt)["logits"]
+                lz = index_to_log_onehot(tokens, spec.n_class)
+                ref_x0 = m.predict_start(lz, tt)
+                ref_post = m.q_posterior(ref_x0, lz, tt)
+                ref_next = m._sample_single_step(lz, tt, skip_step=0, sampling_cfg=rh.sampling_cfg("deterministic"),
+                                                 cond=None).argmax(1)
+            logits = R.denoiser_logits(W, spec, tokens, t)
+            assert ((logits - ref_logits).abs().max() / ref_logits.abs().max()).item() < 2e-5
+            x0 = R.predict_start_from_logits(ref_logits)
+            assert torch.equal(x0, ref_x0)
+            post = R.q_posterior(W, spec, ref_x0, tokens, t)
+            assert (post - ref_post).abs().max().item() == 0.0
+            nxt = R.single_step(W, spec, tokens, t, {"name": "deterministic"})
+            assert torch.equal(nxt, ref_next)
