@@ -341,7 +341,7 @@ def main():
                 + ("all-[MASK] start)" if a.cond == "unconditional" else
                    "cond=c sequences built as helpers/task.py:94-110, n~U{1..25} elements per layout)"),
         "config": {"workload": workload, "precision_mode": a.precision, "hipgraph": not a.no_graph,
-                   "chunk_layouts": min(eng.cfg.chunk or 512, B),
+                   "chunk_layouts": eng.chunk, "lanes": eng.lanes,
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
         "algorithmic_tflops": res["algorithmic_tflops"],
     }
@@ -386,8 +386,8 @@ def main():
         if sym:
             vals, note = measure_traffic(sym, a.dataset, a.precision)
             if vals:
-                rows_probe = 512 * spec.seq_len  # tools/pmc_probe.py launches M = 64000-row kernels
-                rows_launch = min(eng.cfg.chunk or 512, B) * spec.seq_len
+                rows_probe = 256 * spec.seq_len  # tools/pmc_probe.py: default chunk = 256 layouts per launch
+                rows_launch = eng.chunk * spec.seq_len
                 scale = rows_launch / rows_probe
                 out["roofline"]["traffic"] = int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 * scale)
                 out["roofline"]["traffic_detail"] = {

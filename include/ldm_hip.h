@@ -67,11 +67,11 @@ typedef struct {
   int32_t n_step;      /* T = 100 */
   int32_t precision;   /* LDM_PREC_* */
   int32_t max_batch;   /* largest B any call will use (workspace is sized for it) */
-  int32_t chunk;       /* layouts processed per pass through the network (0 = auto) so that the
+  int32_t chunk;       /* layouts processed per pass through the network (0 = auto = 256) so that the
                           activation working set stays inside the 256 MiB Infinity Cache */
   int32_t q_type;      /* LDM_Q_* (ABI 2) */
   int32_t lanes;       /* chunk pipelines run concurrently, each on its own stream / hipGraph, phase-shifted so that
-                          their HBM-bound phases do not coincide (0 or 1 = one; ABI 3) */
+                          their HBM-bound phases do not coincide (0 = auto = 2, 1 = one pipeline; ABI 3) */
 } ldm_config;
 
 /* sampling_cfg of the reference (helpers/sampling.py dataclasses) */
@@ -185,6 +185,8 @@ int ldm_profile_get(ldm_handle* h, int idx, const char** name, double* total_ms,
                     double* flops, double* bytes);
 int ldm_profile_reset(ldm_handle* h);
 int ldm_abi_version(void);
+/* layouts per chunk and number of concurrent lanes the handle was created with (after the 0 = auto defaults) */
+int ldm_get_layout(const ldm_handle* h, int* chunk, int* lanes);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = (
     "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
     "ldm_decode_layouts", "ldm_relation_update",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
-    "ldm_abi_version",
+    "ldm_abi_version", "ldm_get_layout",
 )
 
 
@@ -93,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.ldm_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ldm_profile_reset.argtypes = [vp]
+    lib.ldm_get_layout.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for name in EXPORTS:
         if name not in ("ldm_destroy", "ldm_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -148,6 +149,9 @@ class Engine:
             raise RuntimeError(f"ldm_create failed ({rc}): {self.lib.ldm_last_error(None).decode()}")
         self._h = h
         self._keep = {}  # tensors referenced by cached graphs must stay alive
+        ck, ln = C.c_int(), C.c_int()
+        self._check(self.lib.ldm_get_layout(self._h, C.byref(ck), C.byref(ln)), "ldm_get_layout")
+        self.chunk, self.lanes = int(ck.value), int(ln.value)
 
     def close(self):
         if getattr(self, "_h", None):

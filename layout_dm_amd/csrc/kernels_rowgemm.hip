@@ -242,6 +242,11 @@ template <int OFF>
 __device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+__device__ __forceinline__ float to_agpr(float v) {
+  float r;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+  return r;
+}
 template <int OFF>
 __device__ __forceinline__ void dsr128f(float4& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -347,6 +352,13 @@ struct FfnPipe {
 // V  : 0 = r01 prologue / epilogue (loads sunk to their uses: ~6 + 60 dependent memory round trips per block),
 //      1 = batched prologue (2 round trips), b2 in LDS, epilogue with the residual loaded 30 column groups at a time
 //          (2 round trips), rows >= M written into the padding of `out` (no exec-masked stores); N must be 464.
+//      2 = the residual row is read ONCE: the prologue loads x1 in the ACCUMULATOR layout (lane (row, hi) owns
+//          columns 8g + 4hi .. +3 of every 8-column group g), seeds the GEMM2 accumulators with x1 + b2 and builds
+//          the LN2-normalised fp16 fragments from the same registers — with W1's K axis packed in MFMA k-slot order
+//          (ldm_pack::kslot) a lane's accumulator-layout elements of groups 2ks, 2ks+1 ARE its B-operand fragment of
+//          k16-step ks.  The epilogue then has no loads at all: statistics + stores.  HBM traffic per block:
+//          1 x read + 1 x write of the 128 x 464 fp32 rows instead of 2 x read + 1 x write.  Requires ln.x
+//          (deferred normalisation), res == ln.x, and the k-slot W1 image.
 // img: per 32-wide hidden chunk c one 64-KiB LDS image (ldm_api.cpp pack_ffn_image):
 //   [0, 32 KiB)   W1 rows c*32 .. c*32+31, 1 KiB each, 16-B chunk L of row i at physical chunk L ^ (i & 15)
 //   [32, 62 KiB)  W2 (k-slot ordered K axis) columns c*32..+31 of output rows 0..479, 64 B each, chunk L of row n
@@ -381,14 +393,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     for (int a = 0; a < 4; ++a) dma_lin4(voff, g0 + a * 4096, lds0 + wave * 16384 + a * 4096);
   }
   for (int i = tid; i < n_chunks * 32; i += 256) sb1[i] = b1[i];
-  if constexpr (V == 1)
+  if constexpr (V >= 1)
     for (int i = tid; i < 512; i += 256) sb2[i] = i < N ? b2[i] : 0.f;
   f16x8 xf[KS];
   if (ln.x) {
     stage_ln_params(sp_in, ln, tid);
     __syncthreads();
     if constexpr (V == 1) load_xf_ln_batched<KS, 15>(xf, ln, m < M ? m : M - 1, hi, sp_in);
-    else load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
+    else if constexpr (V == 0) load_xf_ln<KS>(xf, ln, m < M ? m : M - 1, hi, sp_in);
   } else {
     const __half* hrow = H + (size_t)m * ldh + hi * 8;
 #pragma unroll
@@ -403,6 +415,47 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   for (int t = 0; t < NT2; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  if constexpr (V == 2) {
+    // one pass over the row in accumulator layout: acc = x1 + b2 (residual + bias seed), xf = fp16(LN2(x1))
+    constexpr int NGV = 58, GB = 30;  // 58 valid 8-column groups (N = 464); GB groups (= GB loads) per batch
+    const int mr = m < M ? m : M - 1;
+    const float2 st = ln.stats[mr];
+    const float* xr = ln.x + (size_t)mr * ln.ldx + hi * 4;
+    const float* mp = sp_in + hi * 4;
+    const float* bp = sb2 + hi * 4;
+#pragma unroll
+    for (int g0 = 0; g0 < NGV; g0 += GB) {
+      float4 raw[GB];
+#pragma unroll
+      for (int i = 0; i < GB; ++i)
+        if (g0 + i < NGV) raw[i] = *reinterpret_cast<const float4*>(xr + (g0 + i) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const int gg = g0 + i;
+        if (gg < NGV) {
+          const float4 a = raw[i];
+          const float4 ga = *reinterpret_cast<const float4*>(mp + gg * 8);
+          const float4 sa = *reinterpret_cast<const float4*>(mp + LN_DP + gg * 8);
+          const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
+          const int ks = gg >> 1, e0 = (gg & 1) * 4, t = gg >> 2, q0 = (gg & 3) * 4;
+          xf[ks][e0 + 0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
+          xf[ks][e0 + 1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
+          xf[ks][e0 + 2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
+          xf[ks][e0 + 3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
+          // (the seeds are parked in the AGPR half of the register file right away: with plain assignments hipcc keeps
+          //  them in arch VGPRs next to the fragments until the chunk loop and spills ~80 registers to scratch)
+          acc[t][q0 + 0] = to_agpr(a.x + bb.x);
+          acc[t][q0 + 1] = to_agpr(a.y + bb.y);
+          acc[t][q0 + 2] = to_agpr(a.z + bb.z);
+          acc[t][q0 + 3] = to_agpr(a.w + bb.w);
+          if (gg & 1) asm volatile("" : "+v"(xf[ks]));  // pin (see load_xf_ln_batched)
+          if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 
   unsigned relW1[8], relW2[2];
 #pragma unroll
@@ -476,7 +529,23 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     t_end = __builtin_amdgcn_s_memtime();
     t_real1 = __builtin_amdgcn_s_memrealtime();
   }
-  if constexpr (V == 1) {
+  if constexpr (V == 2) {
+    // the accumulators were seeded with x1 + b2: statistics + stores only (rows >= M land in the padding of `out`)
+    int me = m, hie = hi;
+    asm volatile("" : "+v"(me), "+v"(hie));
+    float* orow = out + (size_t)me * ldo + hie * 4;
+    constexpr int NGV = 58;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < NGV; ++gg) {
+      const int t = gg >> 2, rq = gg & 3;
+      const float v0 = acc[t][rq * 4 + 0], v1 = acc[t][rq * 4 + 1], v2 = acc[t][rq * 4 + 2], v3 = acc[t][rq * 4 + 3];
+      s1 += (v0 + v1) + (v2 + v3);
+      s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
+    }
+    if (stats_out) store_row_stats(stats_out, m, M, hi, s1, s2, N);
+  } else if constexpr (V == 1) {
     // residual + bias + row statistics, the residual row pieces fetched GB column groups at a time (the chunk
     // loop's 116 fragment registers are dead here).  The row / lane-half are re-materialised behind an opaque
     // asm so that hipcc cannot hoist the addresses (and then the loads) above the last chunk.
@@ -850,8 +919,16 @@ void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* exp, hipStream_t
   }
 }
 
-void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1, const float* b2, const float* res,
-                      float* out, int ldo, int M, int N, int F, const LnLoad* lnp, float2* stats_out, hipStream_t st) {
+// LDM_FFN_V (latched): 0 = r01 prologue / epilogue, 1 = batched, 2 = single read of the residual row (default)
+int ffn_fused_version() {
+  static const int v = getenv("LDM_FFN_V") ? atoi(getenv("LDM_FFN_V")) : 2;
+  return v;
+}
+
+// img: the W1 | W2 LDS image; for version 2 (img_ks != nullptr is then required) W1's K axis is k-slot ordered.
+void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img_ks, const float* b1, const float* b2,
+                      const float* res, float* out, int ldo, int M, int N, int F, const LnLoad* lnp, float2* stats_out,
+                      hipStream_t st) {
   LnLoad ln{};
   if (lnp) ln = *lnp;
   constexpr int NT2 = 15, KS = 29;  // N <= 480, K <= 464 (d_model 464 = 29 x 16)
@@ -859,10 +936,10 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
   static const int var = getenv("LDM_FFN_VAR") ? atoi(getenv("LDM_FFN_VAR")) : 0;
   static const int skew = getenv("LDM_FFN_SKEW") ? atoi(getenv("LDM_FFN_SKEW")) : 0;
-  // V = 1 (batched prologue / epilogue) needs N == 464 and `out` padded to a multiple of 128 rows (the engine's
-  // workspace is); LDM_FFN_V=0 selects the r01 prologue / epilogue for A/B timing
-  static const int ver_env = getenv("LDM_FFN_V") ? atoi(getenv("LDM_FFN_V")) : 1;
-  const int ver = (N == 464) ? ver_env : 0;
+  // versions 1 / 2 need N == 464 and `out` padded to a multiple of 128 rows (the engine's workspace is); version 2
+  // additionally the deferred-normalisation input with res == ln.x and the k-slot image
+  int ver = (N == 464) ? ffn_fused_version() : 0;
+  if (ver == 2 && !(ln.x && ln.x == res && img_ks && ln.ldx == ldo)) ver = 1;
   using K = void (*)(const __half*, int, const char*, const float*, const float*, const float*, float*, int, int, int,
                      int, LnLoad, float2*, int);
   K kern;
@@ -871,13 +948,15 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1
            : dbg == 2 ? ffn_fused2_k<KS, NT2, 2>
            : dbg == 3 ? ffn_fused2_k<KS, NT2, 3>
                       : ffn_fused2_k<KS, NT2, 0>;
-  else
+  else if (ver == 1)
     kern = dbg == 3   ? ffn_fused2_k<KS, NT2, 3, 8, 2, 1>
            : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 3, 1>
                       : ffn_fused2_k<KS, NT2, 0, 8, 2, 1>;
+  else
+    kern = dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2>;
   allow_big_lds((const void*)kern);
-  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)img, b1, b2, res, out, ldo,
-                     M, N, F / 32, ln, stats_out, skew);
+  hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)(ver == 2 ? img_ks : img), b1,
+                     b2, res, out, ldo, M, N, F / 32, ln, stats_out, skew);
 }
 
 // dev hook: read + reset the phase sums {blocks, cycles, realtime ticks, wait, gemm1, bubble, gemm2, -}

@@ -176,7 +176,7 @@ struct ldm_handle {
                        // (measured: row kernels win for QKV, out-proj, FFN; equal for the head)
   struct FastLayer {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
-    void *ffn_img = nullptr, *attn_img = nullptr;  // LDS-image ordered weight streams of the fused kernels
+    void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
@@ -278,6 +278,13 @@ struct ldm_handle {
 // ------------------------------------------------------------------------------------------ create
 extern "C" int ldm_abi_version(void) { return LDM_ABI_VERSION; }
 
+extern "C" int ldm_get_layout(const ldm_handle* h, int* chunk, int* lanes) {
+  if (!h) return -1;
+  if (chunk) *chunk = h->chunk;
+  if (lanes) *lanes = h->n_lanes;
+  return 0;
+}
+
 extern "C" const char* ldm_last_error(const ldm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
@@ -343,12 +350,14 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
   if (const char* ce = getenv("LDM_CHUNK")) chunk = atoi(ce);  // experiments
-  if (chunk <= 0) chunk = 512;
+  // auto: 256 layouts (M = 32 000 rows = 250 row blocks / 256 per-layout workgroups: one full round of the 256 CUs;
+  // P + Q of a chunk = 119 MB stay inside the 256 MiB Infinity Cache) and two lanes (see Workspace)
+  if (chunk <= 0) chunk = 256;
   chunk = std::min(chunk, cfg->max_batch);
   h->chunk = chunk;
 
   // lanes: LDM_LANES / LDM_LANE_OFFSET_US override cfg->lanes (experiments); more lanes than chunks make no sense
-  h->n_lanes = cfg->lanes > 0 ? cfg->lanes : 1;
+  h->n_lanes = cfg->lanes > 0 ? cfg->lanes : 2;
   if (const char* le = getenv("LDM_LANES")) h->n_lanes = std::max(1, atoi(le));
   h->n_lanes = std::min(h->n_lanes, std::max(1, (cfg->max_batch + chunk - 1) / chunk));
   h->lane_offset_us = 50;
@@ -607,6 +616,13 @@ static int build_fast_weights(ldm_handle* h) {
       const std::vector<uint16_t> h2 = download16(h, f.w2p, (size_t)round_up(D, 256) * Fq, &rc);
       if (rc) return rc;
       if ((rc = upload_image(h, pack_ffn_image(h1.data(), h2.data(), Fq, F, 480), &f.ffn_img))) return rc;
+      {  // W1 with the K axis in k-slot order (fused FFN version 2: fragments built from accumulator-layout loads)
+        __half* w1p = nullptr;
+        if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, kslot, &w1p))) return rc;
+        const std::vector<uint16_t> h1p = download16(h, w1p, (size_t)F * Dq, &rc);
+        if (rc) return rc;
+        if ((rc = upload_image(h, pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480), &f.ffn_img_ks))) return rc;
+      }
       const std::vector<uint16_t> hin = download16(h, f.w_in, (size_t)3 * HD * Dq, &rc);
       if (rc) return rc;
       const std::vector<uint16_t> hout = download16(h, f.w_out_ks, (size_t)round_up(D, 256) * HD, &rc);
@@ -755,7 +771,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     {  // x2 = x1 + FFN(LN2(x1)) -> P (+ stats_a)
       const LnLoad ln2{h->Q, h->stats_b, w.g2, w.be2, D, D, 0};
       ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 4 + D * 8));
-      launch_ffn_fused(nullptr, Dq, f.ffn_img, w.b1, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
+      launch_ffn_fused(nullptr, Dq, f.ffn_img, f.ffn_img_ks, w.b1, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
     }
   }
   {  // logits = LN_head(x)·Wh^T
@@ -819,7 +835,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     }
     if (h->row_impl & 4) {
       ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 2 + D * 8));
-      launch_ffn_fused(h->h16, Dq, f.ffn_img, w.b1, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
+      launch_ffn_fused(h->h16, Dq, f.ffn_img, nullptr, w.b1, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
     } else {
       gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
            gemm_flops(M, F, D), (double)M * (D * 2 + F * 2), false);
@@ -1497,7 +1513,7 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
       r.relu = 0;
       launch_rowgemm(r, 0, nullptr, 0);
     } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
-      launch_ffn_fused(A, Kp, W1b, bias1, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
+      launch_ffn_fused(A, Kp, W1b, nullptr, bias1, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
     } else {
       launch_gemm16(g, cfg, 2, 0);
     }

@@ -87,9 +87,12 @@ struct RowExtra {
   float2* stats_out;    // [M] row statistics of the fp32 output, or nullptr
 };
 void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* ex, hipStream_t st);
-// img: per-chunk LDS image of W1 | W2 (ldm_api.cpp pack_ffn_image)
-void launch_ffn_fused(const __half* H, int ldh, const void* img, const float* b1, const float* b2, const float* res,
-                      float* out, int ldo, int M, int N, int F, const LnLoad* ln, float2* stats_out, hipStream_t st);
+// img: per-chunk LDS image of W1 | W2 (ldm_pack.h pack_ffn_image); img_ks: the same with W1's K axis in MFMA k-slot
+// order (fused-FFN version 2: the residual row is read once, in accumulator layout), or nullptr
+void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img_ks, const float* b1, const float* b2,
+                      const float* res, float* out, int ldo, int M, int N, int F, const LnLoad* ln, float2* stats_out,
+                      hipStream_t st);
+int ffn_fused_version();
 // fused QKV projection + attention, one workgroup per layout (kernels_fusedattn.hip)
 void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
                           int H, int dh, hipStream_t st);

@@ -73,6 +73,26 @@ int main() {
       }
     }
   }
+  // ---------------- fused FFN version 2: W1 with the K axis in k-slot order.  The prologue loads the token row in
+  // ACCUMULATOR layout — lane (row, hi) holds columns 8g + 4hi + i of 8-column group g — and uses groups 2ks, 2ks+1
+  // as the B-operand fragment of k16-step ks: fragment element e <-> column 16ks + 8(e>>2) + 4hi + (e&3).  The A
+  // operand fetched for (ks, hi, e) must therefore be W1[hidden][that column].
+  {
+    std::vector<uint16_t> p_w1ks((size_t)2048 * Dq, 0);
+    for (int n = 0; n < F; ++n) for (int k = 0; k < D; ++k) p_w1ks[(size_t)n * Dq + ldm_pack::kslot(k)] = w1[(size_t)n * D + k];
+    const std::vector<uint16_t> ffn_ks = ldm_pack::pack_ffn_image(p_w1ks.data(), p_w2p.data(), Fq, F, 480);
+    for (int c = 0; c < F / 32; c += 7) {
+      const uint16_t* stage = ffn_ks.data() + (size_t)c * 32768;
+      for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 29; ++ks) {
+        const uint16_t* p = tile_read(stage, r, hi, ks);
+        for (int e = 0; e < 8; ++e) {
+          const int g = 2 * ks + (e >> 2), col = 8 * g + 4 * hi + (e & 3);  // accumulator-layout column of (group, hi, i)
+          CHECK(col == 16 * ks + f_slot(0, hi, e), "column identity");
+          CHECK(p[e] == w1[(size_t)(c * 32 + r) * D + col], "W1(k-slot) c=%d r=%d hi=%d ks=%d e=%d", c, r, hi, ks, e);
+        }
+      }
+    }
+  }
   // ---------------- attention block
   for (int h = 0; h < H; ++h) for (int j = 0; j < 6; ++j) {
     const uint16_t* stage = att.data() + (size_t)(h * 6 + j) * 16384;
