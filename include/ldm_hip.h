@@ -173,6 +173,23 @@ int ldm_relation_update(ldm_handle* h, float* d_logp_inout, const int32_t* d_con
 int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B, const double* d_centres, int box_f64,
                        void* d_bbox, int64_t* d_label, uint8_t* d_mask, void* stream);
 
+/* ---- FID feature extractor ------------------------------------------------
+ * FIDNetV3.extract_features (trainer/fid/model.py:123-164): {bbox, label, padding_mask} -> the 256-d feature of the
+ * [token] slot, which trainer/eval.py feeds to compute_generative_model_scores (helpers/metric.py:37-59: FID,
+ * precision / recall / density / coverage).  Own handle: the network has its own checkpoint (model.py:182-193).
+ * d_bbox (B,N,4) float32, d_label (B,N) int64, d_padding_mask (B,N) uint8 (1 = padded, i.e. ~mask), d_feat (B,256). */
+typedef struct ldm_fid ldm_fid;
+int ldm_fid_create(int num_label, int max_bbox, int d_model, int n_head, int n_layer, int device, ldm_fid** out);
+void ldm_fid_destroy(ldm_fid* h);
+const char* ldm_fid_last_error(const ldm_fid* h); /* h may be NULL: last create error */
+/* key = FIDNetV3 state_dict key (emb_label.weight, fc_bbox.*, enc_fc_in.*, enc_transformer.token,
+ * enc_transformer.core.layers.<i>.{self_attn.in_proj_*, self_attn.out_proj.*, linear1.*, linear2.*, norm1.*, norm2.*});
+ * decoder-half keys are accepted and ignored.  host float32, C-contiguous. */
+int ldm_fid_load_weight(ldm_fid* h, const char* key, const float* h_data, const int64_t* shape, int ndim);
+int ldm_fid_finalize(ldm_fid* h);
+int ldm_fid_features(ldm_fid* h, const float* d_bbox, const int64_t* d_label, const uint8_t* d_padding_mask, int B,
+                     int N, float* d_feat, void* stream);
+
 /* ---- introspection ------------------------------------------------------------------- */
 /* average device time (ms) of the most recent ldm_sample_loop, measured with HIP events on the
  * stream it ran on; blocks until that loop has finished. */

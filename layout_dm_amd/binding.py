@@ -28,6 +28,9 @@ EXPORTS = (
     "ldm_decode_layouts", "ldm_relation_update",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
     "ldm_abi_version", "ldm_get_layout",
+    # FID feature extractor (bound in layout_dm_amd/fid.py)
+    "ldm_fid_create", "ldm_fid_destroy", "ldm_fid_last_error", "ldm_fid_load_weight", "ldm_fid_finalize",
+    "ldm_fid_features",
 )
 
 
@@ -95,7 +98,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.ldm_profile_reset.argtypes = [vp]
     lib.ldm_get_layout.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     for name in EXPORTS:
-        if name not in ("ldm_destroy", "ldm_last_error"):
+        if name not in ("ldm_destroy", "ldm_last_error") and not name.startswith("ldm_fid_"):
             getattr(lib, name).restype = C.c_int
     if lib.ldm_abi_version() != ABI_VERSION:
         raise RuntimeError("libldm_hip.so ABI version mismatch — rebuild the extension")

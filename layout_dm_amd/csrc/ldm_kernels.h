@@ -164,6 +164,28 @@ enum ScheduleRow { kLogAt = 0, kLogBt, kLogCt, kLogCumAt, kLogCumBt, kLogCumCt, 
 void launch_posterior_sample(const PostArgs& p, hipStream_t st);
 void launch_set_rng(uint64_t* rng, uint64_t seed, uint64_t first_layout, hipStream_t st);
 
+// ---- FID feature extractor (kernels_fid.hip): FIDNetV3.extract_features, trainer/fid/model.py:123-164 -------------
+struct FidLayer {            // nn.TransformerEncoderLayer(256, 4, 128), weights TRANSPOSED to [K][N]
+  const float *in_wt, *in_b;     // [256][768], [768]
+  const float *out_wt, *out_b;   // [256][256], [256]
+  const float *w1t, *b1;         // [256][128], [128]
+  const float *w2t, *b2;         // [128][256], [256]
+  const float *n1_g, *n1_b, *n2_g, *n2_b;
+};
+struct FidArgs {
+  const float* bbox;             // (B, N, 4)
+  const int64_t* label;          // (B, N)
+  const uint8_t* padding_mask;   // (B, N) 1 = padded element
+  float* feat;                   // (B, 256)
+  const float *emb_label;        // [num_label][256]
+  const float *fc_bbox_wt, *fc_bbox_b;  // [4][256], [256]
+  const float *fc_in_wt, *fc_in_b;      // [512][256], [256]
+  const float* token;            // [256]
+  FidLayer layer[8];
+  int n_layer, N, num_label;
+};
+void launch_fid_features(const FidArgs& a, int B, hipStream_t st);
+
 // ---- small utilities ---------------------------------------------------------------------
 void launch_delay_us(int us, hipStream_t st);  // one wave spinning for `us` microseconds (lane phase offset)
 void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st);

@@ -257,6 +257,28 @@ def relation_cases(spec, B=2, seed=7):
     return out
 
 
+def fid_cases(num_label=25, B=6, N=25):
+    """FIDNetV3.extract_features (trainer/fid/model.py:147-152) of the REAL reference class on the synthetic
+    checkpoint of oracle/fid.py (decoder-half parameters keep their torch init: they do not enter the features)."""
+    rh.install_stubs()
+    from trainer.fid.model import FIDNetV3
+
+    from . import fid as OF
+
+    torch.manual_seed(0)
+    m = FIDNetV3(num_label=num_label, max_bbox=N)
+    sd = OF.synth_fid_state_dict(num_label, seed=0, max_bbox=N)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and all(
+        k.startswith(("dec_", "pos_token", "fc_out_", "enc_transformer.token_mask")) for k in missing.missing_keys)
+    m.eval()
+    bbox, label, pm = OF.synth_layouts(num_label, B, N, seed=0)
+    with torch.no_grad():
+        feat = m.extract_features(torch.from_numpy(bbox), torch.from_numpy(label), torch.from_numpy(pm))
+    return {"bbox": bbox, "label": label, "padding_mask": pm, "features": feat.numpy(),
+            "num_label": np.int32(num_label)}
+
+
 def main(out_dir=None, only=None):
     """Writes every fixture into out_dir (default tests/golden).  tests/test_oracle_vs_reference.py regenerates them
     into a temporary directory and compares with the committed files, so the pin is re-checked by CI wherever the
@@ -273,11 +295,15 @@ def main(out_dir=None, only=None):
     if only == "vanilla":
         np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(SP.SPECS["rico25"]))
         return
+    if only == "fid":
+        np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
+        return
     if only == "decode":
         for ds in ("rico25", "publaynet"):
             _, tok = rh.build_reference_model(ds, seed=0)
             np.savez_compressed(os.path.join(OUT, f"{ds}_decode.npz"), **decode_cases(tok, SP.SPECS[ds]))
         return
+    np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
     for ds in ("rico25", "publaynet"):
         spec = SP.SPECS[ds]
         m, tok = rh.build_reference_model(ds, seed=0)
