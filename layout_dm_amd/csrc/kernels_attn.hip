@@ -7,6 +7,9 @@
 // staged once in LDS (2 x 125 x 60 x 4 B = 60 KB), one query row per lane, two passes
 // (row max, then exp/accumulate) so the arithmetic has the same form as torch's softmax.
 // All lanes read the same K/V row => LDS broadcast reads (ds_read_b128, no bank conflicts).
+#include <cstdlib>
+#include <string>
+
 #include "ldm_kernels.h"
 
 namespace ldm {
@@ -110,6 +113,112 @@ __global__ __launch_bounds__(128) void attn_rows(const TIn* __restrict__ qkv, fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fp32 MFMA attention (exact / split modes): v_mfma_f32_32x32x2_f32 — fp32 operands, fp32 accumulate, i.e. the same
+// arithmetic class as the reference's fp32 bmm, at 64 FLOP/clk/SIMD instead of the VALU kernel above (which spent
+// 29 % of the exact-mode step at 6 % of the fp32 peak).  One workgroup per (layout, head), wave w owns queries
+// 32w..32w+31; S <= 128, dh <= 64: a single score tile per query block, no online softmax.
+//   S^T[key][query] = K Q^T : A = K fragment from LDS, B = Q fragment held in registers (29 k2-steps)
+//     -> lane (query, hi) holds keys (r&3) + 8(r>>2) + 4hi of every 32-key tile: softmax = in-lane + one lane^32 exchange
+//   O^T[d][query]   = V^T P^T: k2-step r of key tile kt pairs key (r&3)+8(r>>2) (lanes hi=0) with key +4 (lanes hi=1):
+//     accumulator register r of the score tile IS the B operand, A = V rows of those two keys from LDS.
+using f32x16a = __attribute__((ext_vector_type(16))) float;
+
+template <int DH2>  // DH2 = ceil(dh / 2) k2-steps of the score GEMM
+__global__ __launch_bounds__(256) void attn32_mfma_k(const float* __restrict__ qkv, float* __restrict__ out32,
+                                                    __half* __restrict__ out16, __half* __restrict__ out16lo, int S,
+                                                    int H, int dh, int D, int ld, int ldo32, int ldo16, float scale) {
+  constexpr int KP = 2 * DH2 + 1;   // K row stride (odd: conflict-free ds_read_b32 down a column)
+  constexpr int VP = 65;            // V row stride (d tiles 0..63)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                 // [128][KP]
+  float* Vs = smem + 128 * KP;      // [128][VP] (+ tail)
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t row0 = (size_t)b * S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hi = lane >> 5;
+  for (int idx = tid; idx < 128 * KP; idx += 256) {
+    const int key = idx / KP, d = idx % KP;
+    Ks[idx] = (key < S && d < dh) ? qkv[(row0 + key) * ld + D + h * dh + d] : 0.f;
+  }
+  for (int idx = tid; idx < 128 * VP + 64; idx += 256) {
+    const int key = idx / VP, d = idx % VP;
+    Vs[idx] = (key < S && d < dh) ? qkv[(row0 + key) * ld + 2 * D + h * dh + d] : 0.f;
+  }
+  // Q fragment: lane (query j, hi) holds Q[query][2ks + hi]
+  const int q = wave * 32 + j;
+  float qf[DH2];
+  {
+    const float* qr = qkv + (row0 + (q < S ? q : S - 1)) * ld + h * dh;
+#pragma unroll
+    for (int ks = 0; ks < DH2; ++ks) qf[ks] = (2 * ks + hi < dh) ? qr[2 * ks + hi] * scale : 0.f;
+  }
+  __syncthreads();
+  f32x16a sc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+    const float* kr = Ks + (kt * 32 + j) * KP + hi;
+#pragma unroll
+    for (int ks = 0; ks < DH2; ++ks) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[2 * ks], qf[ks], sc[kt], 0, 0, 0);
+  }
+  // softmax over the 128 keys of this lane's query (64 here, 64 in lane^32); keys >= S masked
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (key >= S) sc[kt][r] = -INFINITY;
+      mx = fmaxf(mx, sc[kt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(sc[kt][r] - mx);
+      sc[kt][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  f32x16a o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // this lane half's key of k2-step r
+      const float* vr = Vs + key * VP + j;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], sc[kt][r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], sc[kt][r], o[1], 0, 0, 0);
+    }
+  if (q < S) {
+    // lane (query, hi) holds d = 32dt + (r&3) + 8(r>>2) + 4hi
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (d < dh) {
+          const float v = o[dt][r] * inv;
+          if (out32) out32[(row0 + q) * ldo32 + h * dh + d] = v;
+          if (out16) {
+            const __half hv = __float2half_rn(v);
+            out16[(row0 + q) * ldo16 + h * dh + d] = hv;
+            if (out16lo) out16lo[(row0 + q) * ldo16 + h * dh + d] = __float2half_rn((v - __half2float(hv)) * kLoScaleA);
+          }
+        }
+      }
+  }
+}
+
 template <typename TIn>
 static void launch_rows(const AttnArgs& a, hipStream_t st) {
   const float scale = 1.0f / sqrtf((float)a.dh);
@@ -132,6 +241,16 @@ static void launch_rows(const AttnArgs& a, hipStream_t st) {
 }
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
+  // LDM_ATTN32=rows selects the r01 VALU kernel for A/B timing
+  static const bool use_rows = getenv("LDM_ATTN32") && std::string(getenv("LDM_ATTN32")) == "rows";
+  if (!a.in_f16 && !use_rows && a.S <= 128 && a.S > 96 && a.dh <= 58 && a.dh > 56) {
+    constexpr int DH2 = 29;
+    const size_t sh = (size_t)(128 * (2 * DH2 + 1) + 128 * 65 + 64) * sizeof(float);
+    allow_big_lds((const void*)attn32_mfma_k<DH2>);
+    hipLaunchKernelGGL((attn32_mfma_k<DH2>), dim3(a.B * a.H), dim3(256), sh, st, (const float*)a.qkv, a.out32, a.out16,
+                       a.out16lo, a.S, a.H, a.dh, a.D, a.ld, a.ldo32, a.ldo16, 1.0f / sqrtf((float)a.dh));
+    return;
+  }
   if (a.in_f16)
     launch_rows<__half>(a, st);
   else
