@@ -259,15 +259,21 @@ __device__ __forceinline__ void wait_lgkm() {
 // phase-timing instrumentation (LDM_FFN_DBG=3, dev hook only): sums over chunks of s_memtime deltas
 __device__ unsigned long long g_ffn_phase[12];
 
-template <int KS, int NT2, int PF, int DE = 2, bool TM = false>
+// CH2: GEMM1 runs as TWO interleaved accumulator chains (even / odd k-steps).  A single chain issues a dependent
+// v_mfma every step and runs at ~45 cycles per MFMA instead of 32 (profiles/r02_*phase*: gemm1 1350 vs gemm2 969
+// cycles per chunk for the same MFMA count, independent of where the weight DMA slots sit); two chains put 64
+// cycles between dependent issues.  The bias seeds chain A through the MFMA's C operand (the first MFMA of the
+// chunk), so the 16 bias registers die at once and chain B costs no registers over the single-chain form.
+template <int KS, int NT2, int PF, int DE = 2, bool TM = false, bool CH2 = false>
 struct FfnPipe {
   static constexpr int NIT = KS + 2 * NT2;
   unsigned long long tC, tD;
   f16x8 q[PF];
   unsigned aW1[8], aW2[2];  // per-lane LDS byte addresses inside the current stage
   const f16x8* xf;
-  f32x16 ha;  // (a two-chain even/odd split was measured slower: +32 accumulator registers push the
-              //  activation fragments into AGPRs and add ~250 v_accvgpr copies per chunk)
+  f32x16 ha;  // (r01: a compiler-scheduled two-chain split pushed the activation fragments into AGPRs and added
+              //  ~250 v_accvgpr copies per chunk; the CH2 form below is inline asm with arch-VGPR accumulators)
+  f32x16 hb;  // (CH2) second chain
   f32x16* acc;
   f16x8 pf[2];
   float4 bb[4];
@@ -306,7 +312,23 @@ struct FfnPipe {
       wait_lgkm<after>();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
-      if constexpr (IT == 0) {
+      if constexpr (CH2 && IT < KS) {
+        if constexpr (IT == 0) {
+          f32x16 bv;  // bias in accumulator layout = the C operand of chain A's first MFMA
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            bv[rq * 4 + 0] = bb[rq].x; bv[rq * 4 + 1] = bb[rq].y; bv[rq * 4 + 2] = bb[rq].z; bv[rq * 4 + 3] = bb[rq].w;
+          }
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(ha) : "v"(cur), "v"(xf[0]), "v"(bv));
+        } else if constexpr (IT == 1) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(hb) : "v"(cur), "v"(xf[1]));
+        } else if constexpr (IT % 2 == 0) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[IT]));
+        } else {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hb) : "v"(cur), "v"(xf[IT]));
+        }
+        if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");
+      } else if constexpr (IT == 0) {
         // GEMM1 accumulates in ARCH VGPRs through inline asm: with the builtin hipcc puts `ha` into the AGPR range
         // that the 15 GEMM2 accumulator tiles fill completely and then moves one tile out and back every chunk
         // (32 v_accvgpr copies) plus 16 v_accvgpr_read in the ReLU.  The dependent-MFMA spacing is the same as in
@@ -330,10 +352,17 @@ struct FfnPipe {
         // bias + ReLU + cast: accumulator reg <-> hidden f = (q&3) + 8*(q>>2) + 4*hi of this chunk
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-          pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + bb[rq].x, 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + bb[rq].y, 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + bb[rq].z, 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + bb[rq].w, 0.f);
+          if constexpr (CH2) {  // (the bias went in through chain A's C operand)
+            pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + hb[rq * 4 + 0], 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + hb[rq * 4 + 1], 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + hb[rq * 4 + 2], 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + hb[rq * 4 + 3], 0.f);
+          } else {
+            pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + bb[rq].x, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + bb[rq].y, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + bb[rq].z, 0.f);
+            pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + bb[rq].w, 0.f);
+          }
         }
       }
       step<IT + 1, DMA>();
@@ -364,7 +393,7 @@ struct FfnPipe {
 //   [32, 62 KiB)  W2 (k-slot ordered K axis) columns c*32..+31 of output rows 0..479, 64 B each, chunk L of row n
 //                 at physical chunk L ^ ((n >> 2) & 3);   last 2 KiB padding
 constexpr int FFN_STAGE = 65536;
-template <int KS, int NT2, int ABL, int PF = 8, int DE = 2, int V = 0>
+template <int KS, int NT2, int ABL, int PF = 8, int DE = 2, int V = 0, bool CH2 = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict__ H, int ldh, const char* __restrict__ img,
                                                       const float* __restrict__ b1, const float* __restrict__ b2,
                                                       const float* __restrict__ res, float* __restrict__ out, int ldo,
@@ -472,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     t_start = __builtin_amdgcn_s_memtime();
     t_real0 = __builtin_amdgcn_s_memrealtime();
   }
-  FfnPipe<KS, NT2, PF, DE, TM> P;
+  FfnPipe<KS, NT2, PF, DE, TM, CH2> P;
   P.xf = xf;
   P.acc = acc;
   P.voff = voff;
@@ -936,6 +965,7 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img
   static const int dbg = getenv("LDM_FFN_DBG") ? atoi(getenv("LDM_FFN_DBG")) : 0;
   static const int var = getenv("LDM_FFN_VAR") ? atoi(getenv("LDM_FFN_VAR")) : 0;
   static const int skew = getenv("LDM_FFN_SKEW") ? atoi(getenv("LDM_FFN_SKEW")) : 0;
+  static const int ch = getenv("LDM_FFN_CH") ? atoi(getenv("LDM_FFN_CH")) : 2;  // GEMM1 accumulator chains (version 2)
   // versions 1 / 2 need N == 464 and `out` padded to a multiple of 128 rows (the engine's workspace is); version 2
   // additionally the deferred-normalisation input with res == ln.x and the k-slot image
   int ver = (N == 464) ? ffn_fused_version() : 0;
@@ -953,7 +983,8 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img
            : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 3, 1>
                       : ffn_fused2_k<KS, NT2, 0, 8, 2, 1>;
   else
-    kern = dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2>;
+    kern = ch == 1 ? (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2>)
+                   : (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2, true> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2, true>);
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)(ver == 2 ? img_ks : img), b1,
                      b2, res, out, ldo, M, N, F / 32, ln, stats_out, skew);

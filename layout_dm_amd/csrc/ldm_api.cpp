@@ -45,8 +45,11 @@ struct DeviceGuard {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
+// (also drops a stale sticky error of an unrelated earlier runtime call — e.g. the caller's framework probing a host
+//  pointer with hipPointerGetAttributes — so that the hipGetLastError() after our launches reports only our own)
 #define ON_DEVICE(h)                                                                                    \
   DeviceGuard _dev_guard((h)->device);                                                                  \
+  (void)hipGetLastError();                                                                              \
   if (_dev_guard.err != hipSuccess) return (h)->fail(-2, "hipSetDevice(%d) failed: %s", (h)->device,    \
                                                      hipGetErrorString(_dev_guard.err))
 

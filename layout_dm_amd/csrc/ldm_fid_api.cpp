@@ -166,6 +166,9 @@ extern "C" int ldm_fid_features(ldm_fid* h, const float* d_bbox, const int64_t* 
   if (!d_bbox || !d_label || !d_padding_mask || !d_feat) return h->fail(-1, "null argument");
   Dev g(h->device);
   if (!g.ok) return h->fail(-2, "hipSetDevice failed");
+  // a stale error of an unrelated earlier runtime call (e.g. the caller's framework probing a host pointer with
+  // hipPointerGetAttributes) must not be reported as this launch's
+  (void)hipGetLastError();
   FidArgs a = h->args;
   a.bbox = d_bbox;
   a.label = d_label;
