@@ -48,16 +48,17 @@ __device__ __forceinline__ void wait_lgkm() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// KS reads/MFMAs of one weight tile; SWAP = false: acc = W·X^T, true: acc = X·W^T.
-// CH2: the k-steps alternate between TWO accumulator chains (acc: even steps, seeded with `cinit` — the tile's bias —
-// through the first MFMA's C operand; acc2: odd steps, seeded with 0); the epilogue adds them.  A single chain issues
-// a dependent MFMA every step and runs at ~45 cycles per MFMA instead of 32 (see FfnPipe in kernels_rowgemm.hip).
-template <int KS, int PF, bool CH2 = false>
+// 29 (KS) dependent-free reads/MFMAs of one weight tile; SWAP = false: acc = W·X^T, true: acc = X·W^T.
+// (r02 negative result: splitting the k-steps over TWO accumulator chains — 64 cycles between dependent MFMAs instead
+//  of 32 — did not speed the run up (FFN GEMM1: 1350 -> 1287 cycles per 29 MFMAs; here the compiler-managed second
+//  accumulator made it slower): the ~45 cycles per MFMA of these runs are not an accumulator-dependency stall.
+//  profiles/r02_call6_chains_ab.txt)
+template <int KS, int PF>
 struct TilePipe {
   f16x8 q[PF];
   unsigned aW[8];
   const f16x8* xf;
-  f32x16 acc, acc2, cinit;
+  f32x16 acc;
   const char* gnext;  // image of the next tile + wave*8 KiB (uniform)
   unsigned mnext;     // LDS byte address of the next stage + wave*8 KiB (uniform)
   unsigned voff;      // lane*16
@@ -76,11 +77,6 @@ struct TilePipe {
   __device__ __forceinline__ void dma_slot() {
     if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
   }
-  template <bool SWAP>
-  __device__ __forceinline__ f32x16 mm(const f16x8& w, const f16x8& x, const f32x16& c) {
-    return SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0)
-                : __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
-  }
   template <int IT, bool SWAP>
   __device__ __forceinline__ void step() {
     if constexpr (IT < KS) {
@@ -88,15 +84,13 @@ struct TilePipe {
       wait_lgkm<after>();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
-      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if constexpr (CH2) {
-        if constexpr (IT == 0) acc = mm<SWAP>(cur, xf[0], cinit);
-        else if constexpr (IT == 1) acc2 = mm<SWAP>(cur, xf[1], zero);
-        else if constexpr (IT % 2 == 0) acc = mm<SWAP>(cur, xf[IT], acc);
-        else acc2 = mm<SWAP>(cur, xf[IT], acc2);
+      if constexpr (IT == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[0], cur, zero, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[0], zero, 0, 0, 0);
       } else {
-        if constexpr (IT == 0) acc = mm<SWAP>(cur, xf[0], zero);
-        else acc = mm<SWAP>(cur, xf[IT], acc);
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[IT], cur, acc, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], acc, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT + PF < KS) read_item<IT + PF>();
@@ -117,8 +111,6 @@ struct TilePipe {
     prologue<0>();
     step<0, SWAP>();
   }
-  // tile result, bias included: CH2: chain A carried the bias; else the caller adds it
-  __device__ __forceinline__ float out(int i) const { return CH2 ? acc[i] + acc2[i] : acc[i]; }
 };
 
 template <int S8>
@@ -154,7 +146,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
                                                     int M, float scale_log2e, OutProj op, int skew) {
   constexpr bool REG_OF = FUSE_OUT && (V & 2);
-  constexpr bool CH2 = (V & 4) != 0;  // two accumulator chains per tile, bias through the C operand
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ring = smem;                       // 2 x 32 KiB weight tiles
@@ -253,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   f16x8 qf[4];
   const int ksw = (r >> 1) & 7;
   const unsigned a_bias = lds0 + (unsigned)(reinterpret_cast<char*>(sbias) - smem);
-  TilePipe<KS, PF, CH2> P;
+  TilePipe<KS, PF> P;
   P.xf = xf;
   P.voff = voff;
   f16x8 of[32];  // (REG_OF) B-operand fragments of the out-projection: head h -> of[4h .. 4h+3]
@@ -264,17 +255,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       for (int e = 0; e < 8; ++e) of[i][e] = (_Float16)0.f;
   }
   const int nskew = wave * skew;
-
-  float4 bnx[4];    // (CH2) bias of the NEXT K / Q tile, accumulator layout
-  float bvn = 0.f;  // (CH2) bias of the next V tile
-  if constexpr (CH2) {  // tile 0 (k0 of head 0)
-    const unsigned ab0 = a_bias + (unsigned)((H * 64 + hi * 4) * 4);
-    dsr128f<0>(bnx[0], ab0);
-    dsr128f<32>(bnx[1], ab0);
-    dsr128f<64>(bnx[2], ab0);
-    dsr128f<96>(bnx[3], ab0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
 
   unsigned long long t_pro = 0;
   if constexpr (TM) t_pro = LDM_TM_NOW();
@@ -297,57 +277,24 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     char* Vs = Ks + KV_BYTES;
 #pragma unroll
     for (int k = 0; k < 8; ++k) P.aW[k] = sbase + relW[k];
+    // this tile's bias: read ahead of the weight fragments (older in the LDS queue than everything the pipe
+    // waits on), so the epilogue does not start with an exposed LDS round trip
     const int t = j & 1;
     float4 bpre[4];
     float bvs = 0.f;
-    // bias of tile (hh, jj): K / Q tiles: 16 values in accumulator layout (4 x ds_read_b128), V tiles: one per lane
-    auto read_bias = [&](int hh, int jj, float4(&b4)[4], float& b1) {
-      const int tt = jj & 1;
-      if (jj == 2 || jj == 3) {
-        const unsigned ab = a_bias + (unsigned)(((2 * H + hh) * 64 + tt * 32 + r) * 4);
-        asm volatile("ds_read_b32 %0, %1" : "=v"(b1) : "v"(ab) : "memory");
-      } else {
-        const unsigned ab = a_bias + (unsigned)(((jj < 2 ? H + hh : hh) * 64 + tt * 32 + hi * 4) * 4);
-        dsr128f<0>(b4[0], ab);
-        dsr128f<32>(b4[1], ab);
-        dsr128f<64>(b4[2], ab);
-        dsr128f<96>(b4[3], ab);
-      }
-    };
-    if constexpr (CH2) {
-      // chain A is seeded with the bias (C operand of the tile's first MFMA): the bias registers were filled ONE
-      // TILE AGO (bnx / bvn, below), so no LDS round trip sits in front of the first MFMA
-      if (j == 2 || j == 3) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) P.cinit[i] = bvn;
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          P.cinit[g * 4 + 0] = bnx[g].x; P.cinit[g * 4 + 1] = bnx[g].y;
-          P.cinit[g * 4 + 2] = bnx[g].z; P.cinit[g * 4 + 3] = bnx[g].w;
-        }
-      }
-      asm volatile("" : "+v"(P.cinit));  // materialise before bnx / bvn are overwritten by the next tile's reads
-      if (ti + 1 < n_tiles) read_bias((ti + 1) / 6, (ti + 1) % 6, bnx, bvn);  // older than this tile's fragment reads
-      if (j == 2 || j == 3) P.template run<true>();
-      else P.template run<false>();
+    if (j == 2 || j == 3) {
+      const unsigned ab = a_bias + (unsigned)(((2 * H + h) * 64 + t * 32 + r) * 4);
+      asm volatile("ds_read_b32 %0, %1" : "=v"(bvs) : "v"(ab) : "memory");
+      P.template run<true>();
     } else {
-      // this tile's bias: read ahead of the weight fragments (older in the LDS queue than everything the pipe
-      // waits on), so the epilogue does not start with an exposed LDS round trip
-      read_bias(h, j, bpre, bvs);
-      if (j == 2 || j == 3) P.template run<true>();
-      else P.template run<false>();
+      const unsigned ab = a_bias + (unsigned)(((j < 2 ? H + h : h) * 64 + t * 32 + hi * 4) * 4);
+      dsr128f<0>(bpre[0], ab);
+      dsr128f<32>(bpre[1], ab);
+      dsr128f<64>(bpre[2], ab);
+      dsr128f<96>(bpre[3], ab);
+      P.template run<false>();
     }
-    f32x16 acc;  // tile result; (CH2) bias already inside: the epilogue adds zeros
-    if constexpr (CH2) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = P.acc[i] + P.acc2[i];
-      bvs = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) bpre[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      acc = P.acc;
-    }
+    const f32x16& acc = P.acc;
     if constexpr (TM) tC = LDM_TM_NOW();
     if (j < 2) {
       // K tile: lane (key = row_in, hi) holds d = 32t + 8*rq + 4*hi + i ; k-slot chunk c = 4t + 2s + hi
@@ -509,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     const float ra = rst.y, rb = -rst.x * rst.y;  // xn = x * ra + rb
     const float* rrow = ln.x + m * ln.ldx;
     float* crow = op.C32 + m * op.ldc + hi * 4;
-    TilePipe<32, PF, CH2> Q2;
+    TilePipe<32, PF> Q2;
     Q2.xf = of;
     Q2.voff = voff;
     const int n_out = (op.N + 31) / 32;
@@ -528,14 +475,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     const unsigned a_tb = lds0 + (unsigned)(reinterpret_cast<char*>(sbo) - smem) + hi * 16;
     const unsigned a_gm = lds0 + (unsigned)(reinterpret_cast<char*>(sp) - smem) + hi * 16;
     float s1 = 0.f, s2 = 0.f;
-    float4 tbn[4];  // (CH2) bias + shift of the NEXT out tile, accumulator layout
-    if constexpr (CH2) {
-      dsr128f<0>(tbn[0], a_tb);
-      dsr128f<32>(tbn[1], a_tb);
-      dsr128f<64>(tbn[2], a_tb);
-      dsr128f<96>(tbn[3], a_tb);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
     auto out_tile = [&](int ot, float4(&rc)[4], float4(&rn)[4]) {
       const int ti = n_tiles + ot;
       unsigned long long tA = 0, tB = 0, tC = 0;
@@ -555,27 +494,10 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       // bias+shift and multiplier of this tile's 16 columns: read ahead of the weight fragments (older in the
       // LDS queue than everything the pipe waits on)
       float4 tbv[4], gmv[4];
-      if constexpr (CH2) {
-        // bias + AdaLN shift of this tile's columns seed chain A; they were read one tile ago (tbn), the next
-        // tile's are issued now (clamped for the last tile: never used)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          Q2.cinit[g * 4 + 0] = tbn[g].x; Q2.cinit[g * 4 + 1] = tbn[g].y;
-          Q2.cinit[g * 4 + 2] = tbn[g].z; Q2.cinit[g * 4 + 3] = tbn[g].w;
-          tbv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        asm volatile("" : "+v"(Q2.cinit));
-        const int on = ot + 1 < n_out ? ot + 1 : ot;
-        dsr128f<0>(tbn[0], a_tb + on * 128);
-        dsr128f<32>(tbn[1], a_tb + on * 128);
-        dsr128f<64>(tbn[2], a_tb + on * 128);
-        dsr128f<96>(tbn[3], a_tb + on * 128);
-      } else {
-        dsr128f<0>(tbv[0], a_tb + ot * 128);
-        dsr128f<32>(tbv[1], a_tb + ot * 128);
-        dsr128f<64>(tbv[2], a_tb + ot * 128);
-        dsr128f<96>(tbv[3], a_tb + ot * 128);
-      }
+      dsr128f<0>(tbv[0], a_tb + ot * 128);
+      dsr128f<32>(tbv[1], a_tb + ot * 128);
+      dsr128f<64>(tbv[2], a_tb + ot * 128);
+      dsr128f<96>(tbv[3], a_tb + ot * 128);
       dsr128f<0>(gmv[0], a_gm + ot * 128);
       dsr128f<32>(gmv[1], a_gm + ot * 128);
       dsr128f<64>(gmv[2], a_gm + ot * 128);
@@ -594,10 +516,10 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // x1 = att·Wo^T + (bo + shift) + xn * mult ; padded columns: 0 + 0 + xn * 0
-        const float v0 = fmaf(fmaf(rc[g].x, ra, rb), gmv[g].x, Q2.out(g * 4 + 0) + tbv[g].x);
-        const float v1 = fmaf(fmaf(rc[g].y, ra, rb), gmv[g].y, Q2.out(g * 4 + 1) + tbv[g].y);
-        const float v2 = fmaf(fmaf(rc[g].z, ra, rb), gmv[g].z, Q2.out(g * 4 + 2) + tbv[g].z);
-        const float v3 = fmaf(fmaf(rc[g].w, ra, rb), gmv[g].w, Q2.out(g * 4 + 3) + tbv[g].w);
+        const float v0 = fmaf(fmaf(rc[g].x, ra, rb), gmv[g].x, Q2.acc[g * 4 + 0] + tbv[g].x);
+        const float v1 = fmaf(fmaf(rc[g].y, ra, rb), gmv[g].y, Q2.acc[g * 4 + 1] + tbv[g].y);
+        const float v2 = fmaf(fmaf(rc[g].z, ra, rb), gmv[g].z, Q2.acc[g * 4 + 2] + tbv[g].z);
+        const float v3 = fmaf(fmaf(rc[g].w, ra, rb), gmv[g].w, Q2.acc[g * 4 + 3] + tbv[g].w);
         s1 += (v0 + v1) + (v2 + v3);
         s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
         // (N % 8 == 0: a column group is entirely inside or outside for both lane halves.)  Padding rows of the
@@ -659,7 +581,7 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
 }
 
 // same + out-projection (tiles n_tiles.. of the image).  LDM_ATTN_V: bit 0 batched prologue, bit 1 attention outputs
-// exchanged through registers, bit 2 two accumulator chains per weight tile (default 7; 0 / 1 / 3 for A/B timing).
+// exchanged through registers (default 3); LDM_ATTN_V=0 = the r01 kernel for A/B timing.
 void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
                             const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st) {
@@ -668,15 +590,15 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   const int lds = 2 * STAGE + 4 * KV_BYTES + 3 * H * 64 * 4 + 2 * LN_DP * 4 + 512 * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
   static const int skew = getenv("LDM_ATTN_SKEW") ? atoi(getenv("LDM_ATTN_SKEW")) : 0;
-  static const int ver_env = getenv("LDM_ATTN_V") ? atoi(getenv("LDM_ATTN_V")) : 7;
+  static const int ver_env = getenv("LDM_ATTN_V") ? atoi(getenv("LDM_ATTN_V")) : 3;
   const int ver = (H == 8) ? ver_env : (ver_env & 1);
   using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int);
   K kern;
-  switch (ver & 7) {
+  switch (ver & 3) {
     case 0: kern = tm ? qkv_attn_k<KS, true, true, 0> : qkv_attn_k<KS, true, false, 0>; break;
     case 1: kern = tm ? qkv_attn_k<KS, true, true, 1> : qkv_attn_k<KS, true, false, 1>; break;
-    case 3: kern = tm ? qkv_attn_k<KS, true, true, 3> : qkv_attn_k<KS, true, false, 3>; break;
-    default: kern = tm ? qkv_attn_k<KS, true, true, 7> : qkv_attn_k<KS, true, false, 7>; break;
+    case 2: kern = tm ? qkv_attn_k<KS, true, true, 2> : qkv_attn_k<KS, true, false, 2>; break;
+    default: kern = tm ? qkv_attn_k<KS, true, true, 3> : qkv_attn_k<KS, true, false, 3>; break;
   }
   allow_big_lds((const void*)kern);
   OutProj op{b_out, C32, stats_out, ldc, N};
