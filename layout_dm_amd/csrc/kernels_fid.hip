@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void fid_features_k(FidArgs a) {
   float* y = sc + FID_MAXS * 33;          // [32][256] out-projection / FFN output (pre-residual)
   float* ao = y + FID_MAXS * FID_D;       // [32][256] concatenated head outputs
   float* cat = y;                         // [32][512] embedding concat (y | ao, before the first layer)
-  __shared__ int s_keep[FID_MAXS];        // 1 = token may be attended to
+  // (no static __shared__ here: static + the 160 KiB dynamic maximum requested by allow_big_lds would exceed the CU's
+  //  LDS and make hipFuncSetAttribute fail)
+  int* s_keep = reinterpret_cast<int*>(ao + FID_MAXS * FID_D + 512);  // [32] 1 = token may be attended to
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int N = a.N, S = N + 1;

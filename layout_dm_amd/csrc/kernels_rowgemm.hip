@@ -264,7 +264,7 @@ __device__ unsigned long long g_ffn_phase[12];
 // cycles per chunk for the same MFMA count, independent of where the weight DMA slots sit); two chains put 64
 // cycles between dependent issues.  The bias seeds chain A through the MFMA's C operand (the first MFMA of the
 // chunk), so the 16 bias registers die at once and chain B costs no registers over the single-chain form.
-template <int KS, int NT2, int PF, int DE = 2, bool TM = false, bool CH2 = false>
+template <int KS, int NT2, int PF, int DE = 2, bool TM = false, bool CH2 = false, bool CONSTB = false>
 struct FfnPipe {
   static constexpr int NIT = KS + 2 * NT2;
   unsigned long long tC, tD;
@@ -321,11 +321,11 @@ struct FfnPipe {
           }
           asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(ha) : "v"(cur), "v"(xf[0]), "v"(bv));
         } else if constexpr (IT == 1) {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(hb) : "v"(cur), "v"(xf[1]));
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(hb) : "v"(cur), "v"(xf[CONSTB ? 0 : 1]));
         } else if constexpr (IT % 2 == 0) {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[IT]));
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[CONSTB ? 0 : IT]));
         } else {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hb) : "v"(cur), "v"(xf[IT]));
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hb) : "v"(cur), "v"(xf[CONSTB ? 0 : IT]));
         }
         if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");
       } else if constexpr (IT == 0) {
@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hi = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + r;
-  constexpr bool TM = ABL == 3;
+  // timing ablations (wrong numerics): 4 = phase timing WITHOUT the in-loop weight DMA, 5 = GEMM1 with a CONSTANT B
+  // operand (xf[0] in every step), 6 = both
+  constexpr bool TM = ABL >= 3 && ABL <= 6;
   unsigned long long t_entry = 0;
   if constexpr (TM) t_entry = __builtin_amdgcn_s_memtime();
 
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
     t_start = __builtin_amdgcn_s_memtime();
     t_real0 = __builtin_amdgcn_s_memrealtime();
   }
-  FfnPipe<KS, NT2, PF, DE, TM, CH2> P;
+  FfnPipe<KS, NT2, PF, DE, TM, CH2, (ABL == 5 || ABL == 6)> P;
   P.xf = xf;
   P.acc = acc;
   P.voff = voff;
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused2_k(const __half* __restrict_
   };
   // (a peeled DMA-free last chunk made hipcc spill MFMA operands in the peeled copy: the last chunk simply
   //  prefetches chunk 0 again into the idle stage — 1/58 extra L2 reads, drained below)
-  for (int c = 0; c < n_chunks; ++c) chunk(c, std::true_type{});
+  for (int c = 0; c < n_chunks; ++c) chunk(c, std::integral_constant<bool, ABL != 4 && ABL != 6>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t_end = 0, t_real1 = 0;
@@ -983,8 +985,11 @@ void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img
            : var == 3 ? ffn_fused2_k<KS, NT2, 0, 8, 3, 1>
                       : ffn_fused2_k<KS, NT2, 0, 8, 2, 1>;
   else
-    kern = ch == 1 ? (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2>)
-                   : (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2, true> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2, true>);
+    kern = dbg == 4 ? ffn_fused2_k<KS, NT2, 4, 8, 2, 2, true>
+           : dbg == 5 ? ffn_fused2_k<KS, NT2, 5, 8, 2, 2, true>
+           : dbg == 6 ? ffn_fused2_k<KS, NT2, 6, 8, 2, 2, true>
+           : ch == 1 ? (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2>)
+                     : (dbg == 3 ? ffn_fused2_k<KS, NT2, 3, 8, 2, 2, true> : ffn_fused2_k<KS, NT2, 0, 8, 2, 2, true>);
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, st, H, ldh, (const char*)(ver == 2 ? img_ks : img), b1,
                      b2, res, out, ldo, M, N, F / 32, ln, stats_out, skew);

@@ -23,9 +23,11 @@ inline void allow_big_lds(const void* kern) {
   std::lock_guard<std::mutex> lk(mu);
   if (!done.insert({dev, kern}).second) return;
   const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess)
+  if (e != hipSuccess) {
     fprintf(stderr, "libldm_hip: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on device %d: %s\n", dev,
             hipGetErrorString(e));
+    (void)hipGetLastError();  // the launch that follows reports its own status
+  }
 }
 
 constexpr float kLogEps = -69.07755278982137f;  // log(1e-30): categorical_diffusion/util.py:8
