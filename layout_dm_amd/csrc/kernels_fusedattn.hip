@@ -19,109 +19,12 @@
 
 #include "ldm_kernels.h"
 #include "ldm_dma.h"
+#include "ldm_pipes.h"
 
 namespace ldm {
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-typedef __attribute__((address_space(3))) char* lds_char_ptr;
-
-constexpr int RK = 512;
-constexpr int RKB = RK * 2;
-constexpr int STAGE = 32 * RKB;  // one 32-row weight tile
-constexpr int LN_DP = 512;
-constexpr int KV_BYTES = 128 * 128;  // Ks: 128 keys x 64 halfs ; Vs: 64 d x 128 key-slots (both 16 KiB)
-
-template <int OFF>
-__device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void dsr128f(float4& d, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// 29 (KS) dependent-free reads/MFMAs of one weight tile; SWAP = false: acc = W·X^T, true: acc = X·W^T.
-// (r02 negative result: splitting the k-steps over TWO accumulator chains — 64 cycles between dependent MFMAs instead
-//  of 32 — did not speed the run up (FFN GEMM1: 1350 -> 1287 cycles per 29 MFMAs; here the compiler-managed second
-//  accumulator made it slower): the ~45 cycles per MFMA of these runs are not an accumulator-dependency stall.
-//  profiles/r02_call6_chains_ab.txt)
-template <int KS, int PF>
-struct TilePipe {
-  f16x8 q[PF];
-  unsigned aW[8];
-  const f16x8* xf;
-  f32x16 acc;
-  const char* gnext;  // image of the next tile + wave*8 KiB (uniform)
-  unsigned mnext;     // LDS byte address of the next stage + wave*8 KiB (uniform)
-  unsigned voff;      // lane*16
-
-  template <int IT>
-  __device__ __forceinline__ void read_item() {
-    dsr128<256 * (IT >> 3)>(q[IT % PF], aW[IT & 7]);
-  }
-  // next tile's DMA (linear 32-KiB image per tile, 8 KiB per wave): 1 instruction per slot, M0 rewritten one
-  // step ahead of every 4th
-  template <int J>
-  __device__ __forceinline__ void dma_m0() {
-    if constexpr (J < 8 && (J & 3) == 0) dma_set_m0(mnext + (J >> 2) * 4096);
-  }
-  template <int J>
-  __device__ __forceinline__ void dma_slot() {
-    if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
-  }
-  template <int IT, bool SWAP>
-  __device__ __forceinline__ void step() {
-    if constexpr (IT < KS) {
-      constexpr int after = (KS - 1 - IT) < (PF - 1) ? (KS - 1 - IT) : (PF - 1);
-      wait_lgkm<after>();
-      __builtin_amdgcn_sched_barrier(0);
-      const f16x8 cur = q[IT % PF];
-      if constexpr (IT == 0) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[0], cur, zero, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[0], zero, 0, 0, 0);
-      } else {
-        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[IT], cur, acc, 0, 0, 0)
-                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, xf[IT], acc, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (IT + PF < KS) read_item<IT + PF>();
-      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
-      else dma_m0<IT / 2>();
-      step<IT + 1, SWAP>();
-    }
-  }
-  template <int IT>
-  __device__ __forceinline__ void prologue() {
-    if constexpr (IT < PF) {
-      read_item<IT>();
-      prologue<IT + 1>();
-    }
-  }
-  template <bool SWAP>
-  __device__ __forceinline__ void run() {
-    prologue<0>();
-    step<0, SWAP>();
-  }
-};
-
-template <int S8>
-__device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const float4& b1) {
-  f16x8 o;
-  o[0] = (_Float16)(a[S8 + 0] + b0.x); o[1] = (_Float16)(a[S8 + 1] + b0.y);
-  o[2] = (_Float16)(a[S8 + 2] + b0.z); o[3] = (_Float16)(a[S8 + 3] + b0.w);
-  o[4] = (_Float16)(a[S8 + 4] + b1.x); o[5] = (_Float16)(a[S8 + 5] + b1.y);
-  o[6] = (_Float16)(a[S8 + 6] + b1.z); o[7] = (_Float16)(a[S8 + 7] + b1.w);
-  return o;
-}
+constexpr int STAGE = TILE_STAGE;  // one 32-row weight tile
 
 }  // namespace
 
