@@ -180,13 +180,15 @@ struct ldm_handle {
   struct FastLayer {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
     void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
+    void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 2;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats
+  int fused_attn = 3;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
+                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -401,6 +403,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
+    if (h->fused_attn == 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
@@ -588,6 +591,7 @@ static int upload_image(ldm_handle* h, const std::vector<uint16_t>& img, void** 
 }
 // (index maps and image packers: ldm_pack.h — pure C++, unit-tested on the CPU by tests/cpu_pack_check.cpp)
 using ldm_pack::pack_attn_image;
+using ldm_pack::pack_attn_slab_image;
 using ldm_pack::pack_ffn_image;
 
 static int build_fast_weights(ldm_handle* h) {
@@ -631,6 +635,7 @@ static int build_fast_weights(ldm_handle* h) {
       const std::vector<uint16_t> hout = download16(h, f.w_out_ks, (size_t)round_up(D, 256) * HD, &rc);
       if (rc) return rc;
       if ((rc = upload_image(h, pack_attn_image(hin.data(), hout.data(), H, 15), &f.attn_img))) return rc;
+      if (H == 8 && (rc = upload_image(h, pack_attn_slab_image(hin.data(), hout.data(), H), &f.attn_slab_img))) return rc;
     }
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
@@ -736,6 +741,17 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
     const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
+    if (h->fused_attn == 3) {
+      // the whole layer in one launch, in place: P <- x2 = x1 + FFN(LN2(x1)), x1 = AdaLN(x) + MHA(AdaLN(x)); x1 only
+      // ever exists in the workgroup's registers
+      ldm_handle::Scope sc(h, st, "layer_fused",
+                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) +
+                               2 * gemm_flops(M, F, D),
+                           (double)M * D * 12);
+      launch_layer_fused(f.attn_slab_img, f.b_in, ada, w.b_out, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
+                         h->stats_a, D, Bc, h->S, h->H, h->dh, st);
+      continue;
+    }
     if (h->fused_attn == 2) {
       // whole attention block: x1 = AdaLN(x) + MHA(AdaLN(x)) -> Q (+ stats_b)
       ldm_handle::Scope sc(h, st, "qkv_attention_out",

@@ -102,6 +102,11 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
 void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
                             const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st);
+// one whole transformer layer per launch, in place on x / stats_io (kernels_fusedattn.hip, V = 11):
+// img = ldm_pack::pack_attn_slab_image, ffn_img = pack_ffn_image with W1's K axis in k-slot order
+void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
+                        const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
+                        float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,

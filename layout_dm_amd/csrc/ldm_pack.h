@@ -71,4 +71,29 @@ inline std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_
   return img;
 }
 
+// Attention image of the fused layer kernel (kernels_layer.hip): the 6H in_proj tiles as in pack_attn_image, then the
+// out-projection as 16 K-SLABS (one per 32-wide k chunk c = (head, d-half)): 480 output rows x 64 B, 16-B chunk L of
+// row n at physical chunk L ^ ((n >> 2) & 3) — the W2-slab format of the fused FFN, so the out-projection runs as
+// 30 independent-accumulator MFMAs per slab over 15 persistent output tiles — then one zero stage (last prefetch).
+inline std::vector<uint16_t> pack_attn_slab_image(const uint16_t* w_in, const uint16_t* w_out_ks, int H) {
+  const int n_slab = H * 2;
+  const int nt = H * 6 + n_slab + 1;
+  std::vector<uint16_t> img((size_t)nt * 16384, 0);
+  const uint16_t* rows[32];
+  for (int hh = 0; hh < H; ++hh)
+    for (int j = 0; j < 6; ++j) {
+      const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
+      const int row0 = (which * H + hh) * 64 + (j & 1) * 32;
+      for (int i = 0; i < 32; ++i) rows[i] = w_in + (size_t)(row0 + i) * 512;
+      put_tile_1k(img.data() + (size_t)(hh * 6 + j) * 16384, rows);
+    }
+  for (int c = 0; c < n_slab; ++c) {
+    uint16_t* t2 = img.data() + (size_t)(H * 6 + c) * 16384;
+    for (int n = 0; n < 480; ++n)
+      for (int L = 0; L < 4; ++L)
+        memcpy(t2 + n * 32 + ((L ^ ((n >> 2) & 3)) << 3), w_out_ks + (size_t)n * 512 + c * 32 + L * 8, 16);
+  }
+  return img;
+}
+
 }  // namespace ldm_pack

@@ -247,4 +247,59 @@ struct FfnStream {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// SlabPipe: one 32-wide k chunk of the out-projection in K-SLAB form (fused layer kernel): 2 x NT2 MFMAs on NT2
+// independent accumulator tiles — A = the slab's rows of output tile t (LDS, W2-slab format of ldm_pack.h),
+// B = the chunk's two register-resident attention-output fragments — with the next slab's 32-KiB DMA interleaved.
+template <int NT2, int PF>
+struct SlabPipe {
+  static constexpr int NIT = 2 * NT2;
+  f16x8 q[PF];
+  unsigned aS[2];
+  f32x16* acc;
+  const char* gnext;  // image of the next slab + wave*8 KiB (uniform)
+  unsigned mnext;     // LDS byte address of the next stage + wave*8 KiB (uniform)
+  unsigned voff;      // lane*16
+
+  template <int J>
+  __device__ __forceinline__ void dma_m0() {
+    if constexpr (J < 8 && (J & 3) == 0) dma_set_m0(mnext + (J >> 2) * 4096);
+  }
+  template <int J>
+  __device__ __forceinline__ void dma_slot() {
+    if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
+  }
+  template <int IT>
+  __device__ __forceinline__ void read_item() {
+    constexpr int sx = IT / NT2, t = IT % NT2;
+    dsr128<t * 2048>(q[IT % PF], aS[sx]);
+  }
+  template <int IT>
+  __device__ __forceinline__ void step(const f16x8& b0, const f16x8& b1) {
+    if constexpr (IT < NIT) {
+      constexpr int after = (NIT - 1 - IT) < (PF - 1) ? (NIT - 1 - IT) : (PF - 1);
+      wait_lgkm<after>();
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int sx = IT / NT2, t = IT % NT2;
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[IT % PF], sx ? b1 : b0, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT + PF < NIT) read_item<IT + PF>();
+      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
+      else dma_m0<IT / 2>();
+      step<IT + 1>(b0, b1);
+    }
+  }
+  template <int IT>
+  __device__ __forceinline__ void prologue() {
+    if constexpr (IT < PF) {
+      read_item<IT>();
+      prologue<IT + 1>();
+    }
+  }
+  __device__ __forceinline__ void run(const f16x8& b0, const f16x8& b1) {
+    prologue<0>();
+    step<0>(b0, b1);
+  }
+};
+
 }  // namespace ldm

@@ -119,6 +119,27 @@ int main() {
     }
   }
   for (size_t i = (size_t)63 * 16384; i < att.size(); ++i) CHECK(att[i] == 0, "padding tile not zero");
+  // ---------------- fused layer kernel: in_proj tiles + out-projection K-slabs
+  {
+    const std::vector<uint16_t> sl = ldm_pack::pack_attn_slab_image(p_in.data(), p_out_ks.data(), H);
+    CHECK(sl.size() == (size_t)(48 + 16 + 1) * 16384, "slab image size");
+    for (size_t i = 0; i < (size_t)48 * 16384; ++i) CHECK(sl[i] == att[i], "in_proj tiles differ from pack_attn_image");
+    for (int c = 0; c < 16; ++c) {  // k chunk c: head c/2, d-half c%2; k16-steps ks = 2c + sx
+      const uint16_t* stage = sl.data() + (size_t)(48 + c) * 16384;
+      const int h = c >> 1, dt = c & 1;
+      for (int t = 0; t < 15; ++t) for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int sx = 0; sx < 2; ++sx) {
+        const int byte = t * 2048 + r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);  // kernels_layer.hip slab read
+        const uint16_t* p = stage + byte / 2;
+        const int n = t * 32 + r;
+        for (int e = 0; e < 8; ++e) {
+          const int d = dt * 32 + f_slot(sx, hi, e);
+          const uint16_t want = (n < D && d < dh) ? w_out[(size_t)n * D + h * dh + d] : 0;
+          CHECK(p[e] == want, "Wout slab c=%d t=%d r=%d hi=%d sx=%d e=%d", c, t, r, hi, sx, e);
+        }
+      }
+    }
+    for (size_t i = (size_t)64 * 16384; i < sl.size(); ++i) CHECK(sl[i] == 0, "slab image padding stage not zero");
+  }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
   return 0;
