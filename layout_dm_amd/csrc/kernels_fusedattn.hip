@@ -451,6 +451,8 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         SP.run(of[2 * c], of[2 * c + 1]);
       }
     }
+    unsigned long long t_slab = 0, t_ln2 = 0, t_ffn = 0;
+    if constexpr (TM) t_slab = LDM_TM_NOW();
     // acc = x1 (rows of this layout).  Everybody is done with the attention ring / K,V buffers after this barrier:
     // the FFN ring (2 x 64 KiB at LDS 0) takes their place.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (TM) t_ln2 = LDM_TM_NOW();
     {
       // ---- FFN chunk loop: one continuous LDS-read / MFMA pipeline (ldm_pipes.h FfnStream)
       unsigned relW1[8], relW2[2];
@@ -534,6 +537,12 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TM) {
+      t_ffn = LDM_TM_NOW();
+      s_w2 = t_slab - t_qkv_end;  // residual seed + 16 K slabs
+      s_r2 = t_ln2 - t_slab;      // LN2 + FFN chunk 0 DMA
+      s_e2 = t_ffn - t_ln2;       // FFN chunk loop
     }
     {
       // ---- x2 = acc: row statistics + stores (only the rows of this layout: padding rows of the last wave belong to
@@ -735,7 +744,8 @@ void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, co
   constexpr int KS = 29;
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   const int lds = 2 * STAGE + 4 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
-  auto kern = qkv_attn_k<KS, true, false, 11>;
+  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
+  auto kern = tm ? qkv_attn_k<KS, true, true, 11> : qkv_attn_k<KS, true, false, 11>;
   allow_big_lds((const void*)kern);
   OutProj op{b_out, x, stats_io, ldx, N};
   FfnTail ft{(const char*)ffn_img, b1, b2, g2, be2, F / 32};
