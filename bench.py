@@ -170,7 +170,7 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
     return vals, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), KB per launch"
 
 
-KERNEL_SYMBOL = {"layer_fused": "qkv_attn_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
+KERNEL_SYMBOL = {"layers_fused": "qkv_attn_k", "layer_fused": "qkv_attn_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
                  "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
                  "attention": "attn_"}
 

@@ -16,6 +16,7 @@
 // Reference semantics: torch.nn.MultiheadAttention in/out of trainer/models/transformer_utils.py:140-142,
 // 197-204 with AdaLayerNorm (l.72-83) applied to the input.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ldm_kernels.h"
 #include "ldm_dma.h"
@@ -53,6 +54,8 @@ __device__ __forceinline__ int fresh_lane_id() {
   return l;
 }
 
+constexpr int kMultiLayers = 4;  // layers per launch of the multi-layer kernel (V bit 4)
+
 // phase-timing instrumentation (dev hook only, LDM_ATTN_TM=1): s_memtime sums over blocks
 __device__ unsigned long long g_attn_phase[16];
 #define LDM_TM_NOW() __builtin_amdgcn_s_memtime()
@@ -69,9 +72,16 @@ __device__ unsigned long long g_attn_phase[16];
 template <int KS, bool FUSE_OUT, bool TM = false, int V = 0>
 __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ img, const float* __restrict__ bias,
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
-                                                    int M, float scale_log2e, OutProj op, int skew, FfnTail ft) {
+                                                    int M, float scale_log2e, OutProj op, int skew, FfnTail ft,
+                                                    FusedLayerSet ls) {
   constexpr bool REG_OF = FUSE_OUT && (V & 2);
   constexpr bool LAYER = FUSE_OUT && (V & 8);
+  // V bit 4 (needs bit 3): ALL layers of the stack in this launch.  A layout's rows stay in its workgroup from the
+  // embedding output to the input of the head: at a layer boundary x2 sits in the accumulators; it is written to
+  // memory once (the next layer's residual seed re-reads it) and the next layer's AdaLN-normalised fp16 fragments
+  // are built from the same registers — no operand re-read, no kernel boundary.  The in_proj K axis is k-slot ordered.
+  constexpr bool MULTI = LAYER && (V & 16);
+  static_assert(!(V & 16) || (V & 8), "multi-layer needs the fused layer");
   static_assert(!LAYER || (V & 3) == 3, "fused layer needs the batched prologue and the register exchange");
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,14 +93,9 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   float* sb1 = sbo + 512;                  // (LAYER) linear1 bias [n_chunks*32]
   float* sp2 = sb1 + (LAYER ? ft.n_chunks * 32 : 0);  // (LAYER) norm2 gamma | beta (2 x LN_DP)
   float* sb2 = sp2 + 2 * LN_DP;            // (LAYER) linear2 bias [512], zero beyond N
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hi = lane >> 5;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int b = blockIdx.x;
-  const int row_in = wave * 32 + r;          // token index inside the layout (>= S: padding)
-  const bool valid = row_in < S;
-  const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
 
   unsigned long long t_start = 0, t_real0 = 0, s_wait = 0, s_run = 0, s_epi = 0, s_att = 0, s_w2 = 0, s_r2 = 0, s_e2 = 0;
   if constexpr (TM) {
@@ -98,29 +103,62 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     t_real0 = __builtin_amdgcn_s_memrealtime();
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  unsigned long long t_pro = 0, t_qkv_end = 0;  // (TM; with several layers: the last layer's)
+  f16x8 xf[KS];
+  // The layers are unrolled at compile time (generic lambda, always inlined): a run-time loop makes the fragment
+  // array loop-carried and hipcc then parks it in scratch.  MULTI handles exactly kMultiLayers layers per launch.
+  constexpr int n_layers = MULTI ? kMultiLayers : 1;
+  auto layer_body = [&](auto layer_c) __attribute__((always_inline)) {
+  constexpr int layer = decltype(layer_c)::value;
+  // lane coordinates, derived INSIDE the layer loop from a volatile read of the lane id (MULTI): everything computed
+  // from them is then iteration-local — hipcc otherwise hoists the address arithmetic of every phase out of the loop
+  // and keeps it alive across the phases that need every register
+  const int lane = MULTI ? fresh_lane_id() : (tid0 & 63);  // (MULTI: a fresh value per layer keeps hipcc from sharing
+                                                           //  address arithmetic across the layers' phases)
+  const int tid = wave * 64 + lane;
+  const int r = lane & 31, hi = lane >> 5;
+  const int row_in = wave * 32 + r;          // token index inside the layout (>= S: padding)
+  const bool valid = row_in < S;
+  const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
   const unsigned voff = lane * 16;
+  // per-layer operands: kernel arguments (single layer) or the layer table (MULTI)
+  const char* img_l = MULTI ? (const char*)ls.w[layer].img : img;
+  const float* bias_l = MULTI ? ls.w[layer].bias_in : bias;
+  const float* p0_l = MULTI ? ls.w[layer].ada_scale : ln.p0;
+  const float* p1_l = MULTI ? ls.w[layer].ada_shift : ln.p1;
+  const float* bo_l = MULTI ? ls.w[layer].b_out : op.bias;
+  FfnTail ft_l = ft;
+  if constexpr (MULTI) {
+    ft_l.img = (const char*)ls.w[layer].ffn_img;
+    ft_l.b1 = ls.w[layer].b1; ft_l.b2 = ls.w[layer].b2; ft_l.g2 = ls.w[layer].g2; ft_l.be2 = ls.w[layer].be2;
+  }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) dma_lin4(voff, img + wave * 8192 + a * 4096, lds0 + wave * 8192 + a * 4096);  // tile 0
-  for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias[i];
+  for (int a = 0; a < 2; ++a) dma_lin4(voff, img_l + wave * 8192 + a * 4096, lds0 + wave * 8192 + a * 4096);  // tile 0
+  for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias_l[i];
   // sbo = out-proj bias + AdaLN shift (the residual AdaLN(x) is recomputed in the out-proj epilogue); both
   // tables are zero beyond N / D so that padded output columns come out as exact zeros without masks
   if (FUSE_OUT)
-    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? op.bias[i] + ln.p1[i] : 0.f;
-  for (int i = tid; i < LN_DP; i += 256) {
-    sp[i] = i < ln.D ? (ln.ada ? 1.0f + ln.p0[i] : ln.p0[i]) : 0.f;
-    sp[LN_DP + i] = i < ln.D ? ln.p1[i] : 0.f;
+    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? bo_l[i] + p1_l[i] : 0.f;
+  if (!MULTI || layer == 0) {  // (MULTI: the next layer's table is staged at the end of the previous iteration)
+    for (int i = tid; i < LN_DP; i += 256) {
+      sp[i] = i < ln.D ? (ln.ada ? 1.0f + p0_l[i] : p0_l[i]) : 0.f;
+      sp[LN_DP + i] = i < ln.D ? p1_l[i] : 0.f;
+    }
   }
   if constexpr (LAYER) {
-    for (int i = tid; i < ft.n_chunks * 32; i += 256) sb1[i] = ft.b1[i];
+    for (int i = tid; i < ft_l.n_chunks * 32; i += 256) sb1[i] = ft_l.b1[i];
     for (int i = tid; i < LN_DP; i += 256) {
-      sp2[i] = i < op.N ? ft.g2[i] : 0.f;
-      sp2[LN_DP + i] = i < op.N ? ft.be2[i] : 0.f;
-      sb2[i] = i < op.N ? ft.b2[i] : 0.f;
+      sp2[i] = i < op.N ? ft_l.g2[i] : 0.f;
+      sp2[LN_DP + i] = i < op.N ? ft_l.be2[i] : 0.f;
+      sb2[i] = i < op.N ? ft_l.b2[i] : 0.f;
     }
   }
   __syncthreads();
-  f16x8 xf[KS];
-  if constexpr (V & 1) {
+  if constexpr (MULTI) {
+    if constexpr (layer == 0) {
+      load_xf_ln_acc<KS, 58, 16>(xf, ln, m, hi, sp);
+    }
+  } else if constexpr (V & 1) {
     load_xf_ln_batched<KS, 8>(xf, ln, (int)m, hi, sp);
   } else {
     // AdaLN-on-load in groups of G k-steps, raw row loads double buffered one group ahead.  The (always zero)
@@ -194,7 +232,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   }
   const int nskew = wave * skew;
 
-  unsigned long long t_pro = 0;
   if constexpr (TM) t_pro = LDM_TM_NOW();
   for (int ti = 0; ti < n_tiles; ++ti) {
     const int h = ti / 6, j = ti % 6;
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       tB = LDM_TM_NOW();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    P.gnext = img + (size_t)(ti + 1) * STAGE + wave * 8192;  // (tile n_tiles = first out-proj tile)
+    P.gnext = img_l + (size_t)(ti + 1) * STAGE + wave * 8192;  // (tile n_tiles = first out-proj tile)
     P.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
     const unsigned sbase = lds0 + (ti & 1) * STAGE;
     char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
@@ -377,7 +414,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     }
     if constexpr (TM) s_att += LDM_TM_NOW() - tD;
   }
-  unsigned long long t_qkv_end = 0;
   if constexpr (TM) t_qkv_end = LDM_TM_NOW();
   if constexpr (LAYER) {
     // ================================================================== fused layer: out-projection (K slabs) -> FFN
@@ -399,7 +435,8 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       // residual seed in accumulator layout: AdaLN(x)[row][cols] + (b_out + shift)[cols]; lane (row, hi) owns columns
       // 8g + 4hi .. +3 of every 8-column group g
       constexpr int GB = 20;
-      const float2 rst = ln.stats[m1];
+      if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // x rows written by this workgroup
+      const float2 rst = ln.stats[m1];  // (MULTI, layer > 0: written by this workgroup's previous epilogue)
       const float ra = rst.y, rb = -rst.x * rst.y;  // xn = x * ra + rb
       const float* rrow = ln.x + m1 * ln.ldx + hi1 * 4;
       const float* gmp = sp + hi1 * 4;
@@ -443,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        SP.gnext = img + (size_t)(ti + 1) * STAGE + wave * 8192;  // (stage n_tiles + 16 is zero padding)
+        SP.gnext = img_l + (size_t)(ti + 1) * STAGE + wave * 8192;  // (stage n_tiles + 16 is zero padding)
         SP.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
         const unsigned sbase = lds0 + (ti & 1) * STAGE;
         SP.aS[0] = sbase + relS0;
@@ -459,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {  // FFN chunk 0 -> stage 0 (this wave's 16 KiB); lands while LN2 runs
-      const char* g0 = ft.img + wave * 16384;
+      const char* g0 = ft_l.img + wave * 16384;
 #pragma unroll
       for (int a = 0; a < 4; ++a) dma_lin4(voff, g0 + a * 4096, lds0 + wave * 16384 + a * 4096);
     }
@@ -529,10 +566,10 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       F.ab_next = relB;
       F.read_bias();
       F.template prologue<0>();
-      for (int c = 0; c < ft.n_chunks; ++c) {
-        F.gnext = ft.img + (size_t)(c + 1 == ft.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+      for (int c = 0; c < ft_l.n_chunks; ++c) {
+        F.gnext = ft_l.img + (size_t)(c + 1 == ft_l.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
         F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
-        F.ab_next = relB + (c + 1 == ft.n_chunks ? 0 : c + 1) * 128;
+        F.ab_next = relB + (c + 1 == ft_l.n_chunks ? 0 : c + 1) * 128;
         F.template step<0, true>();
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -564,11 +601,37 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
-      if (valid3 && hie == 0 && op.stats_out) {
-        constexpr float kInvN = 1.0f / 464.0f;
-        const float mean = s1 * kInvN;
-        const float var = fmaxf(s2 * kInvN - mean * mean, 0.f);
-        op.stats_out[me] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+      constexpr float kInvN3 = 1.0f / 464.0f;
+      const float mean3 = s1 * kInvN3;
+      const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
+      if (valid3 && hie == 0 && op.stats_out) op.stats_out[me] = make_float2(mean3, rstd3);
+      if constexpr (MULTI) {
+        if constexpr (layer + 1 < n_layers) {
+          // next layer: its AdaLN table replaces this layer's (dead since the residual seed), then the fragments of
+          // the next QKV phase straight from the accumulators (k-slot order: groups 2ks, 2ks+1 ARE fragment ks)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          const float* np0 = ls.w[layer + 1].ada_scale;
+          const float* np1 = ls.w[layer + 1].ada_shift;
+          for (int i = tid; i < LN_DP; i += 256) {
+            sp[i] = i < ln.D ? 1.0f + np0[i] : 0.f;
+            sp[LN_DP + i] = i < ln.D ? np1[i] : 0.f;
+          }
+          __syncthreads();
+          const float* mp = sp + hie * 4;
+#pragma unroll
+          for (int gg = 0; gg < NGV; ++gg) {
+            const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(mp + gg * 8);
+            const float4 sa = *reinterpret_cast<const float4*>(mp + LN_DP + gg * 8);
+            xf[ks][e0 + 0] = (_Float16)fmaf((acc[t][q0 + 0] - mean3) * rstd3, ga.x, sa.x);
+            xf[ks][e0 + 1] = (_Float16)fmaf((acc[t][q0 + 1] - mean3) * rstd3, ga.y, sa.y);
+            xf[ks][e0 + 2] = (_Float16)fmaf((acc[t][q0 + 2] - mean3) * rstd3, ga.z, sa.z);
+            xf[ks][e0 + 3] = (_Float16)fmaf((acc[t][q0 + 3] - mean3) * rstd3, ga.w, sa.w);
+            if (gg & 1) asm volatile("" : "+v"(xf[ks]));
+            if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
+          // every wave is past its FFN LDS reads (barrier above): the next iteration may refill the ring / tables
+        }
       }
     }
   } else if constexpr (FUSE_OUT) {
@@ -677,11 +740,18 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       op.stats_out[m] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
     }
   }
+  };  // layer_body
+  layer_body(std::integral_constant<int, 0>{});
+  if constexpr (MULTI) {
+    layer_body(std::integral_constant<int, 1>{});
+    layer_body(std::integral_constant<int, 2>{});
+    layer_body(std::integral_constant<int, 3>{});
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (padding) tile prefetch must land before the LDS is released
   if constexpr (TM) {
     const unsigned long long t_end = LDM_TM_NOW();
     const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
+    if (tid0 == 0) {
       atomicAdd(&g_attn_phase[0], 1ull);
       atomicAdd(&g_attn_phase[1], t_end - t_start);
       atomicAdd(&g_attn_phase[2], t_real1 - t_real0);
@@ -708,7 +778,7 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
   allow_big_lds((const void*)kern);
   OutProj op{};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op, 0,
-                     FfnTail{});
+                     FfnTail{}, FusedLayerSet{});
 }
 
 // same + out-projection (tiles n_tiles.. of the image).  LDM_ATTN_V: bit 0 batched prologue, bit 1 attention outputs
@@ -723,7 +793,8 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   static const int skew = getenv("LDM_ATTN_SKEW") ? atoi(getenv("LDM_ATTN_SKEW")) : 0;
   static const int ver_env = getenv("LDM_ATTN_V") ? atoi(getenv("LDM_ATTN_V")) : 3;
   const int ver = (H == 8) ? ver_env : (ver_env & 1);
-  using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int, FfnTail);
+  using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int, FfnTail,
+                     FusedLayerSet);
   K kern;
   switch (ver & 3) {
     case 0: kern = tm ? qkv_attn_k<KS, true, true, 0> : qkv_attn_k<KS, true, false, 0>; break;
@@ -733,7 +804,7 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   allow_big_lds((const void*)kern);
   OutProj op{b_out, C32, stats_out, ldc, N};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op,
-                     skew, FfnTail{});
+                     skew, FfnTail{}, FusedLayerSet{});
 }
 
 // One transformer layer per launch (V = 11): x <- x2 in place.  img: pack_attn_slab_image, ffn_img: pack_ffn_image with
@@ -750,7 +821,24 @@ void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, co
   OutProj op{b_out, x, stats_io, ldx, N};
   FfnTail ft{(const char*)ffn_img, b1, b2, g2, be2, F / 32};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, (__half*)nullptr, 0, S, H, B * S,
-                     scale_log2e, op, 0, ft);
+                     scale_log2e, op, 0, ft, FusedLayerSet{});
+}
+
+// the whole stack in one launch (V = 27).  ls: per-layer weights (k-slot in_proj images); x / stats_io: the embedding
+// output and its row statistics on entry, the last layer's output and statistics on exit.
+void launch_layers_fused(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
+                         int dh, hipStream_t st) {
+  constexpr int KS = 29;
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  const int lds = 2 * STAGE + 4 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
+  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
+  auto kern = tm ? qkv_attn_k<KS, true, true, 27> : qkv_attn_k<KS, true, false, 27>;
+  allow_big_lds((const void*)kern);
+  LnLoad ln{x, stats_io, nullptr, nullptr, ldx, N, 1};
+  OutProj op{nullptr, x, stats_io, ldx, N};
+  FfnTail ft{nullptr, nullptr, nullptr, nullptr, nullptr, F / 32};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)nullptr, (const float*)nullptr, ln, (__half*)nullptr, 0,
+                     S, H, B * S, scale_log2e, op, 0, ft, ls);
 }
 
 void attn_phase_read(unsigned long long* out16) {

@@ -181,14 +181,16 @@ struct ldm_handle {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
     void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
     void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
+    void* attn_slab_img_ks = nullptr;  // same with the in_proj K axis in k-slot order (multi-layer kernel)
     float* b_in = nullptr;
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 3;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
-                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P
+  int fused_attn = 4;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
+                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
+                       // 4: ALL layers in one launch per step (4-layer stacks)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -403,7 +405,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
-    if (h->fused_attn == 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
+    if (h->fused_attn >= 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
+    if (h->fused_attn == 4 && h->L != 4) h->fused_attn = 3;  // the multi-layer kernel is unrolled for 4 layers
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
@@ -636,6 +639,13 @@ static int build_fast_weights(ldm_handle* h) {
       if (rc) return rc;
       if ((rc = upload_image(h, pack_attn_image(hin.data(), hout.data(), H, 15), &f.attn_img))) return rc;
       if (H == 8 && (rc = upload_image(h, pack_attn_slab_image(hin.data(), hout.data(), H), &f.attn_slab_img))) return rc;
+      if (H == 8) {  // in_proj with the K axis in k-slot order: fragments built from accumulator-layout registers
+        __half* w_in_ks = nullptr;
+        if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, kslot, &w_in_ks))) return rc;
+        const std::vector<uint16_t> hin_ks = download16(h, w_in_ks, (size_t)3 * HD * Dq, &rc);
+        if (rc) return rc;
+        if ((rc = upload_image(h, pack_attn_slab_image(hin_ks.data(), hout.data(), H), &f.attn_slab_img_ks))) return rc;
+      }
     }
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
@@ -736,7 +746,24 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     ldm_handle::Scope sc(h, st, "embed_stats", 0, (double)M * D * 8);
     launch_layernorm(a, st);
   }
-  for (int i = 0; i < h->L; ++i) {
+  if (h->fused_attn == 4) {
+    // the whole stack in ONE launch, in place on P / stats_a: a layout's rows stay in their workgroup's registers
+    // from layer to layer
+    FusedLayerSet ls{};
+    ls.n_layer = h->L;
+    for (int i = 0; i < h->L; ++i) {
+      const LayerW& w = h->layers[i];
+      const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+      ls.w[i] = FusedLayerW{h->fast[i].attn_slab_img_ks, h->fast[i].b_in, ss, ss + D, w.b_out, h->fast[i].ffn_img_ks,
+                            w.b1, w.b2, w.g2, w.be2};
+    }
+    ldm_handle::Scope sc(h, st, "layers_fused",
+                         h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
+                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)),
+                         (double)M * D * 4 * (1 + 2 * h->L));
+    launch_layers_fused(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, st);
+  }
+  for (int i = 0; i < (h->fused_attn == 4 ? 0 : h->L); ++i) {
     const LayerW& w = h->layers[i];
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;

@@ -81,4 +81,41 @@ __device__ __forceinline__ void load_xf_ln_batched(dma_f16x8 (&xf)[KS], const Ln
   }
 }
 
+// Same normalisation, but the row is loaded in ACCUMULATOR layout — lane (row, hi) fetches columns 8g + 4hi .. +3 of
+// every 8-column group g — and groups 2ks, 2ks+1 form fragment ks: element e <-> column 16ks + 8(e>>2) + 4hi + (e&3),
+// the MFMA k-slot order (ldm_pack::kslot).  For weights whose K axis is packed in that order; it is the layout in
+// which the fused kernels hold a row in their accumulators, so fragments built from memory and fragments built from
+// registers are interchangeable.  NG = valid 8-column groups (58 for d_model 464), GB = groups per load batch.
+template <int KS, int NG, int GB>
+__device__ __forceinline__ void load_xf_ln_acc(dma_f16x8 (&xf)[KS], const LnLoad& ln, size_t m, int hi, const float* sp) {
+  const float2 st = ln.stats[m];
+  const float* xr = ln.x + m * ln.ldx + hi * 4;
+  const float* mp = sp + hi * 4;
+#pragma unroll
+  for (int g0 = 0; g0 < NG; g0 += GB) {
+    float4 raw[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      if (g0 + i < NG) raw[i] = *reinterpret_cast<const float4*>(xr + (g0 + i) * 8);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int gg = g0 + i;
+      if (gg < NG) {
+        const float4 a = raw[i];
+        const float4 ga = *reinterpret_cast<const float4*>(mp + gg * 8);
+        const float4 sa = *reinterpret_cast<const float4*>(mp + kLnDp + gg * 8);
+        const int ks = gg >> 1, e0 = (gg & 1) * 4;
+        xf[ks][e0 + 0] = (_Float16)fmaf((a.x - st.x) * st.y, ga.x, sa.x);
+        xf[ks][e0 + 1] = (_Float16)fmaf((a.y - st.x) * st.y, ga.y, sa.y);
+        xf[ks][e0 + 2] = (_Float16)fmaf((a.z - st.x) * st.y, ga.z, sa.z);
+        xf[ks][e0 + 3] = (_Float16)fmaf((a.w - st.x) * st.y, ga.w, sa.w);
+        if (gg & 1) asm volatile("" : "+v"(xf[ks]));
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace ldm

@@ -139,6 +139,25 @@ int main() {
       }
     }
     for (size_t i = (size_t)64 * 16384; i < sl.size(); ++i) CHECK(sl[i] == 0, "slab image padding stage not zero");
+    // multi-layer kernel: in_proj with the K axis in k-slot order (fragments come from accumulator-layout registers:
+    // element e of k16-step ks <-> input feature 16ks + f_slot(0, hi, e))
+    std::vector<uint16_t> p_in_ks((size_t)1536 * Dq, 0);
+    for (int n = 0; n < 3 * D; ++n) for (int k = 0; k < D; ++k)
+      p_in_ks[(size_t)ldm_pack::qkv_row(n, D, H, dh) * Dq + ldm_pack::kslot(k)] = w_in[(size_t)n * D + k];
+    const std::vector<uint16_t> slk = ldm_pack::pack_attn_slab_image(p_in_ks.data(), p_out_ks.data(), H);
+    for (int h = 0; h < H; ++h) for (int j = 0; j < 6; ++j) {
+      const uint16_t* stage = slk.data() + (size_t)(h * 6 + j) * 16384;
+      const int which = (j < 2) ? 1 : (j < 4 ? 2 : 0);
+      for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 29; ++ks) {
+        const uint16_t* p = tile_read(stage, r, hi, ks);
+        const int d = (j & 1) * 32 + r;
+        for (int e = 0; e < 8; ++e) {
+          const uint16_t want = d < dh ? w_in[(size_t)(which * D + h * dh + d) * D + 16 * ks + f_slot(0, hi, e)] : 0;
+          CHECK(p[e] == want, "Win(k-slot) h=%d j=%d r=%d hi=%d ks=%d e=%d", h, j, r, hi, ks, e);
+        }
+      }
+    }
+    for (size_t i = (size_t)48 * 16384; i < slk.size(); ++i) CHECK(slk[i] == sl[i], "k-slot image: out-proj slabs must not change");
   }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
