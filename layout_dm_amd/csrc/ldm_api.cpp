@@ -188,9 +188,11 @@ struct ldm_handle {
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 4;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
-                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
-                       // 4: ALL layers in one launch per step (4-layer stacks)
+  int fused_attn = 3;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
+                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P (default);
+                       // 4: ALL layers in one launch per step (4-layer stacks; opt-in through LDM_FUSED_ATTN=4: measured
+                       //    +0.4 % only — the 4x unrolled code no longer fits the instruction cache and the tile
+                       //    runs slow down by as much as the skipped operand reloads save: profiles/r02_call12_*)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;

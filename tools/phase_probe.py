@@ -48,7 +48,7 @@ if a[0]:
     clk = a[1] / max(a[2], 1) * 100.0
     tot = a[1] / n
     print(f"attn: blocks={n} cycles/block={tot:.0f} clock={clk:.0f} MHz  us/block={tot/clk:.1f}")
-    fused = int(os.environ.get("LDM_FUSED_ATTN", "4"))
+    fused = int(os.environ.get("LDM_FUSED_ATTN", "3"))
     layer = fused >= 3
     nl = 4 if fused == 4 else 1  # layers per launch (multi-layer kernel)
     if layer:  # fused layer kernel: slots 9..11 = residual seed + K slabs | LN2 | FFN chunk loop
