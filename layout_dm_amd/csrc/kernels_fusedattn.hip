@@ -374,6 +374,10 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int e = 0; e < 8; ++e) nf[dt * 2 + s2][e] = (_Float16)(o[dt][s2 * 8 + e] * inv);
+      if constexpr (LAYER) {  // park them in AGPRs: the arch VGPRs belong to the activation fragments of the tile runs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nf[i] = to_agpr4(nf[i]);
+      }
 #define LDM_OF_CASE(HH) \
   case HH: of[4 * HH] = nf[0]; of[4 * HH + 1] = nf[1]; of[4 * HH + 2] = nf[2]; of[4 * HH + 3] = nf[3]; break;
       switch (h) {

@@ -27,6 +27,17 @@ template <int OFF>
 __device__ __forceinline__ void dsr128(f16x8& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+// a 4-dword fragment parked in the AGPR half of the register file (written once, read much later as an MFMA operand)
+__device__ __forceinline__ f16x8 to_agpr4(const f16x8& v) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  const f32x4v in = __builtin_bit_cast(f32x4v, v);
+  f32x4v out;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(out[0]) : "v"(in[0]));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(out[1]) : "v"(in[1]));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(out[2]) : "v"(in[2]));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(out[3]) : "v"(in[3]));
+  return __builtin_bit_cast(f16x8, out);
+}
 __device__ __forceinline__ float to_agpr(float v) {
   float r;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
