@@ -188,11 +188,13 @@ struct ldm_handle {
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 3;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
-                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P (default);
+  int fused_attn = 5;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
+                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
                        // 4: ALL layers in one launch per step (4-layer stacks; opt-in through LDM_FUSED_ATTN=4: measured
                        //    +0.4 % only — the 4x unrolled code no longer fits the instruction cache and the tile
                        //    runs slow down by as much as the skipped operand reloads save: profiles/r02_call12_*)
+                       // 5: the whole layer per launch as CONTINUOUS per-head / slab / chunk streams (kernels_layer.hip;
+                       //    default: 220 -> 205 us per launch, profiles/r02_call14_*)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -770,6 +772,16 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
     const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
+    if (h->fused_attn == 5) {
+      // the whole layer in one launch, stream version (kernels_layer.hip): continuous per-head / slab pipelines
+      ldm_handle::Scope sc(h, st, "layer_fused",
+                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) +
+                               2 * gemm_flops(M, F, D),
+                           (double)M * D * 12);
+      launch_layer_stream(f.attn_slab_img, f.b_in, ada, w.b_out, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
+                          h->stats_a, D, Bc, h->S, h->H, h->dh, st);
+      continue;
+    }
     if (h->fused_attn == 3) {
       // the whole layer in one launch, in place: P <- x2 = x1 + FFN(LN2(x1)), x1 = AdaLN(x) + MHA(AdaLN(x)); x1 only
       // ever exists in the workgroup's registers
@@ -1598,10 +1610,12 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
 namespace ldm {
 void ffn_phase_read(unsigned long long* out12);
 void attn_phase_read(unsigned long long* out16);
+void layer_phase_read(unsigned long long* out16);
 }  // namespace ldm
 // dev hooks: s_memtime phase sums of the instrumented kernel variants (LDM_FFN_DBG=3 / LDM_ATTN_TM=1)
 extern "C" void ldm_dev_ffn_phases(unsigned long long* out12) { ldm::ffn_phase_read(out12); }
 extern "C" void ldm_dev_attn_phases(unsigned long long* out16) { ldm::attn_phase_read(out16); }
+extern "C" void ldm_dev_layer_phases(unsigned long long* out16) { ldm::layer_phase_read(out16); }
 
 extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
   const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;

@@ -123,6 +123,10 @@ void launch_layers_fused(const FusedLayerSet& ls, int F, float* x, int ldx, floa
 void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
                         const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
                         float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
+// the same layer as continuous per-head / slab streams (kernels_layer.hip); identical arguments and images
+void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
+                         const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
+                         float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,

@@ -151,7 +151,7 @@ struct FfnStream {
   static constexpr int NIT = KS + 1 + 2 * NT2;  // 60
   static constexpr int SYNC = NIT - PF;         // step whose read is the first of the next chunk
   static_assert(NIT % PF == 0, "queue slots must line up across chunks");
-  unsigned long long tA, tB, tC, tD;
+  unsigned long long tA, tB, tC, tD, t_sync = 0;
   f16x8 q[PF];
   unsigned aW1[8], aW2[2];
   const f16x8* xf;
@@ -233,7 +233,10 @@ struct FfnStream {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if constexpr (TM) tB = __builtin_amdgcn_s_memtime();
+        if constexpr (TM) {
+          tB = __builtin_amdgcn_s_memtime();
+          t_sync += tB - tA;
+        }
         read_bias();
 #pragma unroll
         for (int sx = 0; sx < 2; ++sx) aW2[sx] ^= 0x10000u;  // (last W2 read of this chunk was issued at step SYNC - 1)
@@ -310,6 +313,241 @@ struct SlabPipe {
   __device__ __forceinline__ void run(const f16x8& b0, const f16x8& b1) {
     prologue<0>();
     step<0>(b0, b1);
+  }
+};
+
+}  // namespace ldm
+
+namespace ldm {
+
+// ------------------------------------------------------------------------------------------------
+// HeadStream (kernels_layer.hip): the six in_proj tiles of ONE head (k0 k1 v0 v1 q0 q1, 29 k-steps each) as ONE
+// continuous LDS-read / MFMA pipeline of 174 items.
+//
+// TilePipe restarts its read queue at every tile (s_barrier, PF exposed fragment reads, 29 MFMAs, then an epilogue
+// during which the matrix pipe idles): 175 + 1306 + 439 cycles per tile for 928 cycles of MFMA
+// (profiles/r02_call13_*).  Here
+//   * the queue never drains inside a head: step G issues the read of item G + PF, which for the last PF steps of a
+//     tile is a fragment of the NEXT tile in the other 32-KiB ring stage (addresses toggled in place, ^ 0x8000);
+//   * one s_waitcnt vmcnt(0) + s_barrier per tile at local step KS - PF: every wave has then ISSUED all its reads of
+//     this tile (so the stage may be overwritten by the DMA of tile + 2, first issued > PF steps later) and its own
+//     pieces of the next tile have landed (then everybody's);
+//   * tiles alternate between two accumulators; the epilogue of tile j (fp16 cast + K / V^T ds_write, or the cast
+//     into the Q fragments) is issued inside steps EPI0.. of tile j + 1, in the MFMA shadow;
+//   * the K / Q bias enters through the C operand of the tile's first MFMA (read at the previous tile's barrier step:
+//     older in the LDS queue than the tile's item 0); the V bias is not applied here at all: softmax rows sum to 1,
+//     so P·(V + 1 b^T) = P·V + b^T and the attention core adds b_v to its normalised output;
+//   * the next tile's 32-KiB DMA goes out in steps 0..9 (M0 at 0 and 5), as early as the barrier protocol allows:
+//     a tile lasts only ~1 200 cycles and the pieces must have landed by step KS - PF.
+// lgkmcnt bookkeeping: every wait is counted exactly from a constexpr replay of the issue order (younger()).
+template <bool TM = false>
+struct HeadStream {
+  static constexpr int KS = 29, NT = 6, NIT = KS * NT, PF = 6;
+  static constexpr int SYNC = KS - PF;   // local step of the per-tile barrier
+  static constexpr int EPI0 = 10;        // first local step of the previous tile's epilogue
+  static_assert(NIT % PF == 0, "queue slots line up across heads");
+  f16x8 q[PF];
+  unsigned aW[8];       // LDS byte addresses of the current stage's fragment columns (toggled per tile)
+  const f16x8* xf;      // the wave's 29 activation fragments
+  f32x16 accA, accB;    // even / odd tiles
+  float4 bb[4];         // bias of the next K / Q tile in accumulator layout (C operand of its first MFMA)
+  f16x8* qf;            // [4] Q fragments of this head (B operand of S^T)
+  unsigned aK[2], aV[2];  // ds_write addresses of this lane's K row / V^T row pieces (chunk, chunk ^ 2), head parity applied
+  unsigned a_bias;      // LDS byte address of sbias + hi*16
+  const char* gimg;     // image of this head's tile 0 + wave * 8 KiB (uniform)
+  unsigned lds_w;       // lds0 + wave * 8 KiB (uniform)
+  unsigned voff;        // lane * 16
+  int h, H;
+  unsigned long long t_sync = 0;  // (TM) cycles spent in the per-tile vmcnt(0) + s_barrier
+
+  static constexpr bool tile_has_bias(int j) { return j < 2 || j >= 4; }
+  // bias reads issued at (global) step s: at the barrier step of tile j for tile j + 1
+  static constexpr int bias_at(int s) { return (s % KS == SYNC && s / KS + 1 < NT && tile_has_bias(s / KS + 1)) ? 4 : 0; }
+  // ds_write_b128 issued at step s (epilogue of the previous tile when that was a K or V tile: two stores)
+  static constexpr int writes_at(int s) {
+    const int j = s / KS, it = s % KS;
+    return (j >= 1 && j <= 4 && (it == EPI0 + 2 || it == EPI0 + 5)) ? 1 : 0;
+  }
+  // LDS operations younger than item G when step G waits for it
+  static constexpr int younger(int G) {
+    int cnt = 0;
+    bool seen = false;
+    for (int i = 0; i < PF; ++i) {
+      if (seen) ++cnt;
+      if (i == G) seen = true;
+    }
+    for (int s = 0; s < G; ++s) {
+      if (seen) cnt += bias_at(s);
+      if (s + PF < NIT) {
+        if (seen) ++cnt;
+        if (s + PF == G) seen = true;
+      }
+      if (seen) cnt += writes_at(s);
+    }
+    return cnt;
+  }
+
+  template <int G>
+  __device__ __forceinline__ void read_item() {
+    constexpr int IT = G % KS;
+    dsr128<256 * (IT >> 3)>(q[G % PF], aW[IT & 7]);
+  }
+  // bias of tile j (K: rows H*64.., Q: rows 0..) for head h, d-half t = j & 1 -> bb (assembled into the C operand
+  // at the use point, BEHIND the counted wait: a register copy placed next to the reads would see stale data)
+  template <int J>
+  __device__ __forceinline__ void read_bias() {
+    const unsigned ab = a_bias + (unsigned)((((J < 2 ? H + h : h) * 64) + (J & 1) * 32) * 4);
+    dsr128f<0>(bb[0], ab);
+    dsr128f<32>(bb[1], ab);
+    dsr128f<64>(bb[2], ab);
+    dsr128f<96>(bb[3], ab);
+  }
+  template <int S8>
+  static __device__ __forceinline__ f16x8 cvt8n(const f32x16& a) {
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)a[S8 + e];
+    return o;
+  }
+  // one slice (0..7) of the epilogue of tile J, accumulator `a`: spread over consecutive steps
+  template <int J, int SL>
+  __device__ __forceinline__ void epi_slice(const f32x16& a, f16x8& v0, f16x8& v1) {
+    constexpr int t = J & 1;
+    if constexpr (SL == 0) v0 = cvt8n<0>(a);
+    if constexpr (SL == 1) v1 = cvt8n<8>(a);
+    if constexpr (J < 2) {  // K tile: lane (key row, hi) holds d = 32t + 8rq + 4hi + i -> k-slot chunks 4t + hi, 4t + 2 + hi
+      if constexpr (SL == 2) asm volatile("ds_write_b128 %0, %1" ::"v"(aK[0] ^ (unsigned)(t << 6)), "v"(v0) : "memory");
+      if constexpr (SL == 5) asm volatile("ds_write_b128 %0, %1" ::"v"(aK[1] ^ (unsigned)(t << 6)), "v"(v1) : "memory");
+    } else if constexpr (J < 4) {  // V tile (swapped operands): lane (d = 32t + r, hi) holds this wave's 32 keys
+      if constexpr (SL == 2) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aV[0]), "v"(v0), "n"(t * 8192) : "memory");
+      if constexpr (SL == 5) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(aV[1]), "v"(v1), "n"(t * 8192) : "memory");
+    } else {  // Q tile: stays in registers
+      if constexpr (SL == 2) qf[2 * t] = v0;
+      if constexpr (SL == 5) qf[2 * t + 1] = v1;
+    }
+  }
+
+  template <int G>
+  __device__ __forceinline__ void step(f16x8& e0, f16x8& e1) {
+    if constexpr (G < NIT) {
+      constexpr int J = G / KS, IT = G % KS;
+      constexpr bool SWAP = (J == 2 || J == 3);
+      wait_lgkm<younger(G)>();
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 cur = q[G % PF];
+      f32x16& acc = (J & 1) ? accB : accA;
+      if constexpr (IT == 0) {
+        if constexpr (SWAP) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(xf[0]), "v"(cur));
+        } else {
+          f32x16 bv;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            bv[rq * 4 + 0] = bb[rq].x; bv[rq * 4 + 1] = bb[rq].y; bv[rq * 4 + 2] = bb[rq].z; bv[rq * 4 + 3] = bb[rq].w;
+          }
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(cur), "v"(xf[0]), "v"(bv));
+        }
+      } else {
+        if constexpr (SWAP) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(xf[IT]), "v"(cur));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(cur), "v"(xf[IT]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT == SYNC) {
+        // the next stage is complete (own DMA pieces landed, then everybody's); this stage's reads are all issued
+        unsigned long long tA = 0;
+        if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
+        if constexpr (J + 1 < NT && tile_has_bias(J + 1)) read_bias<(J + 1 < NT ? J + 1 : 0)>();
+      }
+      if constexpr (G + PF < NIT) read_item<G + PF>();
+      if constexpr (IT == KS - 1 - PF) {
+        // item KS - 1 of this tile has just been issued: the addresses now point into the other stage
+#pragma unroll
+        for (int k = 0; k < 8; ++k) aW[k] ^= 0x8000u;
+      }
+      // next tile's DMA (stage of tile J + 1 = the one tile J - 1 was read from): pieces at local steps 1-4, 6-9
+      if constexpr (IT == 0) dma_set_m0(lds_w + ((J + 1) & 1) * TILE_STAGE);
+      if constexpr (IT == 5) dma_set_m0(lds_w + ((J + 1) & 1) * TILE_STAGE + 4096);
+      if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(J + 1) * TILE_STAGE);
+      if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(J + 1) * TILE_STAGE + 4096);
+      // previous tile's epilogue in this tile's MFMA shadow
+      if constexpr (J >= 1 && IT >= EPI0 && IT < EPI0 + 6) epi_slice<J - 1, IT - EPI0>((J & 1) ? accA : accB, e0, e1);
+      __builtin_amdgcn_sched_barrier(0);
+      step<G + 1>(e0, e1);
+    }
+  }
+  // head prologue: bias of tile 0, then the first PF fragments (the stage was certified by the previous barrier)
+  __device__ __forceinline__ void run() {
+    read_bias<0>();
+    read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
+    f16x8 e0, e1;
+    step<0>(e0, e1);
+    // q1's epilogue (exposed: the attention core needs the fragments now)
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    qf[2] = cvt8n<0>(accB);
+    qf[3] = cvt8n<8>(accB);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// SlabStream: the 16 K-slabs of the out-projection (2 x NT2 MFMAs on NT2 independent accumulator tiles each, see
+// SlabPipe) as one continuous pipeline of 16 x 30 items: same barrier / toggle protocol as HeadStream.
+template <int NT2, bool TM = false>
+struct SlabStream {
+  static constexpr int NIT = 2 * NT2, PF = 6, NS = 16, SYNC = NIT - PF;
+  static_assert(NIT % PF == 0, "queue slots line up across slabs");
+  f16x8 q[PF];
+  unsigned aS[2];
+  f32x16* acc;
+  const f16x8* of;      // [32] B fragments: slab c uses of[2c], of[2c + 1]
+  const char* gimg;     // image of slab 0 + wave * 8 KiB (uniform)
+  unsigned lds_w;       // lds0 + wave * 8 KiB
+  unsigned voff;
+  unsigned long long t_sync = 0;
+
+  template <int G>
+  __device__ __forceinline__ void read_item() {
+    constexpr int IT = G % NIT, sx = IT / NT2, t = IT % NT2;
+    dsr128<t * 2048>(q[G % PF], aS[sx]);
+  }
+  template <int G, int STAGE0>
+  __device__ __forceinline__ void step() {
+    if constexpr (G < NS * NIT) {
+      constexpr int C = G / NIT, IT = G % NIT, sx = IT / NT2, t = IT % NT2;
+      constexpr int left = NS * NIT - 1 - G;
+      wait_lgkm<(left < PF - 1 ? left : PF - 1)>();
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[G % PF], of[2 * C + sx], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT == SYNC && C + 1 < NS) {
+        unsigned long long tA = 0;
+        if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
+      }
+      if constexpr (G + PF < NS * NIT) read_item<G + PF>();
+      if constexpr (IT == NT2 - 1 - PF) aS[0] ^= 0x8000u;   // item NT2 - 1 (last of sx = 0) has been issued
+      if constexpr (IT == NIT - 1 - PF) aS[1] ^= 0x8000u;   // item NIT - 1 has been issued
+      if constexpr (C + 1 < NS) {
+        constexpr unsigned st = (unsigned)((STAGE0 + C + 1) & 1) * TILE_STAGE;
+        if constexpr (IT == 0) dma_set_m0(lds_w + st);
+        if constexpr (IT == 5) dma_set_m0(lds_w + st + 4096);
+        if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(C + 1) * TILE_STAGE);
+        if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(C + 1) * TILE_STAGE + 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      step<G + 1, STAGE0>();
+    }
+  }
+  template <int STAGE0>
+  __device__ __forceinline__ void run() {
+    read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
+    step<0, STAGE0>();
   }
 };
 

@@ -23,6 +23,7 @@ f8 = (C.c_ulonglong * 12)()
 a16 = (C.c_ulonglong * 16)()
 lib.ldm_dev_ffn_phases(f8)
 lib.ldm_dev_attn_phases(a16)  # reset after warm-up
+lib.ldm_dev_layer_phases((C.c_ulonglong * 16)())
 N = 3
 for _ in range(N):
     e.denoise_logits(tokens, 50)
@@ -61,5 +62,20 @@ if a[0]:
     for name, v, k in zip(names, a[3:12], per):
         print(f"   {name:16s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per item {v/n/k:7.1f}")
     mf = (48 * 29 + 15 * 32 + 8 * 32 + (58 * 59 if layer else 0)) * 32 * (nl if layer else 1)
+    print(f"   ideal MFMA cycles/block = {mf}  ({100*mf/tot:.1f}% of block)")
+l16 = (C.c_ulonglong * 16)()
+lib.ldm_dev_layer_phases(l16)
+l = list(l16)
+if l[0]:  # stream version of the fused layer kernel (LDM_FUSED_ATTN=5)
+    n = l[0]
+    clk = l[1] / max(l[2], 1) * 100.0
+    tot = l[1] / n
+    print(f"layer(stream): blocks={n} cycles/block={tot:.0f} clock={clk:.0f} MHz  us/block={tot/clk:.1f}")
+    names = ("prologue", "head streams (174 MFMA)", "attn core", "seed + slab stream", "LN2 (+ chunk-0 DMA)", "FFN chunk loop", "store epilogue")
+    per = (1, 8, 8, 1, 1, 58, 1)
+    for name, v, k in zip(names, l[3:10], per):
+        print(f"   {name:24s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per item {v/n/k:8.1f}")
+    print(f"   of which: per-tile sync (vmcnt+barrier) {l[10]/n/48:7.1f} cyc per tile, per-slab sync {l[11]/n/15:7.1f} cyc per slab, per-FFN-chunk sync {l[12]/n/58:7.1f}")
+    mf = (48 * 29 + 16 * 30 + 8 * 32 + 58 * 59) * 32
     print(f"   ideal MFMA cycles/block = {mf}  ({100*mf/tot:.1f}% of block)")
 e.close()
