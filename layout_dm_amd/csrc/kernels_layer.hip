@@ -26,7 +26,7 @@ struct LayerArgs {
   const char* img;      // pack_attn_slab_image: 6H in_proj tiles, 16 out-proj K-slabs, 1 zero stage (32 KiB each)
   const float* bias;    // head-padded in_proj bias [3*H*64]
   LnLoad ln;            // AdaLN of the layer input: x rows, (mean, rstd), scale, shift
-  const float* b_out;   // [N]
+  const float* b_out;   // [N] out_proj bias + W_out b_v (V bias folded on the host, ldm_api.cpp build_fast_weights)
   const char* ffn_img;  // pack_ffn_image (W1 K axis k-slot ordered), 64 KiB per 32-wide hidden chunk
   const float *b1, *b2, *g2, *be2;
   float* out;           // [M, ldo] x2 (may alias ln.x)
@@ -43,12 +43,12 @@ __device__ __forceinline__ int hw_lane_id() {
   return l;
 }
 
-template <bool TM>
+template <bool TM, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kvbuf = smem + 2 * STAGE;          // [2 head parities][Ks 16 KiB | Vs 16 KiB]
-  float* sbias = reinterpret_cast<float*>(kvbuf + 4 * KV_BYTES);  // [3*H*64]
+  char* kvbuf = smem + 3 * STAGE;          // Ks 16 KiB | Vs 16 KiB behind the 3-stage weight ring
+  float* sbias = reinterpret_cast<float*>(kvbuf + 2 * KV_BYTES);  // [3*H*64]
   float* sp = sbias + 3 * a.H * 64;        // AdaLN multiplier / shift (2 x LN_DP)
   float* sbo = sp + 2 * LN_DP;             // out-proj bias + AdaLN shift [512]
   float* sb1 = sbo + 512;                  // linear1 bias [n_chunks*32]
@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
     const size_t m = (size_t)b * S + (row_in < S ? row_in : S - 1);
 #pragma unroll
     for (int k = 0; k < 2; ++k) dma_lin4(voff, a.img + wave * 8192 + k * 4096, lds0 + wave * 8192 + k * 4096);  // tile 0
+#pragma unroll
+    for (int k = 0; k < 2; ++k)  // tile 1 -> stage 1
+      dma_lin4(voff, a.img + STAGE + wave * 8192 + k * 4096, lds0 + STAGE + wave * 8192 + k * 4096);
     for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = a.bias[i];
     // sbo = out-proj bias + AdaLN shift (the residual AdaLN(x) is recomputed at the residual seed); every table is zero
     // beyond N / D so that padded output columns come out as exact zeros without masks
@@ -108,17 +111,30 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
     HS.H = H;
     HS.a_bias = lds0 + (unsigned)(reinterpret_cast<char*>(sbias) - smem) + hi * 16;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) HS.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+    for (int k = 0; k < 8; ++k) {
+      HS.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+      HS.aW2[k] = HS.aW[k] + 2 * STAGE;
+    }
+    const unsigned kv0 = lds0 + 3 * STAGE;  // Ks 16 KiB | Vs 16 KiB (single-buffered: see the header comment)
     {
-      const unsigned kv0 = lds0 + 2 * STAGE;
       const int sw = (row_in >> 1) & 7;
       HS.aK[0] = kv0 + row_in * 128 + ((hi ^ sw) << 4);
       HS.aK[1] = kv0 + row_in * 128 + (((2 + hi) ^ sw) << 4);
       HS.aV[0] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + hi) ^ (r & 15)) << 4);
       HS.aV[1] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + 2 + hi) ^ (r & 15)) << 4);
     }
-    const int ksw = (r >> 1) & 7;
-    // tile 0 has landed (own pieces, then everybody's)
+    AttnCore AC;
+    AC.qf = qf;
+    {
+      const int ksw = (r >> 1) & 7;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) AC.aKr[ks] = kv0 + r * 128 + (((2 * ks + hi) ^ ksw) << 4);
+      AC.aVr = kv0 + KV_BYTES + r * 256 + ((hi ^ (r & 15)) << 4);
+    }
+    AC.scale_log2e = a.scale_log2e;
+    AC.S = S;
+    AC.hi = hi;
+    // tiles 0 and 1 have landed (own pieces, then everybody's)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -129,91 +145,82 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
       HS.gimg = a.img + (size_t)h * 6 * STAGE + wave * 8192;
       HS.run();
       if constexpr (TM) tB = __builtin_amdgcn_s_memtime();
-      const char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
-      const char* Vs = Ks + KV_BYTES;
-      // next head writes the other parity
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        HS.aK[k] ^= (unsigned)(2 * KV_BYTES);
-        HS.aV[k] ^= (unsigned)(2 * KV_BYTES);
-      }
       // ---------------------------------------------------------------- attention core of head h
-      // (every wave wrote its K / V parts before the barriers of tiles q0, q1 => Ks / Vs are complete here)
-      f32x16 sc[4];
+      // (every wave wrote its K / V parts before the barriers of tiles q0, q1 => Ks / Vs are complete here; they are
+      //  not overwritten before every wave is past this core: the next K write sits behind the next head's first
+      //  barrier)
+      f16x8 nf[4];
+      if constexpr (DBG & 1) {
+        // (A/B aid, LDM_LAYER_DBG=1) the compiler-scheduled core of the first stream version
+        const char* Ks = kvbuf;
+        const char* Vs = Ks + KV_BYTES;
+        const int ksw = (r >> 1) & 7;
+        f32x16 sc[4];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
+          for (int i = 0; i < 16; ++i) sc[kt][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {  // ks = 2t + s ; chunk c = 4t + 2s + hi = 2*ks + hi
-          const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (kt * 32 + r) * 128 + (((2 * ks + hi) ^ ksw) << 4));
-          sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[kt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = 96 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-        if (key >= S) sc[3][i] = -INFINITY;
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float nmxs = -mx * a.scale_log2e;
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][i], a.scale_log2e, nmxs));
-          sc[kt][i] = p;
-          sum += p;
-        }
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-      f32x16 o[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          f16x8 pf;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pf[e] = (_Float16)sc[kt][hf * 8 + e];
-          const int c = kt * 4 + hf * 2 + hi;
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const int d = dt * 32 + r;
-            const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + d * 256 + ((c ^ (d & 15)) << 4));
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) {
+            const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + (kt * 32 + r) * 128 + (((2 * ks + hi) ^ ksw) << 4));
+            sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[kt], 0, 0, 0);
           }
         }
-      }
-      // normalise, add the V bias (d = 32dt + 8rq + 4hi + i), cast: fragment (dt, s) of this lane = accumulator regs
-      // 8s..8s+7 IS the out-projection's B operand for k16-step 4h + 2dt + s (k-slot order)
-      f16x8 nf[4];
-      const float* vb = sbias + (2 * H + h) * 64 + hi * 4;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const float4 bq = *reinterpret_cast<const float4*>(vb + dt * 32 + rq * 8);
-          const int f = dt * 2 + (rq >> 1), e0 = (rq & 1) * 4;
-          nf[f][e0 + 0] = (_Float16)fmaf(o[dt][rq * 4 + 0], inv, bq.x);
-          nf[f][e0 + 1] = (_Float16)fmaf(o[dt][rq * 4 + 1], inv, bq.y);
-          nf[f][e0 + 2] = (_Float16)fmaf(o[dt][rq * 4 + 2], inv, bq.z);
-          nf[f][e0 + 3] = (_Float16)fmaf(o[dt][rq * 4 + 3], inv, bq.w);
+        for (int i = 0; i < 16; ++i) {
+          const int key = 96 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+          if (key >= S) sc[3][i] = -INFINITY;
         }
-      // park them in AGPRs: the arch VGPRs belong to the activation fragments of the streams
+        float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nf[i] = to_agpr4(nf[i]);
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmxs = -mx * a.scale_log2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][i], a.scale_log2e, nmxs));
+            sc[kt][i] = p;
+            sum += p;
+          }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            f16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (_Float16)sc[kt][hf * 8 + e];
+            const int c = kt * 4 + hf * 2 + hi;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              const int d = dt * 32 + r;
+              const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + d * 256 + ((c ^ (d & 15)) << 4));
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) nf[dt * 2 + (i >> 3)][i & 7] = (_Float16)(o[dt][i] * inv);
+      } else {
+        AC.run(nf);
+      }
+      // park them in AGPRs (the arch VGPRs belong to the activation fragments of the streams), in place: see park_agpr4
 #define LDM_OF_CASE(HH) \
-  case HH: of[4 * HH] = nf[0]; of[4 * HH + 1] = nf[1]; of[4 * HH + 2] = nf[2]; of[4 * HH + 3] = nf[3]; break;
+  case HH: park_agpr4(of[4 * HH], nf[0]); park_agpr4(of[4 * HH + 1], nf[1]); park_agpr4(of[4 * HH + 2], nf[2]); \
+           park_agpr4(of[4 * HH + 3], nf[3]); break;
       switch (h) {
         LDM_OF_CASE(0) LDM_OF_CASE(1) LDM_OF_CASE(2) LDM_OF_CASE(3)
         LDM_OF_CASE(4) LDM_OF_CASE(5) LDM_OF_CASE(6) LDM_OF_CASE(7)
@@ -283,9 +290,11 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
     SS.of = of;
     SS.voff = voff;
     SS.lds_w = lds0 + wave * 8192;
-    SS.gimg = a.img + (size_t)(6 * 8) * STAGE + wave * 8192;
+    SS.gimg = a.img + (size_t)(6 * H) * STAGE + wave * 8192;
     SS.aS[0] = lds0 + r1 * 64 + (((0 + hi1) ^ ((r1 >> 2) & 3)) << 4);
     SS.aS[1] = lds0 + r1 * 64 + (((2 + hi1) ^ ((r1 >> 2) & 3)) << 4);
+    SS.aS2[0] = SS.aS[0] + 2 * STAGE;
+    SS.aS2[1] = SS.aS[1] + 2 * STAGE;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SS.template run<0>();
     if constexpr (TM) s_ssync = SS.t_sync;
@@ -428,12 +437,21 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
 
 // One transformer layer per launch: x <- x2 in place.  img: pack_attn_slab_image, ffn_img: pack_ffn_image with W1's K
 // axis in k-slot order.  ln: AdaLN of the layer input (x rows, stats = stats_io), N = d_model = 464, 8 heads.
+int layer_stream_debug() {
+  static const int dbg = getenv("LDM_LAYER_DBG") ? atoi(getenv("LDM_LAYER_DBG")) : 0;
+  return dbg;
+}
+
 void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
                          const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
                          float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st) {
-  const int lds = 2 * TILE_STAGE + 4 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
+  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
   auto kern = tm ? layer_stream_k<true> : layer_stream_k<false>;
+  switch (layer_stream_debug()) {
+    case 1: kern = layer_stream_k<false, 1>; break;
+    default: break;
+  }
   allow_big_lds((const void*)kern);
   LayerArgs a{(const char*)img, bias, ln, b_out, (const char*)ffn_img, b1, b2, g2, be2, x, stats_io, ldx, N, S, H, F / 32,
               1.4426950408889634f / sqrtf((float)dh)};

@@ -183,6 +183,7 @@ struct ldm_handle {
     void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
     void* attn_slab_img_ks = nullptr;  // same with the in_proj K axis in k-slot order (multi-layer kernel)
     float* b_in = nullptr;
+    float* b_out_v = nullptr;  // out_proj bias + W_out b_v (the stream layer kernel never adds the V bias: softmax rows sum to 1)
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
@@ -656,6 +657,20 @@ static int build_fast_weights(ldm_handle* h) {
     for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
     if ((rc = h->dalloc(&f.b_in, bp.size(), false))) return rc;
     HIP_OK(h, hipMemcpy(f.b_in, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    {
+      // softmax rows sum to 1, so P (V + 1 b_v^T) = P V + 1 b_v^T and the V bias reaches the block output as the
+      // constant W_out b_v: folded into the out-projection bias once, here (fp64 accumulate)
+      std::vector<float> wo((size_t)D * D), bo(D), bov(D);
+      HIP_OK(h, hipMemcpy(wo.data(), w.w_out, wo.size() * 4, hipMemcpyDeviceToHost));
+      HIP_OK(h, hipMemcpy(bo.data(), w.b_out, bo.size() * 4, hipMemcpyDeviceToHost));
+      for (int n = 0; n < D; ++n) {
+        double acc = bo[n];
+        for (int k = 0; k < D; ++k) acc += (double)wo[(size_t)n * D + k] * (double)b[2 * D + k];
+        bov[n] = (float)acc;
+      }
+      if ((rc = h->dalloc(&f.b_out_v, bov.size(), false))) return rc;
+      HIP_OK(h, hipMemcpy(f.b_out_v, bov.data(), bov.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   return pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, id, &h->fast_head);
 }
@@ -778,7 +793,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
                            gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) +
                                2 * gemm_flops(M, F, D),
                            (double)M * D * 12);
-      launch_layer_stream(f.attn_slab_img, f.b_in, ada, w.b_out, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
+      launch_layer_stream(f.attn_slab_img, f.b_in, ada, f.b_out_v, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
                           h->stats_a, D, Bc, h->S, h->H, h->dh, st);
       continue;
     }

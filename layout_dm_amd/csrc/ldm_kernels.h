@@ -127,6 +127,7 @@ void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, co
 void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
                          const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
                          float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
+int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,

@@ -38,6 +38,20 @@ __device__ __forceinline__ f16x8 to_agpr4(const f16x8& v) {
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(out[3]) : "v"(in[3]));
   return __builtin_bit_cast(f16x8, out);
 }
+// the same, IN PLACE: the new value is written into the AGPRs that hold the old one (read-write operand).  For an array
+// element updated under a run-time index (switch over the head): the updated element stays in its registers on every
+// path, so the merge after the switch needs no copies (with fresh "=a" outputs hipcc shuffled the whole 128-register
+// array through v_accvgpr_mov on every iteration).
+__device__ __forceinline__ void park_agpr4(f16x8& dst, const f16x8& v) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4v;
+  const f32x4v in = __builtin_bit_cast(f32x4v, v);
+  f32x4v out = __builtin_bit_cast(f32x4v, dst);
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(out[0]) : "v"(in[0]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(out[1]) : "v"(in[1]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(out[2]) : "v"(in[2]));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(out[3]) : "v"(in[3]));
+  dst = __builtin_bit_cast(f16x8, out);
+}
 __device__ __forceinline__ float to_agpr(float v) {
   float r;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
@@ -328,17 +342,19 @@ namespace ldm {
 // during which the matrix pipe idles): 175 + 1306 + 439 cycles per tile for 928 cycles of MFMA
 // (profiles/r02_call13_*).  Here
 //   * the queue never drains inside a head: step G issues the read of item G + PF, which for the last PF steps of a
-//     tile is a fragment of the NEXT tile in the other 32-KiB ring stage (addresses toggled in place, ^ 0x8000);
-//   * one s_waitcnt vmcnt(0) + s_barrier per tile at local step KS - PF: every wave has then ISSUED all its reads of
-//     this tile (so the stage may be overwritten by the DMA of tile + 2, first issued > PF steps later) and its own
-//     pieces of the next tile have landed (then everybody's);
+//     tile is a fragment of the NEXT tile in the next stage of a THREE-stage ring (3 x 32 KiB; stage = tile % 3, a
+//     compile-time constant: stages 0 / 1 through the ds_read offset field, stage 2 through a second address set);
+//   * the weight DMA runs TWO tiles ahead: tile j + 2 is issued in steps 1..9 of tile j, so a piece has a whole tile
+//     (~1 200 cycles) to land instead of ~14 steps (with a two-stage ring the barrier step waited 262 cycles per tile
+//     for late pieces: profiles/r02_call16_*);
+//   * one s_waitcnt vmcnt(8) + s_barrier per tile at local step KS - PF: every wave has then ISSUED all its reads of
+//     this tile (so its stage may be overwritten by tile j + 3, first issued > PF steps later) and its own pieces of
+//     tile j + 1 have landed — LDS-DMA pieces retire in order, the 8 youngest are tile j + 2's — then everybody's;
 //   * tiles alternate between two accumulators; the epilogue of tile j (fp16 cast + K / V^T ds_write, or the cast
 //     into the Q fragments) is issued inside steps EPI0.. of tile j + 1, in the MFMA shadow;
 //   * the K / Q bias enters through the C operand of the tile's first MFMA (read at the previous tile's barrier step:
 //     older in the LDS queue than the tile's item 0); the V bias is not applied here at all: softmax rows sum to 1,
-//     so P·(V + 1 b^T) = P·V + b^T and the attention core adds b_v to its normalised output;
-//   * the next tile's 32-KiB DMA goes out in steps 0..9 (M0 at 0 and 5), as early as the barrier protocol allows:
-//     a tile lasts only ~1 200 cycles and the pieces must have landed by step KS - PF.
+//     so P·(V + 1 b^T) = P·V + b^T, a constant the host folds into the out-projection bias (b_out + W_out b_v).
 // lgkmcnt bookkeeping: every wait is counted exactly from a constexpr replay of the issue order (younger()).
 template <bool TM = false>
 struct HeadStream {
@@ -346,19 +362,20 @@ struct HeadStream {
   static constexpr int SYNC = KS - PF;   // local step of the per-tile barrier
   static constexpr int EPI0 = 10;        // first local step of the previous tile's epilogue
   static_assert(NIT % PF == 0, "queue slots line up across heads");
+  static_assert(NT % 3 == 0, "ring stage of a tile is a compile-time constant");
   f16x8 q[PF];
-  unsigned aW[8];       // LDS byte addresses of the current stage's fragment columns (toggled per tile)
+  unsigned aW[8], aW2[8];  // LDS byte addresses of the fragment columns in stage 0 (stage 1: + offset) / stage 2
   const f16x8* xf;      // the wave's 29 activation fragments
   f32x16 accA, accB;    // even / odd tiles
   float4 bb[4];         // bias of the next K / Q tile in accumulator layout (C operand of its first MFMA)
   f16x8* qf;            // [4] Q fragments of this head (B operand of S^T)
-  unsigned aK[2], aV[2];  // ds_write addresses of this lane's K row / V^T row pieces (chunk, chunk ^ 2), head parity applied
+  unsigned aK[2], aV[2];  // ds_write addresses of this lane's K row / V^T row pieces (chunk, chunk ^ 2)
   unsigned a_bias;      // LDS byte address of sbias + hi*16
   const char* gimg;     // image of this head's tile 0 + wave * 8 KiB (uniform)
   unsigned lds_w;       // lds0 + wave * 8 KiB (uniform)
   unsigned voff;        // lane * 16
   int h, H;
-  unsigned long long t_sync = 0;  // (TM) cycles spent in the per-tile vmcnt(0) + s_barrier
+  unsigned long long t_sync = 0;  // (TM) cycles spent in the per-tile vmcnt + s_barrier
 
   static constexpr bool tile_has_bias(int j) { return j < 2 || j >= 4; }
   // bias reads issued at (global) step s: at the barrier step of tile j for tile j + 1
@@ -389,8 +406,9 @@ struct HeadStream {
 
   template <int G>
   __device__ __forceinline__ void read_item() {
-    constexpr int IT = G % KS;
-    dsr128<256 * (IT >> 3)>(q[G % PF], aW[IT & 7]);
+    constexpr int IT = G % KS, ST = (G / KS) % 3;
+    if constexpr (ST == 2) dsr128<256 * (IT >> 3)>(q[G % PF], aW2[IT & 7]);
+    else dsr128<256 * (IT >> 3) + ST * TILE_STAGE>(q[G % PF], aW[IT & 7]);
   }
   // bias of tile j (K: rows H*64.., Q: rows 0..) for head h, d-half t = j & 1 -> bb (assembled into the C operand
   // at the use point, BEHIND the counted wait: a register copy placed next to the reads would see stale data)
@@ -409,7 +427,7 @@ struct HeadStream {
     for (int e = 0; e < 8; ++e) o[e] = (_Float16)a[S8 + e];
     return o;
   }
-  // one slice (0..7) of the epilogue of tile J, accumulator `a`: spread over consecutive steps
+  // one slice (0..5) of the epilogue of tile J, accumulator `a`: spread over consecutive steps
   template <int J, int SL>
   __device__ __forceinline__ void epi_slice(const f32x16& a, f16x8& v0, f16x8& v1) {
     constexpr int t = J & 1;
@@ -453,26 +471,23 @@ struct HeadStream {
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT == SYNC) {
-        // the next stage is complete (own DMA pieces landed, then everybody's); this stage's reads are all issued
+        // tile J + 1 is complete (own DMA pieces landed — the 8 youngest belong to tile J + 2 — then everybody's);
+        // this tile's reads are all issued
         unsigned long long tA = 0;
         if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
         if constexpr (J + 1 < NT && tile_has_bias(J + 1)) read_bias<(J + 1 < NT ? J + 1 : 0)>();
       }
       if constexpr (G + PF < NIT) read_item<G + PF>();
-      if constexpr (IT == KS - 1 - PF) {
-        // item KS - 1 of this tile has just been issued: the addresses now point into the other stage
-#pragma unroll
-        for (int k = 0; k < 8; ++k) aW[k] ^= 0x8000u;
-      }
-      // next tile's DMA (stage of tile J + 1 = the one tile J - 1 was read from): pieces at local steps 1-4, 6-9
-      if constexpr (IT == 0) dma_set_m0(lds_w + ((J + 1) & 1) * TILE_STAGE);
-      if constexpr (IT == 5) dma_set_m0(lds_w + ((J + 1) & 1) * TILE_STAGE + 4096);
-      if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(J + 1) * TILE_STAGE);
-      if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(J + 1) * TILE_STAGE + 4096);
+      // DMA of tile J + 2 into stage (J + 2) % 3 (the one tile J - 1 was read from): pieces at local steps 1-4, 6-9
+      constexpr unsigned st = (unsigned)((J + 2) % 3) * TILE_STAGE;
+      if constexpr (IT == 0) dma_set_m0(lds_w + st);
+      if constexpr (IT == 5) dma_set_m0(lds_w + st + 4096);
+      if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(J + 2) * TILE_STAGE);
+      if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(J + 2) * TILE_STAGE + 4096);
       // previous tile's epilogue in this tile's MFMA shadow
       if constexpr (J >= 1 && IT >= EPI0 && IT < EPI0 + 6) epi_slice<J - 1, IT - EPI0>((J & 1) ? accA : accB, e0, e1);
       __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +501,8 @@ struct HeadStream {
     f16x8 e0, e1;
     step<0>(e0, e1);
     // q1's epilogue (exposed: the attention core needs the fragments now)
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accB));  // (tied to the accumulator: see AttnCore::run)
+    __builtin_amdgcn_sched_barrier(0);
     qf[2] = cvt8n<0>(accB);
     qf[3] = cvt8n<8>(accB);
   }
@@ -494,13 +510,14 @@ struct HeadStream {
 
 // ------------------------------------------------------------------------------------------------
 // SlabStream: the 16 K-slabs of the out-projection (2 x NT2 MFMAs on NT2 independent accumulator tiles each, see
-// SlabPipe) as one continuous pipeline of 16 x 30 items: same barrier / toggle protocol as HeadStream.
+// SlabPipe) as one continuous pipeline of 16 x 30 items on the same three-stage ring (slab c in stage (S0 + c) % 3,
+// DMA two slabs ahead, vmcnt(8) + s_barrier per slab).
 template <int NT2, bool TM = false>
 struct SlabStream {
   static constexpr int NIT = 2 * NT2, PF = 6, NS = 16, SYNC = NIT - PF;
   static_assert(NIT % PF == 0, "queue slots line up across slabs");
   f16x8 q[PF];
-  unsigned aS[2];
+  unsigned aS[2], aS2[2];  // stage 0 (stage 1: + offset) / stage 2
   f32x16* acc;
   const f16x8* of;      // [32] B fragments: slab c uses of[2c], of[2c + 1]
   const char* gimg;     // image of slab 0 + wave * 8 KiB (uniform)
@@ -508,12 +525,13 @@ struct SlabStream {
   unsigned voff;
   unsigned long long t_sync = 0;
 
-  template <int G>
+  template <int G, int S0>
   __device__ __forceinline__ void read_item() {
-    constexpr int IT = G % NIT, sx = IT / NT2, t = IT % NT2;
-    dsr128<t * 2048>(q[G % PF], aS[sx]);
+    constexpr int IT = G % NIT, sx = IT / NT2, t = IT % NT2, ST = (S0 + G / NIT) % 3;
+    if constexpr (ST == 2) dsr128<t * 2048>(q[G % PF], aS2[sx]);
+    else dsr128<t * 2048 + ST * TILE_STAGE>(q[G % PF], aS[sx]);
   }
-  template <int G, int STAGE0>
+  template <int G, int S0>
   __device__ __forceinline__ void step() {
     if constexpr (G < NS * NIT) {
       constexpr int C = G / NIT, IT = G % NIT, sx = IT / NT2, t = IT % NT2;
@@ -525,29 +543,170 @@ struct SlabStream {
       if constexpr (IT == SYNC && C + 1 < NS) {
         unsigned long long tA = 0;
         if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (C + 2 < NS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 youngest: slab C + 2
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
       }
-      if constexpr (G + PF < NS * NIT) read_item<G + PF>();
-      if constexpr (IT == NT2 - 1 - PF) aS[0] ^= 0x8000u;   // item NT2 - 1 (last of sx = 0) has been issued
-      if constexpr (IT == NIT - 1 - PF) aS[1] ^= 0x8000u;   // item NIT - 1 has been issued
-      if constexpr (C + 1 < NS) {
-        constexpr unsigned st = (unsigned)((STAGE0 + C + 1) & 1) * TILE_STAGE;
+      if constexpr (G + PF < NS * NIT) read_item<G + PF, S0>();
+      if constexpr (C + 2 < NS) {
+        constexpr unsigned st = (unsigned)((S0 + C + 2) % 3) * TILE_STAGE;
         if constexpr (IT == 0) dma_set_m0(lds_w + st);
         if constexpr (IT == 5) dma_set_m0(lds_w + st + 4096);
-        if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(C + 1) * TILE_STAGE);
-        if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(C + 1) * TILE_STAGE + 4096);
+        if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(C + 2) * TILE_STAGE);
+        if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(C + 2) * TILE_STAGE + 4096);
       }
       __builtin_amdgcn_sched_barrier(0);
-      step<G + 1, STAGE0>();
+      step<G + 1, S0>();
     }
   }
-  template <int STAGE0>
+  template <int S0>
   __device__ __forceinline__ void run() {
+    read_item<0, S0>(); read_item<1, S0>(); read_item<2, S0>(); read_item<3, S0>(); read_item<4, S0>(); read_item<5, S0>();
+    step<0, S0>();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// AttnCore (kernels_layer.hip): single-tile attention of one head for the wave's 32 queries against the layout's 128
+// key slots — S^T = K Q^T (16 MFMAs), in-register softmax, O^T = V^T P^T (16 MFMAs) — as ONE hand-issued LDS-read
+// queue over the 16 K fragments and the 16 V^T fragments:
+//   * the first V^T fragments are requested while the last S^T MFMAs run and land under the softmax;
+//   * the four score tiles live in arch VGPRs (no v_accvgpr_read per score), the output tiles in AGPRs;
+//   * cross-half reductions through v_permlane32_swap (no LDS round trip), 1/sum through v_rcp_f32;
+//   * scale-and-shift and the row sum in packed f32 (v_pk_fma_f32 / v_pk_add_f32: this phase is VALU-only and one wave
+//     per SIMD issues one instruction per ~4 cycles, so the instruction COUNT is its length).
+// r02 before: 4 400 cycles per head for 1 024 cycles of MFMA (compiler-scheduled, exposed LDS round trips, 540 issued
+// instructions: profiles/r02_call16_*).
+struct AttnCore {
+  static constexpr int PF = 6;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f16x8 q[PF];
+  unsigned aKr[4];     // Ks + r*128 + (((2ks + hi) ^ ksw) << 4); key tile kt through the offset field (kt * 4 KiB)
+  unsigned aVr;        // Vs + r*256 + ((hi ^ (r & 15)) << 4); key chunk (4kt + 2hf) by XOR, d tile through the offset
+  const f16x8* qf;     // [4] Q fragments (B operand of S^T), k16-step ks
+  f32x16 sc[4], o[2];
+  float scale_log2e;
+  int S, hi;
+
+  template <int I>  // I in [0, 32): 16 K fragments (kt = I & 3, ks = I >> 2), then 16 V^T fragments (dt, hf, kt)
+  __device__ __forceinline__ void read_item() {
+    if constexpr (I < 16) {
+      dsr128<(I & 3) * 4096>(q[I % PF], aKr[I >> 2]);
+    } else if constexpr (I < 32) {
+      constexpr int J = I - 16, dt = J & 1, hf = (J >> 1) & 1, kt = J >> 2;
+      dsr128<dt * 8192>(q[I % PF], aVr ^ (unsigned)((kt * 4 + hf * 2) << 4));
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ void qk_step() {
+    if constexpr (I < 16) {
+      constexpr int kt = I & 3, ks = I >> 2;
+      wait_lgkm<PF - 1>();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[0]));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[ks]));
+      __builtin_amdgcn_sched_barrier(0);
+      read_item<I + PF>();
+      qk_step<I + 1>();
+    }
+  }
+  // P fragment of key chunk pair c = J >> 1 (kt = c >> 1, hf = c & 1): accumulator registers 8hf..8hf+7 of score tile kt
+  template <int C>
+  __device__ __forceinline__ void make_pf(f16x8& pf) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pf[e] = (_Float16)sc[C >> 1][(C & 1) * 8 + e];
+  }
+  // gfx950 needs wait states between a VALU write of a VGPR and an MFMA that reads it as an operand; hipcc inserts them
+  // for its own MFMAs but cannot see into inline asm (an MFMA issued right behind the v_cvt_pk of its B operand read
+  // the OLD register contents: NaNs, profiles/r02_call18_*).  So the P fragment of pair c + 1 is cast in the shadow of
+  // pair c's second MFMA, a whole step before its first use (two buffers).
+  template <int J>
+  __device__ __forceinline__ void pv_step(f16x8& pfa, f16x8& pfb) {
+    if constexpr (J < 16) {
+      constexpr int dt = J & 1, c = J >> 1;
+      f16x8& pf = (c & 1) ? pfb : pfa;
+      wait_lgkm<(15 - J < PF - 1 ? 15 - J : PF - 1)>();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (J < 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pf));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pf));
+      __builtin_amdgcn_sched_barrier(0);
+      read_item<J + 16 + PF>();
+      if constexpr (dt == 0 && c + 1 < 8) make_pf<(c + 1 < 8 ? c + 1 : 0)>((c & 1) ? pfa : pfb);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_step<J + 1>(pfa, pfb);
+    }
+  }
+  // nf[2dt + s]: fragment (dt, s) of this lane = output registers 8s..8s+7 of d tile dt, normalised, fp16 — the
+  // out-projection's B operand for k16-step 4h + 2dt + s (k-slot order)
+  __device__ __forceinline__ void run(f16x8 (&nf)[4]) {
     read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
-    step<0, STAGE0>();
+    qk_step<0>();
+    // MFMA results -> VALU reads: the wait states are tied to the accumulators (hipcc does not know the asm above
+    // is an MFMA and would otherwise schedule reads of its outputs in front of the nops)
+    asm volatile("s_nop 15" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
+    __builtin_amdgcn_sched_barrier(0);
+    // keys >= S (rows of the next layout, loaded clamped): key = 96 + (i & 3) + 8 (i >> 2) + 4 hi of the last tile
+    if (S == 125) {  // both datasets of the reference: 25 elements x 5 attributes
+      if (hi) { sc[3][13] = -INFINITY; sc[3][14] = -INFINITY; sc[3][15] = -INFINITY; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (96 + (i & 3) + 8 * (i >> 2) + 4 * hi >= S) sc[3][i] = -INFINITY;
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const f32x2 sc2 = {scale_log2e, scale_log2e};
+    const float nm = -mx * scale_log2e;
+    const f32x2 nm2 = {nm, nm};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 v = {sc[kt][i], sc[kt][i + 1]};
+        v = __builtin_elementwise_fma(v, sc2, nm2);
+        v.x = __builtin_amdgcn_exp2f(v.x);
+        v.y = __builtin_amdgcn_exp2f(v.y);
+        sc[kt][i] = v.x;
+        sc[kt][i + 1] = v.y;
+        sum2 += v;
+      }
+    float sum = sum2.x + sum2.y;
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    {
+      f16x8 pfa, pfb;
+      make_pf<0>(pfa);
+      asm volatile("s_nop 3" : "+v"(pfa));  // VALU write -> MFMA operand read
+      __builtin_amdgcn_sched_barrier(0);
+      pv_step<0>(pfa, pfb);
+      asm volatile("s_nop 15" : "+a"(o[0]), "+a"(o[1]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const f32x2 inv2 = {inv, inv};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 v = {o[dt][s2 * 8 + e], o[dt][s2 * 8 + e + 1]};
+          v = v * inv2;
+          nf[dt * 2 + s2][e] = (_Float16)v.x;
+          nf[dt * 2 + s2][e + 1] = (_Float16)v.y;
+        }
   }
 };
 
