@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
     }
     for (int i = tid; i < a.n_chunks * 32; i += 256) sb1[i] = a.b1[i];
     __syncthreads();
+    // (r02 negative result: issuing 40 of the 58 row loads before the table set-up and the rest two batches deep made
+    //  this phase 12 % LONGER — 32.2k vs 28.8k cycles: it is paced by the all-CU burst on HBM, not by the number of
+    //  exposed round trips: profiles/r02_call21_*)
     load_xf_ln_batched<KS, 8>(xf, a.ln, (int)m, hi, sp);
   }
   if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();

@@ -159,9 +159,10 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 //   * the next chunk's bias is read right after the barrier, i.e. older than the next chunk's item 0, so it has
 //     landed when chain A's first MFMA takes it as its C operand (counted lgkmcnt waits stay exact: +4 younger
 //     operations while waiting for items 55..59).
-template <int KS, int NT2, int DE, bool TM>
+template <int KS, int NT2, int DE, bool TM, int PFQ = 6>
 struct FfnStream {
-  static constexpr int PF = 6;
+  static constexpr int PF = PFQ;   // queue depth (NIT % PF == 0; lgkmcnt is a 4-bit counter: PF - 1 + 4 <= 15).
+                                   // r02: depth 10 instead of 6 changes nothing (profiles/r02_call21_*)
   static constexpr int NIT = KS + 1 + 2 * NT2;  // 60
   static constexpr int SYNC = NIT - PF;         // step whose read is the first of the next chunk
   static_assert(NIT % PF == 0, "queue slots must line up across chunks");
@@ -512,9 +513,9 @@ struct HeadStream {
 // SlabStream: the 16 K-slabs of the out-projection (2 x NT2 MFMAs on NT2 independent accumulator tiles each, see
 // SlabPipe) as one continuous pipeline of 16 x 30 items on the same three-stage ring (slab c in stage (S0 + c) % 3,
 // DMA two slabs ahead, vmcnt(8) + s_barrier per slab).
-template <int NT2, bool TM = false>
+template <int NT2, bool TM = false, int PFQ = 6>
 struct SlabStream {
-  static constexpr int NIT = 2 * NT2, PF = 6, NS = 16, SYNC = NIT - PF;
+  static constexpr int NIT = 2 * NT2, PF = PFQ, NS = 16, SYNC = NIT - PF;
   static_assert(NIT % PF == 0, "queue slots line up across slabs");
   f16x8 q[PF];
   unsigned aS[2], aS2[2];  // stage 0 (stage 1: + offset) / stage 2
@@ -561,9 +562,16 @@ struct SlabStream {
       step<G + 1, S0>();
     }
   }
+  template <int I, int S0>
+  __device__ __forceinline__ void prologue() {
+    if constexpr (I < PF) {
+      read_item<I, S0>();
+      prologue<I + 1, S0>();
+    }
+  }
   template <int S0>
   __device__ __forceinline__ void run() {
-    read_item<0, S0>(); read_item<1, S0>(); read_item<2, S0>(); read_item<3, S0>(); read_item<4, S0>(); read_item<5, S0>();
+    prologue<0, S0>();
     step<0, S0>();
   }
 };
