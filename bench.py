@@ -161,7 +161,8 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
         acc = []
         for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
-                if kernel_substr in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                if any(k in row.get("Kernel_Name", "") for k in kernel_substr.split("|")) and \
+                        row.get("Counter_Name") == counter:
                     acc.append(float(row["Counter_Value"]))
         subprocess.run(["rm", "-rf", out_dir])
         if not acc:
@@ -170,7 +171,9 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
     return vals, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), KB per launch"
 
 
-KERNEL_SYMBOL = {"layers_fused": "qkv_attn_k", "layer_fused": "qkv_attn_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
+# event-profile class -> substring of the kernel symbol in the PMC csv (layer_fused: the stream kernel of kernels_layer.hip
+# by default, the tile-by-tile qkv_attn_k under LDM_FUSED_ATTN=3: both match "layer_stream_k|qkv_attn_k" below)
+KERNEL_SYMBOL = {"layers_fused": "qkv_attn_k", "layer_fused": "layer_stream_k|qkv_attn_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
                  "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
                  "attention": "attn_"}
 

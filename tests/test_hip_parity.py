@@ -70,6 +70,33 @@ def test_denoiser_logits_vs_reference_golden(cuda, golden_dir, ds, precision):
     assert worst <= LOGIT_REL_TOL[precision]
 
 
+def test_layer_kernel_generations_agree(cuda, monkeypatch):
+    """The stream layer kernel (kernels_layer.hip, default) against the tile-by-tile fused layer kernel it replaced
+    (LDM_FUSED_ATTN=3) and the unfused row kernels (LDM_FUSED_ATTN=0): same weights, same tokens, every timestep
+    class of the golden file; all three are also within the reference tolerance of the fp64-softmax oracle.  The
+    generations differ only in fp16 rounding points (V bias folded into the out-projection bias, packed softmax
+    arithmetic, v_rcp_f32)."""
+    from layout_dm_amd.binding import Engine
+
+    spec, W = weights("rico25")
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    g = torch.Generator().manual_seed(11)
+    tokens = torch.randint(0, spec.n_class, (6, spec.seq_len), generator=g).int()
+    ref = R.denoiser_logits(W, spec, tokens.long(), 23)
+    outs = {}
+    for gen in ("5", "3", "0"):
+        monkeypatch.setenv("LDM_FUSED_ATTN", gen)
+        e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+                   n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
+                   max_batch=8)
+        e.load_state_dict(sd)
+        outs[gen] = e.denoise_logits(tokens, 23).cpu()
+        e.close()
+        assert _rel(outs[gen], ref) <= LOGIT_REL_TOL["fast"], gen
+    assert _rel(outs["5"], outs["3"]) <= 5e-4
+    assert _rel(outs["5"], outs["0"]) <= 5e-4
+
+
 @pytest.mark.parametrize("precision", ["exact", "fast"])
 def test_denoiser_ragged_batch_and_chunks(cuda, precision):
     """B not a multiple of the chunk / of the 128-row GEMM tile; rows must not interact."""
