@@ -1,0 +1,458 @@
+// The whole denoiser stack in ONE launch per step, one workgroup per LAYOUT, with the layout's rows RESIDENT in the
+// out-projection accumulators (15 tiles = 240 AGPRs per wave) from the embedding output to the input of the head.
+//
+// The per-layer kernel (kernels_layer.hip) spends a quarter of its cycles in three all-CU memory bursts per layer —
+// operand rows in, residual rows in, result rows out (3 x 59 MB per 256-layout launch, matrix pipes idle) — because the
+// attention heads park their output fragments in the AGPRs the out-projection accumulators need.  Here the
+// out-projection of a head runs RIGHT BEHIND its attention core (SlabPair: the head's two K-slabs), so nothing is
+// parked, the accumulators are alive through the whole layer and carry the residual stream:
+//
+//   prologue      one read of the rows in accumulator layout -> AdaLN fragments (k-slot K order) AND residual seed
+//   per layer     per head: HeadStream (k0 k1 v0 v1 q0 q1) -> AttnCoreV (all-VGPR core) -> SlabPair (acc += o_h·Wo_h^T)
+//                 LN2 + FFN chunk stream on the same accumulators (FfnStream)
+//                 layer boundary, in registers: statistics of x2, next layer's AdaLN fragments, next residual seed
+//   epilogue      statistics + one write of the rows
+//
+// Between layers nothing touches memory but the weight stream.  Weight image per layer: ldm_pack::pack_attn_head_image
+// (per head 6 in_proj tiles + its 2 out-proj slabs, 9-slot ring cycle: see SlabPair) and the k-slot FFN image.
+// Reference semantics: TransformerEncoder / Block.forward, trainer/models/transformer_utils.py:165-246.
+#include <cstdlib>
+
+#include "ldm_kernels.h"
+#include "ldm_dma.h"
+#include "ldm_pipes.h"
+
+namespace ldm {
+
+struct StackArgs {
+  FusedLayerSet ls;     // per layer: head image, in_proj bias, AdaLN scale / shift, b_out + W_out b_v, FFN image, b1 b2 g2 be2
+  float* x;             // [M, ldx] rows in / out (in place)
+  float2* stats;        // [M] (mean, rstd) in / out
+  int ldx, N, S, H, n_chunks;
+  float scale_log2e;
+};
+
+__device__ unsigned long long g_stack_phase[16];
+
+__device__ __forceinline__ int stack_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+template <bool TM>
+__global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
+  constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kvbuf = smem + 3 * STAGE;          // Ks 16 KiB | Vs 16 KiB behind the 3-stage weight ring
+  float* sbias = reinterpret_cast<float*>(kvbuf + 2 * KV_BYTES);  // [3*H*64]
+  float* sp = sbias + 3 * a.H * 64;        // AdaLN multiplier / shift (2 x LN_DP)
+  float* sbo = sp + 2 * LN_DP;             // b_out + W_out b_v + AdaLN shift [512]
+  float* sb1 = sbo + 512;                  // linear1 bias [n_chunks*32]
+  float* sp2 = sb1 + a.n_chunks * 32;      // norm2 gamma | beta (2 x LN_DP)
+  float* sb2 = sp2 + 2 * LN_DP;            // linear2 bias [512], zero beyond N
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, S = a.S, H = a.H, L = a.ls.n_layer;
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  const unsigned voff = (tid & 63) * 16;
+
+  unsigned long long t0 = 0, t_real0 = 0, s_pro = 0, s_stream = 0, s_core = 0, s_slab = 0, s_ln2 = 0, s_ffn = 0, s_bnd = 0, s_bnd_a = 0, s_bnd_b = 0, s_hsync = 0, s_ssync = 0;
+  if constexpr (TM) {
+    t0 = __builtin_amdgcn_s_memtime();
+    t_real0 = __builtin_amdgcn_s_memrealtime();
+  }
+  // parameter tables of one layer, global -> LDS: every load is issued before the first ds_write (a loop of dependent
+  // load / store pairs pays one L2 round trip per iteration: 15 of them made the layer boundary 17k cycles longer,
+  // profiles/r02_call23_*).  Every table is zero beyond N so that padded columns come out as exact zeros without masks.
+  auto stage_tables = [&](const FusedLayerW& w) {
+    float vb[6], v1[8], vs[2], vh[2], vo[2], vg[2], ve[2], v2[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vb[k] = w.bias_in[tid + 256 * k];  // 3 * 8 heads * 64 = 1536 entries (launcher: H == 8)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v1[k] = tid + 256 * k < a.n_chunks * 32 ? w.b1[tid + 256 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k;
+      const bool in = i < a.N;
+      vs[k] = in ? w.ada_scale[i] : -1.f;  // multiplier 1 + scale = 0 beyond N
+      vh[k] = in ? w.ada_shift[i] : 0.f;
+      vo[k] = in ? w.b_out[i] : 0.f;
+      vg[k] = in ? w.g2[i] : 0.f;
+      ve[k] = in ? w.be2[i] : 0.f;
+      v2[k] = in ? w.b2[i] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sbias[tid + 256 * k] = vb[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (tid + 256 * k < a.n_chunks * 32) sb1[tid + 256 * k] = v1[k];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 256 * k;
+      sp[i] = 1.0f + vs[k];
+      sp[LN_DP + i] = vh[k];
+      sbo[i] = vo[k] + vh[k];
+      sp2[i] = vg[k];
+      sp2[LN_DP + i] = ve[k];
+      sb2[i] = v2[k];
+    }
+  };
+  auto dma_first_tiles = [&](const char* img) {  // tiles 0 / 1 of a layer's first head -> stages 0 / 1
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + wave * 8192 + (k >> 1) * STAGE + (k & 1) * 4096,
+                                         lds0 + wave * 8192 + (k >> 1) * STAGE + (k & 1) * 4096);
+  };
+
+  f32x16 acc[NT2];     // the residual stream: x (raw rows) -> seed -> x1 -> x2 of the current layer -> ...
+#pragma unroll
+  for (int i = 8; i < 16; ++i) acc[NT2 - 1][i] = to_agpr(0.f);  // columns 464..479: padding
+  {
+    // ------------------------------------------------------------------ prologue: the rows, raw, in accumulator layout
+    // (lane (row, hi) owns columns 8g + 4hi .. +3 of every 8-column group g); every layer, the first included, then
+    // starts from the accumulators
+    const int lane = stack_lane_id();
+    const int r = lane & 31, hi = lane >> 5;
+    const int row = wave * 32 + r;
+    const size_t m = (size_t)b * S + (row < S ? row : S - 1);
+    constexpr int GB = 20;
+    const float* rrow = a.x + m * a.ldx + hi * 4;
+#pragma unroll
+    for (int g0 = 0; g0 < NGV; g0 += GB) {
+      float4 raw[GB];
+#pragma unroll
+      for (int i = 0; i < GB; ++i)
+        if (g0 + i < NGV) raw[i] = *reinterpret_cast<const float4*>(rrow + (g0 + i) * 8);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const int gg = g0 + i;
+        if (gg < NGV) {
+          const int t = gg >> 2, q0 = (gg & 3) * 4;
+          acc[t][q0 + 0] = to_agpr(raw[i].x);
+          acc[t][q0 + 1] = to_agpr(raw[i].y);
+          acc[t][q0 + 2] = to_agpr(raw[i].z);
+          acc[t][q0 + 3] = to_agpr(raw[i].w);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (TM) s_pro = __builtin_amdgcn_s_memtime() - t0;
+
+  for (int l = 0; l < L; ++l) {
+    const FusedLayerW& w = a.ls.w[l];
+    unsigned long long tL = 0;
+    if constexpr (TM) tL = __builtin_amdgcn_s_memtime();
+    f16x8 xf[KS];        // AdaLN(x) of this layer, fp16 MFMA B fragments (k-slot K order)
+    {
+      // ---------------------------------------------------------------- layer entry, in registers: acc = x (layer
+      // input).  Every wave is past the previous layer's FFN LDS reads and table reads: the ring takes this layer's first
+      // tiles, the tables its parameters; then row statistics, AdaLN fragments and the residual seed
+      // AdaLN(x) + b_out + W_out b_v from the same registers.
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      dma_first_tiles((const char*)w.img);
+      stage_tables(w);
+      __syncthreads();
+      unsigned long long tE1 = 0, tE2 = 0;
+      if constexpr (TM) tE1 = __builtin_amdgcn_s_memtime();
+      const int lane3 = stack_lane_id();
+      const int hi3 = lane3 >> 5;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < NGV; ++gg) {
+        const int t = gg >> 2, q0 = (gg & 3) * 4;
+        const float v0 = get_agpr(acc[t][q0 + 0]), v1 = get_agpr(acc[t][q0 + 1]);
+        const float v2 = get_agpr(acc[t][q0 + 2]), v3 = get_agpr(acc[t][q0 + 3]);
+        s1 += (v0 + v1) + (v2 + v3);
+        s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if constexpr (TM) tE2 = __builtin_amdgcn_s_memtime();
+      constexpr float kInvN3 = 1.0f / 464.0f;
+      const float mean = s1 * kInvN3;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean * mean, 0.f) + 1e-5f);
+      const float ra = rstd, rb = -mean * rstd;
+      const float* gmp = sp + hi3 * 4;
+      const float* tbp = sbo + hi3 * 4;
+#pragma unroll
+      for (int gg = 0; gg < NGV; ++gg) {
+        const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
+        const float4 gm = *reinterpret_cast<const float4*>(gmp + gg * 8);
+        const float4 sh = *reinterpret_cast<const float4*>(gmp + LN_DP + gg * 8);
+        const float4 tb = *reinterpret_cast<const float4*>(tbp + gg * 8);
+        const float n0 = fmaf(get_agpr(acc[t][q0 + 0]), ra, rb), n1 = fmaf(get_agpr(acc[t][q0 + 1]), ra, rb);
+        const float n2 = fmaf(get_agpr(acc[t][q0 + 2]), ra, rb), n3 = fmaf(get_agpr(acc[t][q0 + 3]), ra, rb);
+        xf[ks][e0 + 0] = (_Float16)fmaf(n0, gm.x, sh.x);
+        xf[ks][e0 + 1] = (_Float16)fmaf(n1, gm.y, sh.y);
+        xf[ks][e0 + 2] = (_Float16)fmaf(n2, gm.z, sh.z);
+        xf[ks][e0 + 3] = (_Float16)fmaf(n3, gm.w, sh.w);
+        LDM_SET_AGPR(acc[t][q0 + 0], fmaf(n0, gm.x, tb.x));  // in place: the old element dies here
+        LDM_SET_AGPR(acc[t][q0 + 1], fmaf(n1, gm.y, tb.y));
+        LDM_SET_AGPR(acc[t][q0 + 2], fmaf(n2, gm.z, tb.z));
+        LDM_SET_AGPR(acc[t][q0 + 3], fmaf(n3, gm.w, tb.w));
+        if (gg & 1) asm volatile("" : "+v"(xf[ks]));
+        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (TM) {
+        s_bnd += __builtin_amdgcn_s_memtime() - tL;
+        s_bnd_a += tE1 - tL;
+        s_bnd_b += tE2 - tE1;
+      }
+    }
+    {
+      // ---------------------------------------------------------------- attention block, head by head.  Every phase of
+      // a head re-derives its lane coordinates and LDS addresses from the hardware lane id (an asm hipcc cannot hoist):
+      // the stream's 21 address registers are then dead during the attention core — the register peak of the kernel,
+      // with the 240 accumulator AGPRs and the 116 fragment VGPRs alive around it — and the core's and the slab pair's
+      // during the stream.
+      // Whatever hipcc parked outside the register file around the layer entry comes back HERE: a use of every fragment
+      // and a builtin vmcnt(0) (which its scoreboard sees), so that it places no s_waitcnt vmcnt(n) of its own inside the
+      // streams, where such a wait would also wait for the weight DMA it cannot see (2 300 cycles per head:
+      // profiles/r02_call23_*)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(xf[k]));
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_sched_barrier(0);
+      // tiles 0 and 1 of the first head have landed (own pieces, then everybody's)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned kv0 = lds0 + 3 * STAGE;
+      for (int h = 0; h < H; ++h) {
+        unsigned long long tA = 0, tB = 0, tC = 0;
+        if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
+        const char* gimg = (const char*)w.img + (size_t)h * 8 * STAGE + wave * 8192;
+        f16x8 qf[4];
+        {
+          const int lane = stack_lane_id();
+          const int r = lane & 31, hi = lane >> 5;
+          const int row_in = wave * 32 + r;
+          HeadStream<TM, true> HS;
+          HS.xf = xf;
+          HS.qf = qf;
+          HS.voff = voff;
+          HS.lds_w = lds0 + wave * 8192;
+          HS.H = H;
+          HS.h = h;
+          HS.gimg = gimg;
+          HS.a_bias = lds0 + (unsigned)(reinterpret_cast<char*>(sbias) - smem) + hi * 16;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) HS.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+          const int sw = (row_in >> 1) & 7;
+          HS.aK[0] = kv0 + row_in * 128 + ((hi ^ sw) << 4);
+          HS.aK[1] = kv0 + row_in * 128 + (((2 + hi) ^ sw) << 4);
+          HS.aV[0] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + hi) ^ (r & 15)) << 4);
+          HS.aV[1] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + 2 + hi) ^ (r & 15)) << 4);
+          HS.run();
+          if constexpr (TM) s_hsync += HS.t_sync;
+        }
+        if constexpr (TM) tB = __builtin_amdgcn_s_memtime();
+        f16x8 nf[4];
+        {
+          const int lane = stack_lane_id();
+          const int r = lane & 31, hi = lane >> 5;
+          AttnCoreV AC;
+          AC.qf = qf;
+          AC.aKr = kv0 + r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+          AC.aVr = kv0 + KV_BYTES + r * 256 + ((hi ^ (r & 15)) << 4);
+          AC.scale_log2e = a.scale_log2e;
+          AC.S = S;
+          AC.hi = hi;
+          AC.run(nf);
+        }
+        if constexpr (TM) tC = __builtin_amdgcn_s_memtime();
+        {
+          const int lane = stack_lane_id();
+          const int r = lane & 31, hi = lane >> 5;
+          SlabPair<NT2, TM> SP;
+          SP.acc = acc;
+          SP.voff = voff;
+          SP.lds_w = lds0 + wave * 8192;
+          SP.aS[0] = lds0 + r * 64 + (((0 + hi) ^ ((r >> 2) & 3)) << 4);
+          SP.aS[1] = lds0 + r * 64 + (((2 + hi) ^ ((r >> 2) & 3)) << 4);
+          SP.nf = nf;
+          SP.gnext = gimg + (size_t)8 * STAGE;
+          SP.run();
+          if constexpr (TM) s_ssync += SP.t_sync;
+        }
+        if constexpr (TM) {
+          s_stream += tB - tA;
+          s_core += tC - tB;
+          s_slab += __builtin_amdgcn_s_memtime() - tC;
+        }
+      }
+    }
+    unsigned long long t_att = 0, t_ln2 = 0;
+    if constexpr (TM) t_att = __builtin_amdgcn_s_memtime();
+    // acc = x1.  Everybody is done with the attention ring / K,V buffers after this barrier (and the last head's
+    // padding prefetch has landed): the FFN ring (2 x 64 KiB at LDS 0) takes their place.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {  // FFN chunk 0 -> stage 0 (this wave's 16 KiB); lands while LN2 runs
+      const char* g0 = (const char*)w.ffn_img + wave * 16384;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dma_lin4(voff, g0 + k * 4096, lds0 + wave * 16384 + k * 4096);
+    }
+    const int lane2 = stack_lane_id();
+    const int r2 = lane2 & 31, hi2 = lane2 >> 5;
+    f16x8 xf2[KS];
+    {
+      // LN2 statistics of the row (this lane's half + lane^32), normalised fp16 fragments in k-slot order (groups
+      // 2ks, 2ks+1 of the accumulator layout ARE fragment ks), GEMM2 seed acc = x1 + b2
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < NGV; ++gg) {
+        const int t = gg >> 2, q0 = (gg & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[t][q0 + i];
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      constexpr float kInvN = 1.0f / 464.0f;  // N = 464 (launcher)
+      const float mean = s1 * kInvN;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN - mean * mean, 0.f) + 1e-5f);
+      const float* gp = sp2 + hi2 * 4;
+      const float* bp = sb2 + hi2 * 4;
+#pragma unroll
+      for (int gg = 0; gg < NGV; ++gg) {
+        const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
+        const float4 ga = *reinterpret_cast<const float4*>(gp + gg * 8);
+        const float4 be = *reinterpret_cast<const float4*>(gp + LN_DP + gg * 8);
+        const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
+        const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
+        xf2[ks][e0 + 0] = (_Float16)fmaf((v0 - mean) * rstd, ga.x, be.x);
+        xf2[ks][e0 + 1] = (_Float16)fmaf((v1 - mean) * rstd, ga.y, be.y);
+        xf2[ks][e0 + 2] = (_Float16)fmaf((v2 - mean) * rstd, ga.z, be.z);
+        xf2[ks][e0 + 3] = (_Float16)fmaf((v3 - mean) * rstd, ga.w, be.w);
+        LDM_SET_AGPR(acc[t][q0 + 0], v0 + bb.x);
+        LDM_SET_AGPR(acc[t][q0 + 1], v1 + bb.y);
+        LDM_SET_AGPR(acc[t][q0 + 2], v2 + bb.z);
+        LDM_SET_AGPR(acc[t][q0 + 3], v3 + bb.w);
+        if (gg & 1) asm volatile("" : "+v"(xf2[ks]));
+        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (TM) t_ln2 = __builtin_amdgcn_s_memtime();
+    {
+      // ---- FFN chunk loop: one continuous LDS-read / MFMA pipeline (ldm_pipes.h FfnStream)
+      unsigned relW1[8], relW2[2];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) relW1[k] = r2 * RKB + ((((k << 1) | hi2) ^ (r2 & 15)) << 4);
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) relW2[sx] = r2 * 64 + (((2 * sx + hi2) ^ ((r2 >> 2) & 3)) << 4);
+      const unsigned relB = lds0 + (unsigned)(reinterpret_cast<char*>(sb1) - smem) + hi2 * 16;
+      FfnStream<KS, NT2, 2, false> F;
+      F.xf = xf2;
+      F.acc = acc;
+      F.voff = voff;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // chunk 0 (own pieces), then everybody's
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) F.aW1[k] = lds0 + relW1[k];
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) F.aW2[sx] = lds0 + relW2[sx];
+      F.ab_next = relB;
+      // (same fence as in front of the head loop: every fragment back in its registers, hipcc's scoreboard drained)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(xf2[k]));
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_sched_barrier(0);
+      F.read_bias();
+      F.template prologue<0>();
+      const char* fimg = (const char*)w.ffn_img;
+      for (int c = 0; c < a.n_chunks; ++c) {
+        F.gnext = fimg + (size_t)(c + 1 == a.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+        F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
+        F.ab_next = relB + (c + 1 == a.n_chunks ? 0 : c + 1) * 128;
+        F.template step<0, true>();
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned long long t_ffn = 0;
+    if constexpr (TM) {
+      t_ffn = __builtin_amdgcn_s_memtime();
+      s_ln2 += t_ln2 - t_att;
+      s_ffn += t_ffn - t_ln2;
+    }
+  }
+  unsigned long long t_epi = 0;
+  if constexpr (TM) t_epi = __builtin_amdgcn_s_memtime();
+  {
+    // ---- x_out = acc: row statistics + stores (only the rows of this layout: padding rows of the last wave belong to
+    // the next layout)
+    const int lane3 = stack_lane_id();
+    const int r3 = lane3 & 31, hie = lane3 >> 5;
+    const int row3 = wave * 32 + r3;
+    const bool valid3 = row3 < S;
+    const size_t me = (size_t)b * S + (valid3 ? row3 : S - 1);
+    float* orow = a.x + me * a.ldx + hie * 4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < NGV; ++gg) {
+      const int t = gg >> 2, q0 = (gg & 3) * 4;
+      const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
+      s1 += (v0 + v1) + (v2 + v3);
+      s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      if (valid3) *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    constexpr float kInvN3 = 1.0f / 464.0f;
+    const float mean3 = s1 * kInvN3;
+    const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
+    if (valid3 && hie == 0 && a.stats) a.stats[me] = make_float2(mean3, rstd3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last FFN prefetch must land before the LDS is released
+  if constexpr (TM) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      atomicAdd(&g_stack_phase[0], 1ull);
+      atomicAdd(&g_stack_phase[1], t_end - t0);
+      atomicAdd(&g_stack_phase[2], t_real1 - t_real0);
+      atomicAdd(&g_stack_phase[3], s_pro);
+      atomicAdd(&g_stack_phase[4], s_stream);
+      atomicAdd(&g_stack_phase[5], s_core);
+      atomicAdd(&g_stack_phase[6], s_slab);
+      atomicAdd(&g_stack_phase[7], s_ln2);
+      atomicAdd(&g_stack_phase[8], s_ffn);
+      atomicAdd(&g_stack_phase[9], s_bnd);
+      atomicAdd(&g_stack_phase[10], t_end - t_epi);
+      atomicAdd(&g_stack_phase[11], s_bnd_a);
+      atomicAdd(&g_stack_phase[12], s_bnd_b);
+      atomicAdd(&g_stack_phase[13], s_hsync);
+      atomicAdd(&g_stack_phase[14], s_ssync);
+    }
+  }
+}
+
+void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
+                         int dh, hipStream_t st) {
+  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
+  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
+  auto kern = tm ? stack_stream_k<true> : stack_stream_k<false>;
+  allow_big_lds((const void*)kern);
+  StackArgs a{ls, x, stats_io, ldx, N, S, H, F / 32, 1.4426950408889634f / sqrtf((float)dh)};
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
+}
+
+void stack_phase_read(unsigned long long* out16) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stack_phase), 16 * sizeof(unsigned long long));
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stack_phase), z, sizeof(z));
+}
+
+}  // namespace ldm

@@ -182,6 +182,7 @@ struct ldm_handle {
     void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
     void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
     void* attn_slab_img_ks = nullptr;  // same with the in_proj K axis in k-slot order (multi-layer kernel)
+    void* attn_head_img_ks = nullptr;  // per head: 6 in_proj tiles (k-slot K) + its 2 out-proj slabs (stack kernel)
     float* b_in = nullptr;
     float* b_out_v = nullptr;  // out_proj bias + W_out b_v (the stream layer kernel never adds the V bias: softmax rows sum to 1)
   };
@@ -189,13 +190,15 @@ struct ldm_handle {
   __half* fast_head = nullptr;
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
-  int fused_attn = 5;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
+  int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
                        // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
                        // 4: ALL layers in one launch per step (4-layer stacks; opt-in through LDM_FUSED_ATTN=4: measured
                        //    +0.4 % only — the 4x unrolled code no longer fits the instruction cache and the tile
                        //    runs slow down by as much as the skipped operand reloads save: profiles/r02_call12_*)
-                       // 5: the whole layer per launch as CONTINUOUS per-head / slab / chunk streams (kernels_layer.hip;
-                       //    default: 220 -> 205 us per launch, profiles/r02_call14_*)
+                       // 5: the whole layer per launch as CONTINUOUS per-head / slab / chunk streams (kernels_layer.hip:
+                       //    220 -> 200 us per launch, profiles/r02_call14_*, r02_call20_*)
+                       // 6: ALL layers per launch with the rows RESIDENT in the out-projection accumulators
+                       //    (kernels_stack.hip, default: 4 x 199 -> 743..766 us per step, profiles/r02_call23_*, r02_call25_*)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -412,6 +415,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
     if (h->fused_attn >= 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
     if (h->fused_attn == 4 && h->L != 4) h->fused_attn = 3;  // the multi-layer kernel is unrolled for 4 layers
+    if (h->fused_attn == 6 && h->L > 8) h->fused_attn = 5;   // FusedLayerSet holds 8 layers
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
@@ -649,7 +653,9 @@ static int build_fast_weights(ldm_handle* h) {
         if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, kslot, &w_in_ks))) return rc;
         const std::vector<uint16_t> hin_ks = download16(h, w_in_ks, (size_t)3 * HD * Dq, &rc);
         if (rc) return rc;
-        if ((rc = upload_image(h, pack_attn_slab_image(hin_ks.data(), hout.data(), H), &f.attn_slab_img_ks))) return rc;
+        const std::vector<uint16_t> slab_ks = pack_attn_slab_image(hin_ks.data(), hout.data(), H);
+        if ((rc = upload_image(h, slab_ks, &f.attn_slab_img_ks))) return rc;
+        if ((rc = upload_image(h, ldm_pack::pack_attn_head_image(slab_ks, H), &f.attn_head_img_ks))) return rc;
       }
     }
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
@@ -765,6 +771,23 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     ldm_handle::Scope sc(h, st, "embed_stats", 0, (double)M * D * 8);
     launch_layernorm(a, st);
   }
+  if (h->fused_attn == 6) {
+    // the whole stack in ONE launch (kernels_stack.hip): a layout's rows stay in their workgroup's out-projection
+    // accumulators from the embedding output to the input of the head
+    FusedLayerSet ls{};
+    ls.n_layer = h->L;
+    for (int i = 0; i < h->L; ++i) {
+      const LayerW& w = h->layers[i];
+      const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+      ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
+                            h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
+    }
+    ldm_handle::Scope sc(h, st, "layers_fused",
+                         h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
+                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)),
+                         (double)M * D * 8);
+    launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, st);
+  }
   if (h->fused_attn == 4) {
     // the whole stack in ONE launch, in place on P / stats_a: a layout's rows stay in their workgroup's registers
     // from layer to layer
@@ -782,7 +805,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
                          (double)M * D * 4 * (1 + 2 * h->L));
     launch_layers_fused(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, st);
   }
-  for (int i = 0; i < (h->fused_attn == 4 ? 0 : h->L); ++i) {
+  for (int i = 0; i < ((h->fused_attn == 4 || h->fused_attn == 6) ? 0 : h->L); ++i) {
     const LayerW& w = h->layers[i];
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
@@ -1626,11 +1649,13 @@ namespace ldm {
 void ffn_phase_read(unsigned long long* out12);
 void attn_phase_read(unsigned long long* out16);
 void layer_phase_read(unsigned long long* out16);
+void stack_phase_read(unsigned long long* out16);
 }  // namespace ldm
 // dev hooks: s_memtime phase sums of the instrumented kernel variants (LDM_FFN_DBG=3 / LDM_ATTN_TM=1)
 extern "C" void ldm_dev_ffn_phases(unsigned long long* out12) { ldm::ffn_phase_read(out12); }
 extern "C" void ldm_dev_attn_phases(unsigned long long* out16) { ldm::attn_phase_read(out16); }
 extern "C" void ldm_dev_layer_phases(unsigned long long* out16) { ldm::layer_phase_read(out16); }
+extern "C" void ldm_dev_stack_phases(unsigned long long* out16) { ldm::stack_phase_read(out16); }
 
 extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
   const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;

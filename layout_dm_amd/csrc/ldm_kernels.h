@@ -127,6 +127,10 @@ void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, co
 void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
                          const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
                          float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
+// the whole stack in one launch with the rows resident in the out-projection accumulators (kernels_stack.hip):
+// ls.w[i].img = ldm_pack::pack_attn_head_image, .b_out = out_proj bias + W_out b_v
+void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
+                         int dh, hipStream_t st);
 int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,

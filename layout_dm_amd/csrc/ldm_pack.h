@@ -96,4 +96,21 @@ inline std::vector<uint16_t> pack_attn_slab_image(const uint16_t* w_in, const ui
   return img;
 }
 
+// Attention image of the stack kernel (kernels_stack.hip): per head EIGHT consecutive 32-KiB stages — the six in_proj
+// tiles k0 k1 v0 v1 q0 q1 (K axis in k-slot order: the kernel builds its activation fragments from accumulator-layout
+// registers) followed by the head's two out-projection K-slabs (k chunks 2h, 2h + 1 of pack_attn_slab_image) — so that
+// the out-projection of a head runs right behind its attention core; then two zero stages (the last head's "next head"
+// prefetch needs no branch).  Built from a pack_attn_slab_image image.
+inline std::vector<uint16_t> pack_attn_head_image(const std::vector<uint16_t>& slab_img, int H) {
+  const size_t st = 16384;  // halfs per 32-KiB stage
+  std::vector<uint16_t> img((size_t)(H * 8 + 2) * st, 0);
+  for (int hh = 0; hh < H; ++hh) {
+    for (int j = 0; j < 6; ++j)
+      memcpy(img.data() + (size_t)(hh * 8 + j) * st, slab_img.data() + (size_t)(hh * 6 + j) * st, st * 2);
+    for (int d = 0; d < 2; ++d)
+      memcpy(img.data() + (size_t)(hh * 8 + 6 + d) * st, slab_img.data() + (size_t)(H * 6 + 2 * hh + d) * st, st * 2);
+  }
+  return img;
+}
+
 }  // namespace ldm_pack

@@ -52,6 +52,16 @@ __device__ __forceinline__ void park_agpr4(f16x8& dst, const f16x8& v) {
   asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(out[3]) : "v"(in[3]));
   dst = __builtin_bit_cast(f16x8, out);
 }
+// scalar form of park_agpr4: overwrite an accumulator element in the AGPR that holds it (a macro: a vector element
+// cannot bind to a reference)
+#define LDM_SET_AGPR(dst, v) asm volatile("v_accvgpr_write_b32 %0, %1" : "+a"(dst) : "v"(v))
+// read an accumulator element through a volatile asm: hipcc otherwise merges the reads of a two-pass loop over the
+// accumulators (statistics, then transform) and keeps all 232 values of the first pass alive in VGPRs
+__device__ __forceinline__ float get_agpr(float a) {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
 __device__ __forceinline__ float to_agpr(float v) {
   float r;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
@@ -357,7 +367,11 @@ namespace ldm {
 //     older in the LDS queue than the tile's item 0); the V bias is not applied here at all: softmax rows sum to 1,
 //     so P·(V + 1 b^T) = P·V + b^T, a constant the host folds into the out-projection bias (b_out + W_out b_v).
 // lgkmcnt bookkeeping: every wait is counted exactly from a constexpr replay of the issue order (younger()).
-template <bool TM = false>
+// LEAN (stack kernel, where no AGPR is free to absorb a register peak): the K / Q bias is added in the tile's epilogue
+// (read PF + 1 steps ahead of it: the counted wait of the step before the epilogue then covers it) instead of entering through the first MFMA's C operand — no 16-register bias tuple
+// beside the two accumulators — and the third ring stage is addressed by a v_add in front of the read instead of a
+// second address set.
+template <bool TM = false, bool LEAN = false>
 struct HeadStream {
   static constexpr int KS = 29, NT = 6, NIT = KS * NT, PF = 6;
   static constexpr int SYNC = KS - PF;   // local step of the per-tile barrier
@@ -380,7 +394,11 @@ struct HeadStream {
 
   static constexpr bool tile_has_bias(int j) { return j < 2 || j >= 4; }
   // bias reads issued at (global) step s: at the barrier step of tile j for tile j + 1
-  static constexpr int bias_at(int s) { return (s % KS == SYNC && s / KS + 1 < NT && tile_has_bias(s / KS + 1)) ? 4 : 0; }
+  static constexpr int bias_at(int s) {
+    const int j = s / KS, it = s % KS;
+    if (LEAN) return ((it == EPI0 - PF - 1 && j >= 1 && tile_has_bias(j - 1)) || (j == NT - 1 && it == SYNC)) ? 4 : 0;
+    return (it == SYNC && j + 1 < NT && tile_has_bias(j + 1)) ? 4 : 0;
+  }
   // ds_write_b128 issued at step s (epilogue of the previous tile when that was a K or V tile: two stores)
   static constexpr int writes_at(int s) {
     const int j = s / KS, it = s % KS;
@@ -408,7 +426,8 @@ struct HeadStream {
   template <int G>
   __device__ __forceinline__ void read_item() {
     constexpr int IT = G % KS, ST = (G / KS) % 3;
-    if constexpr (ST == 2) dsr128<256 * (IT >> 3)>(q[G % PF], aW2[IT & 7]);
+    if constexpr (ST == 2 && LEAN) dsr128<256 * (IT >> 3)>(q[G % PF], aW[IT & 7] + 2u * TILE_STAGE);
+    else if constexpr (ST == 2) dsr128<256 * (IT >> 3)>(q[G % PF], aW2[IT & 7]);
     else dsr128<256 * (IT >> 3) + ST * TILE_STAGE>(q[G % PF], aW[IT & 7]);
   }
   // bias of tile j (K: rows H*64.., Q: rows 0..) for head h, d-half t = j & 1 -> bb (assembled into the C operand
@@ -432,8 +451,13 @@ struct HeadStream {
   template <int J, int SL>
   __device__ __forceinline__ void epi_slice(const f32x16& a, f16x8& v0, f16x8& v1) {
     constexpr int t = J & 1;
-    if constexpr (SL == 0) v0 = cvt8n<0>(a);
-    if constexpr (SL == 1) v1 = cvt8n<8>(a);
+    if constexpr (LEAN && tile_has_bias(J)) {
+      if constexpr (SL == 0) v0 = cvt8<0>(a, bb[0], bb[1]);
+      if constexpr (SL == 1) v1 = cvt8<8>(a, bb[2], bb[3]);
+    } else {
+      if constexpr (SL == 0) v0 = cvt8n<0>(a);
+      if constexpr (SL == 1) v1 = cvt8n<8>(a);
+    }
     if constexpr (J < 2) {  // K tile: lane (key row, hi) holds d = 32t + 8rq + 4hi + i -> k-slot chunks 4t + hi, 4t + 2 + hi
       if constexpr (SL == 2) asm volatile("ds_write_b128 %0, %1" ::"v"(aK[0] ^ (unsigned)(t << 6)), "v"(v0) : "memory");
       if constexpr (SL == 5) asm volatile("ds_write_b128 %0, %1" ::"v"(aK[1] ^ (unsigned)(t << 6)), "v"(v1) : "memory");
@@ -458,6 +482,8 @@ struct HeadStream {
       if constexpr (IT == 0) {
         if constexpr (SWAP) {
           asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(xf[0]), "v"(cur));
+        } else if constexpr (LEAN) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(cur), "v"(xf[0]));
         } else {
           f32x16 bv;
 #pragma unroll
@@ -480,8 +506,10 @@ struct HeadStream {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
-        if constexpr (J + 1 < NT && tile_has_bias(J + 1)) read_bias<(J + 1 < NT ? J + 1 : 0)>();
+        if constexpr (!LEAN && J + 1 < NT && tile_has_bias(J + 1)) read_bias<(J + 1 < NT ? J + 1 : 0)>();
+        if constexpr (LEAN && J == NT - 1) read_bias<NT - 1>();  // q1's own bias, for the epilogue behind the stream
       }
+      if constexpr (LEAN && IT == EPI0 - PF - 1 && J >= 1 && tile_has_bias(J >= 1 ? J - 1 : 0)) read_bias<(J >= 1 ? J - 1 : 0)>();
       if constexpr (G + PF < NIT) read_item<G + PF>();
       // DMA of tile J + 2 into stage (J + 2) % 3 (the one tile J - 1 was read from): pieces at local steps 1-4, 6-9
       constexpr unsigned st = (unsigned)((J + 2) % 3) * TILE_STAGE;
@@ -497,15 +525,20 @@ struct HeadStream {
   }
   // head prologue: bias of tile 0, then the first PF fragments (the stage was certified by the previous barrier)
   __device__ __forceinline__ void run() {
-    read_bias<0>();
+    if constexpr (!LEAN) read_bias<0>();
     read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
     f16x8 e0, e1;
     step<0>(e0, e1);
     // q1's epilogue (exposed: the attention core needs the fragments now)
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accB));  // (tied to the accumulator: see AttnCore::run)
     __builtin_amdgcn_sched_barrier(0);
-    qf[2] = cvt8n<0>(accB);
-    qf[3] = cvt8n<8>(accB);
+    if constexpr (LEAN) {
+      qf[2] = cvt8<0>(accB, bb[0], bb[1]);
+      qf[3] = cvt8<8>(accB, bb[2], bb[3]);
+    } else {
+      qf[2] = cvt8n<0>(accB);
+      qf[3] = cvt8n<8>(accB);
+    }
   }
 };
 
@@ -715,6 +748,190 @@ struct AttnCore {
           nf[dt * 2 + s2][e] = (_Float16)v.x;
           nf[dt * 2 + s2][e + 1] = (_Float16)v.y;
         }
+  }
+};
+
+}  // namespace ldm
+
+namespace ldm {
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the STACK kernel (kernels_stack.hip): the out-projection accumulators (240 AGPRs) stay alive
+// through the attention heads — they carry a layout's rows from layer to layer — so the attention core may use arch
+// VGPRs only and the out-projection of a head runs right behind its core.
+//
+// AttnCoreV: AttnCore with every tile in arch VGPRs.  The probabilities are cast to their fp16 MFMA fragments key tile
+// by key tile right behind the exponentials (the 64 score registers shrink to 32 fragment registers before the two
+// output tiles come alive), which also puts every VALU write of an MFMA operand many instructions ahead of its use.
+struct AttnCoreV {
+  static constexpr int PF = 4;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f16x8 q[PF];
+  unsigned aKr;        // Ks + r*128 + ((hi ^ ksw) << 4): k16-step ks by XOR (ks << 5), key tile kt by offset kt * 4 KiB
+  unsigned aVr;        // Vs + r*256 + ((hi ^ (r & 15)) << 4): key chunk (4kt + 2hf) by XOR, d tile by offset 8 KiB
+  const f16x8* qf;     // [4] Q fragments (B operand of S^T)
+  f32x16 sc[4], o[2];
+  f16x8 pfr[8];        // P fragments: pair c = 2kt + hf
+  float scale_log2e;
+  int S, hi;
+
+  template <int I>  // I in [0, 32): 16 K fragments (kt = I & 3, ks = I >> 2), then 16 V^T fragments (dt, hf, kt)
+  __device__ __forceinline__ void read_item() {
+    if constexpr (I < 16) {
+      dsr128<(I & 3) * 4096>(q[I % PF], aKr ^ (unsigned)((I >> 2) << 5));
+    } else if constexpr (I < 32) {
+      constexpr int J = I - 16, dt = J & 1, hf = (J >> 1) & 1, kt = J >> 2;
+      dsr128<dt * 8192>(q[I % PF], aVr ^ (unsigned)((kt * 4 + hf * 2) << 4));
+    }
+  }
+  template <int I>
+  __device__ __forceinline__ void qk_step() {
+    if constexpr (I < 16) {
+      constexpr int kt = I & 3, ks = I >> 2;
+      wait_lgkm<PF - 1>();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[0]));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[ks]));
+      __builtin_amdgcn_sched_barrier(0);
+      read_item<I + PF>();
+      qk_step<I + 1>();
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void pv_step() {
+    if constexpr (J < 16) {
+      constexpr int dt = J & 1, c = J >> 1;
+      wait_lgkm<(15 - J < PF - 1 ? 15 - J : PF - 1)>();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (J < 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pfr[c]));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pfr[c]));
+      __builtin_amdgcn_sched_barrier(0);
+      read_item<J + 16 + PF>();
+      pv_step<J + 1>();
+    }
+  }
+  __device__ __forceinline__ void run(f16x8 (&nf)[4]) {
+    read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>();
+    qk_step<0>();
+    asm volatile("s_nop 15" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));  // MFMA results -> VALU reads
+    __builtin_amdgcn_sched_barrier(0);
+    if (S == 125) {
+      if (hi) { sc[3][13] = -INFINITY; sc[3][14] = -INFINITY; sc[3][15] = -INFINITY; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (96 + (i & 3) + 8 * (i >> 2) + 4 * hi >= S) sc[3][i] = -INFINITY;
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const f32x2 sc2 = {scale_log2e, scale_log2e};
+    const float nm = -mx * scale_log2e;
+    const f32x2 nm2 = {nm, nm};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 v = {sc[kt][i], sc[kt][i + 1]};
+        v = __builtin_elementwise_fma(v, sc2, nm2);
+        v.x = __builtin_amdgcn_exp2f(v.x);
+        v.y = __builtin_amdgcn_exp2f(v.y);
+        sum2 += v;
+        pfr[2 * kt + (i >> 3)][i & 7] = (_Float16)v.x;
+        pfr[2 * kt + (i >> 3)][(i & 7) + 1] = (_Float16)v.y;
+      }
+      asm volatile("" : "+v"(pfr[2 * kt]), "+v"(pfr[2 * kt + 1]));  // pin: the scores of this key tile die here
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float sum = sum2.x + sum2.y;
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    pv_step<0>();
+    asm volatile("s_nop 15" : "+v"(o[0]), "+v"(o[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 inv2 = {inv, inv};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 v = {o[dt][s2 * 8 + e], o[dt][s2 * 8 + e + 1]};
+          v = v * inv2;
+          nf[dt * 2 + s2][e] = (_Float16)v.x;
+          nf[dt * 2 + s2][e + 1] = (_Float16)v.y;
+        }
+  }
+};
+
+// SlabPair: the two out-projection K-slabs of ONE head (d halves 0 / 1; ring stages 0 / 1 = slots 6 / 7 of the head's
+// 9-slot cycle) as one 60-item pipeline on the persistent accumulator tiles, directly behind the head's attention core.
+// B operands: the head's four normalised output fragments nf[2dt + sx].  While slab 1 runs, tile 0 of the NEXT head
+// goes into stage 0 (slab 0's reads were all issued before slab 0's barrier); at slab 1's barrier step that tile and
+// slab 1's reads are certified and tile 1 of the next head follows into stage 1 — so the next HeadStream starts with
+// its first tile resident and its second in flight, exactly the state its vmcnt(8) protocol expects.
+template <int NT2, bool TM = false>
+struct SlabPair {
+  static constexpr int NIT = 2 * NT2, PF = 6, SYNC = NIT - PF;
+  f16x8 q[PF];
+  unsigned aS[2];       // stage 0 addresses of the two k16-steps (stage 1: + offset)
+  f32x16* acc;
+  const f16x8* nf;      // [4]
+  const char* gnext;    // image of the next head's tile 0 + wave * 8 KiB (uniform)
+  unsigned lds_w;       // lds0 + wave * 8 KiB
+  unsigned voff;
+  unsigned long long t_sync = 0;
+
+  template <int G>
+  __device__ __forceinline__ void read_item() {
+    constexpr int C = G / NIT, IT = G % NIT, sx = IT / NT2, t = IT % NT2;
+    dsr128<t * 2048 + C * TILE_STAGE>(q[G % PF], aS[sx]);
+  }
+  template <int G>
+  __device__ __forceinline__ void step() {
+    if constexpr (G < 2 * NIT) {
+      constexpr int C = G / NIT, IT = G % NIT, sx = IT / NT2, t = IT % NT2;
+      constexpr int left = 2 * NIT - 1 - G;
+      wait_lgkm<(left < PF - 1 ? left : PF - 1)>();
+      __builtin_amdgcn_sched_barrier(0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[G % PF], nf[2 * C + sx], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT == SYNC) {
+        unsigned long long tA = 0;
+        if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // C = 0: slab 1 has landed; C = 1: the next head's tile 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
+        if constexpr (C == 1) {  // every read of slab 1 is issued: its stage takes the next head's tile 1
+          dma_lin4(voff, gnext + TILE_STAGE, lds_w + TILE_STAGE);
+          dma_lin4(voff, gnext + TILE_STAGE + 4096, lds_w + TILE_STAGE + 4096);
+        }
+      }
+      if constexpr (G + PF < 2 * NIT) read_item<G + PF>();
+      if constexpr (C == 1) {  // next head's tile 0 -> stage 0
+        if constexpr (IT == 0) dma_set_m0(lds_w);
+        if constexpr (IT == 5) dma_set_m0(lds_w + 4096);
+        if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gnext);
+        if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gnext + 4096);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      step<G + 1>();
+    }
+  }
+  __device__ __forceinline__ void run() {
+    read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
+    step<0>();
   }
 };
 

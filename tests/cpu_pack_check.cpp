@@ -158,6 +158,18 @@ int main() {
       }
     }
     for (size_t i = (size_t)48 * 16384; i < slk.size(); ++i) CHECK(slk[i] == sl[i], "k-slot image: out-proj slabs must not change");
+    // stack kernel: per head 6 in_proj tiles (k-slot K) + its two out-proj slabs, then two zero stages
+    const std::vector<uint16_t> hd = ldm_pack::pack_attn_head_image(slk, H);
+    CHECK(hd.size() == (size_t)(H * 8 + 2) * 16384, "head image size");
+    for (int hh = 0; hh < H; ++hh) {
+      for (int j6 = 0; j6 < 6; ++j6)
+        CHECK(memcmp(hd.data() + (size_t)(hh * 8 + j6) * 16384, slk.data() + (size_t)(hh * 6 + j6) * 16384, 32768) == 0,
+              "head image: tile %d of head %d", j6, hh);
+      for (int d2 = 0; d2 < 2; ++d2)
+        CHECK(memcmp(hd.data() + (size_t)(hh * 8 + 6 + d2) * 16384, slk.data() + (size_t)(48 + 2 * hh + d2) * 16384, 32768) == 0,
+              "head image: slab %d of head %d", d2, hh);
+    }
+    for (size_t i = (size_t)H * 8 * 16384; i < hd.size(); ++i) CHECK(hd[i] == 0, "head image padding stages not zero");
   }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");

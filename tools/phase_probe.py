@@ -24,6 +24,7 @@ a16 = (C.c_ulonglong * 16)()
 lib.ldm_dev_ffn_phases(f8)
 lib.ldm_dev_attn_phases(a16)  # reset after warm-up
 lib.ldm_dev_layer_phases((C.c_ulonglong * 16)())
+lib.ldm_dev_stack_phases((C.c_ulonglong * 16)())
 N = 3
 for _ in range(N):
     e.denoise_logits(tokens, 50)
@@ -77,5 +78,22 @@ if l[0]:  # stream version of the fused layer kernel (LDM_FUSED_ATTN=5)
         print(f"   {name:24s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per item {v/n/k:8.1f}")
     print(f"   of which: per-tile sync (vmcnt+barrier) {l[10]/n/48:7.1f} cyc per tile, per-slab sync {l[11]/n/15:7.1f} cyc per slab, per-FFN-chunk sync {l[12]/n/58:7.1f}")
     mf = (48 * 29 + 16 * 30 + 8 * 32 + 58 * 59) * 32
+    print(f"   ideal MFMA cycles/block = {mf}  ({100*mf/tot:.1f}% of block)")
+k16 = (C.c_ulonglong * 16)()
+lib.ldm_dev_stack_phases(k16)
+k = list(k16)
+if k[0]:  # stack kernel (LDM_FUSED_ATTN=6): all layers per launch, rows resident in the accumulators
+    n = k[0]
+    clk = k[1] / max(k[2], 1) * 100.0
+    tot = k[1] / n
+    print(f"stack: blocks={n} cycles/block={tot:.0f} clock={clk:.0f} MHz  us/block={tot/clk:.1f}  (4 layers per block)")
+    names = ("prologue", "head streams (174 MFMA)", "attn core", "slab pairs (60 MFMA)", "LN2 (+ chunk-0 DMA)", "FFN chunk loop",
+             "layer boundary", "store epilogue")
+    per = (1, 32, 32, 32, 4, 232, 4, 1)
+    for name, v, kk in zip(names, k[3:11], per):
+        print(f"   {name:24s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per item {v/n/kk:8.1f}")
+    print(f"   layer entry: barrier + first tiles + tables {k[11]/n/4:8.1f}, statistics {k[12]/n/4:8.1f}, transform {(k[9]-k[11]-k[12])/n/4:8.1f} cycles per layer")
+    print(f"   sync waits: {k[13]/n/192:6.1f} per tile, {k[14]/n/64:6.1f} per slab")
+    mf = 4 * (48 * 29 + 16 * 30 + 8 * 32 + 58 * 59) * 32
     print(f"   ideal MFMA cycles/block = {mf}  ({100*mf/tot:.1f}% of block)")
 e.close()
