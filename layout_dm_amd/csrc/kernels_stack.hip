@@ -162,13 +162,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       const int hi3 = lane3 >> 5;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4;
-        const float v0 = get_agpr(acc[t][q0 + 0]), v1 = get_agpr(acc[t][q0 + 1]);
-        const float v2 = get_agpr(acc[t][q0 + 2]), v3 = get_agpr(acc[t][q0 + 3]);
-        s1 += (v0 + v1) + (v2 + v3);
-        s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT2; ++t) {
+        const f32x16 tile = acc[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (t * 4 + (i >> 2) < NGV) {
+            s1 += tile[i];
+            s2 += tile[i] * tile[i];
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -180,23 +182,32 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       const float* gmp = sp + hi3 * 4;
       const float* tbp = sbo + hi3 * 4;
 #pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
-        const float4 gm = *reinterpret_cast<const float4*>(gmp + gg * 8);
-        const float4 sh = *reinterpret_cast<const float4*>(gmp + LN_DP + gg * 8);
-        const float4 tb = *reinterpret_cast<const float4*>(tbp + gg * 8);
-        const float n0 = fmaf(get_agpr(acc[t][q0 + 0]), ra, rb), n1 = fmaf(get_agpr(acc[t][q0 + 1]), ra, rb);
-        const float n2 = fmaf(get_agpr(acc[t][q0 + 2]), ra, rb), n3 = fmaf(get_agpr(acc[t][q0 + 3]), ra, rb);
-        xf[ks][e0 + 0] = (_Float16)fmaf(n0, gm.x, sh.x);
-        xf[ks][e0 + 1] = (_Float16)fmaf(n1, gm.y, sh.y);
-        xf[ks][e0 + 2] = (_Float16)fmaf(n2, gm.z, sh.z);
-        xf[ks][e0 + 3] = (_Float16)fmaf(n3, gm.w, sh.w);
-        LDM_SET_AGPR(acc[t][q0 + 0], fmaf(n0, gm.x, tb.x));  // in place: the old element dies here
-        LDM_SET_AGPR(acc[t][q0 + 1], fmaf(n1, gm.y, tb.y));
-        LDM_SET_AGPR(acc[t][q0 + 2], fmaf(n2, gm.z, tb.z));
-        LDM_SET_AGPR(acc[t][q0 + 3], fmaf(n3, gm.w, tb.w));
-        if (gg & 1) asm volatile("" : "+v"(xf[ks]));
-        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT2; ++t) {
+        f32x16 tile = acc[t];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int gg = t * 4 + g;
+          if (gg < NGV) {
+            const int ks = gg >> 1, e0 = (gg & 1) * 4;
+            const float4 gm = *reinterpret_cast<const float4*>(gmp + gg * 8);
+            const float4 sh = *reinterpret_cast<const float4*>(gmp + LN_DP + gg * 8);
+            const float4 tb = *reinterpret_cast<const float4*>(tbp + gg * 8);
+            const float n0 = fmaf(tile[g * 4 + 0], ra, rb), n1 = fmaf(tile[g * 4 + 1], ra, rb);
+            const float n2 = fmaf(tile[g * 4 + 2], ra, rb), n3 = fmaf(tile[g * 4 + 3], ra, rb);
+            xf[ks][e0 + 0] = (_Float16)fmaf(n0, gm.x, sh.x);
+            xf[ks][e0 + 1] = (_Float16)fmaf(n1, gm.y, sh.y);
+            xf[ks][e0 + 2] = (_Float16)fmaf(n2, gm.z, sh.z);
+            xf[ks][e0 + 3] = (_Float16)fmaf(n3, gm.w, sh.w);
+            tile[g * 4 + 0] = fmaf(n0, gm.x, tb.x);
+            tile[g * 4 + 1] = fmaf(n1, gm.y, tb.y);
+            tile[g * 4 + 2] = fmaf(n2, gm.z, tb.z);
+            tile[g * 4 + 3] = fmaf(n3, gm.w, tb.w);
+            if (gg & 1) asm volatile("" : "+v"(xf[ks]));
+          }
+        }
+        asm volatile("" : "+a"(tile));
+        acc[t] = tile;
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (TM) {
         s_bnd += __builtin_amdgcn_s_memtime() - tL;
@@ -305,16 +316,19 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     {
       // LN2 statistics of the row (this lane's half + lane^32), normalised fp16 fragments in k-slot order (groups
       // 2ks, 2ks+1 of the accumulator layout ARE fragment ks), GEMM2 seed acc = x1 + b2
+      // (tile by tile: whole-tuple copies between the accumulator AGPRs and arch VGPRs, no sub-register asm operands —
+      //  with element-wise accumulator updates hipcc split the live ranges of half the tiles through scratch)
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4;
+      for (int t = 0; t < NT2; ++t) {
+        const f32x16 tile = acc[t];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[t][q0 + i];
-          s1 += v;
-          s2 += v * v;
-        }
+        for (int i = 0; i < 16; ++i)
+          if (t * 4 + (i >> 2) < NGV) {
+            s1 += tile[i];
+            s2 += tile[i] * tile[i];
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -324,22 +338,31 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       const float* gp = sp2 + hi2 * 4;
       const float* bp = sb2 + hi2 * 4;
 #pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
-        const float4 ga = *reinterpret_cast<const float4*>(gp + gg * 8);
-        const float4 be = *reinterpret_cast<const float4*>(gp + LN_DP + gg * 8);
-        const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
-        const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
-        xf2[ks][e0 + 0] = (_Float16)fmaf((v0 - mean) * rstd, ga.x, be.x);
-        xf2[ks][e0 + 1] = (_Float16)fmaf((v1 - mean) * rstd, ga.y, be.y);
-        xf2[ks][e0 + 2] = (_Float16)fmaf((v2 - mean) * rstd, ga.z, be.z);
-        xf2[ks][e0 + 3] = (_Float16)fmaf((v3 - mean) * rstd, ga.w, be.w);
-        LDM_SET_AGPR(acc[t][q0 + 0], v0 + bb.x);
-        LDM_SET_AGPR(acc[t][q0 + 1], v1 + bb.y);
-        LDM_SET_AGPR(acc[t][q0 + 2], v2 + bb.z);
-        LDM_SET_AGPR(acc[t][q0 + 3], v3 + bb.w);
-        if (gg & 1) asm volatile("" : "+v"(xf2[ks]));
-        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT2; ++t) {
+        f32x16 tile = acc[t];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int gg = t * 4 + g;
+          if (gg < NGV) {
+            const int ks = gg >> 1, e0 = (gg & 1) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gp + gg * 8);
+            const float4 be = *reinterpret_cast<const float4*>(gp + LN_DP + gg * 8);
+            const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
+            const float v0 = tile[g * 4 + 0], v1 = tile[g * 4 + 1], v2 = tile[g * 4 + 2], v3 = tile[g * 4 + 3];
+            xf2[ks][e0 + 0] = (_Float16)fmaf((v0 - mean) * rstd, ga.x, be.x);
+            xf2[ks][e0 + 1] = (_Float16)fmaf((v1 - mean) * rstd, ga.y, be.y);
+            xf2[ks][e0 + 2] = (_Float16)fmaf((v2 - mean) * rstd, ga.z, be.z);
+            xf2[ks][e0 + 3] = (_Float16)fmaf((v3 - mean) * rstd, ga.w, be.w);
+            tile[g * 4 + 0] = v0 + bb.x;
+            tile[g * 4 + 1] = v1 + bb.y;
+            tile[g * 4 + 2] = v2 + bb.z;
+            tile[g * 4 + 3] = v3 + bb.w;
+            if (gg & 1) asm volatile("" : "+v"(xf2[ks]));
+          }
+        }
+        asm volatile("" : "+a"(tile));
+        acc[t] = tile;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (TM) t_ln2 = __builtin_amdgcn_s_memtime();
