@@ -169,6 +169,9 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 //   * the next chunk's bias is read right after the barrier, i.e. older than the next chunk's item 0, so it has
 //     landed when chain A's first MFMA takes it as its C operand (counted lgkmcnt waits stay exact: +4 younger
 //     operations while waiting for items 55..59).
+// (r02 negative result: GEMM1 as ONE accumulator chain in AGPRs — C = 0, bias added in the ReLU step — instead of the
+//  two chains in arch VGPRs is 2 % slower, profiles/r02_call28_*: the 44-vs-32 cycles per MFMA of GEMM1 vs GEMM2 are
+//  not a VGPR-port effect of VGPR-resident accumulators.)
 template <int KS, int NT2, int DE, bool TM, int PFQ = 6>
 struct FfnStream {
   static constexpr int PF = PFQ;   // queue depth (NIT % PF == 0; lgkmcnt is a 4-bit counter: PF - 1 + 4 <= 15).
