@@ -356,6 +356,19 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
     result = cnt < C - 1 ? cnt : C - 1;
   }
   if (lane == 0) p.tokens_out[row] = result;
+  if (p.x_next) {
+    // the wave that drew the token also writes the row the next reverse step starts from (the separate embedding
+    // launch cannot overlap anything: the stack kernel's workgroups own whole CUs)
+    const int tok = __builtin_amdgcn_readfirstlane(result);
+    const float4* e = reinterpret_cast<const float4*>(p.emb + (size_t)tok * p.D);
+    const float4* ps = reinterpret_cast<const float4*>(p.pos + (size_t)s * p.D);
+    float4* o = reinterpret_cast<float4*>(p.x_next + (size_t)row * p.ldx);
+    const int nvec = p.D >> 2;
+    for (int c = lane; c < nvec; c += 64) {
+      const float4 x = e[c], y = ps[c];
+      o[c] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+  }
 }
 
 __global__ void set_rng_k(uint64_t* rng, uint64_t seed, uint64_t first_layout) {

@@ -762,9 +762,10 @@ static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 // out-proj, fused FFN) emit per-row (mean, rstd) next to their fp32 output; consumers (QKV, FFN, head)
 // normalise while loading their register-resident fragments; the out-proj recomputes its residual
 // AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
-static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
+static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
+                                       bool skip_embed = false) {
   const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
-  {  // x0 = emb[token] + pos -> P (raw) + stats_a
+  if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw) + stats_a   (skipped when the previous step's posterior wrote P)
     LnArgs a{};
     a.tokens = d_tokens; a.emb = h->emb; a.pos = h->pos; a.y32 = h->P; a.stats_out = h->stats_a; a.raw = 1;
     a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq;
@@ -885,8 +886,9 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
 }
 
 // fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
-static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
-  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st);
+static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
+                              bool skip_embed = false) {
+  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
@@ -954,8 +956,8 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
 }
 
 // denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
-static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st) {
-  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st);
+static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed = false) {
+  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
   const int prec = h->cfg.precision;
   const bool f16 = prec != LDM_PREC_EXACT_F32;
@@ -1154,12 +1156,12 @@ static void fill_rel(ldm_handle* h, RelArgs& a, const ldm_relation* rel, size_t 
 // relation graph's CSR offsets.
 static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_model, int t_post, const ldm_cond* cond,
                     const ldm_relation* rel, size_t rel_layout_off, const ldm_sampler* s, int step, int B,
-                    size_t rng_layout_off, hipStream_t st) {
+                    size_t rng_layout_off, hipStream_t st, bool skip_embed = false, bool embed_next = false) {
   if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
     return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
   for (int off = 0; off < B; off += h->chunk) {
     const int Bc = std::min(h->chunk, B - off);
-    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st);
+    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st, skip_embed);
     if (rc) return rc;
     PostArgs p{};
     fill_post(h, p, cond, s, off, Bc);
@@ -1171,6 +1173,9 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
     p.layout_off = (int)(rng_layout_off + off);
     if (!rel) {
       p.tokens_out = tout + (size_t)off * h->S;
+      if (embed_next) {  // (one chunk per call: run_loop_body)
+        p.x_next = h->P; p.emb = h->emb; p.pos = h->pos; p.D = h->D; p.ldx = h->D;
+      }
       ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
       launch_posterior_sample(p, st);
       continue;
@@ -1349,8 +1354,12 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation
     }
     int32_t* cur = h->tok_a + off * S;
     int32_t* nxt = h->tok_b + off * S;
+    // the stack kernel takes raw rows and computes its own row statistics, so the posterior kernel of step i can write
+    // step i + 1's embedding itself (no separate embedding launch inside the loop)
+    const bool fuse_embed = !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6;
     for (int i = 0; i < n_steps; ++i) {
-      int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st);
+      int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st,
+                        fuse_embed && i > 0, fuse_embed && i + 1 < n_steps);
       if (rc) return rc;
       if (d_inter)
         HIP_OK(h, hipMemcpyAsync(d_inter + ((size_t)i * B + off) * S, nxt, (size_t)Bc * S * 4,

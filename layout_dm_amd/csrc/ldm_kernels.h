@@ -191,6 +191,10 @@ struct PostArgs {
   int step;                // reverse-loop index (RNG counter word)
   int B, S;
   VocabTables v;
+  // next step's embedding, fused: x_next[row] = emb[new token] + pos[s] (nn_lib.py:204,220), or nullptr
+  float* x_next;
+  const float *emb, *pos;
+  int D, ldx;
 };
 enum ScheduleRow { kLogAt = 0, kLogBt, kLogCt, kLogCumAt, kLogCumBt, kLogCumCt, kLog1mCt, kLog1mCumCt, kNumSched };
 void launch_posterior_sample(const PostArgs& p, hipStream_t st);

@@ -18,7 +18,7 @@ constexpr int PF = 6, NIT = 30;
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA>
+template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA, int BAR = 0>
 struct Pipe {
   f16x8 q[PF];
   f16x8 xf[30];
@@ -34,7 +34,11 @@ struct Pipe {
   template <int IT>
   __device__ __forceinline__ void step() {
     if constexpr (IT < NIT) {
-      wait_lgkm<PF - 1>();
+      // LDS operations younger than item IT: PF - 1 reads + the epilogue stores issued in steps [IT - PF, IT - 1]
+      constexpr int nw = (BAR & 4) ? ((IT >= 13 && IT <= 18) ? 2 : 0)
+                       : (BAR & 8) ? ((IT >= 13 && IT <= 18) ? 1 : 0) + ((IT >= 14 && IT <= 19) ? 1 : 0) + ((IT >= 16 && IT <= 21) ? 1 : 0) + ((IT >= 17 && IT <= 22) ? 1 : 0)
+                       : (BAR & 2) ? ((IT >= 13 && IT <= 18) ? 1 : 0) + ((IT >= 16 && IT <= 21) ? 1 : 0) : 0;
+      wait_lgkm<PF - 1 + nw>();
       __builtin_amdgcn_sched_barrier(0);
       constexpr int c = IT % NCH;
       const f16x8 bop = BVAR ? xf[IT] : xf[0];
@@ -50,19 +54,36 @@ struct Pipe {
       }
 #pragma unroll
       for (int e = 0; e < EXTRA; ++e) asm volatile("v_cvt_pk_f16_f32 %0, %0, %0" : "+v"(junk));
+      if constexpr ((BAR & 1) && IT == NIT - PF) {  // the streams' per-tile protocol
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if constexpr ((BAR & 2) && !(BAR & 12) && (IT == 12 || IT == 15)) {  // a tile epilogue's K / V^T store
+        asm volatile("ds_write_b128 %0, %1" ::"v"(aW[IT & 7] + 98304u), "v"(xf[IT]) : "memory");
+      }
+      if constexpr ((BAR & 4) && IT == 12) {  // both stores in ONE MFMA gap
+        asm volatile("ds_write_b128 %0, %1" ::"v"(aW[4] + 98304u), "v"(xf[12]) : "memory");
+        asm volatile("ds_write_b128 %0, %1" ::"v"(aW[7] + 98304u), "v"(xf[15]) : "memory");
+      }
+      if constexpr ((BAR & 8) && (IT == 12 || IT == 13 || IT == 15 || IT == 16)) {  // the same bytes as four b64 stores
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        const f2 half = __builtin_bit_cast(f2, __builtin_shufflevector(xf[IT], xf[IT], 0, 1, 2, 3));
+        asm volatile("ds_write_b64 %0, %1" ::"v"(aW[IT & 7] + 98304u), "v"(half) : "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
       step<IT + 1>();
     }
   }
 };
 
-template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA>
+template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA, int BAR = 0>
 __global__ __launch_bounds__(256, 1) void bench(const char* g, float* out, unsigned long long* cyc, int reps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hi = lane >> 5;
   for (int i = threadIdx.x; i < 32768 / 4; i += 256) reinterpret_cast<float*>(smem)[i] = reinterpret_cast<const float*>(g)[i];
   __syncthreads();
-  Pipe<AGPR, BVAR, NCH, EXTRA, DMA> P;
+  Pipe<AGPR, BVAR, NCH, EXTRA, DMA, BAR> P;
   P.voff = lane * 16;
   P.g = g + blockIdx.x % 7 * 32768 + wave * 8192;
   P.junk = 1.f;
@@ -91,9 +112,9 @@ __global__ __launch_bounds__(256, 1) void bench(const char* g, float* out, unsig
   if (threadIdx.x == 0) atomicAdd(cyc, t1 - t0);
 }
 
-template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA>
+template <bool AGPR, bool BVAR, int NCH, int EXTRA, bool DMA, int BAR = 0>
 void run(const char* name, const char* g, float* out, unsigned long long* cyc) {
-  auto k = bench<AGPR, BVAR, NCH, EXTRA, DMA>;
+  auto k = bench<AGPR, BVAR, NCH, EXTRA, DMA, BAR>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int reps = 200, blocks = 256;
   for (int pass = 0; pass < 2; ++pass) {
@@ -135,5 +156,12 @@ int main() {
   run<false, true, 1, 0, true>("acc VGPR, B varies, 1 chain, +DMA", g, out, cyc);
   run<true, true, 1, 0, true>("acc AGPR, B varies, 1 chain, +DMA", g, out, cyc);
   run<true, true, 2, 2, true>("acc AGPR, B varies, 2 chains, +2 VALU +DMA", g, out, cyc);
+  run<false, true, 1, 0, false, 1>("acc VGPR, 1 chain, +barrier per 30", g, out, cyc);
+  run<false, true, 1, 0, true, 1>("acc VGPR, 1 chain, +DMA +vmcnt(8) +barrier", g, out, cyc);
+  run<false, true, 1, 0, true, 3>("acc VGPR, 1 chain, +DMA +barrier +2 ds_write", g, out, cyc);
+  run<false, true, 1, 1, true, 3>("same +1 VALU per step (tile epilogue density)", g, out, cyc);
+  run<false, true, 1, 0, true, 7>("+DMA +barrier, both ds_write_b128 in one gap", g, out, cyc);
+  run<false, true, 1, 0, true, 11>("+DMA +barrier, 4 x ds_write_b64", g, out, cyc);
+  run<false, true, 2, 0, true, 3>("2 chains, +DMA +barrier +2 ds_write_b128", g, out, cyc);
   return 0;
 }
