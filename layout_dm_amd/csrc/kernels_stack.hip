@@ -26,10 +26,15 @@ namespace ldm {
 
 struct StackArgs {
   FusedLayerSet ls;     // per layer: head image, in_proj bias, AdaLN scale / shift, b_out + W_out b_v, FFN image, b1 b2 g2 be2
-  float* x;             // [M, ldx] rows in / out (in place)
-  float2* stats;        // [M] (mean, rstd) in / out
+  float* x;             // [M, ldx] rows in / out (in place; not written when the vocabulary head is fused)
+  float2* stats;        // [M] (mean, rstd) out (same)
   int ldx, N, S, H, n_chunks;
   float scale_log2e;
+  // fused vocabulary head (nn_lib.py:186-189: LayerNorm + Linear without bias), or head_img == nullptr
+  const char* head_img; // n_head_tiles x 32 KiB LDS images of 32 classes each (K axis in k-slot order, zero rows beyond C)
+  const float *head_g, *head_b;
+  float* logits;        // [M, ldl]
+  int ldl, n_head_tiles;
 };
 
 __device__ unsigned long long g_stack_phase[16];
@@ -40,7 +45,7 @@ __device__ __forceinline__ int stack_lane_id() {
   return l;
 }
 
-template <bool TM>
+template <bool TM, bool HEAD>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -412,6 +417,99 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   }
   unsigned long long t_epi = 0;
   if constexpr (TM) t_epi = __builtin_amdgcn_s_memtime();
+  if constexpr (HEAD) {
+    // ---- vocabulary head in the same workgroup: logits = LN_head(x_out) · Wh^T.  The rows never leave the registers:
+    // statistics and the normalised fp16 fragments (k-slot K order) from the accumulators, then n_head_tiles 32-class
+    // weight tiles through a 4-stage ring in the LDS the FFN ring used (TilePipe: 29 MFMAs per tile), 16-byte stores of
+    // the logits.  Replaces the row / statistics store and the separate head GEMM launch (which cannot overlap the
+    // other lane's stack kernel: its workgroups own whole CUs).
+    __builtin_amdgcn_s_barrier();  // every wave is past its FFN LDS reads and the last layer's table reads
+    asm volatile("" ::: "memory");
+    auto dma_head_tile = [&](int ht) {
+      const char* g = a.head_img + (size_t)ht * STAGE + wave * 8192;
+      const unsigned l = lds0 + (unsigned)(ht & 3) * STAGE + wave * 8192;
+      dma_lin4(voff, g, l);
+      dma_lin4(voff, g + 4096, l + 4096);
+    };
+    for (int ht = 0; ht < 3 && ht < a.n_head_tiles; ++ht) dma_head_tile(ht);
+    for (int i = tid; i < LN_DP; i += 256) {
+      sp[i] = i < a.N ? a.head_g[i] : 0.f;
+      sp[LN_DP + i] = i < a.N ? a.head_b[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane3 = stack_lane_id();
+    const int r3 = lane3 & 31, hi3 = lane3 >> 5;
+    const int row3 = wave * 32 + r3;
+    f16x8 xf3[KS];
+    {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x16 tile = acc[t];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (t * 4 + (i >> 2) < NGV) {
+            s1 += tile[i];
+            s2 += tile[i] * tile[i];
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      constexpr float kInvN3 = 1.0f / 464.0f;
+      const float mean = s1 * kInvN3;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean * mean, 0.f) + 1e-5f);
+      const float ra = rstd, rb = -mean * rstd;
+      const float* gmp = sp + hi3 * 4;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x16 tile = acc[t];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int gg = t * 4 + g;
+          if (gg < NGV) {
+            const int ks = gg >> 1, e0 = (gg & 1) * 4;
+            const float4 gm = *reinterpret_cast<const float4*>(gmp + gg * 8);
+            const float4 be = *reinterpret_cast<const float4*>(gmp + LN_DP + gg * 8);
+            xf3[ks][e0 + 0] = (_Float16)fmaf(fmaf(tile[g * 4 + 0], ra, rb), gm.x, be.x);
+            xf3[ks][e0 + 1] = (_Float16)fmaf(fmaf(tile[g * 4 + 1], ra, rb), gm.y, be.y);
+            xf3[ks][e0 + 2] = (_Float16)fmaf(fmaf(tile[g * 4 + 2], ra, rb), gm.z, be.z);
+            xf3[ks][e0 + 3] = (_Float16)fmaf(fmaf(tile[g * 4 + 3], ra, rb), gm.w, be.w);
+            if (gg & 1) asm volatile("" : "+v"(xf3[ks]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) asm volatile("" : "+v"(xf3[k]));
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool valid3 = row3 < S;
+    float* lrow = a.logits + ((size_t)b * S + (valid3 ? row3 : S - 1)) * a.ldl + hi3 * 4;
+    unsigned relW[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) relW[k] = lds0 + r3 * RKB + ((((k << 1) | hi3) ^ (r3 & 15)) << 4);
+    for (int ht = 0; ht < a.n_head_tiles; ++ht) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile ht (and every earlier piece) has landed
+      __builtin_amdgcn_s_barrier();                                // ... everybody's; tile ht - 1 is read by nobody any more
+      asm volatile("" ::: "memory");
+      if (ht + 3 < a.n_head_tiles) dma_head_tile(ht + 3);          // -> stage of tile ht - 1
+      TilePipe<KS, 8> TP;
+      TP.xf = xf3;
+      TP.voff = voff;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) TP.aW[k] = relW[k] + (unsigned)(ht & 3) * STAGE;
+      TP.template run<false, false>();
+      // D[i = class][j = row]: lane (row, hi) holds classes 32 ht + 8 rq + 4 hi + i
+      f32x16 lg = TP.acc;
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(lg));
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        if (valid3)
+          *reinterpret_cast<float4*>(lrow + ht * 32 + rq * 8) = make_float4(lg[rq * 4 + 0], lg[rq * 4 + 1], lg[rq * 4 + 2], lg[rq * 4 + 3]);
+    }
+  } else {
   {
     // ---- x_out = acc: row statistics + stores (only the rows of this layout: padding rows of the last wave belong to
     // the next layout)
@@ -436,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     const float mean3 = s1 * kInvN3;
     const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
     if (valid3 && hie == 0 && a.stats) a.stats[me] = make_float2(mean3, rstd3);
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last FFN prefetch must land before the LDS is released
   if constexpr (TM) {
@@ -462,12 +561,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
 }
 
 void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, hipStream_t st) {
+                         int dh, const StackHead* head, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = tm ? stack_stream_k<true> : stack_stream_k<false>;
+  auto kern = head ? (tm ? stack_stream_k<true, true> : stack_stream_k<false, true>)
+                   : (tm ? stack_stream_k<true, false> : stack_stream_k<false, false>);
   allow_big_lds((const void*)kern);
-  StackArgs a{ls, x, stats_io, ldx, N, S, H, F / 32, 1.4426950408889634f / sqrtf((float)dh)};
+  StackArgs a{ls, x, stats_io, ldx, N, S, H, F / 32, 1.4426950408889634f / sqrtf((float)dh),
+              head ? (const char*)head->img : nullptr, head ? head->g : nullptr, head ? head->b : nullptr,
+              head ? head->logits : nullptr, head ? head->ldl : 0, head ? head->n_tiles : 0};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
 }
 

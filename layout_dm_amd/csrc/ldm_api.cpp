@@ -188,6 +188,7 @@ struct ldm_handle {
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
+  void* head_img_ks = nullptr;  // vocabulary head as 32-class tile images, K axis in k-slot order (stack kernel)
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
@@ -678,6 +679,14 @@ static int build_fast_weights(ldm_handle* h) {
       HIP_OK(h, hipMemcpy(f.b_out_v, bov.data(), bov.size() * 4, hipMemcpyHostToDevice));
     }
   }
+  if (Dq == 512 && D <= 480) {
+    __half* hk = nullptr;
+    auto kslot = [](int k) { return ldm_pack::kslot(k); };
+    if ((rc = pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, kslot, &hk))) return rc;
+    const std::vector<uint16_t> hh = download16(h, hk, (size_t)round_up(C, 256) * Dq, &rc);
+    if (rc) return rc;
+    if ((rc = upload_image(h, ldm_pack::pack_head_image(hh.data(), h->Cp / 32), &h->head_img_ks))) return rc;
+  }
   return pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, id, &h->fast_head);
 }
 
@@ -783,11 +792,17 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
       ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
                             h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
     }
+    // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
+    static const bool fuse_head = !(getenv("LDM_STACK_HEAD") && atoi(getenv("LDM_STACK_HEAD")) == 0);
+    const bool with_head = fuse_head && h->head_img_ks && h->Cp % 32 == 0;
+    const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
     ldm_handle::Scope sc(h, st, "layers_fused",
                          h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
-                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)),
-                         (double)M * D * 8);
-    launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, st);
+                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) +
+                             (with_head ? gemm_flops(M, h->C, D) : 0.0),
+                         (double)M * (D * 4 + (with_head ? h->Cp : D) * 4));
+    launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, with_head ? &hd : nullptr, st);
+    if (with_head) return 0;
   }
   if (h->fused_attn == 4) {
     // the whole stack in ONE launch, in place on P / stats_a: a layout's rows stay in their workgroup's registers

@@ -129,8 +129,16 @@ void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, c
                          float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
 // the whole stack in one launch with the rows resident in the out-projection accumulators (kernels_stack.hip):
 // ls.w[i].img = ldm_pack::pack_attn_head_image, .b_out = out_proj bias + W_out b_v
+// head != nullptr: the vocabulary head (LayerNorm + Linear without bias) runs in the same workgroups and the kernel
+// writes logits instead of rows (img: n_tiles x 32-KiB tile images, K axis in k-slot order: ldm_pack::pack_head_image)
+struct StackHead {
+  const void* img;
+  const float *g, *b;
+  float* logits;
+  int ldl, n_tiles;
+};
 void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, hipStream_t st);
+                         int dh, const StackHead* head, hipStream_t st);
 int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,

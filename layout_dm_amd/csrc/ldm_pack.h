@@ -113,4 +113,16 @@ inline std::vector<uint16_t> pack_attn_head_image(const std::vector<uint16_t>& s
   return img;
 }
 
+// Vocabulary-head image of the stack kernel: n_tiles x 32 KiB, tile t = classes 32t .. 32t + 31 (rows of w: [>= 32 n_tiles
+// rows][512] fp16, K axis already in k-slot order, zero rows beyond the vocabulary), 1-KiB rows with the tile swizzle.
+inline std::vector<uint16_t> pack_head_image(const uint16_t* w, int n_tiles) {
+  std::vector<uint16_t> img((size_t)n_tiles * 16384, 0);
+  const uint16_t* rows[32];
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int i = 0; i < 32; ++i) rows[i] = w + (size_t)(t * 32 + i) * 512;
+    put_tile_1k(img.data() + (size_t)t * 16384, rows);
+  }
+  return img;
+}
+
 }  // namespace ldm_pack

@@ -105,7 +105,7 @@ struct TilePipe {
   __device__ __forceinline__ void dma_slot() {
     if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
   }
-  template <int IT, bool SWAP>
+  template <int IT, bool SWAP, bool DMA = true>
   __device__ __forceinline__ void step() {
     if constexpr (IT < KS) {
       constexpr int after = (KS - 1 - IT) < (PF - 1) ? (KS - 1 - IT) : (PF - 1);
@@ -122,9 +122,9 @@ struct TilePipe {
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT + PF < KS) read_item<IT + PF>();
-      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
-      else dma_m0<IT / 2>();
-      step<IT + 1, SWAP>();
+      if constexpr (DMA && IT % 2 == 1) dma_slot<IT / 2>();
+      else if constexpr (DMA) dma_m0<IT / 2>();
+      step<IT + 1, SWAP, DMA>();
     }
   }
   template <int IT>
@@ -134,10 +134,10 @@ struct TilePipe {
       prologue<IT + 1>();
     }
   }
-  template <bool SWAP>
+  template <bool SWAP, bool DMA = true>
   __device__ __forceinline__ void run() {
     prologue<0>();
-    step<0, SWAP>();
+    step<0, SWAP, DMA>();
   }
 };
 

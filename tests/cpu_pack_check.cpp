@@ -170,6 +170,26 @@ int main() {
               "head image: slab %d of head %d", d2, hh);
     }
     for (size_t i = (size_t)H * 8 * 16384; i < hd.size(); ++i) CHECK(hd[i] == 0, "head image padding stages not zero");
+    // stack kernel's vocabulary head: 32-class tiles with the 1-KiB-row tile swizzle, K axis in k-slot order
+    {
+      const int C = 154, Cp = 160;
+      std::vector<uint16_t> hw((size_t)C * D), hp((size_t)256 * Dq, 0);
+      for (int n = 0; n < C; ++n) for (int k = 0; k < D; ++k) hw[(size_t)n * D + k] = id16(n + 40000, k);
+      for (int n = 0; n < C; ++n) for (int k = 0; k < D; ++k) hp[(size_t)n * Dq + ldm_pack::kslot(k)] = hw[(size_t)n * D + k];
+      const std::vector<uint16_t> hi_img = ldm_pack::pack_head_image(hp.data(), Cp / 32);
+      CHECK(hi_img.size() == (size_t)(Cp / 32) * 16384, "head tile image size");
+      for (int t = 0; t < Cp / 32; ++t)
+        for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 29; ++ks) {
+          const uint16_t* p = tile_read(hi_img.data() + (size_t)t * 16384, r, hi, ks);
+          for (int e = 0; e < 8; ++e) {
+            // fragment element e of k16-step ks, lane half hi <-> accumulator-layout column 16 ks + 8 (e >> 2) + 4 hi + (e & 3)
+            const int k = 16 * ks + 8 * (e >> 2) + 4 * hi + (e & 3);
+            const int n = t * 32 + r;
+            const uint16_t want = (n < C && k < D) ? hw[(size_t)n * D + k] : 0;
+            CHECK(p[e] == want, "head tile t=%d r=%d hi=%d ks=%d e=%d", t, r, hi, ks, e);
+          }
+        }
+    }
   }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
