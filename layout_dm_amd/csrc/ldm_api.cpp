@@ -191,6 +191,7 @@ struct ldm_handle {
   void* head_img_ks = nullptr;  // vocabulary head as 32-class tile images, K axis in k-slot order (stack kernel)
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
+  int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
                        // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
                        // 4: ALL layers in one launch per step (4-layer stacks; opt-in through LDM_FUSED_ATTN=4: measured
@@ -411,6 +412,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
     if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
+    if (const char* sh = getenv("LDM_STACK_HEAD")) h->stack_head = atoi(sh);
     // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
@@ -793,8 +795,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
                             h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
     }
     // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
-    static const bool fuse_head = !(getenv("LDM_STACK_HEAD") && atoi(getenv("LDM_STACK_HEAD")) == 0);
-    const bool with_head = fuse_head && h->head_img_ks && h->Cp % 32 == 0;
+    const bool with_head = h->stack_head && h->head_img_ks && h->Cp % 32 == 0;
     const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
     ldm_handle::Scope sc(h, st, "layers_fused",
                          h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +

@@ -84,8 +84,9 @@ def test_layer_kernel_generations_agree(cuda, monkeypatch):
     tokens = torch.randint(0, spec.n_class, (6, spec.seq_len), generator=g).int()
     ref = R.denoiser_logits(W, spec, tokens.long(), 23)
     outs = {}
-    for gen in ("6", "5", "3", "0"):
-        monkeypatch.setenv("LDM_FUSED_ATTN", gen)
+    for gen in ("6", "6h", "5", "3", "0"):  # 6h: stack kernel with the vocabulary head as a separate launch
+        monkeypatch.setenv("LDM_FUSED_ATTN", gen[0])
+        monkeypatch.setenv("LDM_STACK_HEAD", "0" if gen == "6h" else "1")
         e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
                    n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
                    max_batch=8)
@@ -93,7 +94,7 @@ def test_layer_kernel_generations_agree(cuda, monkeypatch):
         outs[gen] = e.denoise_logits(tokens, 23).cpu()
         e.close()
         assert _rel(outs[gen], ref) <= LOGIT_REL_TOL["fast"], gen
-    for gen in ("5", "3", "0"):
+    for gen in ("6h", "5", "3", "0"):
         assert _rel(outs["6"], outs[gen]) <= 5e-4, gen
 
 
