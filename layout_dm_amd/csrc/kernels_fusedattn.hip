@@ -828,23 +828,6 @@ void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, co
                      scale_log2e, op, 0, ft, FusedLayerSet{});
 }
 
-// the whole stack in one launch (V = 27).  ls: per-layer weights (k-slot in_proj images); x / stats_io: the embedding
-// output and its row statistics on entry, the last layer's output and statistics on exit.
-void launch_layers_fused(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, hipStream_t st) {
-  constexpr int KS = 29;
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  const int lds = 2 * STAGE + 4 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
-  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = tm ? qkv_attn_k<KS, true, true, 27> : qkv_attn_k<KS, true, false, 27>;
-  allow_big_lds((const void*)kern);
-  LnLoad ln{x, stats_io, nullptr, nullptr, ldx, N, 1};
-  OutProj op{nullptr, x, stats_io, ldx, N};
-  FfnTail ft{nullptr, nullptr, nullptr, nullptr, nullptr, F / 32};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)nullptr, (const float*)nullptr, ln, (__half*)nullptr, 0,
-                     S, H, B * S, scale_log2e, op, 0, ft, ls);
-}
-
 void attn_phase_read(unsigned long long* out16) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_attn_phase), 16 * sizeof(unsigned long long));

@@ -20,34 +20,90 @@
 
 namespace ldm {
 
+// ---- wave-wide reductions WITHOUT the LDS: a __shfl_xor is a ds_bpermute_b32 (an LDS round trip, ~130 cycles, and the
+// 6 steps of a reduction are a dependent chain) and this kernel executed ~70 of them per token — its waves lived ~22k
+// cycles for ~2k cycles of arithmetic.  Butterfly on DPP moves inside a 16-lane row (quad_perm, row_half_mirror,
+// row_mirror: one VALU issue each) and the two cross-row exchanges through gfx950's v_permlane16_swap / v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+// values of the other half of every exchange step, for a 32-bit payload
+#define LDM_BFLY32(v, COMBINE)                                                                              \
+  do {                                                                                                      \
+    { const int o = dpp_mov<kDppXor1>(v); COMBINE(o); }                                                      \
+    { const int o = dpp_mov<kDppXor2>(v); COMBINE(o); }                                                      \
+    { const int o = dpp_mov<kDppHalfMirror>(v); COMBINE(o); }                                                \
+    { const int o = dpp_mov<kDppMirror>(v); COMBINE(o); }                                                    \
+  } while (0)
 __device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  int x = __float_as_int(v);
+#define LDM_CMB(o) x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(o)))
+  LDM_BFLY32(x, LDM_CMB);
+  { const auto s = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false); x = __float_as_int(fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]))); }
+  { const auto s = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false); x = __float_as_int(fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]))); }
+#undef LDM_CMB
+  return __int_as_float(x);
 }
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __float_as_int(v);
+#define LDM_CMB(o) x = __float_as_int(__int_as_float(x) + __int_as_float(o))
+  LDM_BFLY32(x, LDM_CMB);
+  { const auto s = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false); x = __float_as_int(__uint_as_float(s[0]) + __uint_as_float(s[1])); }
+  { const auto s = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false); x = __float_as_int(__uint_as_float(s[0]) + __uint_as_float(s[1])); }
+#undef LDM_CMB
+  return __int_as_float(x);
+}
+__device__ __forceinline__ int wsumi(int x) {
+#define LDM_CMB(o) x = x + (o)
+  LDM_BFLY32(x, LDM_CMB);
+  { const auto s = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false); x = (int)(s[0] + s[1]); }
+  { const auto s = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false); x = (int)(s[0] + s[1]); }
+#undef LDM_CMB
+  return x;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_movd(double v) {
+  return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
 }
 __device__ __forceinline__ double wsumd(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ int wsumi(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ double wscan(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double n = __shfl_up(v, o, 64);
-    if (lane >= o) v += n;
+  v += dpp_movd<kDppXor1>(v);
+  v += dpp_movd<kDppXor2>(v);
+  v += dpp_movd<kDppHalfMirror>(v);
+  v += dpp_movd<kDppMirror>(v);
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  }
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
   }
   return v;
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside a row (row_shr 1 / 2 / 4 / 8, zeros shifted in), then the
+// totals of the preceding rows through row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_movd_rows(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ double wscan(double v, int lane) {
+  (void)lane;
+  v += dpp_movd_rows<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_movd_rows<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_movd_rows<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_movd_rows<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_movd_rows<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_movd_rows<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// broadcast of lane 63 (the total of an inclusive scan)
+__device__ __forceinline__ double wlast(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // util.py:19-21
@@ -237,11 +293,26 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
       const int c = lane + 64 * j;
       if (c < C && lp[j] > bv) { bv = lp[j]; bi = c; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    {
+      auto take = [&](float ov, int oi) {
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      };
+      take(__int_as_float(dpp_mov<kDppXor1>(__float_as_int(bv))), dpp_mov<kDppXor1>(bi));
+      take(__int_as_float(dpp_mov<kDppXor2>(__float_as_int(bv))), dpp_mov<kDppXor2>(bi));
+      take(__int_as_float(dpp_mov<kDppHalfMirror>(__float_as_int(bv))), dpp_mov<kDppHalfMirror>(bi));
+      take(__int_as_float(dpp_mov<kDppMirror>(__float_as_int(bv))), dpp_mov<kDppMirror>(bi));
+      {
+        const auto sv = __builtin_amdgcn_permlane16_swap((unsigned)__float_as_int(bv), (unsigned)__float_as_int(bv), false, false);
+        const auto si = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+        bv = __uint_as_float(sv[0]); bi = (int)si[0];
+        take(__uint_as_float(sv[1]), (int)si[1]);
+      }
+      {
+        const auto sv = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(bv), (unsigned)__float_as_int(bv), false, false);
+        const auto si = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+        bv = __uint_as_float(sv[0]); bi = (int)si[0];
+        take(__uint_as_float(sv[1]), (int)si[1]);
+      }
     }
     result = bi;
   } else {
@@ -339,7 +410,7 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const double sc = wscan(pr[j], lane);
-      tot[j] = __shfl(sc, 63, 64);
+      tot[j] = wlast(sc);
       cdf[j] = base + sc;
       base += tot[j];
     }

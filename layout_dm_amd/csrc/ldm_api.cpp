@@ -181,7 +181,6 @@ struct ldm_handle {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
     void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
     void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
-    void* attn_slab_img_ks = nullptr;  // same with the in_proj K axis in k-slot order (multi-layer kernel)
     void* attn_head_img_ks = nullptr;  // per head: 6 in_proj tiles (k-slot K) + its 2 out-proj slabs (stack kernel)
     float* b_in = nullptr;
     float* b_out_v = nullptr;  // out_proj bias + W_out b_v (the stream layer kernel never adds the V bias: softmax rows sum to 1)
@@ -194,9 +193,6 @@ struct ldm_handle {
   int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
                        // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
-                       // 4: ALL layers in one launch per step (4-layer stacks; opt-in through LDM_FUSED_ATTN=4: measured
-                       //    +0.4 % only — the 4x unrolled code no longer fits the instruction cache and the tile
-                       //    runs slow down by as much as the skipped operand reloads save: profiles/r02_call12_*)
                        // 5: the whole layer per launch as CONTINUOUS per-head / slab / chunk streams (kernels_layer.hip:
                        //    220 -> 200 us per launch, profiles/r02_call14_*, r02_call20_*)
                        // 6: ALL layers per launch with the rows RESIDENT in the out-projection accumulators
@@ -417,7 +413,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
     if (h->fused_attn >= 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
-    if (h->fused_attn == 4 && h->L != 4) h->fused_attn = 3;  // the multi-layer kernel is unrolled for 4 layers
+    if (h->fused_attn == 4) h->fused_attn = 6;  // (4 was the r02 tile-by-tile multi-layer experiment: +0.4 % only, removed; profiles/r02_call12_*)
     if (h->fused_attn == 6 && h->L > 8) h->fused_attn = 5;   // FusedLayerSet holds 8 layers
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
@@ -657,7 +653,6 @@ static int build_fast_weights(ldm_handle* h) {
         const std::vector<uint16_t> hin_ks = download16(h, w_in_ks, (size_t)3 * HD * Dq, &rc);
         if (rc) return rc;
         const std::vector<uint16_t> slab_ks = pack_attn_slab_image(hin_ks.data(), hout.data(), H);
-        if ((rc = upload_image(h, slab_ks, &f.attn_slab_img_ks))) return rc;
         if ((rc = upload_image(h, ldm_pack::pack_attn_head_image(slab_ks, H), &f.attn_head_img_ks))) return rc;
       }
     }
@@ -805,24 +800,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, with_head ? &hd : nullptr, st);
     if (with_head) return 0;
   }
-  if (h->fused_attn == 4) {
-    // the whole stack in ONE launch, in place on P / stats_a: a layout's rows stay in their workgroup's registers
-    // from layer to layer
-    FusedLayerSet ls{};
-    ls.n_layer = h->L;
-    for (int i = 0; i < h->L; ++i) {
-      const LayerW& w = h->layers[i];
-      const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
-      ls.w[i] = FusedLayerW{h->fast[i].attn_slab_img_ks, h->fast[i].b_in, ss, ss + D, w.b_out, h->fast[i].ffn_img_ks,
-                            w.b1, w.b2, w.g2, w.be2};
-    }
-    ldm_handle::Scope sc(h, st, "layers_fused",
-                         h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
-                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)),
-                         (double)M * D * 4 * (1 + 2 * h->L));
-    launch_layers_fused(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, st);
-  }
-  for (int i = 0; i < ((h->fused_attn == 4 || h->fused_attn == 6) ? 0 : h->L); ++i) {
+  for (int i = 0; i < (h->fused_attn == 6 ? 0 : h->L); ++i) {
     const LayerW& w = h->layers[i];
     const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;

@@ -102,9 +102,9 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
 void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
                             const float* b_out, float* C32, int ldc, float2* stats_out, int N,
                             int B, int S, int H, int dh, hipStream_t st);
-// per-layer weights of the multi-layer fused kernel (all device pointers)
+// per-layer weights of the stack kernel (all device pointers)
 struct FusedLayerW {
-  const void* img;        // pack_attn_slab_image with the in_proj K axis in k-slot order
+  const void* img;        // ldm_pack::pack_attn_head_image (in_proj K axis in k-slot order)
   const float* bias_in;   // head-padded in_proj bias [3*H*64]
   const float *ada_scale, *ada_shift;  // AdaLN (scale, shift) of this layer at the step's timestep [D] each
   const float* b_out;     // out_proj bias [D]
@@ -115,9 +115,6 @@ struct FusedLayerSet {
   FusedLayerW w[8];
   int n_layer;
 };
-// the WHOLE denoiser stack (n_layer <= 8 layers) in one launch per step, in place on x / stats_io (V = 27)
-void launch_layers_fused(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, hipStream_t st);
 // one whole transformer layer per launch, in place on x / stats_io (kernels_fusedattn.hip, V = 11):
 // img = ldm_pack::pack_attn_slab_image, ffn_img = pack_ffn_image with W1's K axis in k-slot order
 void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
