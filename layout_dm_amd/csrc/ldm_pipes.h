@@ -766,6 +766,9 @@ namespace ldm {
 // AttnCoreV: AttnCore with every tile in arch VGPRs.  The probabilities are cast to their fp16 MFMA fragments key tile
 // by key tile right behind the exponentials (the 64 score registers shrink to 32 fragment registers before the two
 // output tiles come alive), which also puts every VALU write of an MFMA operand many instructions ahead of its use.
+// (r02 negative result: running the next key tile's exponentials in the shadow of the O^T MFMAs, a quarter per step,
+//  made the core 9 % LONGER — 3 242 vs 2 973 cycles per head, profiles/r02_call38_*; so did issuing the next head's
+//  second tile three steps behind SlabPair's barrier instead of at it: +150 cycles per head.)
 struct AttnCoreV {
   static constexpr int PF = 4;
   typedef __attribute__((ext_vector_type(2))) float f32x2;
