@@ -7,6 +7,7 @@
 
 #include "ldm_dma.h"
 #include "ldm_kernels.h"
+#include "ldm_stream_sched.h"
 
 namespace ldm {
 
@@ -376,10 +377,8 @@ namespace ldm {
 // second address set.
 template <bool TM = false, bool LEAN = false>
 struct HeadStream {
-  static constexpr int KS = 29, NT = 6, NIT = KS * NT, PF = 6;
-  static constexpr int SYNC = KS - PF;   // local step of the per-tile barrier
-  static constexpr int EPI0 = 10;        // first local step of the previous tile's epilogue
-  static_assert(NIT % PF == 0, "queue slots line up across heads");
+  using SCH = ldm_sched::HeadSched<LEAN>;  // the issue schedule (pure constexpr: replayed on the CPU by tests/cpu_sched_check.cpp)
+  static constexpr int KS = SCH::KS, NT = SCH::NT, NIT = SCH::NIT, PF = SCH::PF, SYNC = SCH::SYNC, EPI0 = SCH::EPI0;
   static_assert(NT % 3 == 0, "ring stage of a tile is a compile-time constant");
   f16x8 q[PF];
   unsigned aW[8], aW2[8];  // LDS byte addresses of the fragment columns in stage 0 (stage 1: + offset) / stage 2
@@ -395,36 +394,8 @@ struct HeadStream {
   int h, H;
   unsigned long long t_sync = 0;  // (TM) cycles spent in the per-tile vmcnt + s_barrier
 
-  static constexpr bool tile_has_bias(int j) { return j < 2 || j >= 4; }
-  // bias reads issued at (global) step s: at the barrier step of tile j for tile j + 1
-  static constexpr int bias_at(int s) {
-    const int j = s / KS, it = s % KS;
-    if (LEAN) return ((it == EPI0 - PF - 1 && j >= 1 && tile_has_bias(j - 1)) || (j == NT - 1 && it == SYNC)) ? 4 : 0;
-    return (it == SYNC && j + 1 < NT && tile_has_bias(j + 1)) ? 4 : 0;
-  }
-  // ds_write_b128 issued at step s (epilogue of the previous tile when that was a K or V tile: two stores)
-  static constexpr int writes_at(int s) {
-    const int j = s / KS, it = s % KS;
-    return (j >= 1 && j <= 4 && (it == EPI0 + 2 || it == EPI0 + 5)) ? 1 : 0;
-  }
-  // LDS operations younger than item G when step G waits for it
-  static constexpr int younger(int G) {
-    int cnt = 0;
-    bool seen = false;
-    for (int i = 0; i < PF; ++i) {
-      if (seen) ++cnt;
-      if (i == G) seen = true;
-    }
-    for (int s = 0; s < G; ++s) {
-      if (seen) cnt += bias_at(s);
-      if (s + PF < NIT) {
-        if (seen) ++cnt;
-        if (s + PF == G) seen = true;
-      }
-      if (seen) cnt += writes_at(s);
-    }
-    return cnt;
-  }
+  static constexpr bool tile_has_bias(int j) { return SCH::tile_has_bias(j); }
+  static constexpr int younger(int G) { return SCH::younger(G); }
 
   template <int G>
   __device__ __forceinline__ void read_item() {
@@ -512,7 +483,7 @@ struct HeadStream {
         if constexpr (!LEAN && J + 1 < NT && tile_has_bias(J + 1)) read_bias<(J + 1 < NT ? J + 1 : 0)>();
         if constexpr (LEAN && J == NT - 1) read_bias<NT - 1>();  // q1's own bias, for the epilogue behind the stream
       }
-      if constexpr (LEAN && IT == EPI0 - PF - 1 && J >= 1 && tile_has_bias(J >= 1 ? J - 1 : 0)) read_bias<(J >= 1 ? J - 1 : 0)>();
+      if constexpr (LEAN && IT == SCH::BIAS_LEAN && J >= 1 && tile_has_bias(J >= 1 ? J - 1 : 0)) read_bias<(J >= 1 ? J - 1 : 0)>();
       if constexpr (G + PF < NIT) read_item<G + PF>();
       // DMA of tile J + 2 into stage (J + 2) % 3 (the one tile J - 1 was read from): pieces at local steps 1-4, 6-9
       constexpr unsigned st = (unsigned)((J + 2) % 3) * TILE_STAGE;
@@ -532,7 +503,10 @@ struct HeadStream {
     read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
     f16x8 e0, e1;
     step<0>(e0, e1);
-    // q1's epilogue (exposed: the attention core needs the fragments now)
+    // q1's epilogue (exposed: the attention core needs the fragments now).  LEAN: its bias was read at q1's barrier
+    // step, AFTER the last fragments — the last step's counted wait leaves those four reads in flight (found by the CPU
+    // replay of the schedule, tests/cpu_sched_check.cpp)
+    if constexpr (LEAN) wait_lgkm<0>();
     asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accB));  // (tied to the accumulator: see AttnCore::run)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (LEAN) {
