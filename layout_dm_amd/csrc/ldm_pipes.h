@@ -175,11 +175,10 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 //  not a VGPR-port effect of VGPR-resident accumulators.)
 template <int KS, int NT2, int DE, bool TM, int PFQ = 6>
 struct FfnStream {
-  static constexpr int PF = PFQ;   // queue depth (NIT % PF == 0; lgkmcnt is a 4-bit counter: PF - 1 + 4 <= 15).
-                                   // r02: depth 10 instead of 6 changes nothing (profiles/r02_call21_*)
-  static constexpr int NIT = KS + 1 + 2 * NT2;  // 60
-  static constexpr int SYNC = NIT - PF;         // step whose read is the first of the next chunk
-  static_assert(NIT % PF == 0, "queue slots must line up across chunks");
+  using SCH = ldm_sched::FfnSched<KS, NT2, PFQ>;  // (replayed on the CPU: tests/cpu_sched_check.cpp)
+  static constexpr int PF = SCH::PF;   // queue depth.  r02: depth 10 instead of 6 changes nothing (profiles/r02_call21_*)
+  static constexpr int NIT = SCH::NIT;   // 60
+  static constexpr int SYNC = SCH::SYNC; // step whose read is the first of the next chunk
   unsigned long long tA, tB, tC, tD, t_sync = 0;
   f16x8 q[PF];
   unsigned aW1[8], aW2[2];
@@ -222,8 +221,7 @@ struct FfnStream {
   __device__ __forceinline__ void step() {
     if constexpr (IT < NIT) {
       // LDS operations younger than item IT when it is waited for: PF - 1 items, + the 4 bias reads issued at SYNC
-      constexpr int after = (IT > SYNC) ? PF - 1 + 4 : PF - 1;
-      wait_lgkm<after>();
+      wait_lgkm<SCH::after(IT)>();
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 cur = q[IT % PF];
       if constexpr (IT == 0) {

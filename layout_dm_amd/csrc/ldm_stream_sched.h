@@ -50,4 +50,18 @@ struct HeadSched {
   }
 };
 
+// FfnStream (ldm_pipes.h): NIT = KS + 1 + 2 NT2 queue items per 32-wide hidden chunk (KS W1 fragments, one pseudo item
+// for the bias / ReLU / cast step, 2 NT2 W2 fragments), PF deep, CONTINUOUS across chunks: step IT issues item IT + PF,
+// which for IT >= NIT - PF belongs to the next chunk.  At step SYNC = NIT - PF, after the barrier and BEFORE that step's
+// fragment read, the next chunk's bias is read (4 x ds_read_b128); it is the C operand of the next chunk's first MFMA.
+template <int KS, int NT2, int PFQ>
+struct FfnSched {
+  static constexpr int PF = PFQ, NIT = KS + 1 + 2 * NT2, SYNC = NIT - PF;
+  static_assert(NIT % PF == 0, "queue slots must line up across chunks");
+  static_assert(PF - 1 + 4 <= 15, "lgkmcnt is a 4-bit counter");
+  // LDS operations younger than item IT when step IT waits for it: PF - 1 fragments, + the 4 bias reads issued at SYNC
+  // for the items that were issued before them (SYNC < IT < NIT: items IT issued at step IT - PF < SYNC ... see replay)
+  static constexpr int after(int IT) { return IT > SYNC ? PF - 1 + 4 : PF - 1; }
+};
+
 }  // namespace ldm_sched

@@ -118,7 +118,50 @@ static void replay(const char* name) {
   printf("%s: %zu LDS operations replayed\n", name, q.size());
 }
 
+// FfnStream: three chunks of the continuous chunk loop (prologue: bias of chunk 0, then PF fragments)
+template <int KS, int NT2, int PF>
+static void replay_ffn(const char* name) {
+  using S = ldm_sched::FfnSched<KS, NT2, PF>;
+  struct O { int kind, chunk, item; };  // kind 0 = fragment, 1 = bias
+  std::vector<O> q;
+  size_t done = 0;
+  auto wait = [&](int n) {
+    if (q.size() - done > (size_t)n) done = q.size() - n;
+  };
+  auto completed = [&](int kind, int chunk, int item) {
+    bool found = false;
+    for (size_t i = 0; i < q.size(); ++i)
+      if (q[i].kind == kind && q[i].chunk == chunk && (kind == 1 || q[i].item == item)) {
+        found = true;
+        if (i >= done) return false;
+      }
+    return found;
+  };
+  const int NC = 3;
+  for (int i = 0; i < 4; ++i) q.push_back(O{1, 0, i});
+  for (int i = 0; i < PF; ++i) q.push_back(O{0, 0, i});
+  for (int c = 0; c < NC; ++c)
+    for (int IT = 0; IT < S::NIT; ++IT) {
+      size_t pos = q.size();
+      for (size_t i = 0; i < q.size(); ++i)
+        if (q[i].kind == 0 && q[i].chunk == c && q[i].item == IT) pos = i;
+      CHECK(pos < q.size(), "%s: item %d of chunk %d never issued", name, IT, c);
+      const int truth = (int)(q.size() - 1 - pos);
+      CHECK(S::after(IT) == truth, "%s: after(%d) = %d, replay says %d (chunk %d)", name, IT, S::after(IT), truth, c);
+      wait(S::after(IT));
+      CHECK(completed(0, c, IT), "%s: item %d of chunk %d not complete at its step", name, IT, c);
+      if (IT == 0) CHECK(completed(1, c, 0), "%s: bias of chunk %d not complete at its first MFMA", name, c);
+      if (IT == S::SYNC)
+        for (int i = 0; i < 4; ++i) q.push_back(O{1, c + 1, i});
+      const int nxt = IT + PF;
+      q.push_back(O{0, nxt < S::NIT ? c : c + 1, nxt % S::NIT});
+    }
+  printf("%s: %zu LDS operations replayed\n", name, q.size());
+}
+
 int main() {
+  replay_ffn<29, 15, 6>("FfnStream<29,15,PF=6>");
+  replay_ffn<29, 15, 10>("FfnStream<29,15,PF=10>");
   replay<false>("HeadStream");
   replay<true>("HeadStream<LEAN>");
   if (fails) {
