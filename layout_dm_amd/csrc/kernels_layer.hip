@@ -126,14 +126,10 @@ __global__ __launch_bounds__(256, 1) void layer_stream_k(LayerArgs a) {
       HS.aV[0] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + hi) ^ (r & 15)) << 4);
       HS.aV[1] = kv0 + KV_BYTES + r * 256 + (((wave * 4 + 2 + hi) ^ (r & 15)) << 4);
     }
-    AttnCore AC;
+    AttnCoreV AC;  // (the all-VGPR core of the stack kernel: one implementation of the attention core)
     AC.qf = qf;
-    {
-      const int ksw = (r >> 1) & 7;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) AC.aKr[ks] = kv0 + r * 128 + (((2 * ks + hi) ^ ksw) << 4);
-      AC.aVr = kv0 + KV_BYTES + r * 256 + ((hi ^ (r & 15)) << 4);
-    }
+    AC.aKr = kv0 + r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
+    AC.aVr = kv0 + KV_BYTES + r * 256 + ((hi ^ (r & 15)) << 4);
     AC.scale_log2e = a.scale_log2e;
     AC.S = S;
     AC.hi = hi;

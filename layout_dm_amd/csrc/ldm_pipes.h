@@ -584,148 +584,6 @@ struct SlabStream {
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// AttnCore (kernels_layer.hip): single-tile attention of one head for the wave's 32 queries against the layout's 128
-// key slots — S^T = K Q^T (16 MFMAs), in-register softmax, O^T = V^T P^T (16 MFMAs) — as ONE hand-issued LDS-read
-// queue over the 16 K fragments and the 16 V^T fragments:
-//   * the first V^T fragments are requested while the last S^T MFMAs run and land under the softmax;
-//   * the four score tiles live in arch VGPRs (no v_accvgpr_read per score), the output tiles in AGPRs;
-//   * cross-half reductions through v_permlane32_swap (no LDS round trip), 1/sum through v_rcp_f32;
-//   * scale-and-shift and the row sum in packed f32 (v_pk_fma_f32 / v_pk_add_f32: this phase is VALU-only and one wave
-//     per SIMD issues one instruction per ~4 cycles, so the instruction COUNT is its length).
-// r02 before: 4 400 cycles per head for 1 024 cycles of MFMA (compiler-scheduled, exposed LDS round trips, 540 issued
-// instructions: profiles/r02_call16_*).
-struct AttnCore {
-  static constexpr int PF = 6;
-  typedef __attribute__((ext_vector_type(2))) float f32x2;
-  f16x8 q[PF];
-  unsigned aKr[4];     // Ks + r*128 + (((2ks + hi) ^ ksw) << 4); key tile kt through the offset field (kt * 4 KiB)
-  unsigned aVr;        // Vs + r*256 + ((hi ^ (r & 15)) << 4); key chunk (4kt + 2hf) by XOR, d tile through the offset
-  const f16x8* qf;     // [4] Q fragments (B operand of S^T), k16-step ks
-  f32x16 sc[4], o[2];
-  float scale_log2e;
-  int S, hi;
-
-  template <int I>  // I in [0, 32): 16 K fragments (kt = I & 3, ks = I >> 2), then 16 V^T fragments (dt, hf, kt)
-  __device__ __forceinline__ void read_item() {
-    if constexpr (I < 16) {
-      dsr128<(I & 3) * 4096>(q[I % PF], aKr[I >> 2]);
-    } else if constexpr (I < 32) {
-      constexpr int J = I - 16, dt = J & 1, hf = (J >> 1) & 1, kt = J >> 2;
-      dsr128<dt * 8192>(q[I % PF], aVr ^ (unsigned)((kt * 4 + hf * 2) << 4));
-    }
-  }
-  template <int I>
-  __device__ __forceinline__ void qk_step() {
-    if constexpr (I < 16) {
-      constexpr int kt = I & 3, ks = I >> 2;
-      wait_lgkm<PF - 1>();
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[0]));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sc[kt]) : "v"(q[I % PF]), "v"(qf[ks]));
-      __builtin_amdgcn_sched_barrier(0);
-      read_item<I + PF>();
-      qk_step<I + 1>();
-    }
-  }
-  // P fragment of key chunk pair c = J >> 1 (kt = c >> 1, hf = c & 1): accumulator registers 8hf..8hf+7 of score tile kt
-  template <int C>
-  __device__ __forceinline__ void make_pf(f16x8& pf) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pf[e] = (_Float16)sc[C >> 1][(C & 1) * 8 + e];
-  }
-  // gfx950 needs wait states between a VALU write of a VGPR and an MFMA that reads it as an operand; hipcc inserts them
-  // for its own MFMAs but cannot see into inline asm (an MFMA issued right behind the v_cvt_pk of its B operand read
-  // the OLD register contents: NaNs, profiles/r02_call18_*).  So the P fragment of pair c + 1 is cast in the shadow of
-  // pair c's second MFMA, a whole step before its first use (two buffers).
-  template <int J>
-  __device__ __forceinline__ void pv_step(f16x8& pfa, f16x8& pfb) {
-    if constexpr (J < 16) {
-      constexpr int dt = J & 1, c = J >> 1;
-      f16x8& pf = (c & 1) ? pfb : pfa;
-      wait_lgkm<(15 - J < PF - 1 ? 15 - J : PF - 1)>();
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (J < 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pf));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o[dt]) : "v"(q[(J + 16) % PF]), "v"(pf));
-      __builtin_amdgcn_sched_barrier(0);
-      read_item<J + 16 + PF>();
-      if constexpr (dt == 0 && c + 1 < 8) make_pf<(c + 1 < 8 ? c + 1 : 0)>((c & 1) ? pfa : pfb);
-      __builtin_amdgcn_sched_barrier(0);
-      pv_step<J + 1>(pfa, pfb);
-    }
-  }
-  // nf[2dt + s]: fragment (dt, s) of this lane = output registers 8s..8s+7 of d tile dt, normalised, fp16 — the
-  // out-projection's B operand for k16-step 4h + 2dt + s (k-slot order)
-  __device__ __forceinline__ void run(f16x8 (&nf)[4]) {
-    read_item<0>(); read_item<1>(); read_item<2>(); read_item<3>(); read_item<4>(); read_item<5>();
-    qk_step<0>();
-    // MFMA results -> VALU reads: the wait states are tied to the accumulators (hipcc does not know the asm above
-    // is an MFMA and would otherwise schedule reads of its outputs in front of the nops)
-    asm volatile("s_nop 15" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
-    __builtin_amdgcn_sched_barrier(0);
-    // keys >= S (rows of the next layout, loaded clamped): key = 96 + (i & 3) + 8 (i >> 2) + 4 hi of the last tile
-    if (S == 125) {  // both datasets of the reference: 25 elements x 5 attributes
-      if (hi) { sc[3][13] = -INFINITY; sc[3][14] = -INFINITY; sc[3][15] = -INFINITY; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (96 + (i & 3) + 8 * (i >> 2) + 4 * hi >= S) sc[3][i] = -INFINITY;
-    }
-    float mx = sc[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sc[kt][i]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    const f32x2 sc2 = {scale_log2e, scale_log2e};
-    const float nm = -mx * scale_log2e;
-    const f32x2 nm2 = {nm, nm};
-    f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        f32x2 v = {sc[kt][i], sc[kt][i + 1]};
-        v = __builtin_elementwise_fma(v, sc2, nm2);
-        v.x = __builtin_amdgcn_exp2f(v.x);
-        v.y = __builtin_amdgcn_exp2f(v.y);
-        sc[kt][i] = v.x;
-        sc[kt][i + 1] = v.y;
-        sum2 += v;
-      }
-    float sum = sum2.x + sum2.y;
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-      sum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    {
-      f16x8 pfa, pfb;
-      make_pf<0>(pfa);
-      asm volatile("s_nop 3" : "+v"(pfa));  // VALU write -> MFMA operand read
-      __builtin_amdgcn_sched_barrier(0);
-      pv_step<0>(pfa, pfb);
-      asm volatile("s_nop 15" : "+a"(o[0]), "+a"(o[1]));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const f32x2 inv2 = {inv, inv};
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          f32x2 v = {o[dt][s2 * 8 + e], o[dt][s2 * 8 + e + 1]};
-          v = v * inv2;
-          nf[dt * 2 + s2][e] = (_Float16)v.x;
-          nf[dt * 2 + s2][e + 1] = (_Float16)v.y;
-        }
-  }
-};
-
 }  // namespace ldm
 
 namespace ldm {
@@ -735,7 +593,10 @@ namespace ldm {
 // through the attention heads — they carry a layout's rows from layer to layer — so the attention core may use arch
 // VGPRs only and the out-projection of a head runs right behind its core.
 //
-// AttnCoreV: AttnCore with every tile in arch VGPRs.  The probabilities are cast to their fp16 MFMA fragments key tile
+// AttnCoreV: the single-tile attention core — S^T = K Q^T (16 MFMAs), in-register softmax, O^T = V^T P^T (16 MFMAs) as ONE
+// hand-issued LDS-read queue over the 16 K and 16 V^T fragments (the first V^T reads land under the softmax), cross-half
+// reductions through v_permlane32_swap, 1/sum through v_rcp_f32, packed f32 scale-and-shift — with every tile in arch VGPRs
+// (r02 before: 4 400 cycles per head, compiler-scheduled; an earlier variant with the output tiles in AGPRs: 2 970).  The probabilities are cast to their fp16 MFMA fragments key tile
 // by key tile right behind the exponentials (the 64 score registers shrink to 32 fragment registers before the two
 // output tiles come alive), which also puts every VALU write of an MFMA operand many instructions ahead of its use.
 // (r02 negative result: running the next key tile's exponentials in the shadow of the O^T MFMAs, a quarter per step,

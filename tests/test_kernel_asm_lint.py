@@ -1,0 +1,107 @@
+"""Static checks on the gfx950 code hipcc generates for the hand-pipelined kernels (no GPU needed: hipcc cross-compiles).
+
+The pipelines issue their MFMAs, LDS reads and LDS-DMA through inline asm, which hipcc's hazard recogniser and waitcnt
+insertion cannot see into.  Two failure classes found on hardware this round are checked here on the assembly:
+
+* register spills: a reload inside a stream makes hipcc emit an ``s_waitcnt vmcnt(n)`` that also waits for the weight
+  DMA it does not know about (2 300 cycles per head), and spill traffic showed up as 210 MB per launch;
+* VALU write -> MFMA operand read without wait states (an MFMA issued right behind the ``v_cvt_pk`` of its B operand read
+  the old register contents: NaNs).  ``s_nop 3`` (4 wait states) is the distance verified on the MI355X.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+VALU_TO_MFMA_WAIT_STATES = 4
+
+
+def _compile(src: str, tmp_path) -> str:
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (os.path.basename(src) + ".s")
+    subprocess.run([HIPCC, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o",
+                    str(out), os.path.join(ROOT, "layout_dm_amd", "csrc", src), "-Wno-unused-function"],
+                   check=True, capture_output=True, text=True, timeout=900)
+    return out.read_text()
+
+
+def _kernels(asm: str):
+    """name -> list of instruction strings, for every kernel (functions with an .amdhsa_kernel descriptor).  Instructions
+    that come from inline asm (between hipcc's ;;#ASMSTART / ;;#ASMEND markers) carry the prefix "asm:"."""
+    names = set(re.findall(r"\.amdhsa_kernel\s+(\S+)", asm))
+    out, cur, in_asm = {}, None, False
+    for line in asm.splitlines():
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\S+):\s*(;.*)?$", t)
+        if m and m.group(1) in names:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if t.startswith(".Lfunc_end"):
+            cur = None
+        if cur is None or not t or t[0] in ";." or t.endswith(":"):
+            continue
+        cur.append(("asm:" if in_asm else "") + t.split(";")[0].strip())
+    return out
+
+
+def _regs(tok: str):
+    m = re.match(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+@pytest.mark.parametrize("src,kernel_substr", [("kernels_stack.hip", "stack_stream_k"), ("kernels_layer.hip", "layer_stream_k")])
+def test_stream_kernels_no_spills_no_valu_mfma_hazard(tmp_path, src, kernel_substr):
+    asm = _compile(src, tmp_path)
+    kernels = {k: v for k, v in _kernels(asm).items() if kernel_substr in k}
+    assert kernels, "no kernel found"
+    # every variant without the probe instrumentation (TM = false: the first template argument mangles as Lb0) must be
+    # free of scratch; the probe variants may spill a couple of registers around their timers
+    sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
+    for name, instr in kernels.items():
+        product = "ILb0E" in name
+        if product:
+            assert int(sizes[name]) == 0, f"{name}: {sizes[name]} bytes of scratch per lane"
+            assert not [i for i in instr if i.startswith("scratch_")], f"{name}: scratch instructions"
+        n_mfma = 0
+        for i, t in enumerate(instr):
+            # only MFMAs issued through inline asm: for its own (builtin) MFMAs hipcc places the wait states itself
+            if not t.startswith("asm:v_mfma"):
+                continue
+            t = t[4:]
+            n_mfma += 1
+            ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+            src_regs = _regs(ops[1]) | _regs(ops[2])
+            ws = 0
+            for j in range(i - 1, max(i - 10, -1), -1):
+                p = instr[j][4:] if instr[j].startswith("asm:") else instr[j]
+                op = p.split()[0]
+                if op == "s_nop":
+                    ws += int(p.split()[1]) + 1
+                    continue
+                if op.startswith(("ds_read", "global_load", "scratch_load", "buffer_load")):
+                    if _regs(p.split(None, 1)[1].split(",")[0].strip()) & src_regs:
+                        break  # the operand is (re)defined by a load: covered by the counted waits, not by this rule
+                if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_accvgpr_write")):
+                    if _regs(p.split(None, 1)[1].split(",")[0].strip()) & src_regs:
+                        assert ws >= VALU_TO_MFMA_WAIT_STATES, \
+                            f"{name}: '{p}' writes an operand of '{t}' only {ws} wait states ahead"
+                        break
+                # an intervening MFMA holds the matrix pipe for 8 passes: the checked MFMA cannot issue before it has left
+                ws += 8 if op.startswith("v_mfma") else 1
+                if ws >= VALU_TO_MFMA_WAIT_STATES:
+                    break
+        assert n_mfma > 150, f"{name}: only {n_mfma} inline-asm MFMAs found (parser broken?)"
