@@ -16,7 +16,6 @@
 // Reference semantics: torch.nn.MultiheadAttention in/out of trainer/models/transformer_utils.py:140-142,
 // 197-204 with AdaLayerNorm (l.72-83) applied to the input.
 #include <cstdlib>
-#include <type_traits>
 
 #include "ldm_kernels.h"
 #include "ldm_dma.h"
@@ -38,24 +37,6 @@ struct OutProj {
   int ldc, N;
 };
 
-// V bit 3 (fused layer): the FFN half of the block — x2 = x1 + W2 relu(W1 LN2(x1) + b1) + b2
-// (transformer_utils.py:179,208-209) — runs in the same workgroup on the x1 rows it still holds in registers.
-struct FfnTail {
-  const char* img;     // W1 (k-slot K axis) | W2 LDS image, 64 KiB per 32-wide hidden chunk (ldm_pack.h pack_ffn_image)
-  const float *b1, *b2, *g2, *be2;  // linear1 / linear2 bias, norm2 gamma / beta
-  int n_chunks;        // d_ff / 32
-};
-
-// hardware lane id through a volatile asm: every call site re-derives it (a builtin would be CSE'd into ONE value
-// that then lives across whole kernel phases)
-__device__ __forceinline__ int fresh_lane_id() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-
-constexpr int kMultiLayers = 4;  // layers per launch of the multi-layer kernel (V bit 4)
-
 // phase-timing instrumentation (dev hook only, LDM_ATTN_TM=1): s_memtime sums over blocks
 __device__ unsigned long long g_attn_phase[16];
 #define LDM_TM_NOW() __builtin_amdgcn_s_memtime()
@@ -63,36 +44,19 @@ __device__ unsigned long long g_attn_phase[16];
 // V bit 0: batched prologue (row loads in 3 batches instead of 15 dependent double-buffered groups);
 // V bit 1: the per-head attention outputs stay in REGISTERS until the out-projection (they already are its B
 //          operand fragments): no scratch tensor, no reload phase.  Needs FUSE_OUT and H == 8.
-// V bit 3: FUSED LAYER (needs bits 0, 1; N == 464; the slab image of pack_attn_slab_image).  The out-projection runs
-//          in K-slab form on 15 PERSISTENT accumulator tiles seeded with the residual AdaLN(x) + b_out, so x1 ends up
-//          in registers in accumulator layout; LN2 statistics, the normalised fp16 fragments (W1's K axis is k-slot
-//          ordered, as in the fused FFN version 2) and the GEMM2 seed x1 + b2 are formed from those registers and the
-//          FFN chunk loop (FfnStream) follows in the same workgroup.  x1 never exists in memory: per layout and layer
-//          the kernel reads the input rows twice (operand, residual) and writes the output rows once.
+// (The one-launch-per-layer successor of this kernel is kernels_layer.hip, the whole-stack one kernels_stack.hip.)
 template <int KS, bool FUSE_OUT, bool TM = false, int V = 0>
 __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ img, const float* __restrict__ bias,
                                                     LnLoad ln, __half* __restrict__ att, int ldo, int S, int H,
-                                                    int M, float scale_log2e, OutProj op, int skew, FfnTail ft,
-                                                    FusedLayerSet ls) {
+                                                    int M, float scale_log2e, OutProj op, int skew) {
   constexpr bool REG_OF = FUSE_OUT && (V & 2);
-  constexpr bool LAYER = FUSE_OUT && (V & 8);
-  // V bit 4 (needs bit 3): ALL layers of the stack in this launch.  A layout's rows stay in its workgroup from the
-  // embedding output to the input of the head: at a layer boundary x2 sits in the accumulators; it is written to
-  // memory once (the next layer's residual seed re-reads it) and the next layer's AdaLN-normalised fp16 fragments
-  // are built from the same registers — no operand re-read, no kernel boundary.  The in_proj K axis is k-slot ordered.
-  constexpr bool MULTI = LAYER && (V & 16);
-  static_assert(!(V & 16) || (V & 8), "multi-layer needs the fused layer");
-  static_assert(!LAYER || (V & 3) == 3, "fused layer needs the batched prologue and the register exchange");
   constexpr int PF = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ring = smem;                       // 2 x 32 KiB weight tiles
+  // smem: 2 x 32 KiB weight tiles (the ring, addressed through lds0 below), then
   char* kvbuf = smem + 2 * STAGE;          // [2 parities][Ks 16 KiB | Vs 16 KiB]
   float* sbias = reinterpret_cast<float*>(kvbuf + 4 * KV_BYTES);  // [3*H*64]
   float* sp = sbias + 3 * H * 64;          // AdaLN multiplier / shift (2 x LN_DP)
   float* sbo = sp + 2 * LN_DP;             // out-proj bias (FUSE_OUT)
-  float* sb1 = sbo + 512;                  // (LAYER) linear1 bias [n_chunks*32]
-  float* sp2 = sb1 + (LAYER ? ft.n_chunks * 32 : 0);  // (LAYER) norm2 gamma | beta (2 x LN_DP)
-  float* sb2 = sp2 + 2 * LN_DP;            // (LAYER) linear2 bias [512], zero beyond N
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int b = blockIdx.x;
@@ -105,60 +69,26 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
   const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
   unsigned long long t_pro = 0, t_qkv_end = 0;  // (TM; with several layers: the last layer's)
   f16x8 xf[KS];
-  // The layers are unrolled at compile time (generic lambda, always inlined): a run-time loop makes the fragment
-  // array loop-carried and hipcc then parks it in scratch.  MULTI handles exactly kMultiLayers layers per launch.
-  constexpr int n_layers = MULTI ? kMultiLayers : 1;
-  auto layer_body = [&](auto layer_c) __attribute__((always_inline)) {
-  constexpr int layer = decltype(layer_c)::value;
-  // lane coordinates, derived INSIDE the layer loop from a volatile read of the lane id (MULTI): everything computed
-  // from them is then iteration-local — hipcc otherwise hoists the address arithmetic of every phase out of the loop
-  // and keeps it alive across the phases that need every register
-  const int lane = MULTI ? fresh_lane_id() : (tid0 & 63);  // (MULTI: a fresh value per layer keeps hipcc from sharing
-                                                           //  address arithmetic across the layers' phases)
+  const int lane = tid0 & 63;
   const int tid = wave * 64 + lane;
   const int r = lane & 31, hi = lane >> 5;
   const int row_in = wave * 32 + r;          // token index inside the layout (>= S: padding)
   const bool valid = row_in < S;
   const size_t m = (size_t)b * S + (valid ? row_in : S - 1);
   const unsigned voff = lane * 16;
-  // per-layer operands: kernel arguments (single layer) or the layer table (MULTI)
-  const char* img_l = MULTI ? (const char*)ls.w[layer].img : img;
-  const float* bias_l = MULTI ? ls.w[layer].bias_in : bias;
-  const float* p0_l = MULTI ? ls.w[layer].ada_scale : ln.p0;
-  const float* p1_l = MULTI ? ls.w[layer].ada_shift : ln.p1;
-  const float* bo_l = MULTI ? ls.w[layer].b_out : op.bias;
-  FfnTail ft_l = ft;
-  if constexpr (MULTI) {
-    ft_l.img = (const char*)ls.w[layer].ffn_img;
-    ft_l.b1 = ls.w[layer].b1; ft_l.b2 = ls.w[layer].b2; ft_l.g2 = ls.w[layer].g2; ft_l.be2 = ls.w[layer].be2;
-  }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) dma_lin4(voff, img_l + wave * 8192 + a * 4096, lds0 + wave * 8192 + a * 4096);  // tile 0
-  for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias_l[i];
+  for (int a = 0; a < 2; ++a) dma_lin4(voff, img + wave * 8192 + a * 4096, lds0 + wave * 8192 + a * 4096);  // tile 0
+  for (int i = tid; i < 3 * H * 64; i += 256) sbias[i] = bias[i];
   // sbo = out-proj bias + AdaLN shift (the residual AdaLN(x) is recomputed in the out-proj epilogue); both
   // tables are zero beyond N / D so that padded output columns come out as exact zeros without masks
   if (FUSE_OUT)
-    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? bo_l[i] + p1_l[i] : 0.f;
-  if (!MULTI || layer == 0) {  // (MULTI: the next layer's table is staged at the end of the previous iteration)
-    for (int i = tid; i < LN_DP; i += 256) {
-      sp[i] = i < ln.D ? (ln.ada ? 1.0f + p0_l[i] : p0_l[i]) : 0.f;
-      sp[LN_DP + i] = i < ln.D ? p1_l[i] : 0.f;
-    }
-  }
-  if constexpr (LAYER) {
-    for (int i = tid; i < ft_l.n_chunks * 32; i += 256) sb1[i] = ft_l.b1[i];
-    for (int i = tid; i < LN_DP; i += 256) {
-      sp2[i] = i < op.N ? ft_l.g2[i] : 0.f;
-      sp2[LN_DP + i] = i < op.N ? ft_l.be2[i] : 0.f;
-      sb2[i] = i < op.N ? ft_l.b2[i] : 0.f;
-    }
+    for (int i = tid; i < 512; i += 256) sbo[i] = i < op.N ? op.bias[i] + ln.p1[i] : 0.f;
+  for (int i = tid; i < LN_DP; i += 256) {
+    sp[i] = i < ln.D ? (ln.ada ? 1.0f + ln.p0[i] : ln.p0[i]) : 0.f;
+    sp[LN_DP + i] = i < ln.D ? ln.p1[i] : 0.f;
   }
   __syncthreads();
-  if constexpr (MULTI) {
-    if constexpr (layer == 0) {
-      load_xf_ln_acc<KS, 58, 16>(xf, ln, m, hi, sp);
-    }
-  } else if constexpr (V & 1) {
+  if constexpr (V & 1) {
     load_xf_ln_batched<KS, 8>(xf, ln, (int)m, hi, sp);
   } else {
     // AdaLN-on-load in groups of G k-steps, raw row loads double buffered one group ahead.  The (always zero)
@@ -245,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       tB = LDM_TM_NOW();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    P.gnext = img_l + (size_t)(ti + 1) * STAGE + wave * 8192;  // (tile n_tiles = first out-proj tile)
+    P.gnext = img + (size_t)(ti + 1) * STAGE + wave * 8192;  // (tile n_tiles = first out-proj tile)
     P.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
     const unsigned sbase = lds0 + (ti & 1) * STAGE;
     char* Ks = kvbuf + (h & 1) * 2 * KV_BYTES;
@@ -374,10 +304,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
           for (int e = 0; e < 8; ++e) nf[dt * 2 + s2][e] = (_Float16)(o[dt][s2 * 8 + e] * inv);
-      if constexpr (LAYER) {  // park them in AGPRs: the arch VGPRs belong to the activation fragments of the tile runs
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nf[i] = to_agpr4(nf[i]);
-      }
 #define LDM_OF_CASE(HH) \
   case HH: of[4 * HH] = nf[0]; of[4 * HH + 1] = nf[1]; of[4 * HH + 2] = nf[2]; of[4 * HH + 3] = nf[3]; break;
       switch (h) {
@@ -419,226 +345,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
     if constexpr (TM) s_att += LDM_TM_NOW() - tD;
   }
   if constexpr (TM) t_qkv_end = LDM_TM_NOW();
-  if constexpr (LAYER) {
-    // ================================================================== fused layer: out-projection (K slabs) -> FFN
-    constexpr int NT2 = 15, NGV = 58;  // 15 output tiles of 32 columns, 58 valid 8-column groups (N = 464)
-    // lane coordinates re-materialised behind an opaque asm: hipcc otherwise hoists the address arithmetic of the
-    // phases below above the QKV loop, where every register is taken (-> scratch spills inside the tile loop)
-    // (and re-derived from the hardware lane id rather than kept: a value that lives from the prologue to the
-    //  epilogue would be the one register too many)
-    const int lane1 = fresh_lane_id();
-    const int r1 = lane1 & 31, hi1 = lane1 >> 5;
-    const int row1 = wave * 32 + r1;
-    const size_t m1 = (size_t)b * S + (row1 < S ? row1 : S - 1);
-    f32x16 acc[NT2];
-#pragma unroll
-    for (int t = 0; t < NT2; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    {
-      // residual seed in accumulator layout: AdaLN(x)[row][cols] + (b_out + shift)[cols]; lane (row, hi) owns columns
-      // 8g + 4hi .. +3 of every 8-column group g
-      constexpr int GB = 20;
-      if constexpr (MULTI) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // x rows written by this workgroup
-      const float2 rst = ln.stats[m1];  // (MULTI, layer > 0: written by this workgroup's previous epilogue)
-      const float ra = rst.y, rb = -rst.x * rst.y;  // xn = x * ra + rb
-      const float* rrow = ln.x + m1 * ln.ldx + hi1 * 4;
-      const float* gmp = sp + hi1 * 4;
-      const float* tbp = sbo + hi1 * 4;
-#pragma unroll
-      for (int g0 = 0; g0 < NGV; g0 += GB) {
-        float4 raw[GB];
-#pragma unroll
-        for (int i = 0; i < GB; ++i)
-          if (g0 + i < NGV) raw[i] = *reinterpret_cast<const float4*>(rrow + (g0 + i) * 8);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-          const int gg = g0 + i;
-          if (gg < NGV) {
-            const float4 a = raw[i];
-            const float4 gm = *reinterpret_cast<const float4*>(gmp + gg * 8);
-            const float4 tb = *reinterpret_cast<const float4*>(tbp + gg * 8);
-            const int t = gg >> 2, q0 = (gg & 3) * 4;
-            acc[t][q0 + 0] = to_agpr(fmaf(fmaf(a.x, ra, rb), gm.x, tb.x));
-            acc[t][q0 + 1] = to_agpr(fmaf(fmaf(a.y, ra, rb), gm.y, tb.y));
-            acc[t][q0 + 2] = to_agpr(fmaf(fmaf(a.z, ra, rb), gm.z, tb.z));
-            acc[t][q0 + 3] = to_agpr(fmaf(fmaf(a.w, ra, rb), gm.w, tb.w));
-            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    {
-      // 16 K slabs (k chunk c = head c/2, d-half c%2; B operands of[2c], of[2c+1]); slab 0 was prefetched by the last
-      // q tile (image stage n_tiles)
-      SlabPipe<NT2, PF> SP;
-      SP.acc = acc;
-      SP.voff = voff;
-      const unsigned relS0 = r1 * 64 + (((0 + hi1) ^ ((r1 >> 2) & 3)) << 4);
-      const unsigned relS1 = r1 * 64 + (((2 + hi1) ^ ((r1 >> 2) & 3)) << 4);
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int ti = n_tiles + c;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        SP.gnext = img_l + (size_t)(ti + 1) * STAGE + wave * 8192;  // (stage n_tiles + 16 is zero padding)
-        SP.mnext = lds0 + ((ti + 1) & 1) * STAGE + wave * 8192;
-        const unsigned sbase = lds0 + (ti & 1) * STAGE;
-        SP.aS[0] = sbase + relS0;
-        SP.aS[1] = sbase + relS1;
-        SP.run(of[2 * c], of[2 * c + 1]);
-      }
-    }
-    unsigned long long t_slab = 0, t_ln2 = 0, t_ffn = 0;
-    if constexpr (TM) t_slab = LDM_TM_NOW();
-    // acc = x1 (rows of this layout).  Everybody is done with the attention ring / K,V buffers after this barrier:
-    // the FFN ring (2 x 64 KiB at LDS 0) takes their place.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    {  // FFN chunk 0 -> stage 0 (this wave's 16 KiB); lands while LN2 runs
-      const char* g0 = ft_l.img + wave * 16384;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) dma_lin4(voff, g0 + a * 4096, lds0 + wave * 16384 + a * 4096);
-    }
-    const int lane2 = fresh_lane_id();
-    const int r2 = lane2 & 31, hi2 = lane2 >> 5;
-    f16x8 xf2[KS];
-    {
-      // LN2 statistics of the row (this lane's half + lane^32), normalised fp16 fragments in k-slot order (groups
-      // 2ks, 2ks+1 of the accumulator layout ARE fragment ks), GEMM2 seed acc = x1 + b2
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[t][q0 + i];
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      constexpr float kInvN = 1.0f / 464.0f;  // N = 464 (launcher)
-      const float mean = s1 * kInvN;
-      const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN - mean * mean, 0.f) + 1e-5f);
-      const float* gp = sp2 + hi2 * 4;
-      const float* bp = sb2 + hi2 * 4;
-#pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
-        const float4 ga = *reinterpret_cast<const float4*>(gp + gg * 8);
-        const float4 be = *reinterpret_cast<const float4*>(gp + LN_DP + gg * 8);
-        const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
-        const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
-        xf2[ks][e0 + 0] = (_Float16)fmaf((v0 - mean) * rstd, ga.x, be.x);
-        xf2[ks][e0 + 1] = (_Float16)fmaf((v1 - mean) * rstd, ga.y, be.y);
-        xf2[ks][e0 + 2] = (_Float16)fmaf((v2 - mean) * rstd, ga.z, be.z);
-        xf2[ks][e0 + 3] = (_Float16)fmaf((v3 - mean) * rstd, ga.w, be.w);
-        acc[t][q0 + 0] = to_agpr(v0 + bb.x);
-        acc[t][q0 + 1] = to_agpr(v1 + bb.y);
-        acc[t][q0 + 2] = to_agpr(v2 + bb.z);
-        acc[t][q0 + 3] = to_agpr(v3 + bb.w);
-        if (gg & 1) asm volatile("" : "+v"(xf2[ks]));
-        if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if constexpr (TM) t_ln2 = LDM_TM_NOW();
-    {
-      // ---- FFN chunk loop: one continuous LDS-read / MFMA pipeline (ldm_pipes.h FfnStream)
-      unsigned relW1[8], relW2[2];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) relW1[k] = r2 * RKB + ((((k << 1) | hi2) ^ (r2 & 15)) << 4);
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) relW2[sx] = r2 * 64 + (((2 * sx + hi2) ^ ((r2 >> 2) & 3)) << 4);
-      const unsigned relB = lds0 + (unsigned)(reinterpret_cast<char*>(sb1) - smem) + hi2 * 16;
-      FfnStream<KS, NT2, 2, false> F;
-      F.xf = xf2;
-      F.acc = acc;
-      F.voff = voff;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // chunk 0 (own pieces), then everybody's
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < 8; ++k) F.aW1[k] = lds0 + relW1[k];
-#pragma unroll
-      for (int sx = 0; sx < 2; ++sx) F.aW2[sx] = lds0 + relW2[sx];
-      F.ab_next = relB;
-      F.read_bias();
-      F.template prologue<0>();
-      for (int c = 0; c < ft_l.n_chunks; ++c) {
-        F.gnext = ft_l.img + (size_t)(c + 1 == ft_l.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
-        F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
-        F.ab_next = relB + (c + 1 == ft_l.n_chunks ? 0 : c + 1) * 128;
-        F.template step<0, true>();
-      }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (TM) {
-      t_ffn = LDM_TM_NOW();
-      s_w2 = t_slab - t_qkv_end;  // residual seed + 16 K slabs
-      s_r2 = t_ln2 - t_slab;      // LN2 + FFN chunk 0 DMA
-      s_e2 = t_ffn - t_ln2;       // FFN chunk loop
-    }
-    {
-      // ---- x2 = acc: row statistics + stores (only the rows of this layout: padding rows of the last wave belong to
-      // the next layout)
-      const int lane3 = fresh_lane_id();
-      const int r3 = lane3 & 31, hie = lane3 >> 5;
-      const int row3 = wave * 32 + r3;
-      const bool valid3 = row3 < S;
-      const size_t me = (size_t)b * S + (valid3 ? row3 : S - 1);
-      float* orow = op.C32 + me * op.ldc + hie * 4;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < NGV; ++gg) {
-        const int t = gg >> 2, q0 = (gg & 3) * 4;
-        const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
-        s1 += (v0 + v1) + (v2 + v3);
-        s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-        if (valid3) *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
-      }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      constexpr float kInvN3 = 1.0f / 464.0f;
-      const float mean3 = s1 * kInvN3;
-      const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
-      if (valid3 && hie == 0 && op.stats_out) op.stats_out[me] = make_float2(mean3, rstd3);
-      if constexpr (MULTI) {
-        if constexpr (layer + 1 < n_layers) {
-          // next layer: its AdaLN table replaces this layer's (dead since the residual seed), then the fragments of
-          // the next QKV phase straight from the accumulators (k-slot order: groups 2ks, 2ks+1 ARE fragment ks)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          const float* np0 = ls.w[layer + 1].ada_scale;
-          const float* np1 = ls.w[layer + 1].ada_shift;
-          for (int i = tid; i < LN_DP; i += 256) {
-            sp[i] = i < ln.D ? 1.0f + np0[i] : 0.f;
-            sp[LN_DP + i] = i < ln.D ? np1[i] : 0.f;
-          }
-          __syncthreads();
-          const float* mp = sp + hie * 4;
-#pragma unroll
-          for (int gg = 0; gg < NGV; ++gg) {
-            const int t = gg >> 2, q0 = (gg & 3) * 4, ks = gg >> 1, e0 = (gg & 1) * 4;
-            const float4 ga = *reinterpret_cast<const float4*>(mp + gg * 8);
-            const float4 sa = *reinterpret_cast<const float4*>(mp + LN_DP + gg * 8);
-            xf[ks][e0 + 0] = (_Float16)fmaf((acc[t][q0 + 0] - mean3) * rstd3, ga.x, sa.x);
-            xf[ks][e0 + 1] = (_Float16)fmaf((acc[t][q0 + 1] - mean3) * rstd3, ga.y, sa.y);
-            xf[ks][e0 + 2] = (_Float16)fmaf((acc[t][q0 + 2] - mean3) * rstd3, ga.z, sa.z);
-            xf[ks][e0 + 3] = (_Float16)fmaf((acc[t][q0 + 3] - mean3) * rstd3, ga.w, sa.w);
-            if (gg & 1) asm volatile("" : "+v"(xf[ks]));
-            if ((gg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-          }
-          // every wave is past its FFN LDS reads (barrier above): the next iteration may refill the ring / tables
-        }
-      }
-    }
-  } else if constexpr (FUSE_OUT) {
+  if constexpr (FUSE_OUT) {
     // ------------------------------------------------------------------ out-projection phase
     if constexpr (!REG_OF) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own att stores are performed before reading back
@@ -744,13 +451,6 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_k(const char* __restrict__ im
       op.stats_out[m] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
     }
   }
-  };  // layer_body
-  layer_body(std::integral_constant<int, 0>{});
-  if constexpr (MULTI) {
-    layer_body(std::integral_constant<int, 1>{});
-    layer_body(std::integral_constant<int, 2>{});
-    layer_body(std::integral_constant<int, 3>{});
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (padding) tile prefetch must land before the LDS is released
   if constexpr (TM) {
     const unsigned long long t_end = LDM_TM_NOW();
@@ -781,8 +481,7 @@ void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, 
   auto kern = qkv_attn_k<KS, false>;
   allow_big_lds((const void*)kern);
   OutProj op{};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op, 0,
-                     FfnTail{}, FusedLayerSet{});
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op, 0);
 }
 
 // same + out-projection (tiles n_tiles.. of the image).  LDM_ATTN_V: bit 0 batched prologue, bit 1 attention outputs
@@ -797,8 +496,7 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   static const int skew = getenv("LDM_ATTN_SKEW") ? atoi(getenv("LDM_ATTN_SKEW")) : 0;
   static const int ver_env = getenv("LDM_ATTN_V") ? atoi(getenv("LDM_ATTN_V")) : 3;
   const int ver = (H == 8) ? ver_env : (ver_env & 1);
-  using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int, FfnTail,
-                     FusedLayerSet);
+  using K = void (*)(const char*, const float*, LnLoad, __half*, int, int, int, int, float, OutProj, int);
   K kern;
   switch (ver & 3) {
     case 0: kern = tm ? qkv_attn_k<KS, true, true, 0> : qkv_attn_k<KS, true, false, 0>; break;
@@ -808,24 +506,7 @@ void launch_attention_block(const void* img, const float* bias, const LnLoad& ln
   allow_big_lds((const void*)kern);
   OutProj op{b_out, C32, stats_out, ldc, N};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, att, ldo, S, H, B * S, scale_log2e, op,
-                     skew, FfnTail{}, FusedLayerSet{});
-}
-
-// One transformer layer per launch (V = 11): x <- x2 in place.  img: pack_attn_slab_image, ffn_img: pack_ffn_image with
-// W1's K axis in k-slot order.  ln: AdaLN of the layer input (x = C32 rows, stats = stats_io), N = d_model = 464.
-void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
-                        const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
-                        float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st) {
-  constexpr int KS = 29;
-  const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  const int lds = 2 * STAGE + 4 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
-  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = tm ? qkv_attn_k<KS, true, true, 11> : qkv_attn_k<KS, true, false, 11>;
-  allow_big_lds((const void*)kern);
-  OutProj op{b_out, x, stats_io, ldx, N};
-  FfnTail ft{(const char*)ffn_img, b1, b2, g2, be2, F / 32};
-  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, (const char*)img, bias, ln, (__half*)nullptr, 0, S, H, B * S,
-                     scale_log2e, op, 0, ft, FusedLayerSet{});
+                     skew);
 }
 
 void attn_phase_read(unsigned long long* out16) {

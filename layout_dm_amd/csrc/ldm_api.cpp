@@ -111,9 +111,9 @@ struct GraphEntry {
   std::vector<hipGraphExec_t> exec;
   void destroy() {
     for (auto e : exec)
-      if (e) hipGraphExecDestroy(e);
+      if (e) (void)hipGraphExecDestroy(e);
     for (auto g : graph)
-      if (g) hipGraphDestroy(g);
+      if (g) (void)hipGraphDestroy(g);
     exec.clear();
     graph.clear();
   }
@@ -192,8 +192,8 @@ struct ldm_handle {
   int defer_ln = 1;
   int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
-                       // 3: the WHOLE layer (attention block + FFN) in one per-layout kernel, in place on P;
-                       // 5: the whole layer per launch as CONTINUOUS per-head / slab / chunk streams (kernels_layer.hip:
+                       // 5: the WHOLE layer (attention block + FFN) per launch, in place on P, as continuous per-head /
+                       //    slab / chunk streams (kernels_layer.hip:
                        //    220 -> 200 us per launch, profiles/r02_call14_*, r02_call20_*)
                        // 6: ALL layers per launch with the rows RESIDENT in the out-projection accumulators
                        //    (kernels_stack.hip, default: 4 x 199 -> 743..766 us per step, profiles/r02_call23_*, r02_call25_*)
@@ -258,31 +258,34 @@ struct ldm_handle {
     hipStream_t st;
     int entry = -1;
     hipEvent_t a = nullptr, b = nullptr;
+    bool ok = false;
     Scope(ldm_handle* h_, hipStream_t st_, const char* name, double flops, double bytes) : h(h_), st(st_) {
       if (!h->profiling) return;
       entry = h->prof_entry(name);
       h->prof[entry].launches += 1;
       h->prof[entry].flops += flops;
       h->prof[entry].bytes += bytes;
-      hipEventCreate(&a);
-      hipEventCreate(&b);
-      hipEventRecord(a, st);
+      // a failed event call only loses this timing sample (ok stays false); the launch itself is unaffected
+      ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventRecord(a, st) == hipSuccess;
     }
     ~Scope() {
       if (entry < 0) return;
-      hipEventRecord(b, st);
-      h->pending.push_back({entry, a, b});
+      if (ok && hipEventRecord(b, st) == hipSuccess) {
+        h->pending.push_back({entry, a, b});
+        return;
+      }
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
     }
   };
 
   void drain_profile() {
     for (auto& pe : pending) {
-      hipEventSynchronize(pe.b);
       float ms = 0;
-      hipEventElapsedTime(&ms, pe.a, pe.b);
-      prof[pe.entry].ms += ms;
-      hipEventDestroy(pe.a);
-      hipEventDestroy(pe.b);
+      if (hipEventSynchronize(pe.b) == hipSuccess && hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess)
+        prof[pe.entry].ms += ms;
+      (void)hipEventDestroy(pe.a);
+      (void)hipEventDestroy(pe.b);
     }
     pending.clear();
   }
@@ -414,6 +417,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
     if (h->fused_attn >= 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
     if (h->fused_attn == 4) h->fused_attn = 6;  // (4 was the r02 tile-by-tile multi-layer experiment: +0.4 % only, removed; profiles/r02_call12_*)
+    if (h->fused_attn == 3) h->fused_attn = 5;  // (3 was the first one-launch-per-layer kernel, superseded by the stream version)
     if (h->fused_attn == 6 && h->L > 8) h->fused_attn = 5;   // FusedLayerSet holds 8 layers
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
@@ -452,9 +456,12 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     ldm_destroy(h);
     return rc;
   }
-  hipEventCreate(&h->loop_a);
-  hipEventCreate(&h->loop_b);
-  hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming);
+  if (hipEventCreate(&h->loop_a) != hipSuccess || hipEventCreate(&h->loop_b) != hipSuccess ||
+      hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) {
+    g_create_error = "event creation failed";
+    ldm_destroy(h);
+    return -2;
+  }
   h->lane_stream.assign(h->n_lanes, nullptr);
   h->lane_done.assign(h->n_lanes, nullptr);
   for (int l = 1; l < h->n_lanes; ++l) {
@@ -472,19 +479,19 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
 extern "C" void ldm_destroy(ldm_handle* h) {
   if (!h) return;
   DeviceGuard guard(h->device);
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   h->drain_profile();
   for (auto& g : h->graphs) g.destroy();
   for (auto& kv : h->raw)
-    if (kv.second.d) hipFree(kv.second.d);
-  for (void* p : h->owned) hipFree(p);
-  if (h->loop_a) hipEventDestroy(h->loop_a);
-  if (h->loop_b) hipEventDestroy(h->loop_b);
-  if (h->fork_ev) hipEventDestroy(h->fork_ev);
+    if (kv.second.d) (void)hipFree(kv.second.d);
+  for (void* p : h->owned) (void)hipFree(p);
+  if (h->loop_a) (void)hipEventDestroy(h->loop_a);
+  if (h->loop_b) (void)hipEventDestroy(h->loop_b);
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   for (auto st : h->lane_stream)
-    if (st) hipStreamDestroy(st);
+    if (st) (void)hipStreamDestroy(st);
   for (auto ev : h->lane_done)
-    if (ev) hipEventDestroy(ev);
+    if (ev) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -770,7 +777,7 @@ static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 // AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
 static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
                                        bool skip_embed = false) {
-  const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
+  const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD;
   if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw) + stats_a   (skipped when the previous step's posterior wrote P)
     LnArgs a{};
     a.tokens = d_tokens; a.emb = h->emb; a.pos = h->pos; a.y32 = h->P; a.stats_out = h->stats_a; a.raw = 1;
@@ -813,17 +820,6 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
                            (double)M * D * 12);
       launch_layer_stream(f.attn_slab_img, f.b_in, ada, f.b_out_v, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
                           h->stats_a, D, Bc, h->S, h->H, h->dh, st);
-      continue;
-    }
-    if (h->fused_attn == 3) {
-      // the whole layer in one launch, in place: P <- x2 = x1 + FFN(LN2(x1)), x1 = AdaLN(x) + MHA(AdaLN(x)); x1 only
-      // ever exists in the workgroup's registers
-      ldm_handle::Scope sc(h, st, "layer_fused",
-                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) +
-                               2 * gemm_flops(M, F, D),
-                           (double)M * D * 12);
-      launch_layer_fused(f.attn_slab_img, f.b_in, ada, w.b_out, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
-                         h->stats_a, D, Bc, h->S, h->H, h->dh, st);
       continue;
     }
     if (h->fused_attn == 2) {
@@ -1488,9 +1484,9 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
         rc = run_loop_body(h, cond, rel, h_t_model, h_t_post, n_steps, s, B, inter_dst, lanes > 1 ? lane : -1, cap);
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(cap, &graph);
-        hipStreamDestroy(cap);
+        (void)hipStreamDestroy(cap);
         if (rc || e != hipSuccess) {
-          if (graph) hipGraphDestroy(graph);
+          if (graph) (void)hipGraphDestroy(graph);
           ne.destroy();
           if (rc) return rc;
           return h->fail(-2, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -1565,128 +1561,4 @@ extern "C" int ldm_profile_reset(ldm_handle* h) {
   h->drain_profile();
   h->prof.clear();
   return 0;
-}
-
-// ------------------------------------------------------------------------------------------ dev hook
-// Tile-configuration tuning aid (not part of the public ABI): times launch_gemm16 on synthetic
-// operands.  Returns average ms per launch.
-extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float* ms_out) {
-  const int Mp = round_up(M, 256), Np = round_up(N, 256), Kp = round_up(K, 64);
-  std::vector<uint16_t> ha((size_t)Mp * Kp), hw((size_t)Np * Kp);
-  uint32_t s = 12345u;
-  auto rnd = [&]() {
-    s = s * 1664525u + 1013904223u;
-    return ((float)(s >> 8) / 8388608.0f) - 1.0f;
-  };
-  for (auto& x : ha) x = f2h_bits(rnd());
-  for (auto& x : hw) x = f2h_bits(rnd() * 0.05f);
-  __half *A = nullptr, *W = nullptr, *Cc = nullptr;
-  if (hipMalloc((void**)&A, ha.size() * 2) != hipSuccess || hipMalloc((void**)&W, hw.size() * 2) != hipSuccess ||
-      hipMalloc((void**)&Cc, (size_t)Mp * Np * 2) != hipSuccess)
-    return -3;
-  hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
-  hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
-  float* bias = nullptr;
-  hipMalloc((void**)&bias, (size_t)Np * 4);
-  hipMemset(bias, 0, (size_t)Np * 4);
-  GemmArgs g{};
-  g.A = A; g.W = W; g.C16 = Cc; g.ldc16 = Np; g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg));
-  g.lda = Kp; g.ldw = Kp; g.precision = 1; g.bias = bias; g.relu = 1;
-  hipEvent_t a, b;
-  hipEventCreate(&a);
-  hipEventCreate(&b);
-  float *res = nullptr, *out32 = nullptr, *bias1 = nullptr;
-  __half *W1b = nullptr, *W2b = nullptr;
-  if (cfg == 101) {
-    std::vector<uint16_t> h1((size_t)2048 * 512), h2((size_t)512 * 1856);
-    for (auto& x : h1) x = f2h_bits(rnd() * 0.05f);
-    for (auto& x : h2) x = f2h_bits(rnd() * 0.05f);
-    const std::vector<uint16_t> img = pack_ffn_image(h1.data(), h2.data(), 1856, 1856, 480);
-    hipMalloc((void**)&W1b, img.size() * 2);
-    hipMalloc((void**)&bias1, 2048 * 4);
-    hipMemcpy(W1b, img.data(), img.size() * 2, hipMemcpyHostToDevice);
-    hipMemset(bias1, 0, 2048 * 4);
-  }
-  auto run = [&]() {
-    if (cfg == 100) {
-      GemmArgs r = g;
-      r.K = K;
-      r.relu = 0;
-      launch_rowgemm(r, 0, nullptr, 0);
-    } else if (cfg == 101) {  // fused FFN: A = [M,512] LN output, N = d_model (464), hidden 1856
-      launch_ffn_fused(A, Kp, W1b, nullptr, bias1, bias, res, out32, N, M, N, 1856, nullptr, nullptr, 0);
-    } else {
-      launch_gemm16(g, cfg, 2, 0);
-    }
-  };
-  if (cfg == 101) {
-    hipMalloc((void**)&res, (size_t)Mp * N * 4);
-    hipMalloc((void**)&out32, (size_t)Mp * N * 4);
-    hipMemset(res, 0, (size_t)Mp * N * 4);
-  }
-  for (int i = 0; i < 3; ++i) run();
-  hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) run();
-  hipEventRecord(b, 0);
-  hipEventSynchronize(b);
-  float ms = 0;
-  hipEventElapsedTime(&ms, a, b);
-  *ms_out = ms / iters;
-  const hipError_t e = hipGetLastError();
-  hipEventDestroy(a);
-  hipEventDestroy(b);
-  hipFree(A);
-  hipFree(W);
-  hipFree(Cc);
-  hipFree(bias);
-  if (res) hipFree(res);
-  if (out32) hipFree(out32);
-  if (W1b) hipFree(W1b);
-  if (W2b) hipFree(W2b);
-  if (bias1) hipFree(bias1);
-  return e == hipSuccess ? 0 : -2;
-}
-
-// attention micro-benchmark (dev tool): B layouts x 8 heads on random fp16 qkv
-namespace ldm {
-void ffn_phase_read(unsigned long long* out12);
-void attn_phase_read(unsigned long long* out16);
-void layer_phase_read(unsigned long long* out16);
-void stack_phase_read(unsigned long long* out16);
-}  // namespace ldm
-// dev hooks: s_memtime phase sums of the instrumented kernel variants (LDM_FFN_DBG=3 / LDM_ATTN_TM=1)
-extern "C" void ldm_dev_ffn_phases(unsigned long long* out12) { ldm::ffn_phase_read(out12); }
-extern "C" void ldm_dev_attn_phases(unsigned long long* out16) { ldm::attn_phase_read(out16); }
-extern "C" void ldm_dev_layer_phases(unsigned long long* out16) { ldm::layer_phase_read(out16); }
-extern "C" void ldm_dev_stack_phases(unsigned long long* out16) { ldm::stack_phase_read(out16); }
-
-extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
-  const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;
-  const size_t rows = (size_t)B * S + 256;
-  std::vector<uint16_t> hq(rows * ldq);
-  uint32_t s = 777u;
-  for (auto& x : hq) {
-    s = s * 1664525u + 1013904223u;
-    x = f2h_bits(((float)(s >> 8) / 8388608.0f) - 1.0f);
-  }
-  __half *q = nullptr, *o = nullptr;
-  if (hipMalloc((void**)&q, hq.size() * 2) != hipSuccess || hipMalloc((void**)&o, rows * ldo * 2) != hipSuccess) return -3;
-  hipMemcpy(q, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
-  hipEvent_t a, b;
-  hipEventCreate(&a);
-  hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) launch_attention16(q, o, B, S, H, 58, ldq, ldo, 0);
-  hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) launch_attention16(q, o, B, S, H, 58, ldq, ldo, 0);
-  hipEventRecord(b, 0);
-  hipEventSynchronize(b);
-  float ms = 0;
-  hipEventElapsedTime(&ms, a, b);
-  *ms_out = ms / iters;
-  const hipError_t e = hipGetLastError();
-  hipEventDestroy(a);
-  hipEventDestroy(b);
-  hipFree(q);
-  hipFree(o);
-  return e == hipSuccess ? 0 : -2;
 }

@@ -78,8 +78,8 @@ extern "C" int ldm_fid_create(int num_label, int max_bbox, int d_model, int n_he
 extern "C" void ldm_fid_destroy(ldm_fid* h) {
   if (!h) return;
   Dev g(h->device);
-  hipDeviceSynchronize();
-  for (void* p : h->owned) hipFree(p);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->owned) (void)hipFree(p);
   delete h;
 }
 
@@ -123,7 +123,7 @@ extern "C" int ldm_fid_finalize(ldm_fid* h) {
   if (!h) return -1;
   Dev g(h->device);
   if (!g.ok) return h->fail(-2, "hipSetDevice failed");
-  for (void* p : h->owned) hipFree(p);
+  for (void* p : h->owned) (void)hipFree(p);
   h->owned.clear();
   FidArgs& a = h->args;
   a = FidArgs{};

@@ -115,12 +115,8 @@ struct FusedLayerSet {
   FusedLayerW w[8];
   int n_layer;
 };
-// one whole transformer layer per launch, in place on x / stats_io (kernels_fusedattn.hip, V = 11):
-// img = ldm_pack::pack_attn_slab_image, ffn_img = pack_ffn_image with W1's K axis in k-slot order
-void launch_layer_fused(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
-                        const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
-                        float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
-// the same layer as continuous per-head / slab streams (kernels_layer.hip); identical arguments and images
+// one whole transformer layer per launch, in place on x / stats_io, as continuous per-head / slab streams
+// (kernels_layer.hip): img = ldm_pack::pack_attn_slab_image, ffn_img = pack_ffn_image with W1's K axis in k-slot order
 void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
                          const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
                          float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);

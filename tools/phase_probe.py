@@ -50,19 +50,11 @@ if a[0]:
     clk = a[1] / max(a[2], 1) * 100.0
     tot = a[1] / n
     print(f"attn: blocks={n} cycles/block={tot:.0f} clock={clk:.0f} MHz  us/block={tot/clk:.1f}")
-    fused = int(os.environ.get("LDM_FUSED_ATTN", "3"))
-    layer = fused >= 3
-    nl = 4 if fused == 4 else 1  # layers per launch (multi-layer kernel)
-    if layer:  # fused layer kernel: slots 9..11 = residual seed + K slabs | LN2 | FFN chunk loop
-        names = ("prologue", "wait(top)", "run(29 MFMA)", "epilogue", "attn core", "outproj+FFN total", "  seed + 16 slabs",
-                 "  LN2 (+ chunk-0 DMA)", "  FFN chunk loop")
-        per = (1, 48 * nl, 48 * nl, 48 * nl, 8 * nl, 1, 16 * nl, nl, 58 * nl)
-    else:
-        names = ("prologue", "wait(top)", "run(29 MFMA)", "epilogue", "attn core", "outproj total", "  wait2", "  run2(32 MFMA)", "  epi2")
-        per = (1, 48, 48, 48, 8, 1, 15, 15, 15)
+    names = ("prologue", "wait(top)", "run(29 MFMA)", "epilogue", "attn core", "outproj total", "  wait2", "  run2(32 MFMA)", "  epi2")
+    per = (1, 48, 48, 48, 8, 1, 15, 15, 15)
     for name, v, k in zip(names, a[3:12], per):
         print(f"   {name:16s} {v/n:9.0f} cyc/block  {100*v/n/tot:5.1f}%   per item {v/n/k:7.1f}")
-    mf = (48 * 29 + 15 * 32 + 8 * 32 + (58 * 59 if layer else 0)) * 32 * (nl if layer else 1)
+    mf = (48 * 29 + 15 * 32 + 8 * 32) * 32
     print(f"   ideal MFMA cycles/block = {mf}  ({100*mf/tot:.1f}% of block)")
 l16 = (C.c_ulonglong * 16)()
 lib.ldm_dev_layer_phases(l16)
