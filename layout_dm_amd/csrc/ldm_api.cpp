@@ -310,12 +310,26 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   };
   if (!cfg || !out) return bad("null argument");
   if (cfg->abi_version != LDM_ABI_VERSION) return bad("ldm_config.abi_version mismatch");
-  if (cfg->n_attr < 1 || cfg->n_attr > kMaxAttr) return bad("n_attr out of range");
+  if (cfg->n_attr != 5) return bad("only the c-x-y-w-h (5 attribute) vocabulary is supported");
+  if (cfg->n_category < 1 || cfg->n_bin < 1 || cfg->n_layer < 1 || cfg->n_step < 1 || cfg->n_head < 1 || cfg->d_model < 16)
+    return bad("n_category / n_bin / n_layer / n_step / n_head must be >= 1, d_model >= 16");
+  if (cfg->n_category + 4 * cfg->n_bin + 2 > 192)
+    return bad("vocabulary > 192 classes not supported by the fused posterior kernel");
   if (cfg->d_model % 16 || cfg->d_ff % 16 || cfg->d_model > 1024) return bad("d_model/d_ff must be multiples of 16, d_model <= 1024");
   if (cfg->d_model % cfg->n_head) return bad("d_model must be divisible by n_head");
   if (cfg->d_model / cfg->n_head > 64) return bad("head_dim > 64 not supported");
   if (cfg->precision < 0 || cfg->precision > 2) return bad("unknown precision mode");
   if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
+  {
+    // sequence length: the fp16 attention kernels hold a layout's scores in ONE 128 x 128 tile; the fp32 row kernel
+    // keeps K and V of a (layout, head) in LDS (2 x S x head_dim floats <= 160 KiB).  The reference's datasets: S = 125.
+    const int S = cfg->max_elem * cfg->n_attr, dh = cfg->d_model / cfg->n_head;
+    if (S < 1) return bad("max_elem must be >= 1");
+    if (cfg->precision == LDM_PREC_FAST_F16 && S > 128)
+      return bad("precision fast: at most 128 tokens per layout (max_elem * n_attr); use precision exact");
+    if ((size_t)2 * S * ((dh + 3) & ~3) * sizeof(float) > 160 * 1024)
+      return bad("sequence too long for the attention kernels (2 * S * head_dim floats must fit 160 KiB of LDS)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return bad("no HIP device visible: the MI355X path has no CPU fallback");
@@ -337,14 +351,6 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   h->Dp = round_up(h->D, 32);
   h->Fp = round_up(h->F, 32);
   h->Cp = round_up(h->C, 32);
-  if (cfg->n_attr != 5) {
-    delete h;
-    return bad("only the c-x-y-w-h (5 attribute) vocabulary is supported");
-  }
-  if (h->C > 192) {
-    delete h;
-    return bad("vocabulary > 192 classes not supported by the fused posterior kernel");
-  }
   // vocabulary geometry: helpers/layout_tokenizer.py:79-82,429-467
   h->vocab.n_class = h->C;
   h->vocab.n_attr = cfg->n_attr;

@@ -90,6 +90,34 @@ def test_no_gpu_fails_loudly(lib_path):
     assert rc != 0 and b"no HIP device" in lib.ldm_last_error(None)
 
 
+@pytest.mark.parametrize("field,value,msg", [
+    ("abi_version", 1, b"abi_version"),
+    ("n_attr", 4, b"5 attribute"),
+    ("n_bin", 64, b"192 classes"),                 # 25 + 4 * 64 + 2 classes
+    ("d_model", 460, b"multiples of 16"),
+    ("n_head", 5, b"divisible by n_head"),
+    ("n_head", 4, b"head_dim > 64"),
+    ("precision", 3, b"precision"),
+    ("max_batch", 0, b"max_batch"),
+    ("max_elem", 26, b"at most 128 tokens"),       # fast mode: one 128 x 128 score tile per (layout, head)
+    ("n_layer", 0, b">= 1"),
+])
+def test_create_rejects_unsupported_geometry_before_touching_a_device(lib_path, field, value, msg):
+    """Argument validation of ldm_create (include/ldm_hip.h) runs before the device probe, names the offending field
+    and never hands back a handle; the reference's own configurations (rico25 / publaynet x medium backbone) pass it
+    (and then stop at the missing GPU here)."""
+    from layout_dm_amd import binding
+
+    lib = binding.load_library()
+    names = [n for n, _ in binding.LdmConfig._fields_]
+    good = dict(zip(names, (binding.ABI_VERSION, 25, 32, 25, 5, 464, 8, 1856, 4, 100, binding.PREC_FAST_F16, 4, 0, 0, 0)))
+    cfg = binding.LdmConfig(*[value if n == field else good[n] for n in names])
+    h = ctypes.c_void_p()
+    rc = lib.ldm_create(ctypes.byref(cfg), 0, ctypes.byref(h))
+    assert rc == -1 and not h.value
+    assert msg in lib.ldm_last_error(None), lib.ldm_last_error(None)
+
+
 def test_product_package_does_not_import_oracle():
     """The oracle is test infrastructure: nothing under layout_dm_amd/ may reference it."""
     pkg = os.path.join(ROOT, "layout_dm_amd")

@@ -100,6 +100,40 @@ def test_layer_kernel_generations_agree(cuda, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("shape", ["short_sequence", "long_sequence", "small_backbone"])
+def test_denoiser_other_geometries_take_the_generic_kernels(cuda, shape, precision):
+    """The layout-resident kernels are built for the reference's one backbone (medium shrunk by 29/32: d_model 464,
+    8 heads, d_ff 1856) at 96 < S <= 128 tokens.  Any other geometry must still give the reference's numbers through
+    the generic tiled GEMM / attention kernels (ldm_create picks them; nothing is silently approximated)."""
+    import dataclasses
+
+    from layout_dm_amd.binding import Engine
+
+    base = SP.SPECS["rico25"]
+    spec = {"short_sequence": dataclasses.replace(base, name="short", max_elem=10),            # S = 50
+            "long_sequence": dataclasses.replace(base, name="long", max_elem=30, n_layer=2),   # S = 150 (exact only)
+            "small_backbone": dataclasses.replace(base, name="small", d_model=256, n_head=4,   # head dim 64
+                                                  d_ff=1024, n_layer=2, n_step=20)}[shape]
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    W = R.as_torch_weights(sd)
+    kw = dict(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+              n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision=precision,
+              max_batch=8)
+    if shape == "long_sequence" and precision == "fast":
+        with pytest.raises(RuntimeError, match="at most 128 tokens"):  # one 128 x 128 score tile per (layout, head)
+            Engine(**kw)
+        return
+    e = Engine(**kw)
+    e.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randint(0, spec.n_class, (5, spec.seq_len), generator=g)
+    t = spec.n_step // 3
+    out = e.denoise_logits(tokens.int(), t).cpu()
+    e.close()
+    assert _rel(out, R.denoiser_logits(W, spec, tokens, t)) <= LOGIT_REL_TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
 def test_denoiser_ragged_batch_and_chunks(cuda, precision):
     """B not a multiple of the chunk / of the 128-row GEMM tile; rows must not interact."""
     spec, W = weights("rico25")
