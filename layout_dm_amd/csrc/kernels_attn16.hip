@@ -98,12 +98,18 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
     if (q < S) out[(row0 + q) * ldo + (size_t)h * 64 + hi] = __float2half(t);
     return;
   }
-  // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32).  VALU-lean: only the last key
-  // tile can hold padded keys; exp(scale*(s-max)) is one v_fma + one raw v_exp_f32 per score.
+  // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32).  VALU-lean: with the reference's S = 125
+  // only the last key tile holds padded keys (the wave-uniform test skips the other tiles; shorter sequences mask
+  // them too); exp(scale*(s-max)) is one v_fma + one raw v_exp_f32 per score.
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int key = 96 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-    if (key >= S) sc[3][r] = -INFINITY;
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt == 3 || S < (kt + 1) * 32) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= S) sc[kt][r] = -INFINITY;
+      }
+    }
   }
   float mx = -INFINITY;
 #pragma unroll
