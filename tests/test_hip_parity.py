@@ -368,6 +368,37 @@ def test_loop_random_vs_oracle_same_uniforms(cuda):
     assert (final != spec.mask_id).all()
 
 
+@pytest.mark.parametrize("shape", ["short_sequence", "long_sequence", "small_backbone"])
+def test_loop_other_geometries_vs_oracle_same_uniforms(cuda, shape):
+    """The whole reverse loop (denoiser, posterior, draw; hipGraph) at geometries other than the reference's S = 125 /
+    d_model 464: free-running `random` sampling against the oracle on identical Philox uniforms (exact mode)."""
+    import dataclasses
+
+    from layout_dm_amd.binding import Engine
+
+    base = dataclasses.replace(SP.SPECS["publaynet"], n_layer=2, n_step=20)
+    spec = {"short_sequence": dataclasses.replace(base, name="short", max_elem=7),            # S = 35
+            "long_sequence": dataclasses.replace(base, name="long", max_elem=30),             # S = 150
+            "small_backbone": dataclasses.replace(base, name="small", d_model=192, n_head=6,  # head dim 32
+                                                  d_ff=768)}[shape]
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    W = R.as_torch_weights(sd)
+    e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+               n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="exact",
+               max_batch=8)
+    e.load_state_dict(sd)
+    B = 6
+    steps = R.timestep_list(spec.n_step, spec.n_step)
+    tok = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+    cfg = {"name": "random", "temperature": 1.0}
+    out, inter = e.sample_loop(tok, steps, steps, cfg, seed=7, first_layout=40, intermediates=True, use_graph=True)
+    ref = torch.stack(R.sample_loop(W, spec, B, cfg, seed=7, first_layout=40, get_intermediate_results=True)).int()
+    e.close()
+    frac = (inter.cpu() != ref).float().mean().item()
+    assert frac <= 5e-3, frac
+    assert (out.cpu() != spec.mask_id).all()
+
+
 # ----------------------------------------------------------------------------- full size (config 2)
 def test_full_batch_512_properties(cuda):
     """BASELINE config 2 size (Rico25, B=512, T=100): size-independent properties.
