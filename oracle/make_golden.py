@@ -84,7 +84,7 @@ def trajectory(m, spec, B, cfg, cond=None, seed=0):
     prev_states = torch.cat([start[None], states[:-1]])  # state BEFORE each step
     det = rh.sampling_cfg("deterministic")
     for k in cfg:
-        if k.startswith("refine") or k.startswith("relation"):
+        if k.startswith("refine") or k.startswith("relation") or k == "time_difference":
             det[k] = cfg[k]
     greedy, margin = [], []
     steps = [int(i * spec.n_step / T) for i in range(T - 1, -1, -1)]
@@ -141,6 +141,61 @@ def capture_probs(m, spec, tokens, t, cfg, cond=None):
         torch.multinomial = orig
     B, S = tokens.shape
     return captured["p"].view(B, S, spec.n_class).permute(0, 2, 1).contiguous()  # (B,C,S)
+
+
+def cond_variant_cases(m, spec, B=3):
+    """The cond types and sampler options that r01 only checked against the oracle (VERDICT a12 / a13 / f4), now from
+    the reference itself: cond=cwh and cond=partial built as helpers/task.py:61-110 builds them (on synthetic layouts),
+    a time_difference run (base.py:218-226), and the top-k / temperature probabilities at torch.multinomial."""
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    c = synth.synth_cond_c(spec, B, seed=13)
+    A = spec.n_attr
+    full = torch.from_numpy(c["seq"]).clone()          # a complete ("gt") sequence: every attribute of valid elements
+    valid = full != spec.pad_id
+    for a in range(1, A):
+        ids = torch.as_tensor(spec.full_ids(a))
+        rnd = ids[torch.randint(0, spec.n_bin, (B, spec.max_elem), generator=g)]
+        full[:, a::A] = torch.where(valid[:, a::A], rnd, full[:, a::A])
+    elem_valid = valid[:, 0::A]
+    attr = torch.arange(spec.seq_len).view(1, -1) % A
+    # cwh (task.py:91-107): keep c, w, h of valid elements, everything else [MASK]; padded slots [PAD] and fixed
+    keep = (attr == 0) | (attr == 3) | (attr == 4)
+    seq = torch.where(keep, full, torch.full_like(full, spec.mask_id))
+    seq = torch.where(valid, seq, torch.full_like(full, spec.pad_id))
+    mask = (valid & keep) | ~valid
+    cond = {"seq": seq.clone(), "mask": mask.clone(), "type": "cwh"}
+    tr = trajectory(m, spec, B, rh.sampling_cfg("random"), cond, seed=4)
+    for k, v in tr.items():
+        out["cwh_" + k] = v
+    out["cwh_cond_seq"] = seq.numpy().astype(np.int16)
+    out["cwh_cond_mask"] = mask.numpy()
+    # partial (task.py:61-88, no bos): a random subset of the valid elements is kept whole, the rest is [MASK]
+    # (also the padded slots: the number of elements is NOT given in this setting)
+    keep_e = (torch.rand(B, spec.max_elem, generator=g) < 0.4) & elem_valid
+    keep_e[:, 0] = True  # at least one element (task.py:68-72)
+    keep = keep_e.repeat_interleave(A, dim=1)
+    seq = torch.where(keep, full, torch.full_like(full, spec.mask_id))
+    cond = {"seq": seq.clone(), "mask": keep.clone(), "type": "partial"}
+    tr = trajectory(m, spec, B, rh.sampling_cfg("random"), cond, seed=5)
+    for k, v in tr.items():
+        out["partial_" + k] = v
+    out["partial_cond_seq"] = seq.numpy().astype(np.int16)
+    out["partial_cond_mask"] = keep.numpy()
+    # time_difference (base.py:218-226): the posterior is evaluated at t - int(T * time_difference)
+    tr = trajectory(m, spec, B, rh.sampling_cfg("random", time_difference=0.15), None, seed=6)
+    for k, v in tr.items():
+        out["td_" + k] = v
+    # sampler options at torch.multinomial (sampling.py:81-127) on three states of the cwh trajectory
+    cw = {"seq": torch.from_numpy(out["cwh_cond_seq"].astype(np.int64)), "mask": torch.from_numpy(out["cwh_cond_mask"]),
+          "type": "cwh"}
+    for name, cfg in (("top_k", rh.sampling_cfg("top_k", top_k=5, temperature=0.7)),
+                      ("temp", rh.sampling_cfg("random", temperature=0.6)),
+                      ("top_p_temp", rh.sampling_cfg("top_p", top_p=0.8, temperature=1.3))):
+        for i in (0, 60, 99):
+            toks = torch.from_numpy(out["cwh_states_before"][i].astype(np.int64))
+            out[f"probs_{name}_{i}"] = capture_probs(m, spec, toks, int(out["cwh_steps"][i]), cfg, cw).numpy()
+    return out
 
 
 def decode_cases(tok, spec, B=16, seed=11):
@@ -295,6 +350,11 @@ def main(out_dir=None, only=None):
     if only == "vanilla":
         np.savez_compressed(os.path.join(OUT, "rico25_vanilla.npz"), **vanilla_cases(SP.SPECS["rico25"]))
         return
+    if only == "cond_variants":
+        m, _ = rh.build_reference_model("rico25", seed=0)
+        load_synth(m, SP.SPECS["rico25"])
+        np.savez_compressed(os.path.join(OUT, "rico25_cond_variants.npz"), **cond_variant_cases(m, SP.SPECS["rico25"]))
+        return
     if only == "fid":
         np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
         return
@@ -358,6 +418,7 @@ def main(out_dir=None, only=None):
                                                   offset_ratio=0.1)[0].T.contiguous() * 3.0
             tr["weak_table"] = table.numpy()  # [token, class]
             np.savez_compressed(os.path.join(OUT, "rico25_refinement_trajectory.npz"), **tr)
+            np.savez_compressed(os.path.join(OUT, "rico25_cond_variants.npz"), **cond_variant_cases(m, spec))
         else:
             c = synth.synth_cond_c(spec, 4, seed=0)
             cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": "c"}
