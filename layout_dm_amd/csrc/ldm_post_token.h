@@ -27,7 +27,6 @@
 namespace ldm_post {
 
 constexpr float kLogEps = -69.07755278982137f;  // log(1e-30): categorical_diffusion/util.py:8
-constexpr int kMaxLive = 66;                    // body (<= 64 classes) + [PAD] + [MASK]
 
 enum Sampler { kDeterministic = 0, kRandom = 1, kTopP = 2, kTopK = 3, kGumbel = 4 };  // LDM_SAMPLE_* of ldm_hip.h
 
@@ -83,10 +82,15 @@ LDM_PT_HD float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955
 // full id of live slot i: the body in class order, then [PAD], then [MASK] (increasing ids: class order is kept)
 LDM_PT_HD int live_id(const TokenArgs& a, int i) { return i < a.count ? a.start + i : (i == a.count ? a.pad_id : a.mask_id); }
 
+// Working storage: 3 * (count + 2) floats supplied by the caller (a lane of the kernel has no private arrays: indexed
+// private memory would be scratch).  `work` MAY BE the token's own logits row (work == logits, row length >= 3 K): the
+// log-softmax passes only read; the posterior then reads logits[live_id(i)] before it writes work[i], live_id(i) >= i,
+// and everything behind that lives in work alone.
+//
 // log p(x_{t-1} | x_t) of the live classes after the cond overrides -> lp[0 .. count + 1].  F64_LSE: the reference's
 // float64 log-softmax (exact mode); otherwise fp32 (fast mode).
 template <bool F64_LSE>
-LDM_PT_HD void token_log_probs(const TokenArgs& a, const StepSchedule& s, float (&lp)[kMaxLive]) {
+LDM_PT_HD void token_log_probs(const TokenArgs& a, const StepSchedule& s, float* lp) {
   const int K = a.count + 2, C = a.n_class;
   // ---- log-softmax over the C-1 non-MASK classes (all of them: the normaliser needs the dead ones too)
   float mx = -INFINITY;
@@ -102,132 +106,133 @@ LDM_PT_HD void token_log_probs(const TokenArgs& a, const StepSchedule& s, float 
     for (int c = 0; c < C - 1; ++c) se += expf(a.logits[c] - mx);
     lse0f = logf(se);
   }
-  auto log_x0 = [&](int c) {
-    float v;
-    if (c >= C - 1) v = -70.0f;
-    else if (F64_LSE) v = (float)(((double)a.logits[c] - (double)mx) - lse0d);
-    else v = (a.logits[c] - mx) - lse0f;
-    return fminf(fmaxf(v, -70.0f), 0.0f);
-  };
   // ---- constrained posterior on the live classes (constrained.py:166-197)
   const bool x_is_mask = a.tok == a.mask_id;
-  float q[kMaxLive], q1[kMaxLive];
+  // q(x_t | x_{t-1}) (l.175-185) takes three values per token: x_t's own class, any other class, [MASK]
+  const float q1_same = x_is_mask ? s.lc : log_add_exp(0.0f + s.la, s.lb);
+  const float q1_other = x_is_mask ? s.lc : log_add_exp(kLogEps + s.la, s.lb);
+  const float q1_mask = x_is_mask ? 0.0f : kLogEps;
+  const float qt_same = x_is_mask ? s.LC : log_add_exp(0.0f + s.LA, s.LB);  // q(x_t | x_0), l.166-173
+  const float qt_other = x_is_mask ? s.LC : log_add_exp(kLogEps + s.LA, s.LB);
   float qmx = -INFINITY;
   for (int i = 0; i < K; ++i) {
     const int c = live_id(a, i);
+    float q;
     if (c == a.mask_id) {
-      q[i] = kLogEps;                      // l.189
-      q1[i] = x_is_mask ? 0.0f : kLogEps;  // l.179-185
+      q = kLogEps;  // l.189
     } else {
-      float qt;
-      if (x_is_mask) {
-        qt = s.LC;  // l.169-173
-        q1[i] = s.lc;
-      } else {
-        const float e = (c == a.tok) ? 0.0f : kLogEps;  // log one-hot of x_t (util.py:34-40)
-        qt = log_add_exp(e + s.LA, s.LB);
-        q1[i] = log_add_exp(e + s.la, s.lb);
-      }
-      q[i] = log_x0(c) - qt;  // l.188
+      float v;  // log p(x_0 = c | x_t), clamped like predict_start (base.py:140-144)
+      if (F64_LSE) v = (float)(((double)a.logits[c] - (double)mx) - lse0d);
+      else v = (a.logits[c] - mx) - lse0f;
+      v = fminf(fmaxf(v, -70.0f), 0.0f);
+      q = v - (c == a.tok ? qt_same : qt_other);  // l.188
     }
-    qmx = fmaxf(qmx, q[i]);
+    lp[i] = q;
+    qmx = fmaxf(qmx, q);
   }
   float qs = 0.f;
-  for (int i = 0; i < K; ++i) qs += expf(q[i] - qmx);
+  for (int i = 0; i < K; ++i) qs += expf(lp[i] - qmx);
   const float lse = logf(qs) + qmx;  // torch.logsumexp
   for (int i = 0; i < K; ++i) {
     const int c = live_id(a, i);
-    const float qn = q[i] - lse;
+    const float qn = lp[i] - lse;
     const float r = (c == a.mask_id) ? log_add_exp(qn + s.L1Cu, s.LCu) : log_add_exp(qn + s.LAu, s.LBu);
-    lp[i] = fminf(fmaxf((r + q1[i]) + lse, -70.0f), 0.0f);  // l.192-197
-  }
-  // ---- constraint injection (base.py:243-284)
-  for (int i = 0; i < K; ++i) {
-    const int c = live_id(a, i);
-    if (a.strong) lp[i] = (c == a.cond_tok) ? 0.0f : kLogEps;
-    else if (a.weak) lp[i] += a.weak[(long)c * a.weak_stride];
+    const float q1 = (c == a.mask_id) ? q1_mask : (c == a.tok ? q1_same : q1_other);
+    float v = fminf(fmaxf((r + q1) + lse, -70.0f), 0.0f);  // l.192-197
+    // ---- constraint injection (base.py:243-284)
+    if (a.strong) v = (c == a.cond_tok) ? 0.0f : kLogEps;
+    else if (a.weak) v += a.weak[(long)c * a.weak_stride];
+    lp[i] = v;
   }
   if (a.pad_disable) lp[a.count] = kLogEps;
 }
 
-// categorical draw over the live classes (helpers/sampling.py:81-130) -> full id
-LDM_PT_HD int draw_live(const TokenArgs& a, const float (&lp)[kMaxLive]) {
+// categorical draw over the live classes (helpers/sampling.py:81-130) -> full id.  lg = work[0 .. K) holds the
+// log-probabilities on entry and is overwritten; work[K .. 3K) is scratch.
+LDM_PT_HD int draw_live(const TokenArgs& a, float* lg) {
   const int K = a.count + 2;
   if (a.kind == kDeterministic) {  // first maximum in class order
     int bi = 0;
+    float bv = lg[0];
     for (int i = 1; i < K; ++i)
-      if (lp[i] > lp[bi]) bi = i;
+      if (lg[i] > bv) {
+        bv = lg[i];
+        bi = i;
+      }
     return live_id(a, bi);
   }
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
   const uint32_t l0 = (uint32_t)a.layout, l1 = (uint32_t)(a.layout >> 32);
-  float lg[kMaxLive];
-  for (int i = 0; i < K; ++i) lg[i] = lp[i] / a.temperature;
+  float* ex = lg + K;
+  float* keep = lg + 2 * K;
+  for (int i = 0; i < K; ++i) lg[i] = lg[i] / a.temperature;
   if (a.kind == kGumbel) {  // noise per class: counter word 0 = pos | (1 + c / 4) << 16, component c & 3
     for (int i = 0; i < K; ++i) {
       const int c = live_id(a, i);
       uint32_t r[4];
       philox4x32_10(a.pos | ((uint32_t)(1 + (c >> 2)) << 16), a.step, l0, l1, k0, k1, r);
-      lg[i] += -logf(-logf(u01(r[c & 3]) + 1e-30f) + 1e-30f);
+      const uint32_t w = (c & 3) == 0 ? r[0] : (c & 3) == 1 ? r[1] : (c & 3) == 2 ? r[2] : r[3];
+      lg[i] += -logf(-logf(u01(w) + 1e-30f) + 1e-30f);
     }
   }
   if (a.kind == kTopP || a.kind == kTopK) {
     float m1 = -INFINITY;
     for (int i = 0; i < K; ++i) m1 = fmaxf(m1, lg[i]);
-    float ex[kMaxLive], es = 0.f;
+    float es = 0.f;
     for (int i = 0; i < K; ++i) {
       ex[i] = expf(lg[i] - m1);
       es += ex[i];
     }
     // position in the descending (stable) order and the inclusive cumulative probability up to it
-    int rank[kMaxLive];
-    float cum[kMaxLive];
+    float thr = a.kind == kTopK ? INFINITY : -INFINITY;  // top-k: the k-th largest value; top-p: no value threshold
     for (int i = 0; i < K; ++i) {
-      rank[i] = 0;
-      cum[i] = 0.f;
+      int rank = 0;
+      float cum = 0.f;
+      const float li = lg[i];
       for (int o = 0; o < K; ++o) {
-        const bool before = (lg[o] > lg[i]) || (lg[o] == lg[i] && o < i);
+        const float lo = lg[o];
+        const bool before = (lo > li) || (lo == li && o < i);
         if (before) {
-          rank[i] += 1;
-          cum[i] += ex[o] / es;
+          rank += 1;
+          cum += ex[o] / es;
         } else if (o == i) {
-          cum[i] += ex[o] / es;
+          cum += ex[o] / es;
         }
       }
+      if (a.kind == kTopP) {  // drop every class whose inclusive cumulative probability exceeds p, except the first
+        keep[i] = (cum > a.top_p && rank > 0) ? 0.f : 1.f;
+      } else {                // threshold = k-th largest value (sampling.py:73-78)
+        keep[i] = 1.f;
+        if (rank < a.top_k) thr = fminf(thr, li);
+      }
     }
-    if (a.kind == kTopP) {  // drop every class whose inclusive cumulative probability exceeds p, except the first
-      for (int i = 0; i < K; ++i)
-        if (cum[i] > a.top_p && rank[i] > 0) lg[i] = -INFINITY;
-    } else {  // threshold = k-th largest value (sampling.py:73-78); k beyond the live classes keeps all of them
-      float thr = INFINITY;
-      for (int i = 0; i < K; ++i)
-        if (rank[i] < a.top_k) thr = fminf(thr, lg[i]);
-      for (int i = 0; i < K; ++i)
-        if (lg[i] < thr) lg[i] = -INFINITY;
-    }
+    for (int i = 0; i < K; ++i)
+      if (keep[i] == 0.f || lg[i] < thr) lg[i] = -INFINITY;
   }
   // softmax -> inverse CDF in class order (the normaliser cancels: compare against u * total)
   float m2 = -INFINITY;
   for (int i = 0; i < K; ++i) m2 = fmaxf(m2, lg[i]);
-  double cdf[kMaxLive], base = 0.0;
+  double base = 0.0;
   for (int i = 0; i < K; ++i) {
-    base += (double)expf(lg[i] - m2);
-    cdf[i] = base;
+    ex[i] = expf(lg[i] - m2);
+    base += (double)ex[i];
   }
   uint32_t r[4];
   philox4x32_10(a.pos, a.step, l0, l1, k0, k1, r);
   const double thr = (double)u01(r[0]) * base;
+  double cdf = 0.0;
   int n = 0;
-  for (int i = 0; i < K; ++i)
-    if (cdf[i] <= thr) n += 1;
+  for (int i = 0; i < K; ++i) {
+    cdf += (double)ex[i];
+    if (cdf <= thr) n += 1;
+  }
   return live_id(a, n < K - 1 ? n : K - 1);
 }
 
 template <bool F64_LSE>
-LDM_PT_HD int step_token(const TokenArgs& a, const StepSchedule& s) {
-  float lp[kMaxLive];
-  token_log_probs<F64_LSE>(a, s, lp);
-  return draw_live(a, lp);
+LDM_PT_HD int step_token(const TokenArgs& a, const StepSchedule& s, float* work) {
+  token_log_probs<F64_LSE>(a, s, work);
+  return draw_live(a, work);
 }
 
 }  // namespace ldm_post

@@ -1,7 +1,7 @@
 // Host build of layout_dm_amd/csrc/ldm_post_token.h (the per-token scalar tail of a reverse step, the form a lane of the
 // stack kernel runs behind the fused head): reads a case file written by tests/test_post_token_scalar.py, writes the
 // drawn tokens.  File layout (little endian): int32 header[10] = {magic, N, C, pad_id, mask_id, kind, top_k, f64_lse,
-// has_weak, 0}; float temperature, top_p; uint64 seed; then per-token arrays int32 tok, start, count, cond_tok, strong,
+// has_weak, alias_work}; float temperature, top_p; uint64 seed; then per-token arrays int32 tok, start, count, cond_tok, strong,
 // pad_disable, pos, step [N each]; uint64 layout[N]; float sched[N][10]; float logits[N][C]; float weak[N][C] if has_weak.
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +49,15 @@ int main(int argc, char** argv) {
     a.pos = (uint32_t)pos[i]; a.step = (uint32_t)step[i]; a.layout = layout[i]; a.seed = seed[0];
     const float* s = &sched[(size_t)i * 10];
     const ldm_post::StepSchedule sc{s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9]};
-    out[i] = hdr[7] ? ldm_post::step_token<true>(a, sc) : ldm_post::step_token<false>(a, sc);
+    // working storage: separate, or (alias_work) the token's own logits row, as a lane of the kernel uses it
+    std::vector<float> row(logits.begin() + (size_t)i * C, logits.begin() + (size_t)(i + 1) * C);
+    std::vector<float> sep(3 * (size_t)(count[i] + 2));
+    if (hdr[9]) {
+      if ((int)row.size() < 3 * (count[i] + 2)) return 4;
+      a.logits = row.data();
+    }
+    float* work = hdr[9] ? row.data() : sep.data();
+    out[i] = hdr[7] ? ldm_post::step_token<true>(a, sc, work) : ldm_post::step_token<false>(a, sc, work);
   }
   FILE* o = fopen(argv[2], "wb");
   if (!o) return 1;

@@ -32,7 +32,8 @@ def harness(tmp_path_factory):
     return str(exe)
 
 
-def _run(harness, tmp_path, spec, W, tokens, t_post, logits, cfg, step, seed, first_layout, cond=None, f64=False):
+def _run(harness, tmp_path, spec, W, tokens, t_post, logits, cfg, step, seed, first_layout, cond=None, f64=False,
+         alias=True):
     """tokens (B,S) int64, logits (B,S,C) float32 -> tokens drawn by the scalar tail, (B,S) int64."""
     B, S = tokens.shape
     C, A, T = spec.n_class, spec.n_attr, spec.n_step
@@ -65,7 +66,7 @@ def _run(harness, tmp_path, spec, W, tokens, t_post, logits, cfg, step, seed, fi
     path_in, path_out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
     with open(path_in, "wb") as f:
         f.write(np.array([0x4C444D31, N, C, spec.pad_id, spec.mask_id, KINDS[cfg["name"]], int(cfg.get("top_k", 1)),
-                          1 if f64 else 0, 1 if weak is not None else 0, 0], np.int32).tobytes())
+                          1 if f64 else 0, 1 if weak is not None else 0, 1 if alias else 0], np.int32).tobytes())
         f.write(np.array([cfg.get("temperature", 1.0), cfg.get("top_p", 1.0)], np.float32).tobytes())
         f.write(struct.pack("<Q", seed))
         for arr in (tokens.numpy().reshape(-1).astype(np.int32), start, count, cond_tok, strong, pad_dis, pos,
@@ -107,7 +108,9 @@ def test_scalar_tail_greedy_equals_reference_tokens(harness, tmp_path, golden_di
             t = int(g["steps"][i])
             toks = torch.from_numpy(g["states_before"][i].astype(np.int64))
             logits = R.denoiser_logits(W, spec, toks, t)
-            out = _run(harness, tmp_path, spec, W, toks, t, logits, {"name": "deterministic"}, i, 0, 0, cond, f64=f64)
+            # working storage: a separate buffer for the even states, the token's own logits row (as in the kernel) for the odd
+            out = _run(harness, tmp_path, spec, W, toks, t, logits, {"name": "deterministic"}, i, 0, 0, cond, f64=f64,
+                       alias=bool(i & 1))
             ref = torch.from_numpy(g["greedy_next"][i].astype(np.int64))
             mism = out != ref
             if mism.any():  # only where the reference's own top-2 margin is at the fp32 rounding level
