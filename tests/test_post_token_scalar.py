@@ -102,6 +102,10 @@ def test_scalar_tail_greedy_equals_reference_tokens(harness, tmp_path, golden_di
     spec_p, W_p = _weights("publaynet")
     g = np.load(os.path.join(golden_dir, "publaynet_cond_c_trajectory.npz"))
     cases.append((spec_p, W_p, g, {"seq": g["cond_seq"].astype(np.int64), "mask": g["cond_mask"], "type": "c"}))
+    gv = np.load(os.path.join(golden_dir, "rico25_cond_variants.npz"))
+    for ctype in ("cwh", "partial"):  # helpers/task.py:61-110
+        sub = {k[len(ctype) + 1:]: gv[k] for k in gv.files if k.startswith(ctype + "_")}
+        cases.append((spec, W, sub, {"seq": sub["cond_seq"].astype(np.int64), "mask": sub["cond_mask"], "type": ctype}))
     bad = total = 0
     for spec, W, g, cond in cases:
         for i in (0, 25, 50, 75, 99):
