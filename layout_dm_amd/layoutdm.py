@@ -16,7 +16,6 @@ loop runs in libldm_hip.so.
 """
 from __future__ import annotations
 
-import copy
 from typing import Dict, Optional
 
 import torch

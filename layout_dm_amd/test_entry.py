@@ -14,7 +14,6 @@ Two ways to run:
 """
 from __future__ import annotations
 
-import dataclasses
 import os
 import pickle
 import random
