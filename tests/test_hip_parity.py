@@ -453,40 +453,6 @@ def test_loop_ragged_batches_fast_mode(cuda, B, sampler):
     assert torch.equal(full, torch.cat(parts))
 
 
-@pytest.mark.skipif(os.environ.get("LDM_TEST_EXPERIMENTAL") != "1",
-                    reason="LDM_STACK_POST=1 (posterior + draw inside the stack kernel) was written at the end of round 2 "
-                           "and has not run on hardware yet; set LDM_TEST_EXPERIMENTAL=1 to try it")
-@pytest.mark.parametrize("sampler", ["deterministic", "random", "top_p", "top_k", "gumbel"])
-def test_experimental_fused_step_tail_equals_separate_tail(cuda, monkeypatch, sampler):
-    """kernels_stack.hip HEAD == 2 (one lane per token runs csrc/ldm_post_token.h on the layout's logits in LDS) against
-    the verified path (logits to HBM, posterior_sample_k): same uniforms, so the tokens may differ only where fp32
-    summation order moves an argmax tie or a CDF edge."""
-    from layout_dm_amd.binding import Engine
-
-    spec = SP.RICO25
-    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
-    steps = R.timestep_list(spec.n_step, 100)
-    cfg = {"name": sampler, "temperature": 1.0, "top_p": 0.9, "top_k": 5}
-    c = synth.synth_cond_c(spec, 300, seed=3)
-    outs = {}
-    for post in ("0", "1"):
-        monkeypatch.setenv("LDM_STACK_POST", post)
-        e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
-                   n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
-                   max_batch=512)
-        e.load_state_dict(sd)
-        tok = torch.full((300, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
-        free = e.sample_loop(tok, steps, steps, cfg, seed=5, first_layout=9, use_graph=True)[0].cpu()
-        cond = {"seq": c["seq"], "mask": c["mask"], "type": "c"}
-        tok = torch.from_numpy(c["seq"]).int().to(cuda)
-        cnd = e.sample_loop(tok, steps, steps, cfg, cond=cond, seed=5, first_layout=9, use_graph=True)[0].cpu()
-        e.close()
-        outs[post] = (free, cnd)
-    for a, b in zip(outs["0"], outs["1"]):
-        assert (a != b).float().mean().item() <= 2e-3
-        assert (b != spec.mask_id).all()
-
-
 @pytest.mark.parametrize("precision", ["exact", "split", "fast"])
 def test_full_batch_512_one_step_vs_oracle(cuda, precision):
     """Teacher-forced single step at B=512 (M=64000 rows) against the oracle on CPU."""
