@@ -106,7 +106,13 @@ typedef struct {
   int32_t n_graph_total;         /* batch size of the whole sampling call: the loss is a mean over 14*B terms */
 } ldm_relation;
 
-/* ---- lifecycle ---------------------------------------------------------------------- */
+/* ---- lifecycle ----------------------------------------------------------------------
+ * ldm_create validates the whole geometry BEFORE it touches a device and returns -1 with ldm_last_error(NULL) naming
+ * the field: n_attr == 5; d_model, d_ff multiples of 16, d_model <= 1024; d_model % n_head == 0, head dimension <= 64;
+ * n_category + 4 n_bin + 2 <= 192 classes; max_elem * n_attr <= 128 tokens in LDM_PREC_FAST_F16 (one score tile per
+ * head; longer sequences: LDM_PREC_EXACT_F32, bounded by the LDS: 2 * S * head_dim floats <= 160 KiB).  The reference's
+ * own configurations (rico25 / publaynet on the 464 / 8 / 1856 backbone, S = 125) run on the layout-resident kernels,
+ * every other accepted geometry on generic tiled kernels (same numerics contract, lower throughput). */
 int ldm_create(const ldm_config* cfg, int device, ldm_handle** out);
 void ldm_destroy(ldm_handle* h);
 const char* ldm_last_error(const ldm_handle* h); /* h may be NULL: last create error */
