@@ -106,8 +106,9 @@ class HipMaskAndReplaceDiffusion:
         t_model, t_post = timestep_schedule(T, t_eval, td)
         if cond and cond.get("type") == "relation":
             raise NotImplementedError(
-                "cond=relation needs the autograd logit adjustment (logit_adjustment.py); use "
-                "layout_dm_amd.relation.sample_with_relation (split-step API)")
+                "cond=relation needs the relation graph (cond['batch_w_canvas']) turned into the kernel's CSR form: use "
+                "layout_dm_amd.relation.sample_with_relation, which LayoutDM.sample does (the logit adjustment of "
+                "logit_adjustment.py:88-126 then runs inside ldm_sample_loop)")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         B = int(batch_size)
