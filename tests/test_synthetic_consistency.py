@@ -38,6 +38,18 @@ def test_timestep_schedule_matches_oracle():
             skip = prev - t - 1
             assert p == (t - skip if (skip > 0 and t > skip) else t)
             prev = t
+    # with time_difference (base.py:218-226, then the skip-step shift of l.227-235) — the rule oracle.single_step
+    # applies, which tests/test_oracle_golden.py pins to a reference run with time_difference = 0.15
+    for te, td in ((100, 0.15), (100, 0.5), (25, 0.1), (10, 0.99)):
+        tm, tp = timestep_schedule(100, te, td)
+        assert tm == R.timestep_list(100, te)
+        prev = 100
+        for t, p in zip(tm, tp):
+            skip = prev - t - 1
+            noise_t = min(max(t - int(100 * td), 0), 99)
+            assert p == (noise_t - skip if (skip > 0 and noise_t > skip) else noise_t)
+            assert 0 <= p < 100
+            prev = t
 
 
 def test_relation_graph_to_csr_roundtrip():
