@@ -105,3 +105,17 @@ def test_stream_kernels_no_spills_no_valu_mfma_hazard(tmp_path, src, kernel_subs
                 if ws >= VALU_TO_MFMA_WAIT_STATES:
                     break
         assert n_mfma > 150, f"{name}: only {n_mfma} inline-asm MFMAs found (parser broken?)"
+
+
+def test_step_tail_kernels_use_no_scratch(tmp_path):
+    """The other launch of every reverse step (posterior + draw + next step's embedding) and the result packaging: no
+    scratch either — a scratch-using kernel between the scratch-free stack kernels slowed the graph-replayed two-lane loop
+    (profiles/r02_call35_37_*: the same effect as observed with the wide fp32 GEMM tile)."""
+    for src, names in (("kernels_post.hip", ("posterior_sample_k",)), ("kernels_decode.hip", ("decode_layouts_k",))):
+        asm = _compile(src, tmp_path)
+        for name in names:
+            blocks = re.findall(r"\.amdhsa_kernel\s+(\S*%s\S*)(.*?)\.end_amdhsa_kernel" % name, asm, flags=re.S)
+            assert blocks, name
+            for sym, body in blocks:
+                m = re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body)
+                assert m and int(m.group(1)) == 0, (sym, m and m.group(1))
