@@ -21,6 +21,7 @@
 #include "ldm_kernels.h"
 #include "ldm_dma.h"
 #include "ldm_pipes.h"
+#include "ldm_post_token.h"
 
 namespace ldm {
 
@@ -35,7 +36,9 @@ struct StackArgs {
   const float *head_g, *head_b;
   float* logits;        // [M, ldl]
   int ldl, n_head_tiles;
+  PostArgs post;        // HEAD == 2 (experimental): posterior + draw in the same workgroup, tokens out instead of logits
 };
+constexpr int kPostLd = 161;  // floats per token row of the logits in LDS (odd: lanes = tokens read conflict-free)
 
 __device__ unsigned long long g_stack_phase[16];
 
@@ -45,7 +48,8 @@ __device__ __forceinline__ int stack_lane_id() {
   return l;
 }
 
-template <bool TM, bool HEAD>
+// HEAD: 0 = rows + statistics out; 1 = fused vocabulary head, logits out; 2 = head + posterior + draw, tokens out
+template <bool TM, int HEAD>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -490,6 +494,89 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     unsigned relW[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) relW[k] = lds0 + r3 * RKB + ((((k << 1) | hi3) ^ (r3 & 15)) << 4);
+    if constexpr (HEAD == 2) {
+      // ---- EXPERIMENTAL (never run on hardware yet): the step's tail in the same workgroup.  The five 32-class tiles
+      // stay in the (dead) residual accumulators; when the last one is done the weight ring is free and takes the
+      // layout's logits as [token][kPostLd] floats; one lane per token then runs ldm_post::step_token on its row.
+      constexpr int NHT = 5;  // launcher: n_head_tiles == 5
+#pragma unroll
+      for (int ht = 0; ht < NHT; ++ht) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ht + 3 < NHT) dma_head_tile(ht + 3);
+        TilePipe<KS, 8> TP;
+        TP.xf = xf3;
+        TP.voff = voff;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) TP.aW[k] = relW[k] + (unsigned)(ht & 3) * STAGE;
+        TP.template run<false, false>();
+        f32x16 lg = TP.acc;
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(lg));
+        asm volatile("" : "+a"(lg));
+        acc[ht] = lg;
+      }
+      __builtin_amdgcn_s_barrier();  // nobody reads the ring any more
+      asm volatile("" ::: "memory");
+      float* lgs = reinterpret_cast<float*>(smem);
+      int* toks = reinterpret_cast<int*>(smem + 128 * kPostLd * 4);
+      {
+        float* mine = lgs + row3 * kPostLd + hi3 * 4;  // D[i = class][j = row]: classes 32 ht + 8 rq + 4 hi + i
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+          const f32x16 tile = acc[ht];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mine[ht * 32 + (i >> 2) * 8 + (i & 3)] = tile[i];
+        }
+      }
+      __syncthreads();
+      const PostArgs& p = a.post;
+      if (tid < S) {
+        const int s = tid;
+        const size_t row = (size_t)b * S + s;
+        const int attr = s % p.v.n_attr;
+        const int T1 = p.T + 1, t = p.t_post, u = (t - 1 + T1) % T1;  // constrained.py:114
+        auto sch = [&](int kind, int idx) { return p.sched[((size_t)kind * p.v.n_attr + attr) * T1 + idx]; };
+        const ldm_post::StepSchedule sc{sch(kLogAt, t),    sch(kLogBt, t),    sch(kLogCt, t),    sch(kLogCumAt, t),
+                                        sch(kLogCumBt, t), sch(kLogCumCt, t), sch(kLogCumAt, u), sch(kLogCumBt, u),
+                                        sch(kLogCumCt, u), sch(kLog1mCumCt, u)};
+        ldm_post::TokenArgs ta{};
+        ta.logits = lgs + s * kPostLd;
+        ta.tok = p.tokens[row];
+        ta.start = p.v.start[attr];
+        ta.count = p.v.count[attr];
+        ta.pad_id = p.v.pad_id;
+        ta.mask_id = p.v.mask_id;
+        ta.n_class = p.v.n_class;
+        ta.cond_tok = p.cond_seq ? p.cond_seq[row] : -1;
+        ta.strong = p.strong && p.strong[row];
+        ta.weak = p.weak ? p.weak + (size_t)b * p.v.n_class * S + s : nullptr;  // (B, C, S)
+        ta.weak_stride = S;
+        ta.pad_disable = p.pad_disable && p.cond_seq && attr != 0 && ta.cond_tok != p.v.pad_id;  // base.py:272-284
+        ta.kind = p.kind;
+        ta.temperature = p.temperature;
+        ta.top_p = p.top_p;
+        ta.top_k = p.top_k;
+        ta.pos = (uint32_t)s;
+        ta.step = (uint32_t)p.step;
+        ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
+        ta.seed = p.rng[0];
+        const int drawn = ldm_post::step_token<false>(ta, sc, lgs + s * kPostLd);  // working storage = the token's own row
+        p.tokens_out[row] = drawn;
+        toks[s] = drawn;
+      }
+      __syncthreads();
+      if (p.x_next) {  // the row the next reverse step starts from: emb[token] + pos[s] (nn_lib.py:204,220)
+        const int nvec = p.D >> 2;
+        for (int i = tid; i < S * nvec; i += 256) {
+          const int s = i / nvec, c = i - s * nvec;
+          const float4 e = reinterpret_cast<const float4*>(p.emb + (size_t)toks[s] * p.D)[c];
+          const float4 q = reinterpret_cast<const float4*>(p.pos + (size_t)s * p.D)[c];
+          reinterpret_cast<float4*>(p.x_next + ((size_t)b * S + s) * p.ldx)[c] =
+              make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
+        }
+      }
+    } else
     for (int ht = 0; ht < a.n_head_tiles; ++ht) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile ht (and every earlier piece) has landed
       __builtin_amdgcn_s_barrier();                                // ... everybody's; tile ht - 1 is read by nobody any more
@@ -564,12 +651,15 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, floa
                          int dh, const StackHead* head, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = head ? (tm ? stack_stream_k<true, true> : stack_stream_k<false, true>)
-                   : (tm ? stack_stream_k<true, false> : stack_stream_k<false, false>);
+  const bool post = head && head->post;  // (the caller has checked n_tiles == 5 and the sub-vocabulary bound)
+  auto kern = post ? stack_stream_k<false, 2>  // (no probe variant: it would be the one instantiation with spills)
+              : head ? (tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>)
+                     : (tm ? stack_stream_k<true, 0> : stack_stream_k<false, 0>);
   allow_big_lds((const void*)kern);
   StackArgs a{ls, x, stats_io, ldx, N, S, H, F / 32, 1.4426950408889634f / sqrtf((float)dh),
               head ? (const char*)head->img : nullptr, head ? head->g : nullptr, head ? head->b : nullptr,
-              head ? head->logits : nullptr, head ? head->ldl : 0, head ? head->n_tiles : 0};
+              head ? head->logits : nullptr, head ? head->ldl : 0, head ? head->n_tiles : 0,
+              post ? *head->post : PostArgs{}};
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
 }
 

@@ -191,6 +191,7 @@ struct ldm_handle {
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
   int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
+  int stack_post = 0;  // EXPERIMENTAL (LDM_STACK_POST=1): + posterior and draw inside the stack kernel; never run on hardware yet
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
                        // 5: the WHOLE layer (attention block + FFN) per launch, in place on P, as continuous per-head /
                        //    slab / chunk streams (kernels_layer.hip:
@@ -418,6 +419,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
     if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
     if (const char* sh = getenv("LDM_STACK_HEAD")) h->stack_head = atoi(sh);
+    if (const char* sp = getenv("LDM_STACK_POST")) h->stack_post = atoi(sp);
     // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
@@ -782,7 +784,7 @@ static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 // normalise while loading their register-resident fragments; the out-proj recomputes its residual
 // AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
 static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
-                                       bool skip_embed = false) {
+                                       bool skip_embed = false, const PostArgs* fused_post = nullptr) {
   const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD;
   if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw) + stats_a   (skipped when the previous step's posterior wrote P)
     LnArgs a{};
@@ -804,7 +806,9 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     }
     // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
     const bool with_head = h->stack_head && h->head_img_ks && h->Cp % 32 == 0;
-    const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
+    StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
+    if (fused_post && !with_head) return h->fail(-2, "internal: fused step tail requested without the fused head");
+    hd.post = fused_post;  // (experimental, LDM_STACK_POST=1: posterior + draw inside the stack kernel)
     ldm_handle::Scope sc(h, st, "layers_fused",
                          h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
                                  gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) +
@@ -813,6 +817,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, with_head ? &hd : nullptr, st);
     if (with_head) return 0;
   }
+  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
   for (int i = 0; i < (h->fused_attn == 6 ? 0 : h->L); ++i) {
     const LayerW& w = h->layers[i];
     const ldm_handle::FastLayer& f = h->fast[i];
@@ -883,8 +888,9 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
 
 // fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
 static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
-                              bool skip_embed = false) {
-  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed);
+                              bool skip_embed = false, const PostArgs* fused_post = nullptr) {
+  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed, fused_post);
+  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
@@ -952,8 +958,10 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
 }
 
 // denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
-static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed = false) {
-  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed);
+static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed = false,
+                         const PostArgs* fused_post = nullptr) {
+  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed, fused_post);
+  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
   const int prec = h->cfg.precision;
   const bool f16 = prec != LDM_PREC_EXACT_F32;
@@ -1155,10 +1163,15 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
                     size_t rng_layout_off, hipStream_t st, bool skip_embed = false, bool embed_next = false) {
   if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
     return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
+  // EXPERIMENTAL, off by default (LDM_STACK_POST=1; written at the end of round 2, not yet run on hardware): the step's
+  // tail inside the stack kernel (kernels_stack.hip HEAD == 2) — then no logits and no posterior launch
+  int live_max = 0;
+  for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
+  const bool fuse_post = h->stack_post && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln &&
+                         h->fused_attn == 6 && h->stack_head && h->head_img_ks && h->Cp == 160 &&
+                         live_max <= kStackPostMaxLive && h->S <= 128;
   for (int off = 0; off < B; off += h->chunk) {
     const int Bc = std::min(h->chunk, B - off);
-    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st, skip_embed);
-    if (rc) return rc;
     PostArgs p{};
     fill_post(h, p, cond, s, off, Bc);
     p.logits = h->logits;
@@ -1172,6 +1185,11 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       if (embed_next) {  // (one chunk per call: run_loop_body)
         p.x_next = h->P; p.emb = h->emb; p.pos = h->pos; p.D = h->D; p.ldx = h->D;
       }
+    }
+    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st, skip_embed, fuse_post ? &p : nullptr);
+    if (rc) return rc;
+    if (!rel) {
+      if (fuse_post) continue;
       ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
       launch_posterior_sample(p, st);
       continue;

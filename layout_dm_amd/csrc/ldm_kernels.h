@@ -124,12 +124,19 @@ void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, c
 // ls.w[i].img = ldm_pack::pack_attn_head_image, .b_out = out_proj bias + W_out b_v
 // head != nullptr: the vocabulary head (LayerNorm + Linear without bias) runs in the same workgroups and the kernel
 // writes logits instead of rows (img: n_tiles x 32-KiB tile images, K axis in k-slot order: ldm_pack::pack_head_image)
+struct PostArgs;
 struct StackHead {
   const void* img;
   const float *g, *b;
   float* logits;
   int ldl, n_tiles;
+  // EXPERIMENTAL (LDM_STACK_POST=1, written at the end of round 2 and not yet run on hardware): the posterior + draw of
+  // the step behind the head in the same workgroup (one lane per token, csrc/ldm_post_token.h); logits are then not
+  // written.  nullptr = the head writes logits and posterior_sample_k follows as its own launch (the verified path).
+  const PostArgs* post = nullptr;
 };
+// largest sub-vocabulary (body + [PAD] + [MASK]) the fused tail takes: its working storage is the token's logits row
+constexpr int kStackPostMaxLive = 53;
 void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
                          int dh, const StackHead* head, hipStream_t st);
 int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core

@@ -246,9 +246,12 @@ def test_sampler_statistics_match_reference_distribution(cuda):
 #   exact : 0 mismatches against the reference's own argmax tokens;
 #   split / fast : a token may differ from the reference ONLY where the reference's own top-2 log-probability gap
 #   (`greedy_margin`, captured at the reference's sample() call site by oracle/make_golden.py) is below the bound
-#   the mode's logits tolerance allows: fast carries <= 1e-3 relative logits error on logits of magnitude <= ~10,
-#   i.e. <= ~1e-2 absolute per class, so two classes closer than 2e-2 are a legitimate tie for it.
-MARGIN_BOUND = {"exact": 0.0, "split": 1e-4, "fast": 2e-2}
+#   the mode's logits tolerance allows: the fast mode's measured logits error is <= 4.6e-4 of max |logit| (~2 on these
+#   weights), i.e. <= ~1e-3 absolute per class, so only two classes closer than 2e-3 are a legitimate tie for it
+#   (largest margin ever observed among its mismatches: 3.4e-4), AND at most MISMATCH_COUNT_BOUND of the tokens may be
+#   such ties (observed: 1 / 162 500 and 4 / 112 500).  `fast_verified` (tests/test_fast_verified.py) removes even those.
+MARGIN_BOUND = {"exact": 0.0, "split": 1e-4, "fast": 2e-3}
+MISMATCH_COUNT_BOUND = {"exact": 0.0, "split": 2e-5, "fast": 2e-4}
 
 
 def _traj_check(e, g, cfg, cond=None, prefix=""):
@@ -273,7 +276,7 @@ def _assert_traj(name, precision, bad, n, worst):
         assert bad == 0, f"{bad}/{n} tokens differ"
     else:
         assert bad == 0 or worst < MARGIN_BOUND[precision], (bad, worst)
-        assert bad <= 2e-3 * n
+        assert bad <= MISMATCH_COUNT_BOUND[precision] * n, (bad, n)
 
 
 @pytest.mark.parametrize("precision", ["exact", "split", "fast"])
@@ -362,8 +365,13 @@ def test_loop_random_vs_oracle_same_uniforms(cuda):
     ref = R.sample_loop(W, spec, B, {"name": "random", "temperature": 1.0}, seed=123, first_layout=1000,
                         get_intermediate_results=True)
     ref = torch.stack(ref).int()
-    frac = (inter.cpu() != ref).float().mean().item()
-    assert frac <= 5e-3, frac
+    diff = inter.cpu() != ref
+    frac = diff.float().mean().item()
+    # a draw differs only where fp32 rounding moves a CDF edge across u (~1e-4 of the tokens); a layout that took such a
+    # draw then follows its own trajectory, so what is bounded is (a) the first-divergence events and (b) the total
+    print(f"[loop random / exact, B={B}] tokens differing from the oracle on identical uniforms: {int(diff.sum())}/"
+          f"{diff.numel()} = {frac:.2e}; layouts that diverged at some step: {int(diff.any(dim=2).any(dim=0).sum())}/{B}")
+    assert frac <= 1e-3, frac
     final = out.cpu()
     assert (final != spec.mask_id).all()
 
@@ -451,6 +459,40 @@ def test_loop_ragged_batches_fast_mode(cuda, B, sampler):
     if B > cut:
         parts.append(e.sample_loop(mk(B - cut), steps, steps, cfg, seed=11, first_layout=cut, use_graph=True)[0].clone())
     assert torch.equal(full, torch.cat(parts))
+
+
+@pytest.mark.skipif(os.environ.get("LDM_TEST_EXPERIMENTAL") != "1",
+                    reason="LDM_STACK_POST=1 (posterior + draw inside the stack kernel) was written at the end of round 2 "
+                           "and has not run on hardware yet; set LDM_TEST_EXPERIMENTAL=1 to try it")
+@pytest.mark.parametrize("sampler", ["deterministic", "random", "top_p", "top_k", "gumbel"])
+def test_experimental_fused_step_tail_equals_separate_tail(cuda, monkeypatch, sampler):
+    """kernels_stack.hip HEAD == 2 (one lane per token runs csrc/ldm_post_token.h on the layout's logits in LDS) against
+    the verified path (logits to HBM, posterior_sample_k): same uniforms, so the tokens may differ only where fp32
+    summation order moves an argmax tie or a CDF edge."""
+    from layout_dm_amd.binding import Engine
+
+    spec = SP.RICO25
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    steps = R.timestep_list(spec.n_step, 100)
+    cfg = {"name": sampler, "temperature": 1.0, "top_p": 0.9, "top_k": 5}
+    c = synth.synth_cond_c(spec, 300, seed=3)
+    outs = {}
+    for post in ("0", "1"):
+        monkeypatch.setenv("LDM_STACK_POST", post)
+        e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+                   n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
+                   max_batch=512)
+        e.load_state_dict(sd)
+        tok = torch.full((300, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+        free = e.sample_loop(tok, steps, steps, cfg, seed=5, first_layout=9, use_graph=True)[0].cpu()
+        cond = {"seq": c["seq"], "mask": c["mask"], "type": "c"}
+        tok = torch.from_numpy(c["seq"]).int().to(cuda)
+        cnd = e.sample_loop(tok, steps, steps, cfg, cond=cond, seed=5, first_layout=9, use_graph=True)[0].cpu()
+        e.close()
+        outs[post] = (free, cnd)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert (a != b).float().mean().item() <= 2e-3
+        assert (b != spec.mask_id).all()
 
 
 @pytest.mark.parametrize("precision", ["exact", "split", "fast"])
