@@ -203,6 +203,10 @@ struct PostArgs {
   float* x_next;
   const float *emb, *pos;
   int D, ldx;
+  // near-tie report of deterministic decoding: tie_flags[b] = 1 when some token of layout b was decided with a lead over
+  // the runner-up below tie_rel * max |logit of the token| (what the fp16 mode's logits error can move), or nullptr
+  uint8_t* tie_flags;
+  float tie_rel;
 };
 enum ScheduleRow { kLogAt = 0, kLogBt, kLogCt, kLogCumAt, kLogCumBt, kLogCumCt, kLog1mCt, kLog1mCumCt, kNumSched };
 void launch_posterior_sample(const PostArgs& p, hipStream_t st);

@@ -1,24 +1,31 @@
-// The tail of one reverse step for ONE token as straight-line scalar code on the token's sub-vocabulary — the form in
-// which a single lane can run it behind the fused vocabulary head of the stack kernel (logits of a
-// layout in LDS, one lane per token, no cross-lane traffic).  Same arithmetic, in the same order, as the wave-per-token
-// kernel of kernels_post.hip (which stays the parity hook), restricted to the classes that can carry probability:
+// The tail of one reverse step for ONE token — the single source of this arithmetic for every form it runs in:
 //
 //   predict_start tail   log-softmax over the C-1 non-MASK classes, clamp [-70, 0]          base.py:131-144
-//   q_posterior          body of the token's attribute + [PAD] + [MASK] (<= 34 classes for the reference's
-//                        vocabularies; every other class sits at log(1e-30))               constrained.py:135-206
+//   q_posterior          closed form on the token's attribute sub-vocabulary (body + [PAD] + [MASK]); every other class
+//                        sits at log(1e-30)                                                  constrained.py:135-206
 //   cond overrides       strong mask / refinement prior / [PAD] disable                     base.py:243-284
 //   draw                 argmax | temperature, top-k, top-p, gumbel -> inverse CDF          helpers/sampling.py:81-130
 //
-// Dead classes (log 1e-30, i.e. 1e-30 of the probability mass each) are left out of the draw: against the full-vocabulary
-// kernel that moves a CDF edge by < 1e-28 relative, below the fp64 resolution of the comparison.
+// A token is processed by a GROUP of NL cooperating lanes; a lane owns NJ class slots.  The algorithm below is written
+// once against two small policies:
 //
-// Pure C++ (no HIP types): compiled for the device by the kernels and for the host by tests/cpu_post_token_check.cpp,
-// which runs it against the oracle on reference-produced states.
+//   G  (lane group)   lane index inside the group + the group-wide reductions (max, sum, first-argmax, inclusive prefix)
+//        HostLane          NL = 1   plain C++: tests/cpu_post_token_check.cpp runs THIS code against the oracle on states
+//                                   of the reference's own trajectories (tests/test_post_token_scalar.py)
+//        DppGroup<16>      NL = 16  one DPP row: four tokens per wavefront (ldm_post_dpp.h) — the fused tail of the stack
+//                                   kernel (kernels_stack.hip) and posterior_sample_k's default form (kernels_post.hip)
+//        DppGroup<64>      NL = 64  one wavefront per token over the FULL vocabulary: the parity hooks that read or write
+//                                   (B, C, S) log-probability tensors (ldm_posterior / ldm_sample_tokens)
+//   M  (slot map)     SlotMap<NL, NJ, LIVE>: slot j of lane l is candidate l + NL j, in class order; LIVE = the candidates
+//                     are the token's live classes only (dead classes carry 1e-30 of the mass each: leaving them out of
+//                     the draw moves a CDF edge by < 1e-28 relative), else all C classes.
+//
+// Pure C++ apart from the DPP policy: no HIP types here.
 #pragma once
 #include <cmath>
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LDM_PT_HD __host__ __device__ __forceinline__
 #else
 #define LDM_PT_HD inline
@@ -38,8 +45,9 @@ struct StepSchedule {
   float L1Cu;              // log_1_min_cumprod_ct                         at u
 };
 
+// per-token scalars, uniform over the group
 struct TokenArgs {
-  const float* logits;     // [n_class] logits of this token (the [MASK] column is ignored)
+  const float* logits;     // [n_class] logits of this token (HostLane / standalone kernels; the [MASK] column is ignored)
   int tok;                 // x_t
   int start, count;        // body of the token's attribute: full ids start .. start + count - 1
   int pad_id, mask_id, n_class;
@@ -64,6 +72,9 @@ LDM_PT_HD float log_add_exp(float a, float b) {  // util.py:19-21
 
 LDM_PT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                              uint32_t (&out)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -81,18 +92,297 @@ LDM_PT_HD float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955
 
 // full id of live slot i: the body in class order, then [PAD], then [MASK] (increasing ids: class order is kept)
 LDM_PT_HD int live_id(const TokenArgs& a, int i) { return i < a.count ? a.start + i : (i == a.count ? a.pad_id : a.mask_id); }
+LDM_PT_HD bool is_live(const TokenArgs& a, int c) {
+  return (c >= a.start && c < a.start + a.count) || c == a.pad_id || c == a.mask_id;
+}
 
-// Working storage: 3 * (count + 2) floats supplied by the caller (a lane of the kernel has no private arrays: indexed
-// private memory would be scratch).  `work` MAY BE the token's own logits row (work == logits, row length >= 3 K): the
-// log-softmax passes only read; the posterior then reads logits[live_id(i)] before it writes work[i], live_id(i) >= i,
-// and everything behind that lives in work alone.
-//
-// log p(x_{t-1} | x_t) of the live classes after the cond overrides -> lp[0 .. count + 1].  F64_LSE: the reference's
-// float64 log-softmax (exact mode); otherwise fp32 (fast mode).
+// ---- slot map: candidate l + NL j of lane l, in class order
+template <int NL_, int NJ_, bool LIVE_>
+struct SlotMap {
+  static constexpr int NL = NL_, NJ = NJ_;
+  static constexpr bool LIVE = LIVE_;
+  int l;  // lane inside the group
+  LDM_PT_HD int sidx(int j) const { return l + NL_ * j; }                          // candidate index (= scratch index)
+  LDM_PT_HD int n_cand(const TokenArgs& a) const { return LIVE_ ? a.count + 2 : a.n_class; }
+  LDM_PT_HD bool valid(const TokenArgs& a, int j) const { return sidx(j) < n_cand(a); }
+  LDM_PT_HD int cls(const TokenArgs& a, int j) const { return LIVE_ ? live_id(a, sidx(j)) : sidx(j); }
+  LDM_PT_HD bool live(const TokenArgs& a, int j) const { return valid(a, j) && (LIVE_ || is_live(a, sidx(j))); }
+};
+
+// ---- the one-lane group (host)
+struct HostLane {
+  static constexpr int NL = 1;
+  LDM_PT_HD int lane() const { return 0; }
+  LDM_PT_HD float gmax(float v) const { return v; }
+  LDM_PT_HD float gsum(float v) const { return v; }
+  LDM_PT_HD double gsumd(double v) const { return v; }
+  LDM_PT_HD int gsumi(int v) const { return v; }
+  LDM_PT_HD void gargmax(float&, int&) const {}
+  LDM_PT_HD double gscan(double v) const { return v; }  // inclusive prefix over the lanes of the group
+  LDM_PT_HD void sync() const {}                        // scratch written by the group is visible to it
+};
+
+// q(x_t | x_0) and q(x_t | x_{t-1}) take three values per token: x_t's own class, any other class, [MASK]
+// (constrained.py:166-185; util.py:34-40 log-one-hot of x_t)
+struct QTerms {
+  float qt_same, qt_other, q1_same, q1_other, q1_mask;
+};
+LDM_PT_HD QTerms q_terms(bool x_is_mask, const StepSchedule& s) {
+  QTerms k;
+  k.q1_same = x_is_mask ? s.lc : log_add_exp(0.0f + s.la, s.lb);
+  k.q1_other = x_is_mask ? s.lc : log_add_exp(kLogEps + s.la, s.lb);
+  k.q1_mask = x_is_mask ? 0.0f : kLogEps;
+  k.qt_same = x_is_mask ? s.LC : log_add_exp(0.0f + s.LA, s.LB);
+  k.qt_other = x_is_mask ? s.LC : log_add_exp(kLogEps + s.LA, s.LB);
+  return k;
+}
+
+// log p(x_0 = c | x_t) of one class from its logit and the row's (max, log-sum-exp of x - max), clamped like
+// predict_start (base.py:140-144)
+LDM_PT_HD float l0_f32(float x, float mx, float lse0) { return fminf(fmaxf((x - mx) - lse0, -70.0f), 0.0f); }
+LDM_PT_HD float l0_f64(float x, float mx, double lse0) {
+  return fminf(fmaxf((float)(((double)x - (double)mx) - lse0), -70.0f), 0.0f);
+}
+
+// ---- posterior + cond overrides: l0[j] = log p(x_0 = cls(j) | x_t) of the lane's slots (ignored for [MASK] and for
+// dead / invalid slots) -> lp[j] = log p(x_{t-1} = cls(j) | x_t) after the overrides; -inf for invalid slots
+template <class G, class M>
+LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s,
+                               const float (&l0)[M::NJ], float (&lp)[M::NJ]) {
+  constexpr int NJ = M::NJ;
+  const QTerms k = q_terms(a.tok == a.mask_id, s);
+  float q[NJ];
+  float qmx = -INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) {
+    q[j] = -INFINITY;
+    if (m.live(a, j)) {
+      const int c = m.cls(a, j);
+      q[j] = (c == a.mask_id) ? kLogEps                                            // constrained.py:189
+                              : l0[j] - (c == a.tok ? k.qt_same : k.qt_other);     // l.188
+      qmx = fmaxf(qmx, q[j]);
+    }
+  }
+  qmx = g.gmax(qmx);
+  float qs = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j)
+    if (m.live(a, j)) qs += expf(q[j] - qmx);
+  qs = g.gsum(qs);
+  const float lse = logf(qs) + qmx;  // torch.logsumexp
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) {
+    const int c = m.cls(a, j);
+    float v;
+    if (m.live(a, j)) {
+      const float qn = q[j] - lse;
+      const float r = (c == a.mask_id) ? log_add_exp(qn + s.L1Cu, s.LCu) : log_add_exp(qn + s.LAu, s.LBu);
+      const float q1 = (c == a.mask_id) ? k.q1_mask : (c == a.tok ? k.q1_same : k.q1_other);
+      v = fminf(fmaxf((r + q1) + lse, -70.0f), 0.0f);  // l.192-197
+    } else {
+      v = kLogEps;  // p_to_f_log fill (layout_tokenizer.py:544)
+    }
+    if (m.valid(a, j)) {
+      // ---- constraint injection (base.py:243-284)
+      if (a.strong) v = (c == a.cond_tok) ? 0.0f : kLogEps;
+      else if (a.weak) v += a.weak[(long)c * a.weak_stride];
+      if (a.pad_disable && c == a.pad_id) v = kLogEps;
+    } else {
+      v = -INFINITY;
+    }
+    lp[j] = v;
+  }
+}
+
+// only the [PAD] disabling (the stage between ldm_relation_update and the draw: base.py:272-284)
+template <class M>
+LDM_PT_HD void pad_disable_only(const M& m, const TokenArgs& a, float (&lp)[M::NJ]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < M::NJ; ++j)
+    if (a.pad_disable && m.valid(a, j) && m.cls(a, j) == a.pad_id) lp[j] = kLogEps;
+}
+
+struct Draw {
+  int token;   // full id
+  float gap;   // deterministic: log-probability gap between the winner and the runner-up (+inf for the stochastic kinds)
+};
+
+// ---- categorical draw over the group's candidates (helpers/sampling.py:81-130).  lp is consumed.
+// sc_lg / sc_pr: scratch of n_cand floats each, private to the group (top-k / top-p only), indexed by candidate.
+// cand_all: the rank loop of top-k / top-p walks every candidate; else (full-vocabulary map on a posterior it computed
+// itself) only the live ones, which alone can carry mass.
+template <class G, class M>
+LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp)[M::NJ], float* sc_lg, float* sc_pr,
+                          bool cand_all) {
+  constexpr int NJ = M::NJ;
+  Draw out;
+  out.gap = INFINITY;
+  if (a.kind == kDeterministic) {  // first maximum in class order
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j)
+      if (m.valid(a, j) && lp[j] > bv) {
+        bv = lp[j];
+        bi = m.cls(a, j);
+      }
+    g.gargmax(bv, bi);
+    float second = -INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j)
+      if (m.valid(a, j) && m.cls(a, j) != bi) second = fmaxf(second, lp[j]);
+    second = g.gmax(second);
+    out.token = bi;
+    out.gap = bv - second;
+    return out;
+  }
+  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  const uint32_t y0 = (uint32_t)a.layout, y1 = (uint32_t)(a.layout >> 32);
+  float lg[NJ];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) lg[j] = m.valid(a, j) ? lp[j] / a.temperature : -INFINITY;
+  if (a.kind == kGumbel) {  // noise per class: counter word 0 = pos | (1 + c / 4) << 16, component c & 3
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j)
+      if (m.valid(a, j)) {
+        const int c = m.cls(a, j);
+        uint32_t r[4];
+        philox4x32_10(a.pos | ((uint32_t)(1 + (c >> 2)) << 16), a.step, y0, y1, k0, k1, r);
+        const uint32_t w = (c & 3) == 0 ? r[0] : (c & 3) == 1 ? r[1] : (c & 3) == 2 ? r[2] : r[3];
+        lg[j] += -logf(-logf(u01(w) + 1e-30f) + 1e-30f);
+      }
+  }
+  if (a.kind == kTopP || a.kind == kTopK) {
+    // softmax of lg (top-p's cumulative probabilities)
+    float m1 = -INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j) m1 = fmaxf(m1, lg[j]);
+    m1 = g.gmax(m1);
+    float ex[NJ], es = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j) {
+      ex[j] = m.valid(a, j) ? expf(lg[j] - m1) : 0.f;
+      es += ex[j];
+    }
+    es = g.gsum(es);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j)
+      if (m.valid(a, j)) {
+        sc_lg[m.sidx(j)] = lg[j];
+        sc_pr[m.sidx(j)] = ex[j] / es;
+      }
+    g.sync();
+    // position in the descending (stable) order and the inclusive cumulative probability up to it
+    float cum[NJ];
+    int rank[NJ];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j) {
+      cum[j] = 0.f;
+      rank[j] = 0;
+    }
+    const int n_walk = (M::LIVE || cand_all) ? m.n_cand(a) : a.count + 2;
+    for (int oi = 0; oi < n_walk; ++oi) {
+      const int o = (M::LIVE || cand_all) ? oi : live_id(a, oi);  // candidate (= scratch) index, increasing with class
+      const float ol = sc_lg[o];
+      const float op = sc_pr[o];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < NJ; ++j) {
+        const int i = m.sidx(j);
+        const bool before = (ol > lg[j]) || (ol == lg[j] && o < i);
+        if (before) {
+          rank[j] += 1;
+          cum[j] += op;
+        } else if (o == i) {
+          cum[j] += op;  // inclusive
+        }
+      }
+    }
+    if (a.kind == kTopP) {  // drop every class whose inclusive cumulative probability exceeds p, except the first
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < NJ; ++j)
+        if (cum[j] > a.top_p && rank[j] > 0) lg[j] = -INFINITY;
+    } else {                // threshold = k-th largest value (sampling.py:73-78)
+      float thr = INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < NJ; ++j)
+        if (m.valid(a, j) && rank[j] < a.top_k) thr = fminf(thr, lg[j]);
+      thr = -g.gmax(-thr);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < NJ; ++j)
+        if (lg[j] < thr) lg[j] = -INFINITY;
+    }
+  }
+  // softmax -> inverse CDF in class order (the normaliser cancels: compare against u * total)
+  float m2 = -INFINITY;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) m2 = fmaxf(m2, lg[j]);
+  m2 = g.gmax(m2);
+  double cdf[NJ];
+  double base = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) {  // slot j of every lane precedes slot j + 1 of every lane
+    const double pr = m.valid(a, j) ? (double)expf(lg[j] - m2) : 0.0;
+    cdf[j] = base + g.gscan(pr);
+    base += g.gsumd(pr);
+  }
+  uint32_t r[4];
+  philox4x32_10(a.pos, a.step, y0, y1, k0, k1, r);
+  const double thr = (double)u01(r[0]) * base;
+  int n = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j)
+    if (m.valid(a, j) && cdf[j] <= thr) n += 1;
+  n = g.gsumi(n);
+  const int last = m.n_cand(a) - 1;
+  n = n < last ? n : last;
+  out.token = M::LIVE ? live_id(a, n) : n;
+  return out;
+}
+
+// ---- the one-lane form: log-softmax, posterior, overrides, draw on the token's live classes.  work: 2 * (count + 2)
+// floats of scratch (top-k / top-p).  F64_LSE: the reference's float64 log-softmax (exact mode); otherwise fp32 (fast).
+constexpr int kHostMaxLive = 64;
 template <bool F64_LSE>
-LDM_PT_HD void token_log_probs(const TokenArgs& a, const StepSchedule& s, float* lp) {
-  const int K = a.count + 2, C = a.n_class;
-  // ---- log-softmax over the C-1 non-MASK classes (all of them: the normaliser needs the dead ones too)
+LDM_PT_HD Draw step_token_draw(const TokenArgs& a, const StepSchedule& s, float* work) {
+  const int C = a.n_class, K = a.count + 2;
   float mx = -INFINITY;
   for (int c = 0; c < C - 1; ++c) mx = fmaxf(mx, a.logits[c]);
   float lse0f = 0.f;
@@ -106,133 +396,19 @@ LDM_PT_HD void token_log_probs(const TokenArgs& a, const StepSchedule& s, float*
     for (int c = 0; c < C - 1; ++c) se += expf(a.logits[c] - mx);
     lse0f = logf(se);
   }
-  // ---- constrained posterior on the live classes (constrained.py:166-197)
-  const bool x_is_mask = a.tok == a.mask_id;
-  // q(x_t | x_{t-1}) (l.175-185) takes three values per token: x_t's own class, any other class, [MASK]
-  const float q1_same = x_is_mask ? s.lc : log_add_exp(0.0f + s.la, s.lb);
-  const float q1_other = x_is_mask ? s.lc : log_add_exp(kLogEps + s.la, s.lb);
-  const float q1_mask = x_is_mask ? 0.0f : kLogEps;
-  const float qt_same = x_is_mask ? s.LC : log_add_exp(0.0f + s.LA, s.LB);  // q(x_t | x_0), l.166-173
-  const float qt_other = x_is_mask ? s.LC : log_add_exp(kLogEps + s.LA, s.LB);
-  float qmx = -INFINITY;
-  for (int i = 0; i < K; ++i) {
-    const int c = live_id(a, i);
-    float q;
-    if (c == a.mask_id) {
-      q = kLogEps;  // l.189
-    } else {
-      float v;  // log p(x_0 = c | x_t), clamped like predict_start (base.py:140-144)
-      if (F64_LSE) v = (float)(((double)a.logits[c] - (double)mx) - lse0d);
-      else v = (a.logits[c] - mx) - lse0f;
-      v = fminf(fmaxf(v, -70.0f), 0.0f);
-      q = v - (c == a.tok ? qt_same : qt_other);  // l.188
-    }
-    lp[i] = q;
-    qmx = fmaxf(qmx, q);
+  const HostLane g;
+  const SlotMap<1, kHostMaxLive, true> m{0};
+  float l0[kHostMaxLive], lp[kHostMaxLive];
+  for (int j = 0; j < kHostMaxLive; ++j) {
+    l0[j] = 0.f;
+    if (j < K - 1) l0[j] = F64_LSE ? l0_f64(a.logits[live_id(a, j)], mx, lse0d) : l0_f32(a.logits[live_id(a, j)], mx, lse0f);
   }
-  float qs = 0.f;
-  for (int i = 0; i < K; ++i) qs += expf(lp[i] - qmx);
-  const float lse = logf(qs) + qmx;  // torch.logsumexp
-  for (int i = 0; i < K; ++i) {
-    const int c = live_id(a, i);
-    const float qn = lp[i] - lse;
-    const float r = (c == a.mask_id) ? log_add_exp(qn + s.L1Cu, s.LCu) : log_add_exp(qn + s.LAu, s.LBu);
-    const float q1 = (c == a.mask_id) ? q1_mask : (c == a.tok ? q1_same : q1_other);
-    float v = fminf(fmaxf((r + q1) + lse, -70.0f), 0.0f);  // l.192-197
-    // ---- constraint injection (base.py:243-284)
-    if (a.strong) v = (c == a.cond_tok) ? 0.0f : kLogEps;
-    else if (a.weak) v += a.weak[(long)c * a.weak_stride];
-    lp[i] = v;
-  }
-  if (a.pad_disable) lp[a.count] = kLogEps;
+  token_log_probs(g, m, a, s, l0, lp);
+  return draw_token(g, m, a, lp, work, work + K, true);
 }
-
-// categorical draw over the live classes (helpers/sampling.py:81-130) -> full id.  lg = work[0 .. K) holds the
-// log-probabilities on entry and is overwritten; work[K .. 3K) is scratch.
-LDM_PT_HD int draw_live(const TokenArgs& a, float* lg) {
-  const int K = a.count + 2;
-  if (a.kind == kDeterministic) {  // first maximum in class order
-    int bi = 0;
-    float bv = lg[0];
-    for (int i = 1; i < K; ++i)
-      if (lg[i] > bv) {
-        bv = lg[i];
-        bi = i;
-      }
-    return live_id(a, bi);
-  }
-  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-  const uint32_t l0 = (uint32_t)a.layout, l1 = (uint32_t)(a.layout >> 32);
-  float* ex = lg + K;
-  float* keep = lg + 2 * K;
-  for (int i = 0; i < K; ++i) lg[i] = lg[i] / a.temperature;
-  if (a.kind == kGumbel) {  // noise per class: counter word 0 = pos | (1 + c / 4) << 16, component c & 3
-    for (int i = 0; i < K; ++i) {
-      const int c = live_id(a, i);
-      uint32_t r[4];
-      philox4x32_10(a.pos | ((uint32_t)(1 + (c >> 2)) << 16), a.step, l0, l1, k0, k1, r);
-      const uint32_t w = (c & 3) == 0 ? r[0] : (c & 3) == 1 ? r[1] : (c & 3) == 2 ? r[2] : r[3];
-      lg[i] += -logf(-logf(u01(w) + 1e-30f) + 1e-30f);
-    }
-  }
-  if (a.kind == kTopP || a.kind == kTopK) {
-    float m1 = -INFINITY;
-    for (int i = 0; i < K; ++i) m1 = fmaxf(m1, lg[i]);
-    float es = 0.f;
-    for (int i = 0; i < K; ++i) {
-      ex[i] = expf(lg[i] - m1);
-      es += ex[i];
-    }
-    // position in the descending (stable) order and the inclusive cumulative probability up to it
-    float thr = a.kind == kTopK ? INFINITY : -INFINITY;  // top-k: the k-th largest value; top-p: no value threshold
-    for (int i = 0; i < K; ++i) {
-      int rank = 0;
-      float cum = 0.f;
-      const float li = lg[i];
-      for (int o = 0; o < K; ++o) {
-        const float lo = lg[o];
-        const bool before = (lo > li) || (lo == li && o < i);
-        if (before) {
-          rank += 1;
-          cum += ex[o] / es;
-        } else if (o == i) {
-          cum += ex[o] / es;
-        }
-      }
-      if (a.kind == kTopP) {  // drop every class whose inclusive cumulative probability exceeds p, except the first
-        keep[i] = (cum > a.top_p && rank > 0) ? 0.f : 1.f;
-      } else {                // threshold = k-th largest value (sampling.py:73-78)
-        keep[i] = 1.f;
-        if (rank < a.top_k) thr = fminf(thr, li);
-      }
-    }
-    for (int i = 0; i < K; ++i)
-      if (keep[i] == 0.f || lg[i] < thr) lg[i] = -INFINITY;
-  }
-  // softmax -> inverse CDF in class order (the normaliser cancels: compare against u * total)
-  float m2 = -INFINITY;
-  for (int i = 0; i < K; ++i) m2 = fmaxf(m2, lg[i]);
-  double base = 0.0;
-  for (int i = 0; i < K; ++i) {
-    ex[i] = expf(lg[i] - m2);
-    base += (double)ex[i];
-  }
-  uint32_t r[4];
-  philox4x32_10(a.pos, a.step, l0, l1, k0, k1, r);
-  const double thr = (double)u01(r[0]) * base;
-  double cdf = 0.0;
-  int n = 0;
-  for (int i = 0; i < K; ++i) {
-    cdf += (double)ex[i];
-    if (cdf <= thr) n += 1;
-  }
-  return live_id(a, n < K - 1 ? n : K - 1);
-}
-
 template <bool F64_LSE>
 LDM_PT_HD int step_token(const TokenArgs& a, const StepSchedule& s, float* work) {
-  token_log_probs<F64_LSE>(a, s, work);
-  return draw_live(a, work);
+  return step_token_draw<F64_LSE>(a, s, work).token;
 }
 
 }  // namespace ldm_post

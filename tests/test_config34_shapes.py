@@ -33,7 +33,7 @@ CASES = {
 # fraction of teacher-forced draws allowed to differ from the oracle's inverse-CDF draw on the same uniforms:
 # exact = fp32 rounding of a CDF edge only (test_sampler_deterministic_and_inverse_cdf measures the same effect at 2e-3
 # on synthetic wide distributions; real posteriors are far more peaked); fast adds the fp16 logits error.
-STEP_MISMATCH_BOUND = {"exact": 5e-4, "fast": 2e-3}
+STEP_MISMATCH_BOUND = {"exact": 1e-4, "fast": 5e-4}  # measured (profiles/r03_call2_*): 0 / 128 000 and <= 10 / 128 000
 TEACHER_STEPS = (5, 50, 97)  # loop indices (t = 94, 49, 2): mostly-[MASK] states, half-revealed, almost clean
 
 
