@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 3
+#define LDM_ABI_VERSION 4
 
 typedef struct ldm_handle ldm_handle;
 
@@ -152,13 +152,27 @@ int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens
  * h_t_model / h_t_post: host arrays of n_steps timesteps (diffusion_list and the posterior's t).
  * rel: NULL, or the relation graph of the B layouts (cond must then carry d_cond_seq).
  * d_intermediates: optional (n_steps,B,S) int32 (get_intermediate_results=True).
- * use_graph != 0: the whole loop is captured once per (B, schedule, sampler, cond / relation layout) into
+ * In LDM_PREC_FAST_F16 on the reference's backbone (and without rel) the whole loop is ONE launch: every layout's
+ * workgroup runs all its steps (tokens in LDS, the step's tail behind the vocabulary head); use_graph is then moot.
+ * Otherwise, use_graph != 0: the whole loop is captured once per (B, schedule, sampler, cond / relation layout) into
  * a hipGraph and replayed (seed / first_layout live in device memory so replays may change them; cond tensors,
  * the relation graph and the intermediates are staged through handle-owned buffers at fixed addresses). */
 int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond, const ldm_relation* rel,
                     const int32_t* h_t_model, const int32_t* h_t_post, int n_steps, const ldm_sampler* s,
                     uint64_t seed, uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph,
                     void* stream);
+
+/* ---- near-tie report of deterministic decoding (ABI 4) ---------------------------------------
+ * north star: "token indices bit-exact under greedy/argmax decoding".  LDM_PREC_FAST_F16 carries <= 1e-3 relative logits
+ * error, so its argmax (sampling.py:88-90) can differ from the reference's where two classes are closer than that error
+ * can move them.  tie_rel > 0 enables the report: every deterministic ldm_sample_step / ldm_sample_loop then marks, per
+ * (step, layout), whether some token of the layout was decided with a log-probability lead over the runner-up below
+ * tie_rel * max |logit of that token| (6 x the mode's relative logits error bounds the lead's error: DESIGN.md section 3.5).
+ * Unmarked layouts carry the reference's own greedy tokens; the caller re-decides the marked ones in LDM_PREC_EXACT_F32
+ * from the state before their first marked step (layout_dm_amd/verified.py).  tie_rel = 0 disables. */
+int ldm_set_tie_report(ldm_handle* h, float tie_rel);
+/* flags of the most recent deterministic call: d_flags (n_steps, B) uint8, row i = i-th step of that call */
+int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, int B, void* stream);
 
 /* ---- cond=relation, split-step form ------------------------------------------------------- */
 /* The logit adjustment alone (`num_update` SGD steps on the mean relational-constraint loss, analytic gradient;

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16 = 0, 1, 2
 PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16,
@@ -25,7 +25,7 @@ SAMPLERS = {"deterministic": 0, "random": 1, "top_p": 2, "top_k": 3, "gumbel": 4
 EXPORTS = (
     "ldm_create", "ldm_destroy", "ldm_last_error", "ldm_load_weight", "ldm_finalize_weights",
     "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
-    "ldm_decode_layouts", "ldm_relation_update",
+    "ldm_decode_layouts", "ldm_relation_update", "ldm_set_tie_report", "ldm_get_tie_flags",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
     "ldm_abi_version", "ldm_get_layout",
     # FID feature extractor (bound in layout_dm_amd/fid.py)
@@ -90,6 +90,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                     C.POINTER(C.c_int32), i32, C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
     lib.ldm_decode_layouts.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.ldm_relation_update.argtypes = [vp, vp, vp, C.POINTER(LdmRelation), i32, i32, vp]
+    lib.ldm_set_tie_report.argtypes = [vp, C.c_float]
+    lib.ldm_get_tie_flags.argtypes = [vp, vp, i32, i32, vp]
     lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldm_set_profiling.argtypes = [vp, i32]
     lib.ldm_profile_count.argtypes = [vp]
@@ -292,6 +294,19 @@ class Engine:
         if keep and lc_keep is None:
             torch.cuda.current_stream(self.device).synchronize()
         return tokens, inter
+
+    # ------------------------------------------------------------------ near-tie report (deterministic decoding)
+    def set_tie_report(self, tie_rel: float):
+        """tie_rel > 0: deterministic steps / loops mark, per (step, layout), whether some token was decided with a lead
+        over the runner-up below tie_rel * max |logit| (include/ldm_hip.h); 0 disables."""
+        self._check(self.lib.ldm_set_tie_report(self._h, float(tie_rel)), "ldm_set_tie_report")
+
+    def tie_flags(self, n_steps: int, B: int) -> torch.Tensor:
+        """(n_steps, B) uint8 flags of the most recent deterministic call."""
+        out = torch.empty((n_steps, B), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ldm_get_tie_flags(self._h, out.data_ptr(), int(n_steps), int(B), _stream_ptr(self.device)),
+                    "ldm_get_tie_flags")
+        return out
 
     # ------------------------------------------------------------------ cond=relation
     def make_relation(self, graph, centres, canvas_bins, relation_lambda: float, num_update: int, n_graph_total: int):

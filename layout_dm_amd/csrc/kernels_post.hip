@@ -32,7 +32,7 @@ namespace ldm {
 //                              off the layout-resident kernels
 //   NL = 64, full vocabulary   one wavefront per token: the parity hooks that read or write (B, C, S) tensors
 //                              (ldm_posterior, ldm_sample_tokens), and vocabularies whose live set exceeds 48 (vanilla)
-template <int NL, bool LIVE>
+template <int NL, bool LIVE, bool FAST>
 __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
   constexpr int GPW = 64 / NL;            // tokens per wavefront
   constexpr int NJ = LIVE ? 3 : 192 / NL; // class slots per lane
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
   const int b = row / p.S, s = row % p.S;
   const int C = p.v.n_class;
   const int attr = s % p.v.n_attr;
-  const ldm_post::DppGroup<NL> g{lane % NL};
+  const ldm_post::DppGroup<NL, FAST> g{lane % NL};
   const ldm_post::SlotMap<NL, NJ, LIVE> m{lane % NL};
 
   ldm_post::TokenArgs a{};
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
     mx = g.gmax(mx);
     absmax = g.gmax(absmax);
     float l0[NJ];
-    if (p.f32_lse) {  // fast numerics mode: ~1e-7 relative, far inside its 1e-3 logits budget
+    if (FAST) {  // fast numerics mode (p.f32_lse): ~1e-6 relative, far inside its 1e-3 logits budget
       float se = 0.f;
-      for (int c = g.lane(); c < C - 1; c += NL) se += expf(lrow[c] - mx);
-      const float lse0 = logf(g.gsum(se));
+      for (int c = g.lane(); c < C - 1; c += NL) se += g.exp(lrow[c] - mx);
+      const float lse0 = g.log(g.gsum(se));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int c = m.cls(a, j);
@@ -167,10 +167,10 @@ void launch_posterior_sample(const PostArgs& p, hipStream_t st) {
   int live_max = 0;
   for (int a = 0; a < p.v.n_attr; ++a) live_max = live_max > p.v.count[a] + 2 ? live_max : p.v.count[a] + 2;
   static const bool force_wave = getenv("LDM_POST_WAVE") && atoi(getenv("LDM_POST_WAVE")) != 0;  // A/B aid
-  if (p.logp_in || p.logp_out || live_max > 48 || force_wave)
-    hipLaunchKernelGGL((posterior_sample_k<64, false>), dim3((M + 3) / 4), dim3(256), 0, st, p);
-  else
-    hipLaunchKernelGGL((posterior_sample_k<16, true>), dim3((M + 15) / 16), dim3(256), 0, st, p);
+  const bool wave = p.logp_in || p.logp_out || live_max > 48 || force_wave;
+  auto kern = wave ? (p.f32_lse ? posterior_sample_k<64, false, true> : posterior_sample_k<64, false, false>)
+                   : (p.f32_lse ? posterior_sample_k<16, true, true> : posterior_sample_k<16, true, false>);
+  hipLaunchKernelGGL(kern, dim3(wave ? (M + 3) / 4 : (M + 15) / 16), dim3(256), 0, st, p);
 }
 
 }  // namespace ldm

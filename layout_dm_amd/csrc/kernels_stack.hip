@@ -11,7 +11,15 @@
 //   per layer     per head: HeadStream (k0 k1 v0 v1 q0 q1) -> AttnCoreV (all-VGPR core) -> SlabPair (acc += o_h·Wo_h^T)
 //                 LN2 + FFN chunk stream on the same accumulators (FfnStream)
 //                 layer boundary, in registers: statistics of x2, next layer's AdaLN fragments, next residual seed
-//   epilogue      statistics + one write of the rows
+//   epilogue      statistics + one write of the rows (HEAD 0) | vocabulary head, logits out (HEAD 1)
+//
+// HEAD 2 — the whole REVERSE LOOP of a layout in its workgroup (BaseMaskAndReplaceDiffusion.sample, base.py:293-371):
+// layouts never exchange data, so the workgroup that owns a layout runs all its T steps — tokens in LDS, the embedding
+// gathered straight into the accumulators, the stack, the vocabulary head, and behind it the step's tail (log-softmax,
+// constrained posterior, cond overrides, draw: ldm_post_token.h on 16-lane groups, four tokens per wavefront) on the
+// layout's logits in LDS.  One launch per sampling call; per step nothing touches memory but the weight stream (L2 /
+// Infinity Cache resident), the 125 cond tokens and, on request, the intermediate tokens.  No hipGraph, no chunk
+// pipelines, no logits / row / embedding round trips.
 //
 // Between layers nothing touches memory but the weight stream.  Weight image per layer: ldm_pack::pack_attn_head_image
 // (per head 6 in_proj tiles + its 2 out-proj slabs, 9-slot ring cycle: see SlabPair) and the k-slot FFN image.
@@ -21,7 +29,7 @@
 #include "ldm_kernels.h"
 #include "ldm_dma.h"
 #include "ldm_pipes.h"
-#include "ldm_post_token.h"
+#include "ldm_post_dpp.h"
 
 namespace ldm {
 
@@ -36,9 +44,26 @@ struct StackArgs {
   const float *head_g, *head_b;
   float* logits;        // [M, ldl]
   int ldl, n_head_tiles;
-  PostArgs post;        // HEAD == 2 (experimental): posterior + draw in the same workgroup, tokens out instead of logits
+  // HEAD == 2: the reverse loop (see the header).  post carries the tail's parameters (schedule, cond, sampler, RNG,
+  // vocabulary, emb / pos, tokens in = post.tokens, tokens out = post.tokens_out, tie flags of step i at tie_flags + i * tie_ld)
+  PostArgs post;
+  const float* adaln;        // [T][L][2 N] AdaLN (scale | shift) table (transformer_utils.py:79-81)
+  int32_t* inter;            // [n_steps][inter_ld][S] tokens after every step, or nullptr (get_intermediate_results)
+  int n_steps, inter_ld, tie_ld;
+  int16_t t_model[kStackLoopMaxSteps], t_post[kStackLoopMaxSteps];  // the denoiser's timestep and q_posterior's (base.py:218-240)
 };
-constexpr int kPostLd = 161;  // floats per token row of the logits in LDS (odd: lanes = tokens read conflict-free)
+// HEAD == 2 reads its loop parameters from the kernel-argument segment AT THE POINT OF USE, through a pointer hipcc
+// cannot see through: hoisted out of the step loop they would occupy ~60 SGPRs for the whole kernel, which already
+// fills the register file (measured: 224 SGPR spills and, through the VGPRs those need, 116 bytes of scratch per lane).
+typedef const __attribute__((address_space(4))) StackArgs* stack_kargs_ptr;
+__device__ __forceinline__ stack_kargs_ptr stack_kargs() {
+  stack_kargs_ptr q = (stack_kargs_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+}
+constexpr int kPostLd = 161;   // floats per token row of the logits in LDS (odd: the 16-lane groups of a wavefront hit distinct banks)
+constexpr int kPostRows = 128 * kPostLd * 4;  // bytes of the logits rows; behind them one float4 (max, lse, max |x|, -) per row
+constexpr int kStackLoopLds = 1024;           // HEAD == 2: tokens [128] | cond token + strong bit [128] behind the tables
 
 __device__ unsigned long long g_stack_phase[16];
 
@@ -53,39 +78,74 @@ template <bool TM, int HEAD>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* kvbuf = smem + 3 * STAGE;          // Ks 16 KiB | Vs 16 KiB behind the 3-stage weight ring
-  float* sbias = reinterpret_cast<float*>(kvbuf + 2 * KV_BYTES);  // [3*H*64]
-  float* sp = sbias + 3 * a.H * 64;        // AdaLN multiplier / shift (2 x LN_DP)
-  float* sbo = sp + 2 * LN_DP;             // b_out + W_out b_v + AdaLN shift [512]
-  float* sb1 = sbo + 512;                  // linear1 bias [n_chunks*32]
-  float* sp2 = sb1 + a.n_chunks * 32;      // norm2 gamma | beta (2 x LN_DP)
-  float* sb2 = sp2 + 2 * LN_DP;            // linear2 bias [512], zero beyond N
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x, S = a.S, H = a.H, L = a.ls.n_layer;
-  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
-  const unsigned voff = (tid & 63) * 16;
+  const int tid_o = threadIdx.x;
+  const int wave_o = __builtin_amdgcn_readfirstlane(tid_o >> 6);
+  const int b_o = blockIdx.x;
 
   unsigned long long t0 = 0, t_real0 = 0, s_pro = 0, s_stream = 0, s_core = 0, s_slab = 0, s_ln2 = 0, s_ffn = 0, s_bnd = 0, s_bnd_a = 0, s_bnd_b = 0, s_hsync = 0, s_ssync = 0;
   if constexpr (TM) {
     t0 = __builtin_amdgcn_s_memtime();
     t_real0 = __builtin_amdgcn_s_memrealtime();
   }
+  f32x16 acc[NT2];     // the residual stream: x (raw rows) -> seed -> x1 -> x2 of the current layer -> ...
+  if constexpr (HEAD == 2) {
+    // x_t of the layout's tokens and its cond token | strong << 30 (or -1): LDS behind the tables, for the whole loop
+    const stack_kargs_ptr kp = stack_kargs();
+    const int S = kp->S;
+    int* toks = reinterpret_cast<int*>(smem + 3 * STAGE + 2 * KV_BYTES + (3 * kp->H * 64 + 2 * LN_DP + 512 + kp->n_chunks * 32 + 2 * LN_DP + 512) * 4);
+    if (tid_o < 128) {
+      const int s = tid_o < S ? tid_o : S - 1;
+      const size_t row = (size_t)b_o * S + s;
+      toks[tid_o] = kp->post.tokens[row];
+      int cc = -1;
+      if (kp->post.cond_seq) cc = kp->post.cond_seq[row] | ((kp->post.strong && kp->post.strong[row]) ? (1 << 30) : 0);
+      toks[128 + tid_o] = cc;
+    }
+    __syncthreads();
+  }
+  unsigned long long t_epi = 0;
+  int n_iter = 1;
+  if constexpr (HEAD == 2) n_iter = stack_kargs()->n_steps;
+  int it = 0;
+  do {  // (HEAD < 2: the condition is a constant false — no loop exists in those instantiations)
+  // HEAD == 2: everything a step derives from the thread / workgroup coordinates and from the kernel arguments is
+  // re-derived per step from values hipcc cannot see through — hoisted out of the step loop, those ~100 uniform
+  // addresses and parameters would stay live across a body that already fills the register file (170 SGPR spills and
+  // 100 bytes of scratch per lane without this)
+  int tid = tid_o, wave = wave_o, b = b_o;
+  if constexpr (HEAD == 2) asm volatile("" : "+v"(tid), "+s"(wave), "+s"(b));
+  auto&& A = [&]() -> decltype(auto) {
+    if constexpr (HEAD == 2) return (*stack_kargs());
+    else return (a);
+  }();
+  char* kvbuf = smem + 3 * STAGE;          // Ks 16 KiB | Vs 16 KiB behind the 3-stage weight ring
+  float* sbias = reinterpret_cast<float*>(kvbuf + 2 * KV_BYTES);  // [3*H*64]
+  float* sp = sbias + 3 * A.H * 64;        // AdaLN multiplier / shift (2 x LN_DP)
+  float* sbo = sp + 2 * LN_DP;             // b_out + W_out b_v + AdaLN shift [512]
+  float* sb1 = sbo + 512;                  // linear1 bias [n_chunks*32]
+  float* sp2 = sb1 + A.n_chunks * 32;      // norm2 gamma | beta (2 x LN_DP)
+  float* sb2 = sp2 + 2 * LN_DP;            // linear2 bias [512], zero beyond N
+  [[maybe_unused]] int* toks = reinterpret_cast<int*>(sb2 + 512);   // HEAD == 2: x_t of the layout's tokens
+  [[maybe_unused]] int* condc = toks + 128;                         //            cond token | strong << 30 (or -1)
+  const int S = A.S, H = A.H, L = A.ls.n_layer;
+  unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  if constexpr (HEAD == 2) asm volatile("" : "+s"(lds0));
+  const unsigned voff = (tid & 63) * 16;
   // parameter tables of one layer, global -> LDS: every load is issued before the first ds_write (a loop of dependent
   // load / store pairs pays one L2 round trip per iteration: 15 of them made the layer boundary 17k cycles longer,
   // profiles/r02_call23_*).  Every table is zero beyond N so that padded columns come out as exact zeros without masks.
-  auto stage_tables = [&](const FusedLayerW& w) {
+  auto stage_tables = [&](const auto& w, const float* ada_scale, const float* ada_shift) {
     float vb[6], v1[8], vs[2], vh[2], vo[2], vg[2], ve[2], v2[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) vb[k] = w.bias_in[tid + 256 * k];  // 3 * 8 heads * 64 = 1536 entries (launcher: H == 8)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v1[k] = tid + 256 * k < a.n_chunks * 32 ? w.b1[tid + 256 * k] : 0.f;
+    for (int k = 0; k < 8; ++k) v1[k] = tid + 256 * k < A.n_chunks * 32 ? w.b1[tid + 256 * k] : 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + 256 * k;
-      const bool in = i < a.N;
-      vs[k] = in ? w.ada_scale[i] : -1.f;  // multiplier 1 + scale = 0 beyond N
-      vh[k] = in ? w.ada_shift[i] : 0.f;
+      const bool in = i < A.N;
+      vs[k] = in ? ada_scale[i] : -1.f;  // multiplier 1 + scale = 0 beyond N
+      vh[k] = in ? ada_shift[i] : 0.f;
       vo[k] = in ? w.b_out[i] : 0.f;
       vg[k] = in ? w.g2[i] : 0.f;
       ve[k] = in ? w.be2[i] : 0.f;
@@ -96,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     for (int k = 0; k < 6; ++k) sbias[tid + 256 * k] = vb[k];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (tid + 256 * k < a.n_chunks * 32) sb1[tid + 256 * k] = v1[k];
+      if (tid + 256 * k < A.n_chunks * 32) sb1[tid + 256 * k] = v1[k];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + 256 * k;
@@ -113,11 +173,46 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     for (int k = 0; k < 4; ++k) dma_lin4(voff, img + wave * 8192 + (k >> 1) * STAGE + (k & 1) * 4096,
                                          lds0 + wave * 8192 + (k >> 1) * STAGE + (k & 1) * 4096);
   };
-
-  f32x16 acc[NT2];     // the residual stream: x (raw rows) -> seed -> x1 -> x2 of the current layer -> ...
+  int t_model = 0;
+  if constexpr (HEAD == 2) t_model = stack_kargs()->t_model[it];
 #pragma unroll
   for (int i = 8; i < 16; ++i) acc[NT2 - 1][i] = to_agpr(0.f);  // columns 464..479: padding
-  {
+  if constexpr (HEAD == 2) {
+    // ------------------------------------------------------------------ prologue: x = cat_emb[token] + pos[s]
+    // (nn_lib.py:204,220) gathered straight into the accumulator layout; the tables (155 x 464 and 125 x 464 floats)
+    // are L2 resident
+    const int lane = stack_lane_id();
+    const int r = lane & 31, hi = lane >> 5;
+    const int row = wave * 32 + r;
+    const int srow = row < S ? row : S - 1;
+    const stack_kargs_ptr kp = stack_kargs();
+    const float* erow = kp->post.emb + (size_t)toks[srow] * kp->post.D + hi * 4;
+    const float* prow = kp->post.pos + (size_t)srow * kp->post.D + hi * 4;
+    constexpr int GB = 12;
+#pragma unroll
+    for (int g0 = 0; g0 < NGV; g0 += GB) {
+      float4 re[GB], rp[GB];
+#pragma unroll
+      for (int i = 0; i < GB; ++i)
+        if (g0 + i < NGV) {
+          re[i] = *reinterpret_cast<const float4*>(erow + (g0 + i) * 8);
+          rp[i] = *reinterpret_cast<const float4*>(prow + (g0 + i) * 8);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < GB; ++i) {
+        const int gg = g0 + i;
+        if (gg < NGV) {
+          const int t = gg >> 2, q0 = (gg & 3) * 4;
+          acc[t][q0 + 0] = to_agpr(re[i].x + rp[i].x);
+          acc[t][q0 + 1] = to_agpr(re[i].y + rp[i].y);
+          acc[t][q0 + 2] = to_agpr(re[i].z + rp[i].z);
+          acc[t][q0 + 3] = to_agpr(re[i].w + rp[i].w);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
     // ------------------------------------------------------------------ prologue: the rows, raw, in accumulator layout
     // (lane (row, hi) owns columns 8g + 4hi .. +3 of every 8-column group g); every layer, the first included, then
     // starts from the accumulators
@@ -126,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     const int row = wave * 32 + r;
     const size_t m = (size_t)b * S + (row < S ? row : S - 1);
     constexpr int GB = 20;
-    const float* rrow = a.x + m * a.ldx + hi * 4;
+    const float* rrow = A.x + m * A.ldx + hi * 4;
 #pragma unroll
     for (int g0 = 0; g0 < NGV; g0 += GB) {
       float4 raw[GB];
@@ -151,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   if constexpr (TM) s_pro = __builtin_amdgcn_s_memtime() - t0;
 
   for (int l = 0; l < L; ++l) {
-    const FusedLayerW& w = a.ls.w[l];
+    const auto& w = A.ls.w[l];
     unsigned long long tL = 0;
     if constexpr (TM) tL = __builtin_amdgcn_s_memtime();
     f16x8 xf[KS];        // AdaLN(x) of this layer, fp16 MFMA B fragments (k-slot K order)
@@ -163,7 +258,12 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       dma_first_tiles((const char*)w.img);
-      stage_tables(w);
+      if constexpr (HEAD == 2) {
+        const float* ss = stack_kargs()->adaln + ((size_t)t_model * L + l) * 2 * A.N;
+        stage_tables(w, ss, ss + A.N);
+      } else {
+        stage_tables(w, w.ada_scale, w.ada_shift);
+      }
       __syncthreads();
       unsigned long long tE1 = 0, tE2 = 0;
       if constexpr (TM) tE1 = __builtin_amdgcn_s_memtime();
@@ -280,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
           AC.qf = qf;
           AC.aKr = kv0 + r * 128 + ((hi ^ ((r >> 1) & 7)) << 4);
           AC.aVr = kv0 + KV_BYTES + r * 256 + ((hi ^ (r & 15)) << 4);
-          AC.scale_log2e = a.scale_log2e;
+          AC.scale_log2e = A.scale_log2e;
           AC.S = S;
           AC.hi = hi;
           AC.run(nf);
@@ -403,10 +503,10 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       F.read_bias();
       F.template prologue<0>();
       const char* fimg = (const char*)w.ffn_img;
-      for (int c = 0; c < a.n_chunks; ++c) {
-        F.gnext = fimg + (size_t)(c + 1 == a.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+      for (int c = 0; c < A.n_chunks; ++c) {
+        F.gnext = fimg + (size_t)(c + 1 == A.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
         F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
-        F.ab_next = relB + (c + 1 == a.n_chunks ? 0 : c + 1) * 128;
+        F.ab_next = relB + (c + 1 == A.n_chunks ? 0 : c + 1) * 128;
         F.template step<0, true>();
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -419,7 +519,6 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       s_ffn += t_ffn - t_ln2;
     }
   }
-  unsigned long long t_epi = 0;
   if constexpr (TM) t_epi = __builtin_amdgcn_s_memtime();
   if constexpr (HEAD) {
     // ---- vocabulary head in the same workgroup: logits = LN_head(x_out) · Wh^T.  The rows never leave the registers:
@@ -430,15 +529,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     __builtin_amdgcn_s_barrier();  // every wave is past its FFN LDS reads and the last layer's table reads
     asm volatile("" ::: "memory");
     auto dma_head_tile = [&](int ht) {
-      const char* g = a.head_img + (size_t)ht * STAGE + wave * 8192;
+      const char* g = A.head_img + (size_t)ht * STAGE + wave * 8192;
       const unsigned l = lds0 + (unsigned)(ht & 3) * STAGE + wave * 8192;
       dma_lin4(voff, g, l);
       dma_lin4(voff, g + 4096, l + 4096);
     };
-    for (int ht = 0; ht < 3 && ht < a.n_head_tiles; ++ht) dma_head_tile(ht);
+    for (int ht = 0; ht < 3 && ht < A.n_head_tiles; ++ht) dma_head_tile(ht);
     for (int i = tid; i < LN_DP; i += 256) {
-      sp[i] = i < a.N ? a.head_g[i] : 0.f;
-      sp[LN_DP + i] = i < a.N ? a.head_b[i] : 0.f;
+      sp[i] = i < A.N ? A.head_g[i] : 0.f;
+      sp[LN_DP + i] = i < A.N ? A.head_b[i] : 0.f;
     }
     __syncthreads();
     const int lane3 = stack_lane_id();
@@ -490,14 +589,13 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_sched_barrier(0);
     const bool valid3 = row3 < S;
-    float* lrow = a.logits + ((size_t)b * S + (valid3 ? row3 : S - 1)) * a.ldl + hi3 * 4;
+    float* lrow = HEAD == 2 ? nullptr : A.logits + ((size_t)b * S + (valid3 ? row3 : S - 1)) * A.ldl + hi3 * 4;
     unsigned relW[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) relW[k] = lds0 + r3 * RKB + ((((k << 1) | hi3) ^ (r3 & 15)) << 4);
     if constexpr (HEAD == 2) {
-      // ---- EXPERIMENTAL (never run on hardware yet): the step's tail in the same workgroup.  The five 32-class tiles
-      // stay in the (dead) residual accumulators; when the last one is done the weight ring is free and takes the
-      // layout's logits as [token][kPostLd] floats; one lane per token then runs ldm_post::step_token on its row.
+      // ---- the step's tail in the same workgroup.  The five 32-class tiles stay in the (dead) residual accumulators;
+      // when the last one is done the weight ring is free and takes the layout's logits as [token][kPostLd] floats.
       constexpr int NHT = 5;  // launcher: n_head_tiles == 5
 #pragma unroll
       for (int ht = 0; ht < NHT; ++ht) {
@@ -518,70 +616,136 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       }
       __builtin_amdgcn_s_barrier();  // nobody reads the ring any more
       asm volatile("" ::: "memory");
+      const stack_kargs_ptr kp = stack_kargs();
+      const auto& p = kp->post;
       float* lgs = reinterpret_cast<float*>(smem);
-      int* toks = reinterpret_cast<int*>(smem + 128 * kPostLd * 4);
+      float4* rstat = reinterpret_cast<float4*>(smem + kPostRows);          // [128] (max, lse, max |x|, -)
+      float* ssch = reinterpret_cast<float*>(smem + kPostRows + 2048) + wave * 128;  // this wave's copy: [n_attr][10] | [n_attr][2][5] q terms
+      const int Cm1 = p.v.n_class - 1;
+      const int t_post = kp->t_post[it];
       {
-        float* mine = lgs + row3 * kPostLd + hi3 * 4;  // D[i = class][j = row]: classes 32 ht + 8 rq + 4 hi + i
+        // predict_start's log-softmax over the classes [0, C - 1) (base.py:131-144), fp32 (fast numerics mode): row
+        // maximum and log-sum-exp from the registers of the row's two lanes (D[i = class][j = row]: lane (row, hi) holds
+        // classes 32 ht + 8 rq + 4 hi + i), then the raw logits go to LDS
+        float mx = -INFINITY, am = 0.f;
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) {
           const f32x16 tile = acc[ht];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) mine[ht * 32 + (i >> 2) * 8 + (i & 3)] = tile[i];
+          for (int i = 0; i < 16; ++i)
+            if (ht * 32 + (i >> 2) * 8 + hi3 * 4 + (i & 3) < Cm1) {
+              mx = fmaxf(mx, tile[i]);
+              am = fmaxf(am, fabsf(tile[i]));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        float se = 0.f;
+        float* mine = lgs + row3 * kPostLd + hi3 * 4;
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) {
+          const f32x16 tile = acc[ht];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (ht * 32 + (i >> 2) * 8 + hi3 * 4 + (i & 3) < Cm1) se += __expf(tile[i] - mx);
+            mine[ht * 32 + (i >> 2) * 8 + (i & 3)] = tile[i];
+          }
+        }
+        se += __shfl_xor(se, 32, 64);
+        if (hi3 == 0) rstat[row3] = make_float4(mx, __logf(se), am, 0.f);
+        // the step's schedule scalars of every attribute (constrained.py:81-90,114)
+        const int T1 = p.T + 1, u = (t_post - 1 + T1) % T1;
+        if (lane3 < p.v.n_attr * 10) {
+          const int at = lane3 / 10, k = lane3 - at * 10;
+          const int kind = k == 0 ? kLogAt : k == 1 ? kLogBt : k == 2 ? kLogCt : k == 3 ? kLogCumAt : k == 4 ? kLogCumBt
+                         : k == 5 ? kLogCumCt : k == 6 ? kLogCumAt : k == 7 ? kLogCumBt : k == 8 ? kLogCumCt : kLog1mCumCt;
+          ssch[lane3] = p.sched[((size_t)kind * p.v.n_attr + at) * T1 + (k < 6 ? t_post : u)];
         }
       }
-      __syncthreads();
-      const PostArgs& p = a.post;
-      if (tid < S) {
-        const int s = tid;
-        const size_t row = (size_t)b * S + s;
-        const int attr = s % p.v.n_attr;
-        const int T1 = p.T + 1, t = p.t_post, u = (t - 1 + T1) % T1;  // constrained.py:114
-        auto sch = [&](int kind, int idx) { return p.sched[((size_t)kind * p.v.n_attr + attr) * T1 + idx]; };
-        const ldm_post::StepSchedule sc{sch(kLogAt, t),    sch(kLogBt, t),    sch(kLogCt, t),    sch(kLogCumAt, t),
-                                        sch(kLogCumBt, t), sch(kLogCumCt, t), sch(kLogCumAt, u), sch(kLogCumBt, u),
-                                        sch(kLogCumCt, u), sch(kLog1mCumCt, u)};
-        ldm_post::TokenArgs ta{};
-        ta.logits = lgs + s * kPostLd;
-        ta.tok = p.tokens[row];
-        ta.start = p.v.start[attr];
-        ta.count = p.v.count[attr];
-        ta.pad_id = p.v.pad_id;
-        ta.mask_id = p.v.mask_id;
-        ta.n_class = p.v.n_class;
-        ta.cond_tok = p.cond_seq ? p.cond_seq[row] : -1;
-        ta.strong = p.strong && p.strong[row];
-        ta.weak = p.weak ? p.weak + (size_t)b * p.v.n_class * S + s : nullptr;  // (B, C, S)
-        ta.weak_stride = S;
-        ta.pad_disable = p.pad_disable && p.cond_seq && attr != 0 && ta.cond_tok != p.v.pad_id;  // base.py:272-284
-        ta.kind = p.kind;
-        ta.temperature = p.temperature;
-        ta.top_p = p.top_p;
-        ta.top_k = p.top_k;
-        ta.pos = (uint32_t)s;
-        ta.step = (uint32_t)p.step;
-        ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
-        ta.seed = p.rng[0];
-        const int drawn = ldm_post::step_token<false>(ta, sc, lgs + s * kPostLd);  // working storage = the token's own row
-        p.tokens_out[row] = drawn;
-        toks[s] = drawn;
+      // rows 32 wave .. 32 wave + 31 were written by THIS wavefront and are read by it alone: LDS operations of a
+      // wavefront complete in order
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      {
+        // q(x_t | x_0), q(x_t | x_{t-1}) per (attribute, x_t is / is not [MASK]): ten variants per step instead of one
+        // evaluation (12 transcendentals) per token
+        const int lane5 = stack_lane_id();
+        if (lane5 < 2 * p.v.n_attr) {
+          const float* sc10 = ssch + (lane5 >> 1) * 10;
+          const ldm_post::StepSchedule sc{sc10[0], sc10[1], sc10[2], sc10[3], sc10[4],
+                                          sc10[5], sc10[6], sc10[7], sc10[8], sc10[9]};
+          const ldm_post::QTerms k = ldm_post::q_terms(ldm_post::DppGroup<16, true>{0}, (lane5 & 1) != 0, sc);
+          float* o = ssch + 50 + lane5 * 5;  // (launcher: n_attr == 5)
+          o[0] = k.qt_same; o[1] = k.qt_other; o[2] = k.q1_same; o[3] = k.q1_other; o[4] = k.q1_mask;
+        }
       }
-      __syncthreads();
-      if (p.x_next) {  // the row the next reverse step starts from: emb[token] + pos[s] (nn_lib.py:204,220)
-        const int nvec = p.D >> 2;
-        for (int i = tid; i < S * nvec; i += 256) {
-          const int s = i / nvec, c = i - s * nvec;
-          const float4 e = reinterpret_cast<const float4*>(p.emb + (size_t)toks[s] * p.D)[c];
-          const float4 q = reinterpret_cast<const float4*>(p.pos + (size_t)s * p.D)[c];
-          reinterpret_cast<float4*>(p.x_next + ((size_t)b * S + s) * p.ldx)[c] =
-              make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
+      // rows 32 wave .. 32 wave + 31 were written by THIS wavefront and are read by it alone: LDS operations of a
+      // wavefront complete in order
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int lane4 = stack_lane_id();
+        const int grp = lane4 >> 4;
+        const ldm_post::DppGroup<16, true> g{lane4 & 15};
+        const ldm_post::SlotMap<16, 3, true> m{lane4 & 15};
+        const bool last = it + 1 == n_iter;
+#pragma unroll 2
+        for (int rd = 0; rd < 8; ++rd) {
+          const int s = wave * 32 + rd * 4 + grp;
+          if (s < S) {
+            const int attr = s % p.v.n_attr;
+            const float* sc10 = ssch + attr * 10;
+            const ldm_post::StepSchedule sc{sc10[0], sc10[1], sc10[2], sc10[3], sc10[4],
+                                            sc10[5], sc10[6], sc10[7], sc10[8], sc10[9]};
+            const int cc = condc[s];
+            ldm_post::TokenArgs ta{};
+            ta.tok = toks[s];
+            ta.start = p.v.start[attr];
+            ta.count = p.v.count[attr];
+            ta.pad_id = p.v.pad_id;
+            ta.mask_id = p.v.mask_id;
+            ta.n_class = p.v.n_class;
+            ta.cond_tok = cc < 0 ? -1 : (cc & 0x3fffffff);
+            ta.strong = cc >= 0 && (cc >> 30) != 0;
+            ta.weak = p.weak ? p.weak + (size_t)b * p.v.n_class * S + s : nullptr;  // (B, C, S)
+            ta.weak_stride = S;
+            ta.pad_disable = p.pad_disable && cc >= 0 && attr != 0 && ta.cond_tok != p.v.pad_id;  // base.py:272-284
+            ta.kind = p.kind;
+            ta.temperature = p.temperature;
+            ta.top_p = p.top_p;
+            ta.top_k = p.top_k;
+            ta.pos = (uint32_t)s;
+            ta.step = (uint32_t)(p.step + it);
+            ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
+            ta.seed = p.rng[0];
+            float* lrow_s = lgs + s * kPostLd;
+            const float4 rs = rstat[s];
+            float l0[3], lp[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const int c = m.cls(ta, j);
+              l0[j] = (m.valid(ta, j) && c < Cm1) ? ldm_post::l0_f32(lrow_s[c], rs.x, rs.y) : -70.0f;
+            }
+            const float* qk = ssch + 50 + (attr * 2 + (ta.tok == ta.mask_id ? 1 : 0)) * 5;
+            const ldm_post::QTerms k{qk[0], qk[1], qk[2], qk[3], qk[4]};
+            ldm_post::token_log_probs(g, m, ta, sc, k, l0, lp);
+            // (scratch of top-k / top-p: the token's own row — its logits are in registers by now)
+            const ldm_post::Draw d = ldm_post::draw_token(g, m, ta, lp, lrow_s, lrow_s + 48, false);
+            if (g.lane() == 0) {
+              toks[s] = d.token;
+              if (kp->inter) kp->inter[((size_t)it * kp->inter_ld + b) * S + s] = d.token;
+              if (last) p.tokens_out[(size_t)b * S + s] = d.token;
+              if (p.tie_flags && d.gap < p.tie_rel * rs.z) p.tie_flags[(size_t)it * kp->tie_ld + b] = 1;
+            }
+          }
         }
       }
     } else
-    for (int ht = 0; ht < a.n_head_tiles; ++ht) {
+    for (int ht = 0; ht < A.n_head_tiles; ++ht) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tile ht (and every earlier piece) has landed
       __builtin_amdgcn_s_barrier();                                // ... everybody's; tile ht - 1 is read by nobody any more
       asm volatile("" ::: "memory");
-      if (ht + 3 < a.n_head_tiles) dma_head_tile(ht + 3);          // -> stage of tile ht - 1
+      if (ht + 3 < A.n_head_tiles) dma_head_tile(ht + 3);          // -> stage of tile ht - 1
       TilePipe<KS, 8> TP;
       TP.xf = xf3;
       TP.voff = voff;
@@ -605,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     const int row3 = wave * 32 + r3;
     const bool valid3 = row3 < S;
     const size_t me = (size_t)b * S + (valid3 ? row3 : S - 1);
-    float* orow = a.x + me * a.ldx + hie * 4;
+    float* orow = A.x + me * A.ldx + hie * 4;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int gg = 0; gg < NGV; ++gg) {
@@ -620,14 +784,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     constexpr float kInvN3 = 1.0f / 464.0f;
     const float mean3 = s1 * kInvN3;
     const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
-    if (valid3 && hie == 0 && a.stats) a.stats[me] = make_float2(mean3, rstd3);
+    if (valid3 && hie == 0 && A.stats) A.stats[me] = make_float2(mean3, rstd3);
   }
   }
+  } while (HEAD == 2 && ++it < n_iter);  // step loop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last FFN prefetch must land before the LDS is released
   if constexpr (TM) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     const unsigned long long t_real1 = __builtin_amdgcn_s_memrealtime();
-    if (tid == 0) {
+    if (tid_o == 0) {
       atomicAdd(&g_stack_phase[0], 1ull);
       atomicAdd(&g_stack_phase[1], t_end - t0);
       atomicAdd(&g_stack_phase[2], t_real1 - t_real0);
@@ -651,15 +816,36 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, floa
                          int dh, const StackHead* head, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  const bool post = head && head->post;  // (the caller has checked n_tiles == 5 and the sub-vocabulary bound)
-  auto kern = post ? stack_stream_k<false, 2>  // (no probe variant: it would be the one instantiation with spills)
-              : head ? (tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>)
-                     : (tm ? stack_stream_k<true, 0> : stack_stream_k<false, 0>);
+  auto kern = head ? (tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>)
+                   : (tm ? stack_stream_k<true, 0> : stack_stream_k<false, 0>);
   allow_big_lds((const void*)kern);
-  StackArgs a{ls, x, stats_io, ldx, N, S, H, F / 32, 1.4426950408889634f / sqrtf((float)dh),
-              head ? (const char*)head->img : nullptr, head ? head->g : nullptr, head ? head->b : nullptr,
-              head ? head->logits : nullptr, head ? head->ldl : 0, head ? head->n_tiles : 0,
-              post ? *head->post : PostArgs{}};
+  StackArgs a{};
+  a.ls = ls; a.x = x; a.stats = stats_io; a.ldx = ldx; a.N = N; a.S = S; a.H = H; a.n_chunks = F / 32;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  if (head) {
+    a.head_img = (const char*)head->img; a.head_g = head->g; a.head_b = head->b;
+    a.logits = head->logits; a.ldl = head->ldl; a.n_head_tiles = head->n_tiles;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
+}
+
+// HEAD == 2: the whole reverse loop, one workgroup per layout (no probe variant: it would be the one instantiation with
+// spills).  The caller has checked: 5 head tiles, live sub-vocabularies <= 48 classes, S <= 128.
+void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
+                       const StackLoop& lp, hipStream_t st) {
+  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4 + kStackLoopLds;
+  auto kern = stack_stream_k<false, 2>;
+  allow_big_lds((const void*)kern);
+  StackArgs a{};
+  a.ls = ls; a.ldx = N; a.N = N; a.S = S; a.H = H; a.n_chunks = F / 32;
+  a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
+  a.head_img = (const char*)head.img; a.head_g = head.g; a.head_b = head.b; a.n_head_tiles = head.n_tiles;
+  a.post = *lp.post; a.adaln = lp.adaln; a.inter = lp.inter;
+  a.n_steps = lp.n_steps; a.inter_ld = lp.inter_ld; a.tie_ld = lp.tie_ld;
+  for (int i = 0; i < lp.n_steps && i < kStackLoopMaxSteps; ++i) {
+    a.t_model[i] = (int16_t)lp.t_model[i];
+    a.t_post[i] = (int16_t)lp.t_post[i];
+  }
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
 }
 

@@ -88,6 +88,7 @@ struct PendingEvent {
 struct GraphKey {
   int B, n_steps, kind, top_k, has_cond, has_strong, has_weak, pad_disable, has_inter;
   int has_rel = 0, rel_num_update = 0, rel_n_graph = 0, rel_bins[4] = {0, 0, 0, 0};
+  float tie_rel = 0.f;
   float rel_lambda = 0.f;
   const void* rel_edges = nullptr;
   float temperature, top_p;
@@ -96,7 +97,7 @@ struct GraphKey {
   bool operator==(const GraphKey& o) const {
     return B == o.B && n_steps == o.n_steps && kind == o.kind && top_k == o.top_k && has_cond == o.has_cond &&
            has_strong == o.has_strong && has_weak == o.has_weak && pad_disable == o.pad_disable &&
-           has_inter == o.has_inter && has_rel == o.has_rel && rel_num_update == o.rel_num_update &&
+           has_inter == o.has_inter && tie_rel == o.tie_rel && has_rel == o.has_rel && rel_num_update == o.rel_num_update &&
            rel_n_graph == o.rel_n_graph && rel_lambda == o.rel_lambda && rel_edges == o.rel_edges &&
            rel_bins[0] == o.rel_bins[0] && rel_bins[1] == o.rel_bins[1] && rel_bins[2] == o.rel_bins[2] &&
            rel_bins[3] == o.rel_bins[3] && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
@@ -191,7 +192,13 @@ struct ldm_handle {
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
   int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
-  int stack_post = 0;  // EXPERIMENTAL (LDM_STACK_POST=1): + posterior and draw inside the stack kernel; never run on hardware yet
+  int stack_loop = 1;  // the WHOLE reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): one launch per
+                       // sampling call, the step's tail behind the vocabulary head (LDM_STACK_LOOP=0: one stack launch +
+                       // one posterior launch per step, captured in per-lane hipGraphs — the r02 path)
+  // near-tie report of deterministic decoding (ldm_set_tie_report): flags [tie_steps][max_batch]
+  float tie_rel = 0.f;
+  uint8_t* tie_flags = nullptr;
+  int tie_steps = 0;
   int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
                        // 5: the WHOLE layer (attention block + FFN) per launch, in place on P, as continuous per-head /
                        //    slab / chunk streams (kernels_layer.hip:
@@ -419,7 +426,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
     if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
     if (const char* sh = getenv("LDM_STACK_HEAD")) h->stack_head = atoi(sh);
-    if (const char* sp = getenv("LDM_STACK_POST")) h->stack_post = atoi(sp);
+    if (const char* sp = getenv("LDM_STACK_LOOP")) h->stack_loop = atoi(sp);
     // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
     // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
     if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
@@ -784,7 +791,7 @@ static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 // normalise while loading their register-resident fragments; the out-proj recomputes its residual
 // AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
 static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
-                                       bool skip_embed = false, const PostArgs* fused_post = nullptr) {
+                                       bool skip_embed = false) {
   const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD;
   if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw) + stats_a   (skipped when the previous step's posterior wrote P)
     LnArgs a{};
@@ -806,9 +813,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     }
     // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
     const bool with_head = h->stack_head && h->head_img_ks && h->Cp % 32 == 0;
-    StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
-    if (fused_post && !with_head) return h->fail(-2, "internal: fused step tail requested without the fused head");
-    hd.post = fused_post;  // (experimental, LDM_STACK_POST=1: posterior + draw inside the stack kernel)
+    const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
     ldm_handle::Scope sc(h, st, "layers_fused",
                          h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
                                  gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) +
@@ -817,7 +822,6 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
     launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, with_head ? &hd : nullptr, st);
     if (with_head) return 0;
   }
-  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
   for (int i = 0; i < (h->fused_attn == 6 ? 0 : h->L); ++i) {
     const LayerW& w = h->layers[i];
     const ldm_handle::FastLayer& f = h->fast[i];
@@ -888,9 +892,8 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
 
 // fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
 static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
-                              bool skip_embed = false, const PostArgs* fused_post = nullptr) {
-  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed, fused_post);
-  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
+                              bool skip_embed = false) {
+  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
@@ -958,10 +961,8 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
 }
 
 // denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
-static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed = false,
-                         const PostArgs* fused_post = nullptr) {
-  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed, fused_post);
-  if (fused_post) return h->fail(-2, "internal: fused step tail requested off the stack-kernel path");
+static int denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed = false) {
+  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
   const int prec = h->cfg.precision;
   const bool f16 = prec != LDM_PREC_EXACT_F32;
@@ -1160,18 +1161,14 @@ static void fill_rel(ldm_handle* h, RelArgs& a, const ldm_relation* rel, size_t 
 // relation graph's CSR offsets.
 static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_model, int t_post, const ldm_cond* cond,
                     const ldm_relation* rel, size_t rel_layout_off, const ldm_sampler* s, int step, int B,
-                    size_t rng_layout_off, hipStream_t st, bool skip_embed = false, bool embed_next = false) {
+                    size_t rng_layout_off, hipStream_t st, bool skip_embed = false, bool embed_next = false,
+                    int tie_row = -1) {
   if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
     return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
-  // EXPERIMENTAL, off by default (LDM_STACK_POST=1; written at the end of round 2, not yet run on hardware): the step's
-  // tail inside the stack kernel (kernels_stack.hip HEAD == 2) — then no logits and no posterior launch
-  int live_max = 0;
-  for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
-  const bool fuse_post = h->stack_post && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln &&
-                         h->fused_attn == 6 && h->stack_head && h->head_img_ks && h->Cp == 160 &&
-                         live_max <= kStackPostMaxLive && h->S <= 128;
   for (int off = 0; off < B; off += h->chunk) {
     const int Bc = std::min(h->chunk, B - off);
+    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st, skip_embed);
+    if (rc) return rc;
     PostArgs p{};
     fill_post(h, p, cond, s, off, Bc);
     p.logits = h->logits;
@@ -1185,11 +1182,10 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       if (embed_next) {  // (one chunk per call: run_loop_body)
         p.x_next = h->P; p.emb = h->emb; p.pos = h->pos; p.D = h->D; p.ldx = h->D;
       }
-    }
-    int rc = denoise_chunk(h, tin + (size_t)off * h->S, t_model, Bc, st, skip_embed, fuse_post ? &p : nullptr);
-    if (rc) return rc;
-    if (!rel) {
-      if (fuse_post) continue;
+      if (tie_row >= 0 && h->tie_rel > 0.f && h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) {
+        p.tie_flags = h->tie_flags + (size_t)tie_row * h->cfg.max_batch + rng_layout_off + off;
+        p.tie_rel = h->tie_rel;
+      }
       ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
       launch_posterior_sample(p, st);
       continue;
@@ -1224,6 +1220,58 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       ldm_handle::Scope sc(h, st, "pad_disable_sample", 0, (double)Bc * h->S * (h->C * 4 + 8));
       launch_posterior_sample(q, st);
     }
+  }
+  return 0;
+}
+
+// ---- the whole reverse loop in one launch (kernels_stack.hip HEAD == 2) -----------------------------------------
+// Eligible: fast numerics on the layout-resident kernels (the reference's backbone, S <= 128), a vocabulary of 5 head
+// tiles whose attribute sub-vocabularies fit the fused tail, no cond=relation (its logit adjustment couples the
+// elements of a layout through an SGD on the full log-probability tensor: it keeps the per-step path).
+static bool loop_fusable(const ldm_handle* h, const ldm_relation* rel) {
+  int live_max = 0;
+  for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
+  return h->stack_loop && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6 &&
+         h->stack_head && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
+         h->T < 32768 && !h->fast.empty();
+}
+
+// tokens_in -> tokens_out (may alias) through n_steps reverse steps; step0 = loop index of the first one (RNG counter
+// word); cond pointers describe layout 0..B of this call; d_inter (n_steps, B, S) or nullptr; tie_row0 >= 0: near-tie
+// flags of step i go to row tie_row0 + i of h->tie_flags
+static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, const ldm_cond* cond, const int32_t* t_model,
+                          const int32_t* t_post, int n_steps, const ldm_sampler* s, int step0, int B, int32_t* d_inter,
+                          int tie_row0, hipStream_t st) {
+  const int D = h->D, F = h->F, M = B * h->S;
+  FusedLayerSet ls{};
+  ls.n_layer = h->L;
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, nullptr, nullptr, h->fast[i].b_out_v,
+                          h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
+  }
+  const StackHead hd{h->head_img_ks, h->head_g, h->head_b, nullptr, h->Cp, h->Cp / 32};
+  const double step_flops = h->L * (gemm_flops(M, 3 * D, D) + 4.0 * B * h->H * (double)h->S * h->S * h->dh +
+                                    gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) + gemm_flops(M, h->C, D);
+  for (int i0 = 0; i0 < n_steps; i0 += kStackLoopMaxSteps) {  // (timesteps travel in the kernel arguments)
+    const int n = std::min(kStackLoopMaxSteps, n_steps - i0);
+    PostArgs p{};
+    fill_post(h, p, cond, s, 0, B);
+    p.tokens = i0 == 0 ? tin : tout;
+    p.tokens_out = tout;
+    p.step = step0 + i0;
+    p.layout_off = 0;
+    p.emb = h->emb; p.pos = h->pos; p.D = D;
+    if (tie_row0 >= 0 && h->tie_rel > 0.f && h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) {
+      p.tie_flags = h->tie_flags + (size_t)(tie_row0 + i0) * h->cfg.max_batch;
+      p.tie_rel = h->tie_rel;
+    }
+    StackLoop lp{};
+    lp.post = &p; lp.adaln = h->adaln; lp.t_model = t_model + i0; lp.t_post = t_post + i0;
+    lp.inter = d_inter ? d_inter + (size_t)i0 * B * h->S : nullptr;
+    lp.n_steps = n; lp.inter_ld = B; lp.tie_ld = h->cfg.max_batch;
+    ldm_handle::Scope sc(h, st, "layers_fused_loop", n * step_flops, (double)B * h->S * 8);
+    launch_stack_loop(ls, F, D, B, h->S, h->H, h->dh, hd, lp, st);
   }
   return 0;
 }
@@ -1330,6 +1378,45 @@ extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B,
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------ near-tie report
+// Deterministic decoding in the fp16 mode is bit-exact against the reference wherever the winning class leads the
+// runner-up by more than the mode's logits error can move.  With the report enabled every deterministic step marks
+// the layouts in which some token was decided inside that band; the caller re-decides exactly those in the exact
+// mode (layout_dm_amd.verified: greedy decoding is RNG-free and layouts are independent).
+extern "C" int ldm_set_tie_report(ldm_handle* h, float tie_rel) {
+  if (!h) return -1;
+  if (!(tie_rel >= 0.f)) return h->fail(-1, "tie_rel must be >= 0");
+  ON_DEVICE(h);
+  if (tie_rel > 0.f && !h->tie_flags) {
+    h->tie_steps = std::max(h->T, 1);
+    int rc = h->dalloc(&h->tie_flags, (size_t)h->tie_steps * h->cfg.max_batch);
+    if (rc) return rc;
+  }
+  if (tie_rel != h->tie_rel) {  // captured graphs carry the flag pointers / threshold of their capture
+    for (auto& g : h->graphs) g.destroy();
+    h->graphs.clear();
+  }
+  h->tie_rel = tie_rel;
+  return 0;
+}
+extern "C" int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, int B, void* stream) {
+  if (!h || !d_flags) return h ? h->fail(-1, "null argument") : -1;
+  if (!h->tie_flags) return h->fail(-1, "near-tie report not enabled (ldm_set_tie_report)");
+  if (n_steps < 1 || n_steps > h->tie_steps || B < 1 || B > h->cfg.max_batch) return h->fail(-1, "n_steps / B out of range");
+  ON_DEVICE(h);
+  HIP_OK(h, hipMemcpy2DAsync(d_flags, (size_t)B, h->tie_flags, (size_t)h->cfg.max_batch, (size_t)B, (size_t)n_steps,
+                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+// clears the rows a deterministic call is about to fill
+static int tie_begin(ldm_handle* h, const ldm_sampler* s, int n_steps, int B, hipStream_t st) {
+  (void)B;
+  if (!(h->tie_rel > 0.f) || !h->tie_flags || s->kind != LDM_SAMPLE_DETERMINISTIC) return 0;
+  if (n_steps > h->tie_steps) return h->fail(-1, "near-tie report: at most %d steps per call", h->tie_steps);
+  HIP_OK(h, hipMemsetAsync(h->tie_flags, 0, (size_t)n_steps * h->cfg.max_batch, st));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------ hot path
 extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_t* d_tokens_out, int t_model,
                                int t_post, const ldm_cond* cond, const ldm_relation* rel, const ldm_sampler* s,
@@ -1342,7 +1429,15 @@ extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_
   if ((rc = check_relation(h, rel, cond, B))) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
-  if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, rel, 0, s, step, B, 0, st))) return rc;
+  if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
+    return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
+  if ((rc = tie_begin(h, s, 1, B, st))) return rc;
+  if (loop_fusable(h, rel)) {
+    const int32_t tm = t_model, tp = t_post;
+    if ((rc = run_loop_fused(h, d_tokens_in, d_tokens_out, cond, &tm, &tp, 1, s, step, B, nullptr, 0, st))) return rc;
+  } else if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, rel, 0, s, step, B, 0, st, false, false, 0))) {
+    return rc;
+  }
   HIP_OK(h, hipGetLastError());
   return 0;
 }
@@ -1373,7 +1468,7 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation
     const bool fuse_embed = !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6;
     for (int i = 0; i < n_steps; ++i) {
       int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st,
-                        fuse_embed && i > 0, fuse_embed && i + 1 < n_steps);
+                        fuse_embed && i > 0, fuse_embed && i + 1 < n_steps, i);
       if (rc) return rc;
       if (d_inter)
         HIP_OK(h, hipMemcpyAsync(d_inter + ((size_t)i * B + off) * S, nxt, (size_t)Bc * S * 4,
@@ -1403,6 +1498,17 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
   const size_t nbytes = (size_t)B * h->S * 4;
   HIP_OK(h, hipEventRecord(h->loop_a, st));
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
+  if ((rc = tie_begin(h, s, n_steps, B, st))) return rc;
+  if (loop_fusable(h, rel)) {
+    // one launch: every layout's workgroup runs all its steps in place on the caller's tokens (no staging, no graph)
+    if ((rc = run_loop_fused(h, d_tokens_inout, d_tokens_inout, cond, h_t_model, h_t_post, n_steps, s, 0, B,
+                             d_intermediates, 0, st)))
+      return rc;
+    HIP_OK(h, hipEventRecord(h->loop_b, st));
+    h->loop_timed = true;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+  }
   HIP_OK(h, hipMemcpyAsync(h->tok_a, d_tokens_inout, nbytes, hipMemcpyDeviceToDevice, st));
   if (use_graph && !h->profiling) {
     // copy the constraints into handle-owned staging buffers: the captured graph then only ever sees
@@ -1476,6 +1582,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       inter_dst = h->st_inter;
     }
     key.has_inter = inter_dst != nullptr;
+    key.tie_rel = (h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) ? h->tie_rel : 0.f;
     if (rel) {
       key.has_rel = 1;
       key.rel_num_update = rel->num_update;

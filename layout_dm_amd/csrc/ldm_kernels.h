@@ -130,15 +130,25 @@ struct StackHead {
   const float *g, *b;
   float* logits;
   int ldl, n_tiles;
-  // EXPERIMENTAL (LDM_STACK_POST=1, written at the end of round 2 and not yet run on hardware): the posterior + draw of
-  // the step behind the head in the same workgroup (one lane per token, csrc/ldm_post_token.h); logits are then not
-  // written.  nullptr = the head writes logits and posterior_sample_k follows as its own launch (the verified path).
-  const PostArgs* post = nullptr;
 };
-// largest sub-vocabulary (body + [PAD] + [MASK]) the fused tail takes: its working storage is the token's logits row
-constexpr int kStackPostMaxLive = 53;
 void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
                          int dh, const StackHead* head, hipStream_t st);
+// ... and the whole reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): tokens in / out through
+// post->tokens / post->tokens_out, the step's tail (ldm_post_token.h) behind the vocabulary head on the logits in LDS.
+// ls.w[i].ada_scale / ada_shift are ignored: the AdaLN rows of step i come from adaln[t_model[i]].
+struct StackLoop {
+  const PostArgs* post;      // schedule, cond, sampler, RNG, vocabulary, emb / pos / D; post->step = index of the first step
+  const float* adaln;        // [T][L][2 N]
+  const int32_t *t_model, *t_post;  // HOST arrays [n_steps], n_steps <= kStackLoopMaxSteps (longer loops: several launches)
+  int32_t* inter;            // [n_steps][inter_ld][S] or nullptr
+  int n_steps, inter_ld;
+  int tie_ld;                // post->tie_flags of step i at + i * tie_ld (per layout of this launch)
+};
+// largest sub-vocabulary (body + [PAD] + [MASK]) the fused tail takes: 3 class slots on each of a group's 16 lanes
+constexpr int kStackPostMaxLive = 48;
+constexpr int kStackLoopMaxSteps = 128;  // timesteps travel in the kernel arguments
+void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
+                       const StackLoop& lp, hipStream_t st);
 int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,

@@ -49,12 +49,15 @@ __device__ __forceinline__ int swap32_i(int x, int& other) {
   return (int)s[0];
 }
 
-template <int NL_>
+// FAST: exp / log on the hardware's v_exp_f32 / v_log_f32 (the fast numerics mode; ~1e-6 relative) instead of libm
+template <int NL_, bool FAST = false>
 struct DppGroup {
   static_assert(NL_ == 16 || NL_ == 64, "one DPP row or one wavefront");
   static constexpr int NL = NL_;
   int l;  // lane inside the group
   __device__ __forceinline__ int lane() const { return l; }
+  __device__ __forceinline__ float exp(float x) const { return FAST ? __expf(x) : expf(x); }
+  __device__ __forceinline__ float log(float x) const { return FAST ? __logf(x) : logf(x); }
 
   __device__ __forceinline__ float gmax(float v) const {
     v = fmaxf(v, __int_as_float(dpp_mov<kDppXor1>(__float_as_int(v))));

@@ -65,9 +65,12 @@ struct TokenArgs {
   uint64_t layout, seed;   // counter words 2, 3 (global layout index) and the key
 };
 
-LDM_PT_HD float log_add_exp(float a, float b) {  // util.py:19-21
+// util.py:19-21.  exp / log come from the group policy: libm on the host and in the exact numerics mode; in the fast mode
+// the hardware's v_exp_f32 / v_log_f32 (~1e-6 relative, three orders below that mode's fp16 logits error)
+template <class G>
+LDM_PT_HD float log_add_exp(const G& g, float a, float b) {
   const float m = fmaxf(a, b);
-  return m + logf(expf(a - m) + expf(b - m));
+  return m + g.log(g.exp(a - m) + g.exp(b - m));
 }
 
 LDM_PT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -113,6 +116,8 @@ struct SlotMap {
 struct HostLane {
   static constexpr int NL = 1;
   LDM_PT_HD int lane() const { return 0; }
+  LDM_PT_HD float exp(float x) const { return expf(x); }
+  LDM_PT_HD float log(float x) const { return logf(x); }
   LDM_PT_HD float gmax(float v) const { return v; }
   LDM_PT_HD float gsum(float v) const { return v; }
   LDM_PT_HD double gsumd(double v) const { return v; }
@@ -127,13 +132,14 @@ struct HostLane {
 struct QTerms {
   float qt_same, qt_other, q1_same, q1_other, q1_mask;
 };
-LDM_PT_HD QTerms q_terms(bool x_is_mask, const StepSchedule& s) {
+template <class G>
+LDM_PT_HD QTerms q_terms(const G& g, bool x_is_mask, const StepSchedule& s) {
   QTerms k;
-  k.q1_same = x_is_mask ? s.lc : log_add_exp(0.0f + s.la, s.lb);
-  k.q1_other = x_is_mask ? s.lc : log_add_exp(kLogEps + s.la, s.lb);
+  k.q1_same = x_is_mask ? s.lc : log_add_exp(g, 0.0f + s.la, s.lb);
+  k.q1_other = x_is_mask ? s.lc : log_add_exp(g, kLogEps + s.la, s.lb);
   k.q1_mask = x_is_mask ? 0.0f : kLogEps;
-  k.qt_same = x_is_mask ? s.LC : log_add_exp(0.0f + s.LA, s.LB);
-  k.qt_other = x_is_mask ? s.LC : log_add_exp(kLogEps + s.LA, s.LB);
+  k.qt_same = x_is_mask ? s.LC : log_add_exp(g, 0.0f + s.LA, s.LB);
+  k.qt_other = x_is_mask ? s.LC : log_add_exp(g, kLogEps + s.LA, s.LB);
   return k;
 }
 
@@ -145,12 +151,13 @@ LDM_PT_HD float l0_f64(float x, float mx, double lse0) {
 }
 
 // ---- posterior + cond overrides: l0[j] = log p(x_0 = cls(j) | x_t) of the lane's slots (ignored for [MASK] and for
-// dead / invalid slots) -> lp[j] = log p(x_{t-1} = cls(j) | x_t) after the overrides; -inf for invalid slots
+// dead / invalid slots) -> lp[j] = log p(x_{t-1} = cls(j) | x_t) after the overrides; -inf for invalid slots.
+// k = q_terms(g, a.tok == a.mask_id, s): the same for every token of an attribute that is / is not [MASK], so a caller
+// with many tokens per step computes the ten variants once
 template <class G, class M>
-LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s,
+LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s, const QTerms& k,
                                const float (&l0)[M::NJ], float (&lp)[M::NJ]) {
   constexpr int NJ = M::NJ;
-  const QTerms k = q_terms(a.tok == a.mask_id, s);
   float q[NJ];
   float qmx = -INFINITY;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -171,9 +178,9 @@ LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const
 #pragma unroll
 #endif
   for (int j = 0; j < NJ; ++j)
-    if (m.live(a, j)) qs += expf(q[j] - qmx);
+    if (m.live(a, j)) qs += g.exp(q[j] - qmx);
   qs = g.gsum(qs);
-  const float lse = logf(qs) + qmx;  // torch.logsumexp
+  const float lse = g.log(qs) + qmx;  // torch.logsumexp
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -182,7 +189,7 @@ LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const
     float v;
     if (m.live(a, j)) {
       const float qn = q[j] - lse;
-      const float r = (c == a.mask_id) ? log_add_exp(qn + s.L1Cu, s.LCu) : log_add_exp(qn + s.LAu, s.LBu);
+      const float r = (c == a.mask_id) ? log_add_exp(g, qn + s.L1Cu, s.LCu) : log_add_exp(g, qn + s.LAu, s.LBu);
       const float q1 = (c == a.mask_id) ? k.q1_mask : (c == a.tok ? k.q1_same : k.q1_other);
       v = fminf(fmaxf((r + q1) + lse, -70.0f), 0.0f);  // l.192-197
     } else {
@@ -198,6 +205,12 @@ LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const
     }
     lp[j] = v;
   }
+}
+
+template <class G, class M>
+LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s,
+                               const float (&l0)[M::NJ], float (&lp)[M::NJ]) {
+  token_log_probs(g, m, a, s, q_terms(g, a.tok == a.mask_id, s), l0, lp);
 }
 
 // only the [PAD] disabling (the stage between ldm_relation_update and the draw: base.py:272-284)
@@ -265,7 +278,7 @@ LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp
         uint32_t r[4];
         philox4x32_10(a.pos | ((uint32_t)(1 + (c >> 2)) << 16), a.step, y0, y1, k0, k1, r);
         const uint32_t w = (c & 3) == 0 ? r[0] : (c & 3) == 1 ? r[1] : (c & 3) == 2 ? r[2] : r[3];
-        lg[j] += -logf(-logf(u01(w) + 1e-30f) + 1e-30f);
+        lg[j] += -g.log(-g.log(u01(w) + 1e-30f) + 1e-30f);
       }
   }
   if (a.kind == kTopP || a.kind == kTopK) {
@@ -281,7 +294,7 @@ LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp
 #pragma unroll
 #endif
     for (int j = 0; j < NJ; ++j) {
-      ex[j] = m.valid(a, j) ? expf(lg[j] - m1) : 0.f;
+      ex[j] = m.valid(a, j) ? g.exp(lg[j] - m1) : 0.f;
       es += ex[j];
     }
     es = g.gsum(es);
@@ -357,7 +370,7 @@ LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp
 #pragma unroll
 #endif
   for (int j = 0; j < NJ; ++j) {  // slot j of every lane precedes slot j + 1 of every lane
-    const double pr = m.valid(a, j) ? (double)expf(lg[j] - m2) : 0.0;
+    const double pr = m.valid(a, j) ? (double)g.exp(lg[j] - m2) : 0.0;
     cdf[j] = base + g.gscan(pr);
     base += g.gsumd(pr);
   }

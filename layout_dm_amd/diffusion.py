@@ -60,10 +60,21 @@ class HipMaskAndReplaceDiffusion:
                  num_timesteps: int = 100, precision: str = "exact", max_batch: int = 512, chunk: int = 0,
                  device: Optional[int] = None, use_graph: bool = True, q_type: str = "constrained", lanes: int = 0):
         # q_type: Q_TYPES of models/layoutdm.py:20-23 — "constrained" (constrained.py) or "vanilla" (vanilla.py)
-        self.engine = Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
-                             d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
-                             precision=precision, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type,
-                             lanes=lanes)
+        # precision "fast_verified": the fp16 engine for every sampler, plus an exact (fp32) engine of the same weights
+        # that re-decides the near-tie layouts of DETERMINISTIC decoding (layout_dm_amd/verified.py): greedy tokens are
+        # then the exact mode's, i.e. the reference's, bit for bit
+        self.verified = None
+        mk = lambda prec: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
+                                 d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
+                                 precision=prec, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type,
+                                 lanes=lanes)
+        if precision == "fast_verified":
+            from .verified import VerifiedGreedy
+
+            self.engine = mk("fast")
+            self.verified = VerifiedGreedy(self.engine, mk("exact"))
+        else:
+            self.engine = mk(precision)
         self.q_type = q_type
         self.num_timesteps = num_timesteps
         self.num_classes = self.engine.C
@@ -86,6 +97,8 @@ class HipMaskAndReplaceDiffusion:
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         self.engine.load_state_dict(state_dict)
+        if self.verified is not None:
+            self.verified.exact.load_state_dict(state_dict)
         return self
 
     # -- the hot path ----------------------------------------------------------------------------
@@ -138,9 +151,13 @@ class HipMaskAndReplaceDiffusion:
             if cond:
                 sub = {k: (v[off:off + n] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B else v)
                        for k, v in cond.items()}
-            tk, inter = eng.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, sampling_cfg, cond=sub,
-                                        seed=seed, first_layout=first_layout + off,
-                                        intermediates=get_intermediate_results, use_graph=self.use_graph)
+            if self.verified is not None and _cfg_get(sampling_cfg, "name") == "deterministic":
+                tk, inter = self.verified.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, cond=sub,
+                                                      intermediates=get_intermediate_results)
+            else:
+                tk, inter = eng.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, sampling_cfg, cond=sub,
+                                            seed=seed, first_layout=first_layout + off,
+                                            intermediates=get_intermediate_results, use_graph=self.use_graph)
             outs.append(tk)
             inters.append(inter)
         out = torch.cat(outs) if len(outs) > 1 else outs[0]

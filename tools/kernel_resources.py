@@ -34,8 +34,8 @@ def main():
             rows.append(cur)
             continue
         for key, pat in (("vgpr", r"\bVGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r"SGPRs: (\d+)"),
-                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vspill", r"VGPR Spill: (\d+)"),
-                         ("sspill", r"SGPR Spill: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"),
+                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vspill", r"VGPRs? Spill: (\d+)"),
+                         ("sspill", r"SGPRs? Spill: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"),
                          ("occ", r"Occupancy \[waves/SIMD\]: (\d+)")):
             m = re.search(pat, line)
             if m and cur is not None:
