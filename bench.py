@@ -13,9 +13,16 @@ Workloads (BASELINE.json configs), selected with --config:
   4  Rico25    cond=unconditional  T=100  1024 layouts/GPU  sampling=random    (default at --gpus N>1: 8 GPUs = 8192)
 Random-init synthetic weights with the reference's init distributions (no checkpoints offline).
 
-The ONE JSON line carries the headline numerics mode (--precision, default `fast`) at top level and, at N=1, every
-numerics mode under "modes" (exact = fp32 MFMA, the mode of the bit-exact token tests; split = fp16x3; fast = fp16
-operands / fp32 accumulate), each with its own roofline fraction against its own peak.
+The ONE JSON line carries the headline numerics mode (--precision, default `fast`) at top level and, at N=1:
+  "modes"     every numerics mode on the headline workload, each with its own roofline against its own peak: exact (fp32
+              MFMA, the mode of the bit-exact token tests), fast (fp16 operands / fp32 accumulate), and — config 2
+              verbatim, i.e. GREEDY decoding — fast_verified (fast + exact re-decision of the near-tie layouts: the exact
+              mode's tokens, checked here against the exact engine) next to the plain fast greedy figure;
+  "configs"   the other BASELINE configurations and the "next" rows of SURVEY section 8f at a few steps each: 3 (PubLayNet
+              cond=c top-p, 1024), 4 (the per-GPU shard of the scaling run, 1024), refinement, relation (512 each);
+  "fid_features"  layouts/s of the FID feature extractor (section 8f row 3);
+  "tokens_sha256" of the first 512 layouts of a fixed-seed Rico25 unconditional run: independent of N by construction
+              (Philox keyed by global layout index), so a scaling run can prove it.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run (one rank
 per GPU).  Rank 0 prints ONE JSON line.
@@ -40,14 +47,18 @@ FLOP_PER_TOKEN_STEP = {  # 4 x [QKV + attn + out-proj + FFN] + he
     "publaynet": 21_721_696,
 }
 # MI355X_MICROARCH.md dense MFMA peaks; split = 3 fp16 MFMA passes per product (divide by the passes)
-PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3}
-DTYPE = {"exact": "f32", "fast": "f16 (f32 accumulate)", "split": "f16x3 split (f32 accumulate)"}
+PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3, "fast_verified": 2500.0}
+DTYPE = {"exact": "f32", "fast": "f16 (f32 accumulate)", "split": "f16x3 split (f32 accumulate)",
+         "fast_verified": "f16 (f32 accumulate) + f32 re-decision of near-tie layouts"}
 CONFIGS = {
     2: dict(dataset="rico25", cond="unconditional", batch=512, sampling="random"),
     3: dict(dataset="publaynet", cond="c", batch=1024, sampling="top_p"),
     4: dict(dataset="rico25", cond="unconditional", batch=1024, sampling="random"),
 }
 GEMM_CLASSES = ("gemm", "ffn", "qkv", "layer")
+FETCH_CALIBRATION = 2.0           # profiles/r03_fetch_size_calibration.txt
+WEIGHT_IMAGE_BYTES = 23.4e6       # fast mode: LDS weight images of the 4 layers + head, fp16
+SHA_LAYOUTS, SHA_SEED = 512, 20260926
 
 
 def parse():
@@ -64,7 +75,12 @@ def parse():
     ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "fast"),
                     choices=["exact", "fast", "split"])
     ap.add_argument("--modes", default=None,
-                    help="comma list of numerics modes reported under 'modes' (default: all three at N=1, none at N>1)")
+                    help="comma list of numerics modes reported under 'modes' (default: exact,fast,fast_verified at N=1, "
+                         "none at N>1; split = the fp16x3 cross-check mode, on request)")
+    ap.add_argument("--no-extras", action="store_true", help="skip 'configs', 'fid_features' (N=1 extras)")
+    ap.add_argument("--total", type=int, default=0,
+                    help="STRONG scaling: total layouts per step over all GPUs (sharded by global layout index); "
+                         "0 = weak scaling with --batch / the config's batch per GPU")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0, help="concurrent chunk pipelines (0 = library default)")
     ap.add_argument("--no-graph", action="store_true")
@@ -173,47 +189,69 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
 
 # event-profile class -> substring of the kernel symbol in the PMC csv (layer_fused: the stream kernel of kernels_layer.hip
 # under LDM_FUSED_ATTN=5; layers_fused: the stack kernel of kernels_stack.hip, default)
-KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layer_fused": "layer_stream_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
+KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_stream_k", "layer_fused": "layer_stream_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
                  "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
                  "attention": "attn_"}
 
 
-# ----------------------------------------------------------------------------------------- one numerics mode
-def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, local_rank, dist, with_roofline):
-    """Times `steps` passes of the workload in one numerics mode; returns (result dict, engine, last tokens)."""
+# ----------------------------------------------------------------------------------------- one workload, one mode
+def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, local_rank, dist, with_roofline,
+             sampling=None, relation_graph=None, total=0, verified=False):
+    """Times `steps` passes of one workload in one numerics mode.  B = this rank's layouts per step (weak scaling) or,
+    with total > 0, the rank's shard of `total` (strong scaling).  cond_np: this rank's cond arrays (type c / refinement /
+    relation) or None.  verified: greedy decoding through layout_dm_amd.verified (fast + exact re-decision).
+    Returns (result dict, engine, last tokens)."""
     import torch
 
     from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion, timestep_schedule
-    from layout_dm_amd.distributed import sample_sharded
+    from layout_dm_amd.distributed import sample_sharded, shard_range
 
+    sampling = sampling or a.sampling
     model = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
                                        d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
-                                       num_timesteps=spec.n_step, precision=precision, max_batch=B, chunk=a.chunk,
-                                       device=local_rank, use_graph=not a.no_graph, lanes=a.lanes)
+                                       num_timesteps=spec.n_step, precision="fast_verified" if verified else precision,
+                                       max_batch=B, chunk=a.chunk, device=local_rank, use_graph=not a.no_graph,
+                                       lanes=a.lanes)
     model.load_state_dict(sd)
     eng = model.engine
-    cfg = {"name": a.sampling, "temperature": 1.0, "top_p": 0.9, "top_k": 5, "num_timesteps": a.timesteps}
+    cfg = {"name": sampling, "temperature": 1.0, "top_p": 0.9, "top_k": 5, "num_timesteps": a.timesteps}
     t_model, t_post = timestep_schedule(spec.n_step, a.timesteps)
     dev = eng.device
-    if cond_local is None:
+    relation = None
+    if cond_np is None:
         init = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=dev)
         lc_keep = None
     else:
-        init = torch.from_numpy(cond_local["seq"]).to(device=dev, dtype=torch.int32).contiguous()
-        lc_keep = eng.make_cond({"seq": init, "mask": torch.from_numpy(cond_local["mask"]).to(dev), "type": "c"}, B)
+        init = torch.from_numpy(cond_np["seq"]).to(device=dev, dtype=torch.int32).contiguous()
+        cd = {"seq": init, "mask": torch.from_numpy(cond_np["mask"]).to(dev), "type": cond_np["type"]}
+        if cond_np["type"] == "refinement":
+            cd["weak_logits"] = torch.from_numpy(cond_np["weak_logits"]).to(dev)
+        lc_keep = eng.make_cond(cd, B)
+        if relation_graph is not None:
+            from layout_dm_amd.synthetic import linear_bin_centres
+
+            # hyper-parameters: the reference's defaults (hydra_configs.py:44-47); canvas = bins of the box (.5, .5, 1, 1)
+            relation = eng.make_relation(relation_graph, linear_bin_centres(spec.n_bin),
+                                         [spec.n_bin // 2, spec.n_bin // 2, spec.n_bin - 1, spec.n_bin - 1], 3e6, 3, B)
     tokens = torch.empty_like(init)
     seed_box = [0]
+    my_lo = shard_range(total, rank, world)[0] if total else rank * B
 
     def sample_fn(first_layout, count):  # this rank's shard: `count` layouts starting at global index `first_layout`
-        assert count == B
+        assert count == B and (world == 1 or first_layout == my_lo)
         tokens.copy_(init)  # inputs resident in HBM
-        eng.sample_loop(tokens, t_model, t_post, cfg, seed=seed_box[0], first_layout=first_layout,
-                        use_graph=not a.no_graph, lc_keep=lc_keep)
+        if verified:
+            model.verified.sample_loop(tokens, t_model, t_post, cond=None)
+        else:
+            eng.sample_loop(tokens, t_model, t_post, cfg, seed=seed_box[0], first_layout=first_layout,
+                            use_graph=not a.no_graph, lc_keep=lc_keep, relation=relation)
         return tokens
+
+    n_global = total if total else world * B
 
     def one_step(i):
         seed_box[0] = 1000 + i
-        return sample_sharded(sample_fn, world * B)  # world == 1: no collective; else ONE all_gather of the tokens
+        return sample_sharded(sample_fn, n_global)  # world == 1: no collective; else ONE all_gather of the tokens
 
     def sync():
         if dist is not None:
@@ -234,25 +272,30 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, 
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fin = final.cpu()
-    assert fin.shape[0] == world * B
+    assert fin.shape[0] == n_global
     assert (fin != eng.mask_id).all(), "sampling left [MASK] tokens"
-    if cond_local is not None:  # conditioned categories survive (strong mask)
-        m = torch.from_numpy(cond_local["mask"])
-        mine = fin[rank * B:(rank + 1) * B]
-        assert (mine[m] == torch.from_numpy(cond_local["seq"])[m].int()).all(), "strong-masked tokens changed"
+    if cond_np is not None:  # conditioned tokens survive (strong mask)
+        m = torch.from_numpy(cond_np["mask"])
+        mine = fin[my_lo:my_lo + B]
+        assert (mine[m] == torch.from_numpy(cond_np["seq"])[m].int()).all(), "strong-masked tokens changed"
 
-    value = world * B * steps / dt
-    flop_layout = FLOP_PER_TOKEN_STEP[a.dataset] * spec.seq_len * a.timesteps
+    value = n_global * steps / dt
+    flop_layout = FLOP_PER_TOKEN_STEP[spec.name] * spec.seq_len * a.timesteps
     res = {"value": round(value, 2), "unit": "layouts/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": round(1e3 * dt / steps, 3), "dtype": DTYPE[precision],
+           "ms_per_step": round(1e3 * dt / steps, 3), "dtype": DTYPE["fast_verified" if verified else precision],
+           "sampling": sampling,
            "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
            "frac_of_mfma_peak_whole_job": round(value * flop_layout / 1e12 / (world * PEAK_TFLOPS[precision]), 4)}
-    if with_roofline and rank == 0:
+    if verified:
+        res["verification"] = dict(model.verified.last_stats, tie_rel=model.verified.tie_rel)
+    if with_roofline and rank == 0 and not verified:
         # per-kernel durations: HIP events around every launch, on the stream the kernels run on, over one more step of
-        # the same workload (eager launches — events cannot bracket graph nodes)
+        # the same workload (eager launches — events cannot bracket graph nodes; the one-launch loop of the fast mode is
+        # the same launch either way)
         eng.set_profiling(True)
         tokens.copy_(init)
-        eng.sample_loop(tokens, t_model, t_post, cfg, seed=999, first_layout=0, use_graph=False, lc_keep=lc_keep)
+        eng.sample_loop(tokens, t_model, t_post, cfg, seed=999, first_layout=0, use_graph=False, lc_keep=lc_keep,
+                        relation=relation)
         torch.cuda.synchronize()
         rows = eng.profile(reset=True)
         eng.set_profiling(False)
@@ -272,7 +315,13 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, 
         roof.update({"avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                      "share_of_step": round(dom["ms"] / tot, 3),
                      "algorithmic_per_launch": dom["flops"] / dom["launches"] if dom["flops"] > 0
-                     else dom["bytes"] / dom["launches"]})
+                     else dom["bytes"] / dom["launches"],
+                     "launch_configuration": "eager pass, one chunk pipeline" if dom["launches"] > 1 else
+                     "the timed launch itself (one launch per sampling call)"})
+        if dom["name"] == "layers_fused_loop":
+            # one launch = every layout's whole loop; per (layout, reverse step) of a workgroup:
+            n_wg_rounds = -(-B // 256)
+            roof["ms_per_workgroup_step"] = round(avg_ms / (a.timesteps * n_wg_rounds), 4)
         res["roofline"] = roof
         res["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
         gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(GEMM_CLASSES))
@@ -280,6 +329,31 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_local, rank, world, 
         if gemm_ms > 0:
             res["gemm_mfma_utilisation"] = round(gemm_fl / (gemm_ms * 1e-3) / 1e12 / PEAK_TFLOPS[precision], 4)
     return res, eng, tokens
+
+
+def tokens_sha256(a, sd, spec, rank, world, local_rank, dist):
+    """sha256 of the first SHA_LAYOUTS layouts of a fixed-seed Rico25-shaped unconditional `random` run, sharded over the
+    ranks like the timed workload: the same digest for every N (and every batch cut) or the sharding is wrong."""
+    import hashlib
+
+    import torch
+
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion
+    from layout_dm_amd.distributed import sample_sharded, shard_range
+
+    total = max(SHA_LAYOUTS, world)
+    lo, hi = shard_range(total, rank, world)
+    m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
+                                   d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
+                                   num_timesteps=spec.n_step, precision=a.precision, max_batch=max(hi - lo, 1),
+                                   device=local_rank)
+    m.load_state_dict(sd)
+    cfg = {"name": "random", "temperature": 1.0, "num_timesteps": a.timesteps}
+    fn = lambda first, count: m.sample(batch_size=count, sampling_cfg=cfg, seed=SHA_SEED, first_layout=first,
+                                       return_device_tensor=True)
+    out = sample_sharded(fn, total)[:SHA_LAYOUTS].cpu().contiguous()
+    m.engine.close()
+    return hashlib.sha256(out.numpy().tobytes()).hexdigest()
 
 
 def main():
@@ -296,6 +370,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    # one process per GPU: keep this rank's host threads on a contiguous slice of the cores (launch latency, and the
+    # cpu_baseline leg must not spread over every rank's cores)
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // world)
+            os.sched_setaffinity(0, set(cores[local_rank * per:(local_rank + 1) * per]))
+        except OSError:
+            pass
     dist = None
     # LDM_BENCH_FORCE_DIST=1 (dev): take the RCCL code path (init, all_gather, barrier, all_reduce) with ONE rank, so
     # the multi-GPU plumbing can be smoke-tested on a single-GPU box under torch.distributed.run --nproc-per-node 1
@@ -313,18 +396,25 @@ def main():
     a.dataset = a.dataset or base["dataset"]
     a.cond = a.cond or base["cond"]
     a.sampling = a.sampling or base["sampling"]
-    B = a.batch or base["batch"]
     spec = SP.SPECS[a.dataset]
     sd = SP.synth_state_dict(spec, seed=0, perturb=False)  # the reference's init distributions
+    if a.total:  # strong scaling: `total` layouts per step, sharded by global layout index (ragged shards allowed)
+        lo, hi = shard_range(a.total, rank, world)
+        B, n_global = hi - lo, a.total
+        if B < 1:
+            raise SystemExit("--total smaller than the number of GPUs")
+    else:
+        B = a.batch or base["batch"]
+        lo, hi, n_global = rank * B, (rank + 1) * B, world * B
     cond_global = cond_local = None
     if a.cond == "c":
-        cond_global = SP.synth_cond_c(spec, world * B, seed=0)
-        lo, hi = shard_range(world * B, rank, world)
-        cond_local = {k: cond_global[k][lo:hi] for k in ("seq", "mask")}
+        cond_global = SP.synth_cond_c(spec, n_global, seed=0)
+        cond_local = {"seq": cond_global["seq"][lo:hi], "mask": cond_global["mask"][lo:hi], "type": "c"}
 
     res, eng, tokens = run_mode(a, spec, sd, a.precision, B, a.steps, a.warmup, cond_local, rank, world, local_rank,
-                                dist, with_roofline=not a.no_roofline)
-    workload = (f"BASELINE config {config}: {a.dataset} cond={a.cond} T={a.timesteps} batch={B}/GPU "
+                                dist, with_roofline=not a.no_roofline, total=a.total)
+    per_gpu = f"{B}/GPU" if not a.total else f"{a.total} total ({B} on rank 0)"
+    workload = (f"BASELINE config {config}: {a.dataset} cond={a.cond} T={a.timesteps} batch={per_gpu} "
                 f"sampling={a.sampling}" + (" top_p=0.9" if a.sampling == "top_p" else ""))
     dsname = {"rico25": "Rico25", "publaynet": "PubLayNet"}[a.dataset]
     cname = {"unconditional": "uncond", "c": "cond=c"}[a.cond]
@@ -337,14 +427,18 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": res["ms_per_step"],
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if a.total else "weak",
         "vs_baseline": None,
         "dtype": DTYPE[a.precision],
         "data": "synthetic (random-init weights with the reference's init distributions; "
                 + ("all-[MASK] start)" if a.cond == "unconditional" else
                    "cond=c sequences built as helpers/task.py:94-110, n~U{1..25} elements per layout)"),
-        "config": {"workload": workload, "precision_mode": a.precision, "hipgraph": not a.no_graph,
+        "config": {"workload": workload, "precision_mode": a.precision,
+                   "launch": "one launch per sampling call (reverse loop resident in the layout's workgroup)"
+                   if (a.precision == "fast" and os.environ.get("LDM_STACK_LOOP", "1") != "0") else
+                   ("per-step launches in hipGraphs" if not a.no_graph else "per-step launches, eager"),
                    "chunk_layouts": eng.chunk, "lanes": eng.lanes,
+                   "env_overrides": {k: v for k, v in os.environ.items() if k.startswith("LDM_") and k != "LDM_BENCH_PRECISION"},
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
         "algorithmic_tflops": res["algorithmic_tflops"],
     }
@@ -365,39 +459,56 @@ def main():
         dec_ms = 1e3 * (time.perf_counter() - t1) / reps
         assert host["bbox"].shape == (B, spec.max_elem, 4)
         out["decode"] = {"ms_per_batch_incl_d2h": round(dec_ms, 3), "valid_elements": int(host["mask"].sum()),
-                         "layouts_per_s_incl_decode": round(world * B / ((res["ms_per_step"] + dec_ms) * 1e-3), 2)}
+                         "layouts_per_s_incl_decode": round(n_global / ((res["ms_per_step"] + dec_ms) * 1e-3), 2)}
     eng.close()
 
     # every numerics mode in the one line (N=1): the bit-exact mode's throughput next to the headline's
-    modes = a.modes if a.modes is not None else ("exact,split,fast" if world == 1 else "")
+    modes = a.modes if a.modes is not None else ("exact,fast,fast_verified" if world == 1 else "")
     modes = [m for m in modes.split(",") if m and m != "none"]
     if modes:
         out["modes"] = {}
         for m in modes:
             if m == a.precision:
                 r = dict(res)
+            elif m == "fast_verified":
+                # BASELINE config 2 verbatim: GREEDY decoding; fast + exact re-decision == the exact engine's tokens
+                if a.cond != "unconditional":
+                    continue
+                r, e2, tk = run_mode(a, spec, sd, "fast", B, min(a.steps, 3), 1, None, rank, world, local_rank, dist,
+                                     with_roofline=False, sampling="deterministic", verified=True)
+                e2.close()
+                g, e3, _ = run_mode(a, spec, sd, "fast", B, min(a.steps, 3), 1, None, rank, world, local_rank, dist,
+                                    with_roofline=False, sampling="deterministic")
+                e3.close()
+                x, e4, tx = run_mode(a, spec, sd, "exact", B, 1, 0, None, rank, world, local_rank, dist,
+                                     with_roofline=False, sampling="deterministic")
+                r["tokens_equal_exact_mode"] = bool(torch.equal(tk, tx))
+                e4.close()
+                r["plain_fast_greedy_layouts_per_s"] = g["value"]
             else:
-                k = a.steps if m == "fast" else min(a.steps, 2)  # exact / split steps take seconds each
+                k = a.steps if m == "fast" else min(a.steps, 5)  # exact steps take ~1.5 s each
                 r, e2, _ = run_mode(a, spec, sd, m, B, k, 1, cond_local, rank, world, local_rank, dist,
                                     with_roofline=not a.no_roofline)
                 e2.close()
             r.pop("kernel_breakdown_ms", None)
             out["modes"][m] = r
 
+    if world == 1 and not a.no_extras and not a.total and not a.batch:
+        out["configs"] = extras(a, SP, config, rank, world, local_rank, dist)
+        out["fid_features"] = fid_timing(SP, local_rank)
+    if not a.no_extras:
+        out["tokens_sha256"] = {"sha256": tokens_sha256(a, SP.synth_state_dict(SP.SPECS["rico25"], seed=0), SP.SPECS["rico25"],
+                                                        rank, world, local_rank, dist),
+                                "of": f"first {SHA_LAYOUTS} layouts, Rico25 uncond random T={a.timesteps}, seed {SHA_SEED}, "
+                                      f"precision {a.precision}; must not depend on n_gpus"}
+
     if rank == 0 and world == 1 and not a.no_roofline and not a.no_traffic and "roofline" in out:
         sym = KERNEL_SYMBOL.get(out["roofline"]["kernel"])
         if sym:
             vals, note = measure_traffic(sym, a.dataset, a.precision)
             if vals:
-                rows_probe = 256 * spec.seq_len  # tools/pmc_probe.py: default chunk = 256 layouts per launch
-                rows_launch = eng.chunk * spec.seq_len
-                scale = rows_launch / rows_probe
-                out["roofline"]["traffic"] = int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 * scale)
-                out["roofline"]["traffic_detail"] = {
-                    "fetch_bytes_raw": int(vals["FETCH_SIZE"] * 1024 * scale),
-                    "write_bytes_raw": int(vals["WRITE_SIZE"] * 1024 * scale),
-                    "source": note + "; raw counter values (the guide's x2 FETCH_SIZE correction applies to 16 B/lane "
-                                     "coalesced streams; see profiles/ for the calibration on this kernel's pattern)"}
+                out["roofline"]["traffic"] = int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+                out["roofline"]["traffic_detail"] = traffic_detail(vals, note, out["roofline"]["kernel"], spec)
             else:
                 out["roofline"]["traffic_detail"] = {"source": f"live PMC collection unavailable: {note}"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -407,6 +518,97 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def extras(a, SP, headline_config, rank, world, local_rank, dist):
+    """The other BASELINE configurations and SURVEY section 8f's rows, a few steps each (N = 1)."""
+    import copy
+
+    out = {}
+    for key in ("3", "4", "refinement", "relation"):
+        if key == str(headline_config):
+            continue
+        b = copy.copy(a)
+        graph = None
+        if key in ("3", "4"):
+            base = CONFIGS[int(key)]
+            b.dataset, b.cond, b.sampling, B = base["dataset"], base["cond"], base["sampling"], base["batch"]
+            spec = SP.SPECS[b.dataset]
+            cond = dict(SP.synth_cond_c(spec, B, seed=0), type="c") if b.cond == "c" else None
+            what = f"BASELINE config {key}: {b.dataset} cond={b.cond} T={a.timesteps} batch={B} sampling={b.sampling}"
+        else:
+            b.dataset, b.sampling, B = "rico25", "random", 512
+            spec = SP.SPECS["rico25"]
+            if key == "refinement":
+                cond = SP.synth_cond_refinement(spec, B, seed=0)
+                what = (f"rico25 cond=refinement (prior table as helpers/task.py:154-224, lambda 3, offset 0.1) T={a.timesteps} "
+                        f"batch={B} sampling=random")
+            else:
+                cond, graph = SP.synth_cond_relation(spec, B, seed=0)
+                what = (f"rico25 cond=relation (graphs as data/util.py:111-177, edge_ratio 0.1; relation_lambda 3e6, "
+                        f"3 updates, t >= 10) T={a.timesteps} batch={B} sampling=random")
+        sd = SP.synth_state_dict(spec, seed=0, perturb=False)
+        r, e, _ = run_mode(b, spec, sd, a.precision, B, 3, 1, cond, rank, world, local_rank, dist,
+                           with_roofline=not a.no_roofline, relation_graph=graph)
+        e.close()
+        entry = {"workload": what, "value": r["value"], "unit": "layouts/s", "ms_per_step": r["ms_per_step"], "steps": 3}
+        if "roofline" in r:
+            entry["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "frac", "avg_launch_ms", "share_of_step")}
+            entry["kernel_breakdown_ms"] = r["kernel_breakdown_ms"]
+        out[key] = entry
+    return out
+
+
+def fid_timing(SP, local_rank):
+    """FIDNetV3.extract_features (trainer/fid/model.py:123-164) on 512 x 25 random elements, random weights."""
+    import numpy as np
+    import torch
+
+    from layout_dm_amd.fid import FIDNetV3
+
+    B, N, L = 512, 25, 25
+    m = FIDNetV3(num_label=L, max_bbox=N, device=local_rank)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in SP.synth_fid_state_dict(L, seed=0, max_bbox=N).items()})
+    rng = np.random.default_rng(0)
+    n = rng.integers(1, N + 1, size=B)
+    dev = torch.device("cuda", local_rank)
+    bbox = torch.from_numpy(rng.random((B, N, 4)).astype(np.float32)).to(dev)
+    label = torch.from_numpy(rng.integers(0, L, size=(B, N))).to(dev)
+    pm = torch.from_numpy(~(np.arange(N)[None] < n[:, None])).to(dev)
+    for _ in range(3):
+        f = m.extract_features(bbox, label, pm)
+    torch.cuda.synchronize()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f = m.extract_features(bbox, label, pm)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    assert f.shape == (B, 256) and bool(torch.isfinite(f).all())
+    return {"value": round(B / (ms * 1e-3), 1), "unit": "layouts/s", "ms_per_batch": round(ms, 4), "batch": B,
+            "what": "fid_features_k: FIDNetV3 encoder (26 x 256, 4 layers) per layout, fp32, inputs resident in HBM"}
+
+
+def traffic_detail(vals, note, kernel, spec):
+    """Raw and calibrated HBM bytes per launch of the dominant kernel.  Calibration (profiles/r03_fetch_size_calibration.txt,
+    tools/microbench/rowio under --pmc): FETCH_SIZE reports half the bytes of 16 B/lane coalesced streams on gfx950
+    (global_load_dwordx4 and global_load_lds_dwordx4 alike), WRITE_SIZE is exact."""
+    fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    d = {"fetch_bytes_raw": int(fetch), "write_bytes_raw": int(write),
+         "fetch_bytes_calibrated": int(fetch * FETCH_CALIBRATION), "write_bytes_calibrated": int(write),
+         "calibration": f"FETCH_SIZE x {FETCH_CALIBRATION} (profiles/r03_fetch_size_calibration.txt), WRITE_SIZE x 1",
+         "source": note}
+    if kernel == "layers_fused_loop":
+        # tools/pmc_probe.py: 512 layouts x 100 reverse steps in ONE launch = the timed launch of config 2.  Algorithmic
+        # HBM traffic of that launch: the weight images once (every workgroup-step re-reads them, from L2 / Infinity
+        # Cache when resident), the embedding / AdaLN tables, and the tokens in and out.
+        steps, layouts = 100, 512
+        alg = WEIGHT_IMAGE_BYTES + layouts * spec.seq_len * 8
+        d["algorithmic_bytes_per_launch"] = int(alg)
+        d["probe_launch"] = f"{layouts} layouts x {steps} reverse steps"
+        d["ratio_calibrated_to_algorithmic"] = round((fetch * FETCH_CALIBRATION + write) / alg, 2)
+        d["weight_stream_bytes_requested_from_l2"] = int(WEIGHT_IMAGE_BYTES * layouts * steps)
+    return d
 
 
 if __name__ == "__main__":

@@ -73,6 +73,14 @@ __device__ __forceinline__ int stack_lane_id() {
   return l;
 }
 
+// the other half of a row's lane pair (lanes r and r + 32) through v_permlane32_swap: __shfl_xor takes the lane id as a
+// bpermute index, which hipcc hoists out of the step loop of HEAD == 2 into one more long-lived VGPR
+__device__ __forceinline__ float stack_xor32_swap(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return (stack_lane_id() & 32) ? __uint_as_float(sw[0]) : __uint_as_float(sw[1]);
+}
+#define LDM_XOR32(v) (HEAD == 2 ? stack_xor32_swap(v) : __shfl_xor(v, 32, 64))
+
 // HEAD: 0 = rows + statistics out; 1 = fused vocabulary head, logits out; 2 = head + posterior + draw, tokens out
 template <bool TM, int HEAD>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
@@ -112,8 +120,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   // re-derived per step from values hipcc cannot see through — hoisted out of the step loop, those ~100 uniform
   // addresses and parameters would stay live across a body that already fills the register file (170 SGPR spills and
   // 100 bytes of scratch per lane without this)
-  int tid = tid_o, wave = wave_o, b = b_o;
-  if constexpr (HEAD == 2) asm volatile("" : "+v"(tid), "+s"(wave), "+s"(b));
+  int wave = wave_o, b = b_o;
+  if constexpr (HEAD == 2) asm volatile("" : "+s"(wave), "+s"(b));
+  // the thread index: HEAD == 2 re-derives it from the hardware lane id at every use (no VGPR carried across the
+  // streams, which fill the register file)
+  [[maybe_unused]] const int tid = tid_o;
+  auto tid_now = [&]() {
+    if constexpr (HEAD == 2) return wave * 64 + stack_lane_id();
+    else return tid;
+  };
   auto&& A = [&]() -> decltype(auto) {
     if constexpr (HEAD == 2) return (*stack_kargs());
     else return (a);
@@ -130,11 +145,11 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   const int S = A.S, H = A.H, L = A.ls.n_layer;
   unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
   if constexpr (HEAD == 2) asm volatile("" : "+s"(lds0));
-  const unsigned voff = (tid & 63) * 16;
+  const unsigned voff = HEAD == 2 ? (unsigned)stack_lane_id() * 16 : (tid & 63) * 16;
   // parameter tables of one layer, global -> LDS: every load is issued before the first ds_write (a loop of dependent
   // load / store pairs pays one L2 round trip per iteration: 15 of them made the layer boundary 17k cycles longer,
   // profiles/r02_call23_*).  Every table is zero beyond N so that padded columns come out as exact zeros without masks.
-  auto stage_tables = [&](const auto& w, const float* ada_scale, const float* ada_shift) {
+  auto stage_tables = [&](const auto& w, const float* ada_scale, const float* ada_shift, int tid) {
     float vb[6], v1[8], vs[2], vh[2], vo[2], vg[2], ve[2], v2[2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) vb[k] = w.bias_in[tid + 256 * k];  // 3 * 8 heads * 64 = 1536 entries (launcher: H == 8)
@@ -259,10 +274,13 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       asm volatile("" ::: "memory");
       dma_first_tiles((const char*)w.img);
       if constexpr (HEAD == 2) {
+        // (the thread index through an opaque copy: hoisted out of the layer loop, the 30 table addresses and bounds
+        //  masks of stage_tables do not fit beside the loop-carried state and go to scratch)
+        const int tid_l = tid_now();
         const float* ss = stack_kargs()->adaln + ((size_t)t_model * L + l) * 2 * A.N;
-        stage_tables(w, ss, ss + A.N);
+        stage_tables(w, ss, ss + A.N, tid_l);
       } else {
-        stage_tables(w, w.ada_scale, w.ada_shift);
+        stage_tables(w, w.ada_scale, w.ada_shift, tid);
       }
       __syncthreads();
       unsigned long long tE1 = 0, tE2 = 0;
@@ -281,8 +299,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s1 += LDM_XOR32(s1);
+      s2 += LDM_XOR32(s2);
       if constexpr (TM) tE2 = __builtin_amdgcn_s_memtime();
       constexpr float kInvN3 = 1.0f / 464.0f;
       const float mean = s1 * kInvN3;
@@ -439,8 +457,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s1 += LDM_XOR32(s1);
+      s2 += LDM_XOR32(s2);
       constexpr float kInvN = 1.0f / 464.0f;  // N = 464 (launcher)
       const float mean = s1 * kInvN;
       const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN - mean * mean, 0.f) + 1e-5f);
@@ -535,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       dma_lin4(voff, g + 4096, l + 4096);
     };
     for (int ht = 0; ht < 3 && ht < A.n_head_tiles; ++ht) dma_head_tile(ht);
-    for (int i = tid; i < LN_DP; i += 256) {
+    for (int i = tid_now(); i < LN_DP; i += 256) {
       sp[i] = i < A.N ? A.head_g[i] : 0.f;
       sp[LN_DP + i] = i < A.N ? A.head_b[i] : 0.f;
     }
@@ -557,8 +575,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s1 += LDM_XOR32(s1);
+      s2 += LDM_XOR32(s2);
       constexpr float kInvN3 = 1.0f / 464.0f;
       const float mean = s1 * kInvN3;
       const float rstd = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean * mean, 0.f) + 1e-5f);
@@ -638,8 +656,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
               am = fmaxf(am, fabsf(tile[i]));
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        mx = fmaxf(mx, LDM_XOR32(mx));
+        am = fmaxf(am, LDM_XOR32(am));
         float se = 0.f;
         float* mine = lgs + row3 * kPostLd + hi3 * 4;
 #pragma unroll
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             mine[ht * 32 + (i >> 2) * 8 + (i & 3)] = tile[i];
           }
         }
-        se += __shfl_xor(se, 32, 64);
+        se += LDM_XOR32(se);
         if (hi3 == 0) rstat[row3] = make_float4(mx, __logf(se), am, 0.f);
         // the step's schedule scalars of every attribute (constrained.py:81-90,114)
         const int T1 = p.T + 1, u = (t_post - 1 + T1) % T1;
@@ -660,6 +678,11 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
           const int kind = k == 0 ? kLogAt : k == 1 ? kLogBt : k == 2 ? kLogCt : k == 3 ? kLogCumAt : k == 4 ? kLogCumBt
                          : k == 5 ? kLogCumCt : k == 6 ? kLogCumAt : k == 7 ? kLogCumBt : k == 8 ? kLogCumCt : kLog1mCumCt;
           ssch[lane3] = p.sched[((size_t)kind * p.v.n_attr + at) * T1 + (k < 6 ? t_post : u)];
+        }
+        // ... and the body of every attribute's sub-vocabulary (indexed per lane below: from LDS, not from a private copy)
+        if (lane3 < p.v.n_attr) {
+          reinterpret_cast<int*>(ssch)[100 + 2 * lane3] = p.v.start[lane3];
+          reinterpret_cast<int*>(ssch)[101 + 2 * lane3] = p.v.count[lane3];
         }
       }
       // rows 32 wave .. 32 wave + 31 were written by THIS wavefront and are read by it alone: LDS operations of a
@@ -700,8 +723,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             const int cc = condc[s];
             ldm_post::TokenArgs ta{};
             ta.tok = toks[s];
-            ta.start = p.v.start[attr];
-            ta.count = p.v.count[attr];
+            ta.start = reinterpret_cast<const int*>(ssch)[100 + 2 * attr];
+            ta.count = reinterpret_cast<const int*>(ssch)[101 + 2 * attr];
             ta.pad_id = p.v.pad_id;
             ta.mask_id = p.v.mask_id;
             ta.n_class = p.v.n_class;
@@ -727,7 +750,9 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
               l0[j] = (m.valid(ta, j) && c < Cm1) ? ldm_post::l0_f32(lrow_s[c], rs.x, rs.y) : -70.0f;
             }
             const float* qk = ssch + 50 + (attr * 2 + (ta.tok == ta.mask_id ? 1 : 0)) * 5;
-            const ldm_post::QTerms k{qk[0], qk[1], qk[2], qk[3], qk[4]};
+            float k0 = qk[0], k1 = qk[1], k2 = qk[2], k3 = qk[3], k4 = qk[4];
+            asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "+v"(k4));  // (registers, not a private array hipcc indexes)
+            const ldm_post::QTerms k{k0, k1, k2, k3, k4};
             ldm_post::token_log_probs(g, m, ta, sc, k, l0, lp);
             // (scratch of top-k / top-p: the token's own row — its logits are in registers by now)
             const ldm_post::Draw d = ldm_post::draw_token(g, m, ta, lp, lrow_s, lrow_s + 48, false);
@@ -779,8 +804,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
       if (valid3) *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s1 += LDM_XOR32(s1);
+    s2 += LDM_XOR32(s2);
     constexpr float kInvN3 = 1.0f / 464.0f;
     const float mean3 = s1 * kInvN3;
     const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);

@@ -239,13 +239,21 @@ struct FfnStream {
         if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");  // MFMA result -> VALU read (next step)
       } else if constexpr (IT == KS) {
         // bias (already inside chain A) + ReLU + cast: accumulator reg <-> hidden f = (q&3) + 8*(q>>2) + 4*hi
+        // Packed: 8 v_pk_add_f32 + 8 v_cvt_pk_f16_f32 + 4 v_pk_max_f16 instead of 16 add + 16 max + 8 cvt — the matrix
+        // pipe idles through this step (it consumes GEMM1's result and produces GEMM2's operand), so every VALU issue
+        // here is exposed (tools/microbench/dma_feed.hip: 2 270 cycles per chunk with no DMA at all against 59 x 32 = 1 888).
+        // ReLU after the rounding: rounding is monotonic and keeps the sign, max(-0, 0) feeds a zero either way.
         (void)cur;
+        typedef __attribute__((ext_vector_type(2))) float f32x2v;
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          pf[rq >> 1][(rq & 1) * 4 + 0] = (_Float16)fmaxf(ha[rq * 4 + 0] + hb[rq * 4 + 0], 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 1] = (_Float16)fmaxf(ha[rq * 4 + 1] + hb[rq * 4 + 1], 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 2] = (_Float16)fmaxf(ha[rq * 4 + 2] + hb[rq * 4 + 2], 0.f);
-          pf[rq >> 1][(rq & 1) * 4 + 3] = (_Float16)fmaxf(ha[rq * 4 + 3] + hb[rq * 4 + 3], 0.f);
+        for (int i = 0; i < 8; ++i) {
+          const f32x2v sa = {ha[2 * i], ha[2 * i + 1]}, sb = {hb[2 * i], hb[2 * i + 1]};
+          const f16x2v hv = __builtin_convertvector(sa + sb, f16x2v);
+          const f16x2v zero = {(_Float16)0.f, (_Float16)0.f};
+          const f16x2v r = __builtin_elementwise_max(hv, zero);
+          pf[i >> 2][(i & 3) * 2 + 0] = r[0];
+          pf[i >> 2][(i & 3) * 2 + 1] = r[1];
         }
       } else {
         constexpr int sx = (IT - KS - 1) / NT2, t = (IT - KS - 1) % NT2;

@@ -155,9 +155,12 @@ LDM_PT_HD float l0_f64(float x, float mx, double lse0) {
 // k = q_terms(g, a.tok == a.mask_id, s): the same for every token of an attribute that is / is not [MASK], so a caller
 // with many tokens per step computes the ten variants once
 template <class G, class M>
-LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s, const QTerms& k,
+LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const StepSchedule& s, const QTerms& kq,
                                const float (&l0)[M::NJ], float (&lp)[M::NJ]) {
   constexpr int NJ = M::NJ;
+  // (scalars: selecting between the MEMBERS of a struct per class makes hipcc keep the struct in private memory and
+  //  index it)
+  const float qt_same = kq.qt_same, qt_other = kq.qt_other, q1_same = kq.q1_same, q1_other = kq.q1_other, q1_mask = kq.q1_mask;
   float q[NJ];
   float qmx = -INFINITY;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -168,7 +171,7 @@ LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const
     if (m.live(a, j)) {
       const int c = m.cls(a, j);
       q[j] = (c == a.mask_id) ? kLogEps                                            // constrained.py:189
-                              : l0[j] - (c == a.tok ? k.qt_same : k.qt_other);     // l.188
+                              : l0[j] - (c == a.tok ? qt_same : qt_other);         // l.188
       qmx = fmaxf(qmx, q[j]);
     }
   }
@@ -190,7 +193,7 @@ LDM_PT_HD void token_log_probs(const G& g, const M& m, const TokenArgs& a, const
     if (m.live(a, j)) {
       const float qn = q[j] - lse;
       const float r = (c == a.mask_id) ? log_add_exp(g, qn + s.L1Cu, s.LCu) : log_add_exp(g, qn + s.LAu, s.LBu);
-      const float q1 = (c == a.mask_id) ? k.q1_mask : (c == a.tok ? k.q1_same : k.q1_other);
+      const float q1 = (c == a.mask_id) ? q1_mask : (c == a.tok ? q1_same : q1_other);
       v = fminf(fmaxf((r + q1) + lse, -70.0f), 0.0f);  // l.192-197
     } else {
       v = kLogEps;  // p_to_f_log fill (layout_tokenizer.py:544)

@@ -202,3 +202,90 @@ def synth_cond_c(spec: ModelSpec, batch: int, seed: int = 0):
             seq[b, e * A + 1:(e + 1) * A] = spec.mask_id
             mask[b, e * A + 1:(e + 1) * A] = False
     return {"seq": seq, "mask": mask, "type": "c", "num_element": n_elem}
+
+
+def linear_bin_centres(n_bin: int) -> np.ndarray:
+    """(4, n_bin) box-coordinate centres of the linear quantisation in x, y, w, h order (helpers/bbox_tokenizer.py:
+    x / y bins start at 0, w / h bins at 1 / n_bin — the `DummyClusteringModel` the reference builds for
+    bbox_quantization=linear)."""
+    lo = np.linspace(0.0, 1.0 - 1.0 / n_bin, n_bin)
+    hi = np.linspace(1.0 / n_bin, 1.0, n_bin)
+    return np.stack([lo, lo, hi, hi])
+
+
+def synth_cond_refinement(spec: ModelSpec, batch: int, seed: int = 0, refine_lambda: float = 3.0,
+                          offset_ratio: float = 0.1):
+    """Synthetic cond=refinement inputs shaped like helpers/task.py:127-138 + set_additional_conditions_for_refinement
+    (task.py:204-224, `uniform` mode): a random full layout as the noisy `seq_orig`; `seq` keeps its categories, [MASK]
+    on the other attributes of valid elements, [PAD] on padded elements; `mask` = category slots + padded slots;
+    `weak_logits` (B, C, S) = refine_lambda * Table[seq_orig] with Table = identity outside the coordinate
+    vocabularies and 1[|centre_i - centre_j| < offset_ratio] inside each of them."""
+    rng = np.random.default_rng(seed + 177)
+    S, A, C, N = spec.seq_len, spec.n_attr, spec.n_class, spec.n_bin
+    c = synth_cond_c(spec, batch, seed=seed + 1)
+    seq_orig = c["seq"].copy()
+    for a in range(1, A):  # a random bin of the attribute's own sub-vocabulary on every valid element
+        start = spec.n_category + (a - 1) * N
+        col = seq_orig[:, a::A]
+        valid = col == spec.mask_id
+        col[valid] = start + rng.integers(0, N, size=int(valid.sum()))
+    table = np.eye(C, dtype=np.float32)
+    cen = linear_bin_centres(N)
+    for i in range(4):
+        sl = slice(spec.n_category + i * N, spec.n_category + (i + 1) * N)
+        table[sl, sl] = (np.abs(cen[i][:, None] - cen[i][None, :]) < offset_ratio).astype(np.float32)
+    weak = (table[seq_orig].transpose(0, 2, 1) * refine_lambda).astype(np.float32)  # (B, C, S)
+    return {"seq": c["seq"], "mask": c["mask"], "type": "refinement", "seq_orig": seq_orig,
+            "weak_logits": np.ascontiguousarray(weak)}
+
+
+def synth_cond_relation(spec: ModelSpec, batch: int, seed: int = 0, edge_ratio: float = 0.1):
+    """Synthetic cond=relation inputs: cond=c sequences plus relation graphs in the reference's format (AddCanvasElement
+    + AddRelationConstraints(edge_ratio), trainer/data/util.py:111-177): node 0 of every layout is the canvas, every
+    pair of nodes carries an edge with probability edge_ratio, edge_attr = 1 << size relation | 1 << location relation
+    (sizes 0..3; locations 4..9 between elements, 4..6 + 9 against the canvas are all accepted by the losses).
+    Returns (cond, graph): graph = {y, edge_index (2, E) GLOBAL node ids, edge_attr, batch} as numpy arrays."""
+    rng = np.random.default_rng(seed + 277)
+    c = synth_cond_c(spec, batch, seed=seed + 2)
+    A = spec.n_attr
+    ys, src, dst, attr, bt = [], [], [], [], []
+    off = 0
+    for b in range(batch):
+        n = int(c["num_element"][b])
+        ys.append(np.concatenate([[0], c["seq"][b, 0:n * A:A] + 1]))
+        ii, jj = np.triu_indices(n + 1, k=1)
+        keep = rng.random(ii.size) < edge_ratio
+        ii, jj = ii[keep], jj[keep]
+        src.append(off + ii)
+        dst.append(off + jj)
+        attr.append((1 << rng.integers(0, 4, size=ii.size)) | (1 << rng.integers(4, 10, size=ii.size)))
+        bt.append(np.full(n + 1, b))
+        off += n + 1
+    graph = {"y": np.concatenate(ys).astype(np.int64),
+             "edge_index": np.stack([np.concatenate(src), np.concatenate(dst)]).astype(np.int64),
+             "edge_attr": np.concatenate(attr).astype(np.int64), "batch": np.concatenate(bt).astype(np.int64)}
+    cond = {"seq": c["seq"], "mask": c["mask"], "type": "relation"}
+    return cond, graph
+
+
+def synth_fid_state_dict(num_label: int, seed: int = 0, max_bbox: int = 25):
+    """Random FIDNetV3 encoder weights (trainer/fid/model.py:123-164 key names; 256-d, 4 heads, FFN 128, 4 layers) for
+    timing the feature extractor without a checkpoint."""
+    D, FF, LAYERS = 256, 128, 4
+    rng = np.random.default_rng(seed + 4242)
+    w = lambda *s: (rng.standard_normal(s) * 0.05).astype(np.float32)
+    b = lambda n: (rng.standard_normal(n) * 0.1).astype(np.float32)
+    g = lambda n: (1.0 + rng.standard_normal(n) * 0.1).astype(np.float32)
+    sd = {"emb_label.weight": (rng.standard_normal((num_label, D)) * 0.5).astype(np.float32),
+          "fc_bbox.weight": (rng.standard_normal((D, 4)) * 0.5).astype(np.float32), "fc_bbox.bias": b(D),
+          "enc_fc_in.weight": w(D, 2 * D), "enc_fc_in.bias": b(D),
+          "enc_transformer.token": rng.standard_normal((1, 1, D)).astype(np.float32)}
+    for i in range(LAYERS):
+        p = f"enc_transformer.core.layers.{i}."
+        sd[p + "self_attn.in_proj_weight"], sd[p + "self_attn.in_proj_bias"] = w(3 * D, D), b(3 * D)
+        sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"] = w(D, D), b(D)
+        sd[p + "linear1.weight"], sd[p + "linear1.bias"] = w(FF, D), b(FF)
+        sd[p + "linear2.weight"], sd[p + "linear2.bias"] = w(D, FF), b(D)
+        sd[p + "norm1.weight"], sd[p + "norm1.bias"] = g(D), b(D)
+        sd[p + "norm2.weight"], sd[p + "norm2.bias"] = g(D), b(D)
+    return sd
