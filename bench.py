@@ -599,15 +599,20 @@ def traffic_detail(vals, note, kernel, spec):
          "calibration": f"FETCH_SIZE x {FETCH_CALIBRATION} (profiles/r03_fetch_size_calibration.txt), WRITE_SIZE x 1",
          "source": note}
     if kernel == "layers_fused_loop":
-        # tools/pmc_probe.py: 512 layouts x 100 reverse steps in ONE launch = the timed launch of config 2.  Algorithmic
-        # HBM traffic of that launch: the weight images once (every workgroup-step re-reads them, from L2 / Infinity
-        # Cache when resident), the embedding / AdaLN tables, and the tokens in and out.
+        # tools/pmc_probe.py: 512 layouts x 100 reverse steps in ONE launch = the timed launch of config 2, i.e. 200
+        # workgroup-round-steps of 256 layouts.  FETCH_SIZE counts the L2's fabric-side requests (Infinity-Cache hits
+        # included, MI355X_MICROARCH.md), so it measures what misses the 8 per-XCD L2s, not HBM: the 23.4 MB of weight
+        # images live in the 256-MiB Infinity Cache across steps; each XCD's 32 workgroups stream them through their 4-MiB
+        # L2 once per step when they run in step with each other.
         steps, layouts = 100, 512
-        alg = WEIGHT_IMAGE_BYTES + layouts * spec.seq_len * 8
-        d["algorithmic_bytes_per_launch"] = int(alg)
-        d["probe_launch"] = f"{layouts} layouts x {steps} reverse steps"
-        d["ratio_calibrated_to_algorithmic"] = round((fetch * FETCH_CALIBRATION + write) / alg, 2)
-        d["weight_stream_bytes_requested_from_l2"] = int(WEIGHT_IMAGE_BYTES * layouts * steps)
+        rounds = -(-layouts // 256)
+        per = (fetch * FETCH_CALIBRATION + write) / (steps * rounds)
+        d["probe_launch"] = f"{layouts} layouts x {steps} reverse steps = {steps * rounds} rounds of 256 workgroup-steps"
+        d["bytes_per_256_workgroup_steps_calibrated"] = int(per)
+        d["weights_once_per_xcd_bytes"] = int(8 * WEIGHT_IMAGE_BYTES)
+        d["ratio_to_weights_once_per_xcd"] = round(per / (8 * WEIGHT_IMAGE_BYTES), 2)
+        d["algorithmic_hbm_bytes_per_launch"] = int(WEIGHT_IMAGE_BYTES + layouts * spec.seq_len * 8)
+        d["weight_stream_bytes_requested_from_l2_per_launch"] = int(WEIGHT_IMAGE_BYTES * layouts * steps)
     return d
 
 

@@ -75,6 +75,19 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
     a.seed = p.rng[0];
   }
 
+  if (LIVE && ldm_post::strong_shortcut(a)) {  // conditioned token: every sampler returns it (ldm_post_token.h)
+    if (g.lane() == 0) p.tokens_out[row] = a.cond_tok;
+    if (p.x_next) {
+      const float4* e = reinterpret_cast<const float4*>(p.emb + (size_t)a.cond_tok * p.D);
+      const float4* ps = reinterpret_cast<const float4*>(p.pos + (size_t)s * p.D);
+      float4* o = reinterpret_cast<float4*>(p.x_next + (size_t)row * p.ldx);
+      for (int c = g.lane(); c < (p.D >> 2); c += NL) {
+        const float4 x = e[c], y = ps[c];
+        o[c] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+    }
+    return;
+  }
   float lp[NJ];  // log p(x_{t-1} | x_t) of this lane's slots
   float absmax = 0.f;
   if (p.logp_in) {
@@ -166,7 +179,8 @@ void launch_posterior_sample(const PostArgs& p, hipStream_t st) {
   const int M = p.B * p.S;
   int live_max = 0;
   for (int a = 0; a < p.v.n_attr; ++a) live_max = live_max > p.v.count[a] + 2 ? live_max : p.v.count[a] + 2;
-  static const bool force_wave = getenv("LDM_POST_WAVE") && atoi(getenv("LDM_POST_WAVE")) != 0;  // A/B aid
+  const char* fw = getenv("LDM_POST_WAVE");  // A/B aid and test hook (read per launch: tests toggle it)
+  const bool force_wave = fw && atoi(fw) != 0;
   const bool wave = p.logp_in || p.logp_out || live_max > 48 || force_wave;
   auto kern = wave ? (p.f32_lse ? posterior_sample_k<64, false, true> : posterior_sample_k<64, false, false>)
                    : (p.f32_lse ? posterior_sample_k<16, true, true> : posterior_sample_k<16, true, false>);

@@ -741,6 +741,14 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             ta.step = (uint32_t)(p.step + it);
             ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
             ta.seed = p.rng[0];
+            if (ldm_post::strong_shortcut(ta)) {  // conditioned token: every sampler returns it (ldm_post_token.h)
+              if (g.lane() == 0) {
+                toks[s] = ta.cond_tok;
+                if (kp->inter) kp->inter[((size_t)it * kp->inter_ld + b) * S + s] = ta.cond_tok;
+                if (last) p.tokens_out[(size_t)b * S + s] = ta.cond_tok;
+              }
+              continue;
+            }
             float* lrow_s = lgs + s * kPostLd;
             const float4 rs = rstat[s];
             float l0[3], lp[3];

@@ -231,6 +231,13 @@ struct Draw {
   float gap;   // deterministic: log-probability gap between the winner and the runner-up (+inf for the stochastic kinds)
 };
 
+// A strong-masked position (base.py:245-251) carries log-probability 0 on its conditioned token and log(1e-30) on every
+// other class: argmax returns the conditioned token, and so does every stochastic draw this sampler can make — the other
+// classes hold < 2e-28 of the mass, below the 2^-24 resolution of the uniform (and gumbel noise spans < 20 of the 69 nats
+// between them).  Callers skip the posterior and the draw for such tokens; the tokens are identical either way
+// (tests/test_hip_parity.py::test_strong_mask_shortcut_is_an_identity).
+LDM_PT_HD bool strong_shortcut(const TokenArgs& a) { return a.strong && a.cond_tok >= 0 && a.cond_tok < a.n_class; }
+
 // ---- categorical draw over the group's candidates (helpers/sampling.py:81-130).  lp is consumed.
 // sc_lg / sc_pr: scratch of n_cand floats each, private to the group (top-k / top-p only), indexed by candidate.
 // cand_all: the rank loop of top-k / top-p walks every candidate; else (full-vocabulary map on a posterior it computed
@@ -321,6 +328,9 @@ LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp
       rank[j] = 0;
     }
     const int n_walk = (M::LIVE || cand_all) ? m.n_cand(a) : a.count + 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4  // (four candidates' scratch reads in flight: with one wavefront per SIMD nothing else hides their latency)
+#endif
     for (int oi = 0; oi < n_walk; ++oi) {
       const int o = (M::LIVE || cand_all) ? oi : live_id(a, oi);  // candidate (= scratch) index, increasing with class
       const float ol = sc_lg[o];

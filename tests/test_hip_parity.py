@@ -510,6 +510,29 @@ def test_fused_loop_equals_per_step_path(cuda, monkeypatch, sampler):
     assert torch.equal(outs["1"][1].long()[m], torch.from_numpy(c["seq"])[m]), "strong-masked tokens changed"
 
 
+@pytest.mark.parametrize("sampler", ["deterministic", "random", "top_p", "top_k", "gumbel"])
+def test_strong_mask_shortcut_is_an_identity(cuda, monkeypatch, sampler):
+    """Strong-masked positions skip the posterior and the draw and take their conditioned token (csrc/ldm_post_token.h
+    strong_shortcut): the 16-lane-group kernel (with the shortcut) against the wavefront-per-token kernel (LDM_POST_WAVE=1:
+    full vocabulary, no shortcut, every position goes through posterior + draw) — bit-exact tokens over a cond=c loop,
+    every sampler, exact numerics (the per-step path, where both kernels are selectable)."""
+    spec = SP.PUBLAYNET
+    e = engine("publaynet", "exact", max_batch=64)
+    c = synth.synth_cond_c(spec, 64, seed=11)
+    cond = {"seq": c["seq"], "mask": c["mask"], "type": "c"}
+    steps = R.timestep_list(spec.n_step, 20)
+    cfg = {"name": sampler, "temperature": 1.0, "top_p": 0.9, "top_k": 5}
+    outs = []
+    for wave in ("0", "1"):
+        monkeypatch.setenv("LDM_POST_WAVE", wave)
+        tok = torch.from_numpy(c["seq"]).int().to(cuda)
+        outs.append(e.sample_loop(tok, steps, steps, cfg, cond=cond, seed=4, first_layout=2, intermediates=True,
+                                  use_graph=False)[1].cpu().clone())
+    assert torch.equal(outs[0], outs[1])
+    m = torch.from_numpy(c["mask"])
+    assert torch.equal(outs[0][-1].long()[m], torch.from_numpy(c["seq"])[m])
+
+
 @pytest.mark.parametrize("precision", ["exact", "split", "fast"])
 def test_full_batch_512_one_step_vs_oracle(cuda, precision):
     """Teacher-forced single step at B=512 (M=64000 rows) against the oracle on CPU."""
