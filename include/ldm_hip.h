@@ -210,6 +210,14 @@ int ldm_fid_finalize(ldm_fid* h);
 int ldm_fid_features(ldm_fid* h, const float* d_bbox, const int64_t* d_label, const uint8_t* d_padding_mask, int B,
                      int N, float* d_feat, void* stream);
 
+/* Precision / recall / density / coverage of two feature sets (the other four entries of compute_generative_model_scores,
+ * helpers/metric.py:37-59, which the reference takes from prdc.compute_prdc(real_features, fake_features, nearest_k=5)):
+ * d_real (n_real, dim), d_fake (n_fake, dim) float32 device; h_out4 = {precision, recall, density, coverage} on the HOST
+ * (the call synchronises `stream`); 1 <= nearest_k <= 7.  Uses the current device; workspace is allocated and freed
+ * inside the call (max(n_real, n_fake)^2 floats). */
+int ldm_prdc(const float* d_real, int n_real, const float* d_fake, int n_fake, int dim, int nearest_k, float* h_out4,
+             void* stream);
+
 /* ---- introspection ------------------------------------------------------------------- */
 /* average device time (ms) of the most recent ldm_sample_loop, measured with HIP events on the
  * stream it ran on; blocks until that loop has finished. */

@@ -30,7 +30,7 @@ EXPORTS = (
     "ldm_abi_version", "ldm_get_layout",
     # FID feature extractor (bound in layout_dm_amd/fid.py)
     "ldm_fid_create", "ldm_fid_destroy", "ldm_fid_last_error", "ldm_fid_load_weight", "ldm_fid_finalize",
-    "ldm_fid_features",
+    "ldm_fid_features", "ldm_prdc",
 )
 
 

@@ -48,6 +48,7 @@ struct StackArgs {
   // vocabulary, emb / pos, tokens in = post.tokens, tokens out = post.tokens_out, tie flags of step i at tie_flags + i * tie_ld)
   PostArgs post;
   const float* adaln;        // [T][L][2 N] AdaLN (scale | shift) table (transformer_utils.py:79-81)
+  StackTables tbl;           // the same parameters as LDS images (ldm_kernels.h): DMA'd one phase ahead of their use
   int32_t* inter;            // [n_steps][inter_ld][S] tokens after every step, or nullptr (get_intermediate_results)
   int n_steps, inter_ld, tie_ld;
   int16_t t_model[kStackLoopMaxSteps], t_post[kStackLoopMaxSteps];  // the denoiser's timestep and q_posterior's (base.py:218-240)
@@ -63,6 +64,7 @@ __device__ __forceinline__ stack_kargs_ptr stack_kargs() {
 }
 constexpr int kPostLd = 161;   // floats per token row of the logits in LDS (odd: the 16-lane groups of a wavefront hit distinct banks)
 constexpr int kPostRows = 128 * kPostLd * 4;  // bytes of the logits rows; behind them one float4 (max, lse, max |x|, -) per row
+constexpr int kStackLoopB1 = 2048;            // HEAD == 2: the linear1 bias table is padded to whole 1-KiB DMA pieces
 constexpr int kStackLoopLds = 1024;           // HEAD == 2: tokens [128] | cond token + strong bit [128] behind the tables
 
 __device__ unsigned long long g_stack_phase[16];
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     // x_t of the layout's tokens and its cond token | strong << 30 (or -1): LDS behind the tables, for the whole loop
     const stack_kargs_ptr kp = stack_kargs();
     const int S = kp->S;
-    int* toks = reinterpret_cast<int*>(smem + 3 * STAGE + 2 * KV_BYTES + (3 * kp->H * 64 + 2 * LN_DP + 512 + kp->n_chunks * 32 + 2 * LN_DP + 512) * 4);
+    int* toks = reinterpret_cast<int*>(smem + 3 * STAGE + 2 * KV_BYTES + (3 * kp->H * 64 + 2 * LN_DP + 512 + kStackLoopB1 + 2 * LN_DP + 512) * 4);
     if (tid_o < 128) {
       const int s = tid_o < S ? tid_o : S - 1;
       const size_t row = (size_t)b_o * S + s;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   float* sp = sbias + 3 * A.H * 64;        // AdaLN multiplier / shift (2 x LN_DP)
   float* sbo = sp + 2 * LN_DP;             // b_out + W_out b_v + AdaLN shift [512]
   float* sb1 = sbo + 512;                  // linear1 bias [n_chunks*32]
-  float* sp2 = sb1 + A.n_chunks * 32;      // norm2 gamma | beta (2 x LN_DP)
+  float* sp2 = sb1 + (HEAD == 2 ? kStackLoopB1 : A.n_chunks * 32);  // norm2 gamma | beta (2 x LN_DP)
   float* sb2 = sp2 + 2 * LN_DP;            // linear2 bias [512], zero beyond N
   [[maybe_unused]] int* toks = reinterpret_cast<int*>(sb2 + 512);   // HEAD == 2: x_t of the layout's tokens
   [[maybe_unused]] int* condc = toks + 128;                         //            cond token | strong << 30 (or -1)
@@ -183,6 +185,15 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       sb2[i] = v2[k];
     }
   };
+  // HEAD == 2: a parameter table image, n_kib 1-KiB pieces dealt round-robin to the four wavefronts (landing is covered by
+  // the next s_waitcnt vmcnt(0) of every wavefront + the barrier behind it, which every consumer below already has)
+  auto dma_table = [&](const float* g, const float* lds_dst, int n_kib) {
+    const unsigned dst = lds0 + (unsigned)(reinterpret_cast<const char*>(lds_dst) - smem);
+    for (int k = wave; k < n_kib; k += 4) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(dst + k * 1024) : "memory");
+      dma_lin<0>(voff, reinterpret_cast<const char*>(g) + (size_t)k * 1024);
+    }
+  };
   auto dma_first_tiles = [&](const char* img) {  // tiles 0 / 1 of a layer's first head -> stages 0 / 1
 #pragma unroll
     for (int k = 0; k < 4; ++k) dma_lin4(voff, img + wave * 8192 + (k >> 1) * STAGE + (k & 1) * 4096,
@@ -201,6 +212,10 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     const int row = wave * 32 + r;
     const int srow = row < S ? row : S - 1;
     const stack_kargs_ptr kp = stack_kargs();
+    // attention-phase tables of layer 0 at this step's timestep (every wavefront is past the previous step's head phase,
+    // the last reader of these LDS regions): they land while the embedding is gathered
+    dma_table(kp->tbl.att_static, sbias, kStackTblAttStatic / 256);
+    dma_table(kp->tbl.att_dyn + (size_t)t_model * L * kStackTblAttDyn, sp, kStackTblAttDyn / 256);
     const float* erow = kp->post.emb + (size_t)toks[srow] * kp->post.D + hi * 4;
     const float* prow = kp->post.pos + (size_t)srow * kp->post.D + hi * 4;
     constexpr int GB = 12;
@@ -270,19 +285,21 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       // input).  Every wave is past the previous layer's FFN LDS reads and table reads: the ring takes this layer's first
       // tiles, the tables its parameters; then row statistics, AdaLN fragments and the residual seed
       // AdaLN(x) + b_out + W_out b_v from the same registers.
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      dma_first_tiles((const char*)w.img);
       if constexpr (HEAD == 2) {
-        // (the thread index through an opaque copy: hoisted out of the layer loop, the 30 table addresses and bounds
-        //  masks of stage_tables do not fit beside the loop-carried state and go to scratch)
-        const int tid_l = tid_now();
-        const float* ss = stack_kargs()->adaln + ((size_t)t_model * L + l) * 2 * A.N;
-        stage_tables(w, ss, ss + A.N, tid_l);
+        // this layer's attention-phase tables were issued a phase ago (step prologue / previous layer's LN2): own pieces
+        // landed, then everybody's; the FFN-phase tables follow the first tiles and land under the attention block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_first_tiles((const char*)w.img);
+        dma_table(stack_kargs()->tbl.ffn + (size_t)l * kStackTblFfn, sb1, kStackTblFfn / 256);
       } else {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_first_tiles((const char*)w.img);
         stage_tables(w, w.ada_scale, w.ada_shift, tid);
+        __syncthreads();
       }
-      __syncthreads();
       unsigned long long tE1 = 0, tE2 = 0;
       if constexpr (TM) tE1 = __builtin_amdgcn_s_memtime();
       const int lane3 = stack_lane_id();
@@ -437,6 +454,17 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) dma_lin4(voff, g0 + k * 4096, lds0 + wave * 16384 + k * 4096);
     }
+    if constexpr (HEAD == 2) {
+      // the NEXT consumer's attention-phase tables (every wavefront is past this layer's heads and its layer entry, the
+      // readers of these regions): the next layer's, or behind the last layer the vocabulary head's LayerNorm affine
+      const stack_kargs_ptr kp = stack_kargs();
+      if (l + 1 < L) {
+        dma_table(kp->tbl.att_static + (size_t)(l + 1) * kStackTblAttStatic, sbias, kStackTblAttStatic / 256);
+        dma_table(kp->tbl.att_dyn + ((size_t)t_model * L + l + 1) * kStackTblAttDyn, sp, kStackTblAttDyn / 256);
+      } else {
+        dma_table(kp->tbl.head, sp, kStackTblAttDyn / 256);
+      }
+    }
     const int lane2 = stack_lane_id();
     const int r2 = lane2 & 31, hi2 = lane2 >> 5;
     f16x8 xf2[KS];
@@ -553,9 +581,11 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       dma_lin4(voff, g + 4096, l + 4096);
     };
     for (int ht = 0; ht < 3 && ht < A.n_head_tiles; ++ht) dma_head_tile(ht);
-    for (int i = tid_now(); i < LN_DP; i += 256) {
-      sp[i] = i < A.N ? A.head_g[i] : 0.f;
-      sp[LN_DP + i] = i < A.N ? A.head_b[i] : 0.f;
+    if constexpr (HEAD != 2) {  // (HEAD == 2: the image was issued at the last layer's LN2; the FFN stream ends on vmcnt(0))
+      for (int i = tid_now(); i < LN_DP; i += 256) {
+        sp[i] = i < A.N ? A.head_g[i] : 0.f;
+        sp[LN_DP + i] = i < A.N ? A.head_b[i] : 0.f;
+      }
     }
     __syncthreads();
     const int lane3 = stack_lane_id();
@@ -866,14 +896,14 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, floa
 // spills).  The caller has checked: 5 head tiles, live sub-vocabularies <= 48 classes, S <= 128.
 void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
                        const StackLoop& lp, hipStream_t st) {
-  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4 + kStackLoopLds;
+  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + kStackLoopB1 + 2 * LN_DP + 512) * 4 + kStackLoopLds;
   auto kern = stack_stream_k<false, 2>;
   allow_big_lds((const void*)kern);
   StackArgs a{};
   a.ls = ls; a.ldx = N; a.N = N; a.S = S; a.H = H; a.n_chunks = F / 32;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   a.head_img = (const char*)head.img; a.head_g = head.g; a.head_b = head.b; a.n_head_tiles = head.n_tiles;
-  a.post = *lp.post; a.adaln = lp.adaln; a.inter = lp.inter;
+  a.post = *lp.post; a.adaln = lp.adaln; a.tbl = lp.tables; a.inter = lp.inter;
   a.n_steps = lp.n_steps; a.inter_ld = lp.inter_ld; a.tie_ld = lp.tie_ld;
   for (int i = 0; i < lp.n_steps && i < kStackLoopMaxSteps; ++i) {
     a.t_model[i] = (int16_t)lp.t_model[i];

@@ -192,6 +192,8 @@ struct ldm_handle {
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
   int defer_ln = 1;
   int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
+  // parameter-table LDS images of the loop kernel (ldm_kernels.h StackTables), built by build_loop_tables
+  float *tbl_att_static = nullptr, *tbl_att_dyn = nullptr, *tbl_ffn = nullptr, *tbl_head = nullptr;
   int stack_loop = 1;  // the WHOLE reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): one launch per
                        // sampling call, the step's tail behind the vocabulary head (LDM_STACK_LOOP=0: one stack launch +
                        // one posterior launch per step, captured in per-lane hipGraphs — the r02 path)
@@ -709,6 +711,65 @@ static int build_fast_weights(ldm_handle* h) {
   return pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, id, &h->fast_head);
 }
 
+// Parameter tables of the loop kernel as LDS images (kernels_stack.hip HEAD == 2 copies them global -> LDS with the DMA,
+// one phase ahead of their use, instead of 26 loads per thread behind a barrier at every layer entry):
+//   att_static[l]      kStackTblAttStatic floats   head-padded in_proj bias
+//   att_dyn[t][l]      kStackTblAttDyn floats      1 + AdaLN scale | AdaLN shift | b_out + W_out b_v + shift   (0 beyond d_model)
+//   ffn[l]             kStackTblFfn floats         linear1 bias (0-padded to 2048) | norm2 gamma | norm2 beta | linear2 bias
+//   head               kStackTblAttDyn floats      head LayerNorm gamma | beta | 0      (takes the att_dyn slot behind the last layer)
+static int build_loop_tables(ldm_handle* h) {
+  const int D = h->D, F = h->F, L = h->L, T = h->T;
+  if (h->H * 64 * 3 != kStackTblAttStatic || D > 512 || F > 2048) return 0;  // geometry the loop kernel does not cover
+  std::vector<float> ada((size_t)T * L * 2 * D);
+  HIP_OK(h, hipDeviceSynchronize());  // (the AdaLN table kernels)
+  HIP_OK(h, hipMemcpy(ada.data(), h->adaln, ada.size() * 4, hipMemcpyDeviceToHost));
+  auto pull = [&](const float* d, size_t n, std::vector<float>& out) -> int {
+    out.resize(n);
+    HIP_OK(h, hipMemcpy(out.data(), d, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+  };
+  std::vector<float> att_static((size_t)L * kStackTblAttStatic, 0.f), att_dyn((size_t)T * L * kStackTblAttDyn, 0.f),
+      ffn((size_t)L * kStackTblFfn, 0.f), head(kStackTblAttDyn, 0.f), v;
+  int rc;
+  for (int l = 0; l < L; ++l) {
+    if ((rc = pull(h->fast[l].b_in, kStackTblAttStatic, v))) return rc;
+    std::copy(v.begin(), v.end(), att_static.begin() + (size_t)l * kStackTblAttStatic);
+    std::vector<float> bov;
+    if ((rc = pull(h->fast[l].b_out_v, D, bov))) return rc;
+    for (int t = 0; t < T; ++t) {
+      const float* ss = &ada[((size_t)t * L + l) * 2 * D];
+      float* o = &att_dyn[((size_t)t * L + l) * kStackTblAttDyn];
+      for (int i = 0; i < D; ++i) {
+        o[i] = 1.0f + ss[i];           // multiplier (0 beyond d_model: padded columns come out as exact zeros)
+        o[512 + i] = ss[D + i];        // shift
+        o[1024 + i] = bov[i] + ss[D + i];
+      }
+    }
+    float* f = &ffn[(size_t)l * kStackTblFfn];
+    if ((rc = pull(h->layers[l].b1, F, v))) return rc;
+    std::copy(v.begin(), v.end(), f);
+    if ((rc = pull(h->layers[l].g2, D, v))) return rc;
+    std::copy(v.begin(), v.end(), f + 2048);
+    if ((rc = pull(h->layers[l].be2, D, v))) return rc;
+    std::copy(v.begin(), v.end(), f + 2048 + 512);
+    if ((rc = pull(h->layers[l].b2, D, v))) return rc;
+    std::copy(v.begin(), v.end(), f + 2048 + 1024);
+  }
+  if ((rc = pull(h->head_g, D, v))) return rc;
+  std::copy(v.begin(), v.end(), head.begin());
+  if ((rc = pull(h->head_b, D, v))) return rc;
+  std::copy(v.begin(), v.end(), head.begin() + 512);
+  auto push = [&](const std::vector<float>& src, float** dst) -> int {
+    if (!*dst && (rc = h->dalloc(dst, src.size(), false))) return rc;
+    HIP_OK(h, hipMemcpy(*dst, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+  };
+  if ((rc = push(att_static, &h->tbl_att_static))) return rc;
+  if ((rc = push(att_dyn, &h->tbl_att_dyn))) return rc;
+  if ((rc = push(ffn, &h->tbl_ffn))) return rc;
+  return push(head, &h->tbl_head);
+}
+
 extern "C" int ldm_finalize_weights(ldm_handle* h) {
   if (!h) return -1;
   ON_DEVICE(h);
@@ -754,6 +815,7 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   }
   if (h->cfg.precision == LDM_PREC_FAST_F16) {
     if ((rc = build_fast_weights(h))) return rc;
+    if ((rc = build_loop_tables(h))) return rc;
   } else if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo))) {
     return rc;
   }
@@ -1233,7 +1295,7 @@ static bool loop_fusable(const ldm_handle* h, const ldm_relation* rel) {
   for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
   return h->stack_loop && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6 &&
          h->stack_head && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
-         h->T < 32768 && !h->fast.empty();
+         h->T < 32768 && !h->fast.empty() && h->tbl_att_dyn && h->D == 464 && h->F <= 2048;
 }
 
 // tokens_in -> tokens_out (may alias) through n_steps reverse steps; step0 = loop index of the first one (RNG counter
@@ -1267,6 +1329,7 @@ static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, cons
       p.tie_rel = h->tie_rel;
     }
     StackLoop lp{};
+    lp.tables = StackTables{h->tbl_att_static, h->tbl_att_dyn, h->tbl_ffn, h->tbl_head};
     lp.post = &p; lp.adaln = h->adaln; lp.t_model = t_model + i0; lp.t_post = t_post + i0;
     lp.inter = d_inter ? d_inter + (size_t)i0 * B * h->S : nullptr;
     lp.n_steps = n; lp.inter_ld = B; lp.tie_ld = h->cfg.max_batch;

@@ -136,7 +136,18 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, floa
 // ... and the whole reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): tokens in / out through
 // post->tokens / post->tokens_out, the step's tail (ldm_post_token.h) behind the vocabulary head on the logits in LDS.
 // ls.w[i].ada_scale / ada_shift are ignored: the AdaLN rows of step i come from adaln[t_model[i]].
+// parameter tables of the loop kernel as LDS images (floats; built on the host by ldm_api.cpp build_loop_tables)
+constexpr int kStackTblAttStatic = 1536;  // in_proj bias [3 * 8 heads * 64]
+constexpr int kStackTblAttDyn = 1536;     // 1 + AdaLN scale [512] | shift [512] | b_out + W_out b_v + shift [512]
+constexpr int kStackTblFfn = 3584;        // linear1 bias [2048] | norm2 gamma [512] | beta [512] | linear2 bias [512]
+struct StackTables {
+  const float* att_static;  // [L][kStackTblAttStatic]
+  const float* att_dyn;     // [T][L][kStackTblAttDyn]
+  const float* ffn;         // [L][kStackTblFfn]
+  const float* head;        // [kStackTblAttDyn]: head LayerNorm gamma | beta | 0
+};
 struct StackLoop {
+  StackTables tables;
   const PostArgs* post;      // schedule, cond, sampler, RNG, vocabulary, emb / pos / D; post->step = index of the first step
   const float* adaln;        // [T][L][2 N]
   const int32_t *t_model, *t_post;  // HOST arrays [n_steps], n_steps <= kStackLoopMaxSteps (longer loops: several launches)
@@ -243,6 +254,14 @@ struct FidArgs {
   int n_layer, N, num_label;
 };
 void launch_fid_features(const FidArgs& a, int B, hipStream_t st);
+
+// ---- precision / recall / density / coverage (kernels_prdc.hip): helpers/metric.py:37-59 via prdc ^0.2 ----------------
+void launch_prdc_pdist2(const float* A, int n, const float* B, int m, int dim, float* D, hipStream_t st);
+void launch_prdc_kth(const float* D, int n, int m, int k1, float* r2, hipStream_t st);
+// counts[4] (zeroed by the caller) += {fakes inside a real radius, reals with a fake inside that fake's radius,
+// sum over fakes of reals whose radius holds them, reals whose nearest fake is inside their radius}
+void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, const float* r2_fake, unsigned* counts,
+                        hipStream_t st);
 
 // ---- small utilities ---------------------------------------------------------------------
 void launch_delay_us(int us, hipStream_t st);  // one wave spinning for `us` microseconds (lane phase offset)

@@ -142,6 +142,41 @@ def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
     return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
 
 
+def _as_array(f) -> np.ndarray:
+    if isinstance(f, (list, tuple)):  # list of batch-processed features (helpers/metric.py:25-32)
+        return np.concatenate([x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x) for x in f])
+    return f.detach().cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f)
+
+
+def compute_prdc(real_features, fake_features, nearest_k: int = 5, device=None) -> dict:
+    """prdc.compute_prdc(real_features, fake_features, nearest_k) (prdc ^0.2, imported at helpers/metric.py:10) on the
+    device: k-NN radii of both sets and the four counts over the real x fake distance matrix (kernels_prdc.hip)."""
+    lib = load_library()
+    lib.ldm_prdc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+    lib.ldm_prdc.restype = C.c_int
+    if not torch.cuda.is_available():
+        raise RuntimeError("layout_dm_amd needs a ROCm GPU (MI355X); there is no CPU path")
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    with torch.cuda.device(dev):
+        r = torch.as_tensor(_as_array(real_features), dtype=torch.float32).to(dev).contiguous()
+        f = torch.as_tensor(_as_array(fake_features), dtype=torch.float32).to(dev).contiguous()
+        assert r.dim() == 2 and f.dim() == 2 and r.shape[1] == f.shape[1]
+        out = (C.c_float * 4)()
+        rc = lib.ldm_prdc(r.data_ptr(), r.shape[0], f.data_ptr(), f.shape[0], r.shape[1], int(nearest_k), out,
+                          int(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"ldm_prdc failed ({rc}): need 1 <= nearest_k <= 7 and more than nearest_k samples per set")
+    return {"precision": float(out[0]), "recall": float(out[1]), "density": float(out[2]), "coverage": float(out[3])}
+
+
+def compute_generative_model_scores(feats_real, feats_fake) -> dict:
+    """compute_generative_model_scores (helpers/metric.py:37-59): precision, recall, density, coverage (nearest_k = 5) and
+    FID of two sets of FIDNetV3 features."""
+    results = compute_prdc(feats_real, feats_fake, nearest_k=5)
+    results["fid"] = compute_fid(feats_real, feats_fake)
+    return results
+
+
 def compute_fid(feats_real, feats_fake) -> float:
     """The "fid" entry of compute_generative_model_scores (helpers/metric.py:37-59)."""
     def arr(f):

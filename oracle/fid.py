@@ -74,3 +74,27 @@ def extract_features(sd, bbox, label, padding_mask, dtype=torch.float32):
                      W[p + "linear2.weight"], W[p + "linear2.bias"])
         x = F.layer_norm(x + f, (D,), W[p + "norm2.weight"], W[p + "norm2.bias"], 1e-5)
     return x[:, 0]                                                                         # l.152
+
+
+def compute_prdc(real_features, fake_features, nearest_k: int = 5):
+    """Restatement of prdc.compute_prdc (package prdc ^0.2 pinned by the reference's pyproject.toml:34, called at
+    helpers/metric.py:52-54; NOT vendored under /root/reference and not installed here, so this follows the published
+    algorithm — Naeem et al., ICML 2020 — as the package implements it): Euclidean pairwise distances in float64,
+    radius = the (nearest_k + 1)-th smallest entry of a set's own distance rows (the smallest is the zero
+    self-distance), strict '<' everywhere.  parity unpinned by the reference itself (it ships no vectors for it)."""
+    r = np.asarray(real_features, dtype=np.float64)
+    f = np.asarray(fake_features, dtype=np.float64)
+
+    def pdist(a, b):
+        return np.sqrt(np.maximum(((a[:, None, :] - b[None, :, :]) ** 2).sum(-1), 0.0))
+
+    def radii(x):
+        d = pdist(x, x)
+        return np.partition(d, nearest_k, axis=-1)[:, :nearest_k + 1].max(axis=-1)
+
+    rr, rf = radii(r), radii(f)
+    d = pdist(r, f)
+    return {"precision": float((d < rr[:, None]).any(axis=0).mean()),
+            "recall": float((d < rf[None, :]).any(axis=1).mean()),
+            "density": float((1.0 / nearest_k) * (d < rr[:, None]).sum(axis=0).mean()),
+            "coverage": float((d.min(axis=1) < rr).mean())}

@@ -67,3 +67,26 @@ def test_fid_rejects_bad_geometry():
     m, _ = _model(25)
     with pytest.raises(RuntimeError):
         m.extract_features(torch.zeros(1, 26, 4), torch.zeros(1, 26, dtype=torch.long), torch.zeros(1, 26, dtype=torch.bool))
+
+
+@pytest.mark.parametrize("n_real,n_fake,dim,k", [(700, 500, 256, 5), (64, 333, 48, 3), (257, 257, 256, 7)])
+def test_prdc_vs_oracle(n_real, n_fake, dim, k):
+    """ldm_prdc (kernels_prdc.hip) == the restatement of prdc.compute_prdc on random feature clouds that overlap only
+    partly (so that none of the four numbers is trivially 0 or 1); identical sets give precision = recall = coverage = 1."""
+    from layout_dm_amd.fid import compute_generative_model_scores, compute_prdc
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device (no CPU fallback exists)")
+    rng = np.random.default_rng(n_real + dim)
+    real = rng.standard_normal((n_real, dim)).astype(np.float32)
+    fake = (rng.standard_normal((n_fake, dim)) * 1.15 + 0.08).astype(np.float32)
+    got, ref = compute_prdc(real, fake, nearest_k=k), OF.compute_prdc(real, fake, nearest_k=k)
+    print(f"[prdc n={n_real}x{n_fake} dim={dim} k={k}] device {got}  oracle {ref}")
+    for key in ("precision", "recall", "density", "coverage"):
+        assert 0.0 < ref[key] or key in ("precision", "recall")
+        assert abs(got[key] - ref[key]) <= 2.0 / min(n_real, n_fake) + 1e-6, (key, got[key], ref[key])  # <= 2 samples on a '<' edge
+    same = compute_prdc(real, real, nearest_k=k)
+    assert same["precision"] == 1.0 and same["recall"] == 1.0 and same["coverage"] == 1.0
+    if k == 5:
+        full = compute_generative_model_scores([torch.from_numpy(real[:300]), torch.from_numpy(real[300:])], torch.from_numpy(fake))
+        assert set(full) == {"precision", "recall", "density", "coverage", "fid"} and full["fid"] > 0
