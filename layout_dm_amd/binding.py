@@ -66,7 +66,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("LDM_HIP_LIB") or LIB_PATH  # LDM_HIP_LIB: dev A/B of two builds on one GPU box
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the MI355X HIP extension is not built (run `python -m layout_dm_amd.build` "

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
 #pragma unroll
       for (int sx = 0; sx < 2; ++sx) relW2[sx] = r2 * 64 + (((2 * sx + hi2) ^ ((r2 >> 2) & 3)) << 4);
       const unsigned relB = lds0 + (unsigned)(reinterpret_cast<char*>(sb1) - smem) + hi2 * 16;
-      FfnStream<KS, NT2, 2, false> F;
+      FfnStream<KS, NT2, 2, false, 6, true> F;
       F.xf = xf2;
       F.acc = acc;
       F.voff = voff;
@@ -548,11 +548,18 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       F.read_bias();
       F.template prologue<0>();
+      {
+        const f16x8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f,
+                         (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        F.pf[0] = F.pf[1] = F.pfn[0] = F.pfn[1] = z;  // iteration 0's GEMM2 multiplies zero fragments (and a zero W2 half)
+      }
+      // software-pipelined chunk stream (ldm_pipes.h FfnStream PIPE): iteration c = GEMM1 of chunk c + GEMM2 of chunk
+      // c - 1 on stage c = W1 tile c | W2 slab c - 1 (ldm_pack::pack_ffn_image_pipelined); n_chunks + 1 iterations
       const char* fimg = (const char*)w.ffn_img;
-      for (int c = 0; c < A.n_chunks; ++c) {
-        F.gnext = fimg + (size_t)(c + 1 == A.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+      for (int c = 0; c <= A.n_chunks; ++c) {
+        F.gnext = fimg + (size_t)(c == A.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
         F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
-        F.ab_next = relB + (c + 1 == A.n_chunks ? 0 : c + 1) * 128;
+        F.ab_next = relB + (c + 1 >= A.n_chunks ? 0 : c + 1) * 128;
         F.template step<0, true>();
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -181,6 +181,7 @@ struct ldm_handle {
   struct FastLayer {
     __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
     void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
+    void* ffn_img_pipe = nullptr;  // ffn_img_ks re-timed for the software-pipelined chunk stream of the stack kernel
     void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
     void* attn_head_img_ks = nullptr;  // per head: 6 in_proj tiles (k-slot K) + its 2 out-proj slabs (stack kernel)
     float* b_in = nullptr;
@@ -663,7 +664,9 @@ static int build_fast_weights(ldm_handle* h) {
         if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, kslot, &w1p))) return rc;
         const std::vector<uint16_t> h1p = download16(h, w1p, (size_t)F * Dq, &rc);
         if (rc) return rc;
-        if ((rc = upload_image(h, pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480), &f.ffn_img_ks))) return rc;
+        const std::vector<uint16_t> ks = pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480);
+        if ((rc = upload_image(h, ks, &f.ffn_img_ks))) return rc;
+        if ((rc = upload_image(h, ldm_pack::pack_ffn_image_pipelined(ks, F / 32), &f.ffn_img_pipe))) return rc;
       }
       const std::vector<uint16_t> hin = download16(h, f.w_in, (size_t)3 * HD * Dq, &rc);
       if (rc) return rc;
@@ -871,7 +874,7 @@ static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, i
       const LayerW& w = h->layers[i];
       const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
       ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
-                            h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
+                            h->fast[i].ffn_img_pipe, w.b1, w.b2, w.g2, w.be2};
     }
     // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
     const bool with_head = h->stack_head && h->head_img_ks && h->Cp % 32 == 0;
@@ -1310,7 +1313,7 @@ static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, cons
   for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
     ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, nullptr, nullptr, h->fast[i].b_out_v,
-                          h->fast[i].ffn_img_ks, w.b1, w.b2, w.g2, w.be2};
+                          h->fast[i].ffn_img_pipe, w.b1, w.b2, w.g2, w.be2};
   }
   const StackHead hd{h->head_img_ks, h->head_g, h->head_b, nullptr, h->Cp, h->Cp / 32};
   const double step_flops = h->L * (gemm_flops(M, 3 * D, D) + 4.0 * B * h->H * (double)h->S * h->S * h->dh +

@@ -51,6 +51,20 @@ inline std::vector<uint16_t> pack_ffn_image(const uint16_t* w1, const uint16_t* 
   return img;
 }
 
+// The same weights RE-TIMED for the software-pipelined chunk stream (FfnStream<..., PIPE = true>): iteration i of the
+// stream runs GEMM1 of chunk i and GEMM2 of chunk i - 1 — the ReLU / cast of chunk i sits in the MFMA shadows of that
+// GEMM2 instead of idling the matrix pipe between the two GEMMs of one chunk — so stage i holds W1 tile i | W2 slab i - 1.
+// nc + 1 stages: stage 0 has a zero W2 half (GEMM2 of iteration 0 multiplies zero fragments), stage nc a zero W1 half
+// (its GEMM1 result is never used).
+inline std::vector<uint16_t> pack_ffn_image_pipelined(const std::vector<uint16_t>& img, int nc) {
+  std::vector<uint16_t> out((size_t)(nc + 1) * 32768, 0);
+  for (int i = 0; i <= nc; ++i) {
+    if (i < nc) memcpy(out.data() + (size_t)i * 32768, img.data() + (size_t)i * 32768, 16384 * 2);
+    if (i > 0) memcpy(out.data() + (size_t)i * 32768 + 16384, img.data() + (size_t)(i - 1) * 32768 + 16384, 16384 * 2);
+  }
+  return out;
+}
+
 // w_in: [3*H*64][512] head-padded in_proj (q | k | v), w_out_ks: [>=32*n_out_tiles][512] out_proj with head-padded
 // k-slot K.  Tiles: h*6 + {k0 k1 v0 v1 q0 q1}, then the out_proj tiles, then one zero tile.
 inline std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_t* w_out_ks, int H, int n_out_tiles) {

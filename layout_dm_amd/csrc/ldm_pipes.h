@@ -173,7 +173,15 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, const float4& b0, const f
 // (r02 negative result: GEMM1 as ONE accumulator chain in AGPRs — C = 0, bias added in the ReLU step — instead of the
 //  two chains in arch VGPRs is 2 % slower, profiles/r02_call28_*: the 44-vs-32 cycles per MFMA of GEMM1 vs GEMM2 are
 //  not a VGPR-port effect of VGPR-resident accumulators.)
-template <int KS, int NT2, int DE, bool TM, int PFQ = 6>
+// PIPE (the stack kernel): SOFTWARE-PIPELINED chunks.  Between the two GEMMs of a chunk the matrix pipe idles: GEMM1's
+// result has to drain (MFMA -> VALU hazard), then 24 VALU issues of bias / ReLU / cast, then GEMM2 can start — ~230 of a
+// chunk's 2 390 cycles (tools/microbench/dma_feed.hip, profiles/r03_call13_*: 2 387 -> 2 160 cycles per chunk).  With
+// PIPE an iteration runs GEMM1 of chunk i and GEMM2 of chunk i - 1 (weights re-timed on the host:
+// ldm_pack::pack_ffn_image_pipelined, stage i = W1 tile i | W2 slab i - 1; nc + 1 iterations), and the ReLU / cast of
+// chunk i is issued in the shadows of that GEMM2's MFMAs 2..9: pf = fragments of chunk i - 1 (in use), pfn = fragments
+// of chunk i (being built), copied at the top of the next iteration.  The LDS traffic, its order and every counted wait
+// are unchanged (ldm_stream_sched.h).
+template <int KS, int NT2, int DE, bool TM, int PFQ = 6, bool PIPE = false>
 struct FfnStream {
   using SCH = ldm_sched::FfnSched<KS, NT2, PFQ>;  // (replayed on the CPU: tests/cpu_sched_check.cpp)
   static constexpr int PF = SCH::PF;   // queue depth.  r02: depth 10 instead of 6 changes nothing (profiles/r02_call21_*)
@@ -185,7 +193,7 @@ struct FfnStream {
   const f16x8* xf;
   f32x16 ha, hb;
   f32x16* acc;
-  f16x8 pf[2];
+  f16x8 pf[2], pfn[2];
   float4 bb[4];
   static constexpr int IPW = 16;
   const char* gnext;
@@ -236,7 +244,9 @@ struct FfnStream {
       } else if constexpr (IT < KS) {
         if constexpr (IT % 2 == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[IT]));
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hb) : "v"(cur), "v"(xf[IT]));
-        if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");  // MFMA result -> VALU read (next step)
+        if constexpr (IT == KS - 1 && !PIPE) asm volatile("s_nop 15" ::: "memory");  // MFMA result -> VALU read (next step)
+      } else if constexpr (IT == KS && PIPE) {
+        (void)cur;  // the slot keeps the queue bookkeeping uniform; chunk i's ReLU runs inside GEMM2 below
       } else if constexpr (IT == KS) {
         // bias (already inside chain A) + ReLU + cast: accumulator reg <-> hidden f = (q&3) + 8*(q>>2) + 4*hi
         // Packed: 8 v_pk_add_f32 + 8 v_cvt_pk_f16_f32 + 4 v_pk_max_f16 instead of 16 add + 16 max + 8 cvt — the matrix
@@ -258,6 +268,25 @@ struct FfnStream {
       } else {
         constexpr int sx = (IT - KS - 1) / NT2, t = (IT - KS - 1) % NT2;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
+        if constexpr (PIPE) {
+          // bias (inside chain A) + ReLU + cast of the GEMM1 that finished >= 3 MFMAs (96 cycles) ago, one accumulator
+          // pair per MFMA shadow: add, add, cvt_pk, pk_max — scalar adds, packed f32 VALU is slow beside MFMAs
+          constexpr int g = IT - KS - 1;
+          if constexpr (g >= 2 && g < 10) {
+            constexpr int i = g - 2;
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+            const float s0 = ha[2 * i] + hb[2 * i], s1 = ha[2 * i + 1] + hb[2 * i + 1];
+            f16x2v hv = {(_Float16)s0, (_Float16)s1};
+            const f16x2v zero = {(_Float16)0.f, (_Float16)0.f};
+            hv = __builtin_elementwise_max(hv, zero);
+            pfn[i >> 2][(i & 3) * 2 + 0] = hv[0];
+            pfn[i >> 2][(i & 3) * 2 + 1] = hv[1];
+          }
+        }
+      }
+      if constexpr (PIPE && IT == 0) {  // the fragments finished during the previous GEMM2 (which no longer reads pf)
+        pf[0] = pfn[0];
+        pf[1] = pfn[1];
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (TM && IT == KS - 1) tC = __builtin_amdgcn_s_memtime();

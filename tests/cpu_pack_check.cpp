@@ -81,6 +81,21 @@ int main() {
     std::vector<uint16_t> p_w1ks((size_t)2048 * Dq, 0);
     for (int n = 0; n < F; ++n) for (int k = 0; k < D; ++k) p_w1ks[(size_t)n * Dq + ldm_pack::kslot(k)] = w1[(size_t)n * D + k];
     const std::vector<uint16_t> ffn_ks = ldm_pack::pack_ffn_image(p_w1ks.data(), p_w2p.data(), Fq, F, 480);
+    {
+      // the re-timed image of the software-pipelined chunk stream (FfnStream PIPE): stage i = W1 tile of chunk i (what
+      // iteration i's GEMM1 reads: the first 32 KiB of the stage) | W2 slab of chunk i - 1 (what its GEMM2 reads: the
+      // second 32 KiB); stage 0 has a zero W2 half, stage nc a zero W1 half
+      const int nc = F / 32;
+      const std::vector<uint16_t> pipe = ldm_pack::pack_ffn_image_pipelined(ffn_ks, nc);
+      CHECK(pipe.size() == (size_t)(nc + 1) * 32768, "pipelined ffn image size");
+      for (int i = 0; i <= nc; ++i)
+        for (int e = 0; e < 16384; ++e) {
+          const uint16_t w1_want = i < nc ? ffn_ks[(size_t)i * 32768 + e] : 0;
+          const uint16_t w2_want = i > 0 ? ffn_ks[(size_t)(i - 1) * 32768 + 16384 + e] : 0;
+          CHECK(pipe[(size_t)i * 32768 + e] == w1_want, "pipelined W1 half: stage %d half-word %d", i, e);
+          CHECK(pipe[(size_t)i * 32768 + 16384 + e] == w2_want, "pipelined W2 half: stage %d half-word %d", i, e);
+        }
+    }
     for (int c = 0; c < F / 32; c += 7) {
       const uint16_t* stage = ffn_ks.data() + (size_t)c * 32768;
       for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int ks = 0; ks < 29; ++ks) {

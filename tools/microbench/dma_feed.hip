@@ -30,13 +30,13 @@ __host__ __device__ constexpr int piece_at(int it) {  // index of the piece issu
   return -1;
 }
 
-template <int PLACE>
+template <int PLACE, bool PIPE = false>
 struct Pipe {
   f16x8 q[PF];
   f16x8 xf[KS];
   f32x16 ha, hb;
   f32x16 acc[NT2];
-  f16x8 pf[2];
+  f16x8 pf[2], pfn[2];
   unsigned aW1[8], aW2[2];
   unsigned voff, mnext;
   const char* gnext;
@@ -61,15 +61,33 @@ struct Pipe {
       if constexpr (IT < KS) {
         if constexpr (IT % 2 == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ha) : "v"(cur), "v"(xf[IT]));
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(hb) : "v"(cur), "v"(xf[IT]));
-        if constexpr (IT == KS - 1) asm volatile("s_nop 15" ::: "memory");
+        if constexpr (IT == KS - 1 && !PIPE) asm volatile("s_nop 15" ::: "memory");
+        if constexpr (IT == 0 && PIPE) { pf[0] = pfn[0]; pf[1] = pfn[1]; }  // the fragments finished during the last GEMM2
       } else if constexpr (IT == KS) {
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
+          for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pf[rq >> 1][(rq & 1) * 4 + e] = (_Float16)fmaxf(ha[rq * 4 + e] + hb[rq * 4 + e], 0.f);
+            for (int e = 0; e < 4; ++e) pf[rq >> 1][(rq & 1) * 4 + e] = (_Float16)fmaxf(ha[rq * 4 + e] + hb[rq * 4 + e], 0.f);
+        }
       } else {
         constexpr int sx = (IT - KS - 1) / NT2, t = (IT - KS - 1) % NT2;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, pf[sx], acc[t], 0, 0, 0);
+        if constexpr (PIPE) {
+          // software-pipelined FFN: this GEMM2 multiplies the PREVIOUS chunk's hidden fragments; the ReLU / cast of the
+          // GEMM1 that just finished runs in the shadows of GEMM2 steps 2..9 (one accumulator pair each)
+          constexpr int g = IT - KS - 1;
+          if constexpr (g >= 2 && g < 10) {
+            constexpr int i = g - 2;
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
+            const float s0 = ha[2 * i] + hb[2 * i], s1 = ha[2 * i + 1] + hb[2 * i + 1];
+            f16x2v hv = {(_Float16)s0, (_Float16)s1};
+            const f16x2v zero = {(_Float16)0.f, (_Float16)0.f};
+            hv = __builtin_elementwise_max(hv, zero);
+            pfn[i >> 2][(i & 3) * 2 + 0] = hv[0];
+            pfn[i >> 2][(i & 3) * 2 + 1] = hv[1];
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (IT == SYNC) {
@@ -98,13 +116,15 @@ struct Pipe {
   }
 };
 
-template <int PLACE, int SRC>
+template <int PLACE, int SRC, bool PIPE = false>
 __global__ __launch_bounds__(256, 1) void bench(const char* g, int n_img_chunks, float* out, unsigned long long* cyc, int chunks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hi = lane >> 5;
   for (int i = threadIdx.x; i < 2 * STAGE / 4; i += 256) reinterpret_cast<float*>(smem)[i] = reinterpret_cast<const float*>(g)[i];
   __syncthreads();
-  Pipe<PLACE> P;
+  Pipe<PLACE, PIPE> P;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) P.pfn[0][e] = P.pfn[1][e] = P.pf[0][e] = P.pf[1][e] = (_Float16)0.25f;
   P.voff = lane * 16;
 #pragma unroll
   for (int k = 0; k < 8; ++k) P.aW1[k] = r * 1024 + ((((k << 1) | hi) ^ (r & 15)) << 4);
@@ -140,9 +160,9 @@ __global__ __launch_bounds__(256, 1) void bench(const char* g, int n_img_chunks,
   if (threadIdx.x == 0) atomicAdd(cyc, t1 - t0);
 }
 
-template <int PLACE, int SRC>
+template <int PLACE, int SRC, bool PIPE = false>
 void run(const char* name, const char* g, int n_img_chunks, float* out, unsigned long long* cyc) {
-  auto k = bench<PLACE, SRC>;
+  auto k = bench<PLACE, SRC, PIPE>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int chunks = 232 * 4, blocks = 256;
   hipEvent_t a, b;
@@ -183,6 +203,9 @@ int main() {
   run<3, 1>("16 pieces at odd steps 29..59 (inside GEMM2), 23.6 MB image", g, n_img_chunks, out, cyc);
   run<4, 1>("8 pairs of pieces at steps 3, 7, .. 31, 23.6 MB image", g, n_img_chunks, out, cyc);
   run<5, 1>("8 pieces at steps 1, 5, .. 29 (half the bytes), 23.6 MB image", g, n_img_chunks, out, cyc);
+  run<0, 0, true>("PIPELINED (ReLU inside the next GEMM2), no DMA", g, n_img_chunks, out, cyc);
+  run<1, 1, true>("PIPELINED, 16 pieces at odd steps 1..31, 23.6 MB image", g, n_img_chunks, out, cyc);
+  run<1, 1>("16 pieces at odd steps 1..31 (shipping), 23.6 MB image (again)", g, n_img_chunks, out, cyc);
   run<0, 0>("no DMA (again)", g, n_img_chunks, out, cyc);
   return 0;
 }
