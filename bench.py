@@ -187,9 +187,8 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
     return vals, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), KB per launch"
 
 
-# event-profile class -> substring of the kernel symbol in the PMC csv (layer_fused: the stream kernel of kernels_layer.hip
-# under LDM_FUSED_ATTN=5; layers_fused: the stack kernel of kernels_stack.hip, default)
-KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_stream_k", "layer_fused": "layer_stream_k", "ffn_fused": "ffn_fused2_k", "qkv_attention_out": "qkv_attn_k", "gemm_head": "rowgemm_k",
+# event-profile class -> substring of the kernel symbol in the PMC csv
+KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_stream_k",
                  "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
                  "attention": "attn_"}
 

@@ -1,7 +1,7 @@
 // The whole denoiser stack in ONE launch per step, one workgroup per LAYOUT, with the layout's rows RESIDENT in the
 // out-projection accumulators (15 tiles = 240 AGPRs per wave) from the embedding output to the input of the head.
 //
-// The per-layer kernel (kernels_layer.hip) spends a quarter of its cycles in three all-CU memory bursts per layer —
+// A per-layer kernel (r02's layer_stream_k, removed in r03) spends a quarter of its cycles in three all-CU memory bursts per layer —
 // operand rows in, residual rows in, result rows out (3 x 59 MB per 256-layout launch, matrix pipes idle) — because the
 // attention heads park their output fragments in the AGPRs the out-projection accumulators need.  Here the
 // out-projection of a head runs RIGHT BEHIND its attention core (SlabPair: the head's two K-slabs), so nothing is
@@ -35,8 +35,7 @@ namespace ldm {
 
 struct StackArgs {
   FusedLayerSet ls;     // per layer: head image, in_proj bias, AdaLN scale / shift, b_out + W_out b_v, FFN image, b1 b2 g2 be2
-  float* x;             // [M, ldx] rows in / out (in place; not written when the vocabulary head is fused)
-  float2* stats;        // [M] (mean, rstd) out (same)
+  float* x;             // [M, ldx] rows in (HEAD 1)
   int ldx, N, S, H, n_chunks;
   float scale_log2e;
   // fused vocabulary head (nn_lib.py:186-189: LayerNorm + Linear without bias), or head_img == nullptr
@@ -83,7 +82,7 @@ __device__ __forceinline__ float stack_xor32_swap(float v) {
 }
 #define LDM_XOR32(v) (HEAD == 2 ? stack_xor32_swap(v) : __shfl_xor(v, 32, 64))
 
-// HEAD: 0 = rows + statistics out; 1 = fused vocabulary head, logits out; 2 = head + posterior + draw, tokens out
+// HEAD: 1 = one denoiser pass: rows in, logits out (parity hook + per-step path); 2 = the whole reverse loop: tokens in, tokens out
 template <bool TM, int HEAD>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
@@ -573,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
     }
   }
   if constexpr (TM) t_epi = __builtin_amdgcn_s_memtime();
-  if constexpr (HEAD) {
+  {
     // ---- vocabulary head in the same workgroup: logits = LN_head(x_out) · Wh^T.  The rows never leave the registers:
     // statistics and the normalised fp16 fragments (k-slot K order) from the accumulators, then n_head_tiles 32-class
     // weight tiles through a 4-stage ring in the LDS the FFN ring used (TilePipe: 29 MFMAs per tile), 16-byte stores of
@@ -830,32 +829,6 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
         if (valid3)
           *reinterpret_cast<float4*>(lrow + ht * 32 + rq * 8) = make_float4(lg[rq * 4 + 0], lg[rq * 4 + 1], lg[rq * 4 + 2], lg[rq * 4 + 3]);
     }
-  } else {
-  {
-    // ---- x_out = acc: row statistics + stores (only the rows of this layout: padding rows of the last wave belong to
-    // the next layout)
-    const int lane3 = stack_lane_id();
-    const int r3 = lane3 & 31, hie = lane3 >> 5;
-    const int row3 = wave * 32 + r3;
-    const bool valid3 = row3 < S;
-    const size_t me = (size_t)b * S + (valid3 ? row3 : S - 1);
-    float* orow = A.x + me * A.ldx + hie * 4;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int gg = 0; gg < NGV; ++gg) {
-      const int t = gg >> 2, q0 = (gg & 3) * 4;
-      const float v0 = acc[t][q0 + 0], v1 = acc[t][q0 + 1], v2 = acc[t][q0 + 2], v3 = acc[t][q0 + 3];
-      s1 += (v0 + v1) + (v2 + v3);
-      s2 += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-      if (valid3) *reinterpret_cast<float4*>(orow + gg * 8) = make_float4(v0, v1, v2, v3);
-    }
-    s1 += LDM_XOR32(s1);
-    s2 += LDM_XOR32(s2);
-    constexpr float kInvN3 = 1.0f / 464.0f;
-    const float mean3 = s1 * kInvN3;
-    const float rstd3 = 1.0f / sqrtf(fmaxf(s2 * kInvN3 - mean3 * mean3, 0.f) + 1e-5f);
-    if (valid3 && hie == 0 && A.stats) A.stats[me] = make_float2(mean3, rstd3);
-  }
   }
   } while (HEAD == 2 && ++it < n_iter);  // step loop
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last FFN prefetch must land before the LDS is released
@@ -882,20 +855,17 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
   }
 }
 
-void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, const StackHead* head, hipStream_t st) {
+void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int B, int S, int H, int dh,
+                         const StackHead& head, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
   static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
-  auto kern = head ? (tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>)
-                   : (tm ? stack_stream_k<true, 0> : stack_stream_k<false, 0>);
+  auto kern = tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>;
   allow_big_lds((const void*)kern);
   StackArgs a{};
-  a.ls = ls; a.x = x; a.stats = stats_io; a.ldx = ldx; a.N = N; a.S = S; a.H = H; a.n_chunks = F / 32;
+  a.ls = ls; a.x = x; a.ldx = ldx; a.N = ldx; a.S = S; a.H = H; a.n_chunks = F / 32;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  if (head) {
-    a.head_img = (const char*)head->img; a.head_g = head->g; a.head_b = head->b;
-    a.logits = head->logits; a.ldl = head->ldl; a.n_head_tiles = head->n_tiles;
-  }
+  a.head_img = (const char*)head.img; a.head_g = head.g; a.head_b = head.b;
+  a.logits = head.logits; a.ldl = head.ldl; a.n_head_tiles = head.n_tiles;
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds, st, a);
 }
 

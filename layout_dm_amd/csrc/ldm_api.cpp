@@ -176,23 +176,21 @@ struct ldm_handle {
   // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64
   int Dq = 0, HD = 0, Fq = 0, Mpad = 0;
   int gemm_cfg[5] = {0, 0, 0, 0, 0};  // qkv, attn_out, ffn1, ffn2, head
-  int row_impl = 0x7;  // bit0 QKV, bit1 out-proj, bit2 fused FFN, bit3 head use the row-stationary kernels
-                       // (measured: row kernels win for QKV, out-proj, FFN; equal for the head)
   struct FastLayer {
-    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr, *w2p = nullptr, *w_out_ks = nullptr;
-    void *ffn_img = nullptr, *ffn_img_ks = nullptr, *attn_img = nullptr;  // LDS-image weight streams of the fused kernels
-    void* ffn_img_pipe = nullptr;  // ffn_img_ks re-timed for the software-pipelined chunk stream of the stack kernel
-    void* attn_slab_img = nullptr;  // in_proj tiles + out-projection K slabs (fused layer kernel)
+    __half *w_in = nullptr, *w_out = nullptr, *w1 = nullptr, *w2 = nullptr;  // head-padded fp16 copies (generic tiled GEMMs)
     void* attn_head_img_ks = nullptr;  // per head: 6 in_proj tiles (k-slot K) + its 2 out-proj slabs (stack kernel)
+    void* ffn_img_pipe = nullptr;      // W1 tile i | W2 slab i - 1 per stage: the software-pipelined chunk stream (stack kernel)
     float* b_in = nullptr;
-    float* b_out_v = nullptr;  // out_proj bias + W_out b_v (the stream layer kernel never adds the V bias: softmax rows sum to 1)
+    float* b_out_v = nullptr;  // out_proj bias + W_out b_v (the stack kernel never adds the V bias: softmax rows sum to 1)
   };
   std::vector<FastLayer> fast;
   __half* fast_head = nullptr;
   void* head_img_ks = nullptr;  // vocabulary head as 32-class tile images, K axis in k-slot order (stack kernel)
   float2 *stats_a = nullptr, *stats_b = nullptr;  // deferred normalisation: per-row (mean, rstd) of P / Q
-  int defer_ln = 1;
-  int stack_head = 1;  // fused_attn == 6: the vocabulary head runs inside the stack kernel (LDM_STACK_HEAD=0: separate rowgemm)
+  int fused_attn = 6;  // 6: the layout-resident stack kernel (kernels_stack.hip: all layers + vocabulary head per launch, rows
+                       //    in the out-projection accumulators; the reference's backbone on both of its datasets);
+                       // 0: generic tiled kernels (LayerNorm -> gemm16 -> attention16 -> ...) for every other accepted
+                       //    geometry (and as an A/B / cross-check of the stack kernel: LDM_FUSED_ATTN=0)
   // parameter-table LDS images of the loop kernel (ldm_kernels.h StackTables), built by build_loop_tables
   float *tbl_att_static = nullptr, *tbl_att_dyn = nullptr, *tbl_ffn = nullptr, *tbl_head = nullptr;
   int stack_loop = 1;  // the WHOLE reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): one launch per
@@ -202,12 +200,6 @@ struct ldm_handle {
   float tie_rel = 0.f;
   uint8_t* tie_flags = nullptr;
   int tie_steps = 0;
-  int fused_attn = 6;  // 1: QKV + attention in one per-layout kernel; 2: + out-projection/residual/stats;
-                       // 5: the WHOLE layer (attention block + FFN) per launch, in place on P, as continuous per-head /
-                       //    slab / chunk streams (kernels_layer.hip:
-                       //    220 -> 200 us per launch, profiles/r02_call14_*, r02_call20_*)
-                       // 6: ALL layers per launch with the rows RESIDENT in the out-projection accumulators
-                       //    (kernels_stack.hip, default: 4 x 199 -> 743..766 us per step, profiles/r02_call23_*, r02_call25_*)
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
   int32_t* st_cond_seq = nullptr;
   uint8_t* st_strong = nullptr;
@@ -423,29 +415,22 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     int defaults[5] = {5, 5, 5, 5, 5};
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
-    if (const char* ri = getenv("LDM_ROW_IMPL")) h->row_impl = atoi(ri);
-    if (h->D > 464 || h->Dq != 512 || h->HD != 512 || h->F % 32) h->row_impl = 0;  // row kernels: K <= 512, d_model <= 464
-    if (const char* dl = getenv("LDM_DEFER_LN")) h->defer_ln = atoi(dl);
-    if ((h->row_impl & 7) != 7 || h->D % 16) h->defer_ln = 0;  // needs the row-stationary QKV / out-proj / FFN
-    if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa);
-    if (const char* sh = getenv("LDM_STACK_HEAD")) h->stack_head = atoi(sh);
+    if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa) == 0 ? 0 : 6;
     if (const char* sp = getenv("LDM_STACK_LOOP")) h->stack_loop = atoi(sp);
-    // per-layout kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row
-    // (its exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128
-    if (!h->defer_ln || h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464) h->fused_attn = 0;
-    if (h->fused_attn >= 3 && (h->H != 8 || h->F % 32 || h->F > 2048)) h->fused_attn = 2;  // fused layer: 8 heads, LDS budget
-    if (h->fused_attn == 4) h->fused_attn = 6;  // (4 was the r02 tile-by-tile multi-layer experiment: +0.4 % only, removed; profiles/r02_call12_*)
-    if (h->fused_attn == 3) h->fused_attn = 5;  // (3 was the first one-launch-per-layer kernel, superseded by the stream version)
-    if (h->fused_attn == 6 && h->L > 8) h->fused_attn = 5;   // FusedLayerSet holds 8 layers
+    // stack kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row (its
+    // exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128; d_model 464 in 8 heads, K padded to 512
+    if (h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464 || h->Dq != 512 || h->HD != 512 || h->H != 8 ||
+        h->F % 32 || h->F > 2048 || h->L > 8 || h->Cp % 32)
+      h->fused_attn = 0;
     A(&h->att16, Mp * h->HD);
     A(&h->qkv16, Mp * 3 * h->HD);
     A(&h->stats_a, Mp);
     A(&h->stats_b, Mp);
-    if (!h->defer_ln) {  // LayerNorm outputs only exist on the non-deferred path
+    if (h->fused_attn == 0) {  // LayerNorm outputs and the FFN hidden activation only exist on the generic path
       A(&h->a16, Mp * h->Dq);
       A(&h->h16, Mp * h->Dq);
+      A(&h->hid16, Mp * h->Fq);
     }
-    if (!(h->row_impl & 4)) A(&h->hid16, Mp * h->Fq);  // FFN hidden only without the fused FFN kernel
   } else {
     A(&h->a16, Mc * h->Dp);
     A(&h->att16, Mc * h->Dp);
@@ -605,8 +590,8 @@ static int pack_w16(ldm_handle* h, const float* d_src, int N, int K, int Np, int
   return 0;
 }
 
-// ---- LDS-image weight streams (kernels_rowgemm.hip ffn_fused2_k / kernels_fusedattn.hip qkv_attn_k): the fused
-// kernels copy their weights global -> LDS with linear 1-KiB DMA instructions, so the global copy is stored in
+// ---- LDS-image weight streams: the stack kernel
+// copies their weights global -> LDS with linear 1-KiB DMA instructions, so the global copy is stored in
 // consumption order with the LDS bank swizzle already applied.
 static std::vector<uint16_t> download16(ldm_handle* h, const __half* d, size_t n, int* rc) {
   std::vector<uint16_t> v(n);
@@ -626,9 +611,6 @@ static int upload_image(ldm_handle* h, const std::vector<uint16_t>& img, void** 
   return 0;
 }
 // (index maps and image packers: ldm_pack.h — pure C++, unit-tested on the CPU by tests/cpu_pack_check.cpp)
-using ldm_pack::pack_attn_image;
-using ldm_pack::pack_attn_slab_image;
-using ldm_pack::pack_ffn_image;
 
 static int build_fast_weights(ldm_handle* h) {
   const int D = h->D, F = h->F, C = h->C, H = h->H, dh = h->dh, HD = h->HD, Dq = h->Dq, Fq = h->Fq;
@@ -637,58 +619,46 @@ static int build_fast_weights(ldm_handle* h) {
   auto qkv_row = [=](int n) { return ldm_pack::qkv_row(n, D, H, dh); };
   // out_proj column k = head*dh + d -> head*64 + d (matches the attention kernel's output layout)
   auto head_col = [=](int k) { return ldm_pack::head_col(k, dh); };
+  auto kslot = [](int k) { return ldm_pack::kslot(k); };
+  const bool stack = h->fused_attn == 6;  // (geometry checked in ldm_create)
   h->fast.assign(h->L, ldm_handle::FastLayer{});
   int rc;
   for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
     ldm_handle::FastLayer& f = h->fast[i];
-    if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, id, &f.w_in))) return rc;
-    if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_col, &f.w_out))) return rc;
-    if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, id, &f.w1))) return rc;
-    if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, id, &f.w2))) return rc;
-    // fused FFN: K axis of W2 in MFMA k-slot order inside every 32-wide hidden chunk:
-    // position 16s + 8g + e  <-  hidden 16s + 8(e>>2) + 4g + (e&3)   (kernels_rowgemm.hip)
-    auto kslot = [](int k) { return ldm_pack::kslot(k); };
-    if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &f.w2p))) return rc;
-    // fused attention block: the attention rows come back in accumulator (k-slot) order per head d-tile
-    auto head_kslot = [=](int k) { return kslot(head_col(k)); };
-    if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_kslot, &f.w_out_ks))) return rc;
-    if (Dq == 512 && HD == 512 && F % 32 == 0 && D <= 480) {  // geometry of the fused kernels
-      const std::vector<uint16_t> h1 = download16(h, f.w1, (size_t)F * Dq, &rc);
+    if (!stack) {  // head-padded fp16 copies for the generic tiled GEMMs + attention16
+      if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, id, &f.w_in))) return rc;
+      if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_col, &f.w_out))) return rc;
+      if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, id, &f.w1))) return rc;
+      if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, id, &f.w2))) return rc;
+    } else {
+      // LDS images of the stack kernel.  K axes in MFMA k-slot order (position 16s + 8g + e <- index 16s + 8(e>>2) + 4g +
+      // (e&3)): a lane's accumulator-layout registers of column groups 2ks, 2ks+1 ARE its fragment of k16-step ks
+      __half *w1p = nullptr, *w2p = nullptr, *w_in_ks = nullptr, *w_out_ks = nullptr;
+      auto head_kslot = [=](int k) { return kslot(head_col(k)); };
+      if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, kslot, &w1p))) return rc;
+      if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &w2p))) return rc;
+      if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, kslot, &w_in_ks))) return rc;
+      if ((rc = pack_w16(h, w.w_out, D, D, round_up(D, 256), HD, id, head_kslot, &w_out_ks))) return rc;
+      const std::vector<uint16_t> h1p = download16(h, w1p, (size_t)F * Dq, &rc);
       if (rc) return rc;
-      const std::vector<uint16_t> h2 = download16(h, f.w2p, (size_t)round_up(D, 256) * Fq, &rc);
+      const std::vector<uint16_t> h2 = download16(h, w2p, (size_t)round_up(D, 256) * Fq, &rc);
       if (rc) return rc;
-      if ((rc = upload_image(h, pack_ffn_image(h1.data(), h2.data(), Fq, F, 480), &f.ffn_img))) return rc;
-      {  // W1 with the K axis in k-slot order (fused FFN version 2: fragments built from accumulator-layout loads)
-        __half* w1p = nullptr;
-        if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), Dq, id, kslot, &w1p))) return rc;
-        const std::vector<uint16_t> h1p = download16(h, w1p, (size_t)F * Dq, &rc);
-        if (rc) return rc;
-        const std::vector<uint16_t> ks = pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480);
-        if ((rc = upload_image(h, ks, &f.ffn_img_ks))) return rc;
-        if ((rc = upload_image(h, ldm_pack::pack_ffn_image_pipelined(ks, F / 32), &f.ffn_img_pipe))) return rc;
-      }
-      const std::vector<uint16_t> hin = download16(h, f.w_in, (size_t)3 * HD * Dq, &rc);
+      const std::vector<uint16_t> ffn = ldm_pack::pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480);
+      if ((rc = upload_image(h, ldm_pack::pack_ffn_image_pipelined(ffn, F / 32), &f.ffn_img_pipe))) return rc;
+      const std::vector<uint16_t> hin_ks = download16(h, w_in_ks, (size_t)3 * HD * Dq, &rc);
       if (rc) return rc;
-      const std::vector<uint16_t> hout = download16(h, f.w_out_ks, (size_t)round_up(D, 256) * HD, &rc);
+      const std::vector<uint16_t> hout = download16(h, w_out_ks, (size_t)round_up(D, 256) * HD, &rc);
       if (rc) return rc;
-      if ((rc = upload_image(h, pack_attn_image(hin.data(), hout.data(), H, 15), &f.attn_img))) return rc;
-      if (H == 8 && (rc = upload_image(h, pack_attn_slab_image(hin.data(), hout.data(), H), &f.attn_slab_img))) return rc;
-      if (H == 8) {  // in_proj with the K axis in k-slot order: fragments built from accumulator-layout registers
-        __half* w_in_ks = nullptr;
-        if ((rc = pack_w16(h, w.w_in, 3 * D, D, round_up(3 * HD, 256), Dq, qkv_row, kslot, &w_in_ks))) return rc;
-        const std::vector<uint16_t> hin_ks = download16(h, w_in_ks, (size_t)3 * HD * Dq, &rc);
-        if (rc) return rc;
-        const std::vector<uint16_t> slab_ks = pack_attn_slab_image(hin_ks.data(), hout.data(), H);
-        if ((rc = upload_image(h, ldm_pack::pack_attn_head_image(slab_ks, H), &f.attn_head_img_ks))) return rc;
-      }
+      const std::vector<uint16_t> slab_ks = ldm_pack::pack_attn_slab_image(hin_ks.data(), hout.data(), H);
+      if ((rc = upload_image(h, ldm_pack::pack_attn_head_image(slab_ks, H), &f.attn_head_img_ks))) return rc;
     }
     std::vector<float> b(3 * D), bp((size_t)3 * HD, 0.f);
     HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
     for (int n = 0; n < 3 * D; ++n) bp[qkv_row(n)] = b[n];
     if ((rc = h->dalloc(&f.b_in, bp.size(), false))) return rc;
     HIP_OK(h, hipMemcpy(f.b_in, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
-    {
+    if (stack) {
       // softmax rows sum to 1, so P (V + 1 b_v^T) = P V + 1 b_v^T and the V bias reaches the block output as the
       // constant W_out b_v: folded into the out-projection bias once, here (fp64 accumulate)
       std::vector<float> wo((size_t)D * D), bo(D), bov(D);
@@ -703,13 +673,12 @@ static int build_fast_weights(ldm_handle* h) {
       HIP_OK(h, hipMemcpy(f.b_out_v, bov.data(), bov.size() * 4, hipMemcpyHostToDevice));
     }
   }
-  if (Dq == 512 && D <= 480) {
+  if (stack) {
     __half* hk = nullptr;
-    auto kslot = [](int k) { return ldm_pack::kslot(k); };
     if ((rc = pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, kslot, &hk))) return rc;
     const std::vector<uint16_t> hh = download16(h, hk, (size_t)round_up(C, 256) * Dq, &rc);
     if (rc) return rc;
-    if ((rc = upload_image(h, ldm_pack::pack_head_image(hh.data(), h->Cp / 32), &h->head_img_ks))) return rc;
+    return upload_image(h, ldm_pack::pack_head_image(hh.data(), h->Cp / 32), &h->head_img_ks);
   }
   return pack_w16(h, h->head_w, C, D, round_up(C, 256), Dq, id, id, &h->fast_head);
 }
@@ -851,130 +820,52 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
 // ------------------------------------------------------------------------------------------ one pass
 static double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 
-// fast mode with DEFERRED NORMALISATION: no LayerNorm kernel, no LN output tensor.  Producers (embedding,
-// out-proj, fused FFN) emit per-row (mean, rstd) next to their fp32 output; consumers (QKV, FFN, head)
-// normalise while loading their register-resident fragments; the out-proj recomputes its residual
-// AdaLN(x) on the fly (the reference adds the residual onto the NORMED x, transformer_utils.py:175-178).
-static int denoise_chunk_fast_deferred(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
-                                       bool skip_embed = false) {
-  const int M = Bc * h->S, D = h->D, F = h->F, Dq = h->Dq, HD = h->HD;
-  if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw) + stats_a   (skipped when the previous step's posterior wrote P)
+// fast mode on the reference's backbone: the stack kernel (kernels_stack.hip) — ONE launch for all layers and the
+// vocabulary head, a layout's rows in its workgroup's out-projection accumulators from the embedding output to the
+// logits.  Normalisation is deferred into the kernel (no LayerNorm launch, no LN output tensor): the embedding writes raw
+// rows, the kernel computes its own row statistics.  (The one-launch reverse loop, run_loop_fused, does not come here: it
+// gathers the embedding itself.)
+static int denoise_chunk_stack(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
+  const int M = Bc * h->S, D = h->D, F = h->F;
+  if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw)   (skipped when the previous step's posterior wrote P)
     LnArgs a{};
     a.tokens = d_tokens; a.emb = h->emb; a.pos = h->pos; a.y32 = h->P; a.stats_out = h->stats_a; a.raw = 1;
-    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = h->Dq;
     ldm_handle::Scope sc(h, st, "embed_stats", 0, (double)M * D * 8);
     launch_layernorm(a, st);
   }
-  if (h->fused_attn == 6) {
-    // the whole stack in ONE launch (kernels_stack.hip): a layout's rows stay in their workgroup's out-projection
-    // accumulators from the embedding output to the input of the head
-    FusedLayerSet ls{};
-    ls.n_layer = h->L;
-    for (int i = 0; i < h->L; ++i) {
-      const LayerW& w = h->layers[i];
-      const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
-      ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
-                            h->fast[i].ffn_img_pipe, w.b1, w.b2, w.g2, w.be2};
-    }
-    // ... and, by default, through the vocabulary head: the kernel then writes logits instead of rows
-    const bool with_head = h->stack_head && h->head_img_ks && h->Cp % 32 == 0;
-    const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
-    ldm_handle::Scope sc(h, st, "layers_fused",
-                         h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
-                                 gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) +
-                             (with_head ? gemm_flops(M, h->C, D) : 0.0),
-                         (double)M * (D * 4 + (with_head ? h->Cp : D) * 4));
-    launch_stack_stream(ls, F, h->P, D, h->stats_a, D, Bc, h->S, h->H, h->dh, with_head ? &hd : nullptr, st);
-    if (with_head) return 0;
-  }
-  for (int i = 0; i < (h->fused_attn == 6 ? 0 : h->L); ++i) {
+  FusedLayerSet ls{};
+  ls.n_layer = h->L;
+  for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
-    const ldm_handle::FastLayer& f = h->fast[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
-    const LnLoad ada{h->P, h->stats_a, ss, ss + D, D, D, 1};
-    if (h->fused_attn == 5) {
-      // the whole layer in one launch, stream version (kernels_layer.hip): continuous per-head / slab pipelines
-      ldm_handle::Scope sc(h, st, "layer_fused",
-                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) +
-                               2 * gemm_flops(M, F, D),
-                           (double)M * D * 12);
-      launch_layer_stream(f.attn_slab_img, f.b_in, ada, f.b_out_v, f.ffn_img_ks, w.b1, w.b2, w.g2, w.be2, F, h->P, D,
-                          h->stats_a, D, Bc, h->S, h->H, h->dh, st);
-      continue;
-    }
-    if (h->fused_attn == 2) {
-      // whole attention block: x1 = AdaLN(x) + MHA(AdaLN(x)) -> Q (+ stats_b)
-      ldm_handle::Scope sc(h, st, "qkv_attention_out",
-                           gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D),
-                           (double)M * (D * 8 + D * 4));
-      launch_attention_block(f.attn_img, f.b_in, ada, h->att16, HD, w.b_out, h->Q, D, h->stats_b, D, Bc, h->S,
-                             h->H, h->dh, st);
-    } else if (h->fused_attn) {
-      ldm_handle::Scope sc(h, st, "qkv_attention", gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
-                           (double)M * (D * 4 + HD * 2));
-      launch_qkv_attention(f.attn_img, f.b_in, ada, h->att16, HD, Bc, h->S, h->H, h->dh, st);
-    } else {
-      // QKV = AdaLN(x)·Win^T + b   (AdaLN applied while loading the fragments)
-      GemmArgs g{};
-      g.W = f.w_in; g.bias = f.b_in; g.C16 = h->qkv16; g.ldc16 = 3 * HD;
-      g.M = M; g.N = 3 * HD; g.K = D; g.lda = Dq; g.ldw = Dq; g.precision = 1;
-      RowExtra ex{};
-      ex.in = ada;
-      {
-        ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * (D * 4 + 3 * HD * 2));
-        launch_rowgemm(g, 0, &ex, st);
-      }
-      ldm_handle::Scope sc2(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
-      launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
-    }
-    if (h->fused_attn != 2) {  // x1 = AdaLN(x) + att·Wo^T + bo -> Q (+ stats_b)
-      GemmArgs g{};
-      g.A = h->att16; g.W = f.w_out; g.bias = w.b_out; g.res = h->P; g.ldres = D; g.C32 = h->Q; g.ldc32 = D;
-      g.M = M; g.N = D; g.K = HD; g.lda = HD; g.ldw = HD; g.precision = 1;
-      RowExtra ex{};
-      ex.res = ada;
-      ex.stats_out = h->stats_b;
-      ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
-      launch_rowgemm(g, 1, &ex, st);
-    }
-    {  // x2 = x1 + FFN(LN2(x1)) -> P (+ stats_a)
-      const LnLoad ln2{h->Q, h->stats_b, w.g2, w.be2, D, D, 0};
-      ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 4 + D * 8));
-      launch_ffn_fused(nullptr, Dq, f.ffn_img, f.ffn_img_ks, w.b1, w.b2, h->Q, h->P, D, M, D, F, &ln2, h->stats_a, st);
-    }
+    ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
+                          h->fast[i].ffn_img_pipe, w.b1, w.b2, w.g2, w.be2};
   }
-  {  // logits = LN_head(x)·Wh^T
-    GemmArgs g{};
-    g.W = h->fast_head; g.C32 = h->logits; g.ldc32 = h->Cp;
-    g.M = M; g.N = h->Cp; g.K = D; g.lda = Dq; g.ldw = Dq; g.precision = 1;
-    RowExtra ex{};
-    ex.in = LnLoad{h->P, h->stats_a, h->head_g, h->head_b, D, D, 0};
-    ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, h->C, D), (double)M * (D * 4 + h->C * 4));
-    launch_rowgemm(g, 4, &ex, st);
-  }
+  const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
+  ldm_handle::Scope sc(h, st, "layers_fused",
+                       h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
+                               gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) + gemm_flops(M, h->C, D),
+                       (double)M * (D * 4 + h->Cp * 4));
+  launch_stack_stream(ls, F, h->P, D, Bc, h->S, h->H, h->dh, hd, st);
   return 0;
 }
 
-// fast mode: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
+// fast mode, every other accepted geometry: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
 static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
                               bool skip_embed = false) {
-  if (h->defer_ln) return denoise_chunk_fast_deferred(h, d_tokens, t, Bc, st, skip_embed);
+  if (h->fused_attn == 6) return denoise_chunk_stack(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
   auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
                   const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
-                  double flops, double bytes, bool row) {
+                  double flops, double bytes) {
     GemmArgs g{};
     g.A = A; g.W = W; g.bias = bias; g.relu = relu; g.res = res; g.ldres = D;
     g.C32 = C32; g.ldc32 = ldc32; g.C16 = C16; g.ldc16 = ldc16;
     const int cfg = h->gemm_cfg[tag];
     g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg)); g.lda = lda; g.ldw = ldw; g.precision = 1;
     ldm_handle::Scope sc(h, st, name, flops, bytes);
-    if (row) {
-      g.K = K;
-      launch_rowgemm(g, tag, nullptr, st);
-    } else {
-      launch_gemm16(g, cfg, tag, st);
-    }
+    launch_gemm16(g, cfg, tag, st);
   };
   for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
@@ -989,13 +880,13 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
       launch_layernorm(a, st);
     }
     gemm("gemm_qkv", 0, h->a16, Dq, D, f.w_in, Dq, 3 * HD, f.b_in, 0, nullptr, nullptr, 0, h->qkv16,
-         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2), (h->row_impl & 1) != 0);
+         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2));
     {
       ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
       launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
     }
     gemm("gemm_attn_out", 1, h->att16, HD, HD, f.w_out, HD, D, w.b_out, 0, h->P, h->Q, D, nullptr, 0,
-         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8), (h->row_impl & 2) != 0);
+         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
     {
       LnArgs a{};
       a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2; a.y16 = h->h16;
@@ -1003,15 +894,10 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
       ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * 6);
       launch_layernorm(a, st);
     }
-    if (h->row_impl & 4) {
-      ldm_handle::Scope sc(h, st, "ffn_fused", 2 * gemm_flops(M, F, D), (double)M * (D * 2 + D * 8));
-      launch_ffn_fused(h->h16, Dq, f.ffn_img, nullptr, w.b1, w.b2, h->Q, h->P, D, M, D, F, nullptr, nullptr, st);
-    } else {
-      gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
-           gemm_flops(M, F, D), (double)M * (D * 2 + F * 2), false);
-      gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
-           gemm_flops(M, D, F), (double)M * (F * 2 + D * 8), false);
-    }
+    gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
+         gemm_flops(M, F, D), (double)M * (D * 2 + F * 2));
+    gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
+         gemm_flops(M, D, F), (double)M * (F * 2 + D * 8));
   }
   {
     LnArgs a{};
@@ -1021,7 +907,7 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
     launch_layernorm(a, st);
   }
   gemm("gemm_head", 4, h->h16, Dq, D, h->fast_head, Dq, h->Cp, nullptr, 0, nullptr, h->logits, h->Cp,
-       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4), (h->row_impl & 8) != 0);
+       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4));
   return 0;
 }
 
@@ -1296,8 +1182,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
 static bool loop_fusable(const ldm_handle* h, const ldm_relation* rel) {
   int live_max = 0;
   for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
-  return h->stack_loop && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6 &&
-         h->stack_head && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
+  return h->stack_loop && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6 && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
          h->T < 32768 && !h->fast.empty() && h->tbl_att_dyn && h->D == 464 && h->F <= 2048;
 }
 
@@ -1531,7 +1416,7 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation
     int32_t* nxt = h->tok_b + off * S;
     // the stack kernel takes raw rows and computes its own row statistics, so the posterior kernel of step i can write
     // step i + 1's embedding itself (no separate embedding launch inside the loop)
-    const bool fuse_embed = !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->defer_ln && h->fused_attn == 6;
+    const bool fuse_embed = !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6;
     for (int i = 0; i < n_steps; ++i) {
       int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st,
                         fuse_embed && i > 0, fuse_embed && i + 1 < n_steps, i);

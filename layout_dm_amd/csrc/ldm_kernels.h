@@ -73,35 +73,6 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);
-// row-stationary kernels (kernels_rowgemm.hip)
-// Deferred normalisation (fast mode): instead of materialising LayerNorm outputs, producers emit per-row
-// (mean, rstd) and consumers normalise while loading their register-resident activation fragments.
-struct LnLoad {
-  const float* x;       // [M, ldx] fp32 un-normalised rows (nullptr: operand is already fp16 in GemmArgs.A)
-  const float2* stats;  // [M] (mean, rstd)
-  const float* p0;      // scale (ada) / gamma   [D]
-  const float* p1;      // shift (ada) / beta    [D]
-  int ldx, D, ada;
-};
-struct RowExtra {
-  LnLoad in;            // LN-on-load of the A operand
-  LnLoad res;           // residual = LN(res.x) recomputed on the fly (out-proj: AdaLN of the layer input)
-  float2* stats_out;    // [M] row statistics of the fp32 output, or nullptr
-};
-void launch_rowgemm(const GemmArgs& g, int tag, const RowExtra* ex, hipStream_t st);
-// img: per-chunk LDS image of W1 | W2 (ldm_pack.h pack_ffn_image); img_ks: the same with W1's K axis in MFMA k-slot
-// order (fused-FFN version 2: the residual row is read once, in accumulator layout), or nullptr
-void launch_ffn_fused(const __half* H, int ldh, const void* img, const void* img_ks, const float* b1, const float* b2,
-                      const float* res, float* out, int ldo, int M, int N, int F, const LnLoad* ln, float2* stats_out,
-                      hipStream_t st);
-int ffn_fused_version();
-// fused QKV projection + attention, one workgroup per layout (kernels_fusedattn.hip)
-void launch_qkv_attention(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo, int B, int S,
-                          int H, int dh, hipStream_t st);
-// same + out-projection, AdaLN residual and row statistics (Wout_ks: K axis head-padded + k-slot order)
-void launch_attention_block(const void* img, const float* bias, const LnLoad& ln, __half* att, int ldo,
-                            const float* b_out, float* C32, int ldc, float2* stats_out, int N,
-                            int B, int S, int H, int dh, hipStream_t st);
 // per-layer weights of the stack kernel (all device pointers)
 struct FusedLayerW {
   const void* img;        // ldm_pack::pack_attn_head_image (in_proj K axis in k-slot order)
@@ -115,11 +86,6 @@ struct FusedLayerSet {
   FusedLayerW w[8];
   int n_layer;
 };
-// one whole transformer layer per launch, in place on x / stats_io, as continuous per-head / slab streams
-// (kernels_layer.hip): img = ldm_pack::pack_attn_slab_image, ffn_img = pack_ffn_image with W1's K axis in k-slot order
-void launch_layer_stream(const void* img, const float* bias, const LnLoad& ln, const float* b_out, const void* ffn_img,
-                         const float* b1, const float* b2, const float* g2, const float* be2, int F, float* x, int ldx,
-                         float2* stats_io, int N, int B, int S, int H, int dh, hipStream_t st);
 // the whole stack in one launch with the rows resident in the out-projection accumulators (kernels_stack.hip):
 // ls.w[i].img = ldm_pack::pack_attn_head_image, .b_out = out_proj bias + W_out b_v
 // head != nullptr: the vocabulary head (LayerNorm + Linear without bias) runs in the same workgroups and the kernel
@@ -131,8 +97,8 @@ struct StackHead {
   float* logits;
   int ldl, n_tiles;
 };
-void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, float2* stats_io, int N, int B, int S, int H,
-                         int dh, const StackHead* head, hipStream_t st);
+void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int B, int S, int H, int dh,
+                         const StackHead& head, hipStream_t st);
 // ... and the whole reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): tokens in / out through
 // post->tokens / post->tokens_out, the step's tail (ldm_post_token.h) behind the vocabulary head on the logits in LDS.
 // ls.w[i].ada_scale / ada_shift are ignored: the AdaLN rows of step i come from adaln[t_model[i]].
@@ -160,7 +126,6 @@ constexpr int kStackPostMaxLive = 48;
 constexpr int kStackLoopMaxSteps = 128;  // timesteps travel in the kernel arguments
 void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
                        const StackLoop& lp, hipStream_t st);
-int layer_stream_debug();  // LDM_LAYER_DBG (A/B aid): bit 0 = compiler-scheduled attention core
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,

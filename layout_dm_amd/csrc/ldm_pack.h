@@ -6,7 +6,7 @@
 //   head_col   out_proj col k = head*dh + d            ->  head*64 + d
 //   kslot      MFMA k-slot order inside every 32-wide K chunk: position 16s + 8g + e holds logical 16s + 8(e>>2) + 4g + (e&3),
 //              i.e. the accumulator layout of v_mfma_f32_32x32x16_f16 (lane half g, register 8s + e) IS the B operand
-//              of the next MFMA (kernels_rowgemm.hip fused FFN GEMM2, kernels_fusedattn.hip out-projection)
+//              of the next MFMA (FFN GEMM2 and the out-projection slabs of the stack kernel)
 // LDS images: global memory holds exactly what the kernels want in LDS (tiles in consumption order, bank swizzle
 // applied), so the weight stream is a linear copy.
 #pragma once
@@ -85,7 +85,7 @@ inline std::vector<uint16_t> pack_attn_image(const uint16_t* w_in, const uint16_
   return img;
 }
 
-// Attention image of the fused layer kernel (kernels_layer.hip): the 6H in_proj tiles as in pack_attn_image, then the
+// Attention image in slab form (the building block of pack_attn_head_image): the 6H in_proj tiles as in pack_attn_image, then the
 // out-projection as 16 K-SLABS (one per 32-wide k chunk c = (head, d-half)): 480 output rows x 64 B, 16-B chunk L of
 // row n at physical chunk L ^ ((n >> 2) & 3) — the W2-slab format of the fused FFN, so the out-projection runs as
 // 30 independent-accumulator MFMAs per slab over 15 persistent output tiles — then one zero stage (last prefetch).

@@ -1,5 +1,4 @@
-// Device-side building blocks shared by the row-stationary kernels (kernels_rowgemm.hip, kernels_fusedattn.hip,
-// kernels_layer.hip): hand-issued LDS reads with counted waits, the weight-tile pipeline of the attention block and
+// Device-side building blocks of the stack kernel (kernels_stack.hip): hand-issued LDS reads with counted waits, the weight-tile pipeline of the attention block and
 // the continuous chunk pipeline of the fused FFN.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -326,66 +325,7 @@ struct FfnStream {
 };
 
 // ------------------------------------------------------------------------------------------------
-// SlabPipe: one 32-wide k chunk of the out-projection in K-SLAB form (fused layer kernel): 2 x NT2 MFMAs on NT2
-// independent accumulator tiles — A = the slab's rows of output tile t (LDS, W2-slab format of ldm_pack.h),
-// B = the chunk's two register-resident attention-output fragments — with the next slab's 32-KiB DMA interleaved.
-template <int NT2, int PF>
-struct SlabPipe {
-  static constexpr int NIT = 2 * NT2;
-  f16x8 q[PF];
-  unsigned aS[2];
-  f32x16* acc;
-  const char* gnext;  // image of the next slab + wave*8 KiB (uniform)
-  unsigned mnext;     // LDS byte address of the next stage + wave*8 KiB (uniform)
-  unsigned voff;      // lane*16
-
-  template <int J>
-  __device__ __forceinline__ void dma_m0() {
-    if constexpr (J < 8 && (J & 3) == 0) dma_set_m0(mnext + (J >> 2) * 4096);
-  }
-  template <int J>
-  __device__ __forceinline__ void dma_slot() {
-    if constexpr (J < 8) dma_lin<(J & 3) * 1024>(voff, gnext + (J >> 2) * 4096);
-  }
-  template <int IT>
-  __device__ __forceinline__ void read_item() {
-    constexpr int sx = IT / NT2, t = IT % NT2;
-    dsr128<t * 2048>(q[IT % PF], aS[sx]);
-  }
-  template <int IT>
-  __device__ __forceinline__ void step(const f16x8& b0, const f16x8& b1) {
-    if constexpr (IT < NIT) {
-      constexpr int after = (NIT - 1 - IT) < (PF - 1) ? (NIT - 1 - IT) : (PF - 1);
-      wait_lgkm<after>();
-      __builtin_amdgcn_sched_barrier(0);
-      constexpr int sx = IT / NT2, t = IT % NT2;
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[IT % PF], sx ? b1 : b0, acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (IT + PF < NIT) read_item<IT + PF>();
-      if constexpr (IT % 2 == 1) dma_slot<IT / 2>();
-      else dma_m0<IT / 2>();
-      step<IT + 1>(b0, b1);
-    }
-  }
-  template <int IT>
-  __device__ __forceinline__ void prologue() {
-    if constexpr (IT < PF) {
-      read_item<IT>();
-      prologue<IT + 1>();
-    }
-  }
-  __device__ __forceinline__ void run(const f16x8& b0, const f16x8& b1) {
-    prologue<0>();
-    step<0>(b0, b1);
-  }
-};
-
-}  // namespace ldm
-
-namespace ldm {
-
-// ------------------------------------------------------------------------------------------------
-// HeadStream (kernels_layer.hip): the six in_proj tiles of ONE head (k0 k1 v0 v1 q0 q1, 29 k-steps each) as ONE
+// HeadStream: the six in_proj tiles of ONE head (k0 k1 v0 v1 q0 q1, 29 k-steps each) as ONE
 // continuous LDS-read / MFMA pipeline of 174 items.
 //
 // TilePipe restarts its read queue at every tile (s_barrier, PF exposed fragment reads, 29 MFMAs, then an epilogue
@@ -553,77 +493,6 @@ struct HeadStream {
     }
   }
 };
-
-// ------------------------------------------------------------------------------------------------
-// SlabStream: the 16 K-slabs of the out-projection (2 x NT2 MFMAs on NT2 independent accumulator tiles each, see
-// SlabPipe) as one continuous pipeline of 16 x 30 items on the same three-stage ring (slab c in stage (S0 + c) % 3,
-// DMA two slabs ahead, vmcnt(8) + s_barrier per slab).
-template <int NT2, bool TM = false, int PFQ = 6>
-struct SlabStream {
-  static constexpr int NIT = 2 * NT2, PF = PFQ, NS = 16, SYNC = NIT - PF;
-  static_assert(NIT % PF == 0, "queue slots line up across slabs");
-  f16x8 q[PF];
-  unsigned aS[2], aS2[2];  // stage 0 (stage 1: + offset) / stage 2
-  f32x16* acc;
-  const f16x8* of;      // [32] B fragments: slab c uses of[2c], of[2c + 1]
-  const char* gimg;     // image of slab 0 + wave * 8 KiB (uniform)
-  unsigned lds_w;       // lds0 + wave * 8 KiB
-  unsigned voff;
-  unsigned long long t_sync = 0;
-
-  template <int G, int S0>
-  __device__ __forceinline__ void read_item() {
-    constexpr int IT = G % NIT, sx = IT / NT2, t = IT % NT2, ST = (S0 + G / NIT) % 3;
-    if constexpr (ST == 2) dsr128<t * 2048>(q[G % PF], aS2[sx]);
-    else dsr128<t * 2048 + ST * TILE_STAGE>(q[G % PF], aS[sx]);
-  }
-  template <int G, int S0>
-  __device__ __forceinline__ void step() {
-    if constexpr (G < NS * NIT) {
-      constexpr int C = G / NIT, IT = G % NIT, sx = IT / NT2, t = IT % NT2;
-      constexpr int left = NS * NIT - 1 - G;
-      wait_lgkm<(left < PF - 1 ? left : PF - 1)>();
-      __builtin_amdgcn_sched_barrier(0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q[G % PF], of[2 * C + sx], acc[t], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (IT == SYNC && C + 1 < NS) {
-        unsigned long long tA = 0;
-        if constexpr (TM) tA = __builtin_amdgcn_s_memtime();
-        if constexpr (C + 2 < NS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 youngest: slab C + 2
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (TM) t_sync += __builtin_amdgcn_s_memtime() - tA;
-      }
-      if constexpr (G + PF < NS * NIT) read_item<G + PF, S0>();
-      if constexpr (C + 2 < NS) {
-        constexpr unsigned st = (unsigned)((S0 + C + 2) % 3) * TILE_STAGE;
-        if constexpr (IT == 0) dma_set_m0(lds_w + st);
-        if constexpr (IT == 5) dma_set_m0(lds_w + st + 4096);
-        if constexpr (IT >= 1 && IT <= 4) dma_lin<(IT - 1) * 1024>(voff, gimg + (size_t)(C + 2) * TILE_STAGE);
-        if constexpr (IT >= 6 && IT <= 9) dma_lin<(IT - 6) * 1024>(voff, gimg + (size_t)(C + 2) * TILE_STAGE + 4096);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      step<G + 1, S0>();
-    }
-  }
-  template <int I, int S0>
-  __device__ __forceinline__ void prologue() {
-    if constexpr (I < PF) {
-      read_item<I, S0>();
-      prologue<I + 1, S0>();
-    }
-  }
-  template <int S0>
-  __device__ __forceinline__ void run() {
-    prologue<0, S0>();
-    step<0, S0>();
-  }
-};
-
-}  // namespace ldm
-
-namespace ldm {
 
 // ------------------------------------------------------------------------------------------------
 // Building blocks of the STACK kernel (kernels_stack.hip): the out-projection accumulators (240 AGPRs) stay alive

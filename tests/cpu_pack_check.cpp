@@ -1,5 +1,5 @@
 // CPU unit test of the weight repacking (layout_dm_amd/csrc/ldm_pack.h) against the read formulas of the fused
-// kernels (kernels_rowgemm.hip ffn_fused2_k, kernels_fusedattn.hip qkv_attn_k).  Compiled with plain g++ by
+// kernels (csrc/ldm_pipes.h: the pipelines of kernels_stack.hip).  Compiled with plain g++ by
 // tests/test_pack_images.py.  Weights are filled with unique 16-bit ids so every fetched element can be identified.
 //
 // What the kernels do (restated here):
@@ -143,7 +143,7 @@ int main() {
       const uint16_t* stage = sl.data() + (size_t)(48 + c) * 16384;
       const int h = c >> 1, dt = c & 1;
       for (int t = 0; t < 15; ++t) for (int r = 0; r < 32; ++r) for (int hi = 0; hi < 2; ++hi) for (int sx = 0; sx < 2; ++sx) {
-        const int byte = t * 2048 + r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);  // kernels_layer.hip slab read
+        const int byte = t * 2048 + r * 64 + (((2 * sx + hi) ^ ((r >> 2) & 3)) << 4);  // SlabPair slab read (ldm_pipes.h)
         const uint16_t* p = stage + byte / 2;
         const int n = t * 32 + r;
         for (int e = 0; e < 8; ++e) {

@@ -63,7 +63,7 @@ def _regs(tok: str):
     return {(m.group(1), int(m.group(2)))} if m else set()
 
 
-@pytest.mark.parametrize("src,kernel_substr", [("kernels_stack.hip", "stack_stream_k"), ("kernels_layer.hip", "layer_stream_k")])
+@pytest.mark.parametrize("src,kernel_substr", [("kernels_stack.hip", "stack_stream_k")])
 def test_stream_kernels_no_spills_no_valu_mfma_hazard(tmp_path, src, kernel_substr):
     asm = _compile(src, tmp_path)
     kernels = {k: v for k, v in _kernels(asm).items() if kernel_substr in k}

@@ -33,5 +33,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 150 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o run -- python $ROOT/tools/pmc_probe.py > $OUT/pmc_$c.log 2>&1
 done
 cd $ROOT
-python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; grep -A3 "ffn_fused2\|qkv_attn\|posterior\|rowgemm_k\|ln_rows" $OUT/pmc_summary.txt | head -60
+python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; grep -A3 "stack_stream\|posterior\|ln_rows" $OUT/pmc_summary.txt | head -60
 rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE

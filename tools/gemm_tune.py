@@ -1,4 +1,4 @@
-"""Dev tool: time every fp16 GEMM tile configuration on the denoiser's shapes (MI355X only)."""
+"""Dev tool: time the fp16 tile configurations of the generic fast path (gemm16) on the denoiser's shapes (MI355X only)."""
 import ctypes as C
 import json
 import os
@@ -11,7 +11,7 @@ lib = load_library()
 lib.ldm_dev_bench_gemm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16000
 shapes = {"qkv": (1536, 464), "attn_out": (464, 512), "ffn1": (1856, 464), "ffn2": (464, 1856), "head": (155, 464)}
-cfgs = [5, 6, 100]
+cfgs = [5, 6]
 out = {}
 for name, (N, K) in shapes.items():
     for cfg in cfgs:
@@ -20,9 +20,4 @@ for name, (N, K) in shapes.items():
         tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0.0
         out[f"{name}/cfg{cfg}"] = {"ms": round(ms.value, 4), "TF": round(tf, 1), "rc": rc}
         print(f"{name:9s} M={M} N={N} K={K} cfg{cfg}: {ms.value:.4f} ms  {tf:7.1f} TF  rc={rc}", flush=True)
-ms = C.c_float()
-rc = lib.ldm_dev_bench_gemm(M, 464, 464, 101, 20, C.byref(ms))
-tf = 2.0 * 2.0 * M * 464 * 1856 / (ms.value * 1e-3) / 1e12 if rc == 0 and ms.value > 0 else 0.0
-print(f"ffn_fused M={M}: {ms.value:.4f} ms  {tf:7.1f} TF  rc={rc}", flush=True)
-out["ffn_fused"] = {"ms": round(ms.value, 4), "TF": round(tf, 1), "rc": rc}
 json.dump(out, open(os.path.join("gpurun_out", f"gemm_tune_M{M}.json"), "w"), indent=1)

@@ -1,6 +1,6 @@
 """Dev tool (GPU box): A/B timing of kernel variants selected by environment variables.
 
-    python tools/kernel_ab.py "LDM_ATTN_V=0 LDM_FFN_V=0" "LDM_ATTN_V=3" "LDM_ATTN_V=3 LDM_ATTN_SKEW=1" ...
+    python tools/kernel_ab.py "LDM_FUSED_ATTN=6" "LDM_FUSED_ATTN=0" "LDM_HIP_LIB=tools/ab/libldm_hip_prev.so" ...
 
 Every configuration runs in its own process (the variants are latched in static initialisers): one eager,
 event-profiled denoiser pass at B=512 (the bench workload's launch shapes) repeated a few times; prints the

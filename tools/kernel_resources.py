@@ -1,7 +1,7 @@
 """Dev tool (no GPU needed): compile one csrc/*.hip for gfx950 and print, per kernel, the register / scratch /
 LDS budget hipcc reports (-Rpass-analysis=kernel-resource-usage), plus the assembly when asked.
 
-    python tools/kernel_resources.py kernels_fusedattn.hip [name-filter] [--asm out.s]
+    python tools/kernel_resources.py kernels_stack.hip [name-filter] [--asm out.s]
 
 A non-zero "scratch" or "spill" column on a fused kernel is a bug: these kernels are written to live exactly inside
 the 512-register file of one wave per SIMD."""
