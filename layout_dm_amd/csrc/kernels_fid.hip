@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void fid_features_k(FidArgs a) {
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int N = a.N, S = N + 1;
+  // The column kernels below accumulate over all FID_MAXS rows whatever S is (their results for rows >= S are
+  // discarded): zero every activation buffer once so that those rows are defined values, not whatever the LDS held.
+  for (int i = tid; i < (int)((ao + FID_MAXS * FID_D + 512) - sm); i += 256) sm[i] = 0.f;
+  __syncthreads();
 
   // ---- embedding: [fc_bbox(bbox) | emb_label(label)] -> enc_fc_in -> relu   (rows 1..N), row 0 = token
   for (int i = tid; i < N * 512; i += 256) {

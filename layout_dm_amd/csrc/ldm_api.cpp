@@ -691,7 +691,7 @@ static int build_fast_weights(ldm_handle* h) {
 //   head               kStackTblAttDyn floats      head LayerNorm gamma | beta | 0      (takes the att_dyn slot behind the last layer)
 static int build_loop_tables(ldm_handle* h) {
   const int D = h->D, F = h->F, L = h->L, T = h->T;
-  if (h->H * 64 * 3 != kStackTblAttStatic || D > 512 || F > 2048) return 0;  // geometry the loop kernel does not cover
+  if (h->fused_attn != 6 || h->H * 64 * 3 != kStackTblAttStatic || D > 512 || F > 2048) return 0;  // not on the stack kernel
   std::vector<float> ada((size_t)T * L * 2 * D);
   HIP_OK(h, hipDeviceSynchronize());  // (the AdaLN table kernels)
   HIP_OK(h, hipMemcpy(ada.data(), h->adaln, ada.size() * 4, hipMemcpyDeviceToHost));
@@ -1494,10 +1494,22 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       if (ne < 0) return h->fail(-1, "ldm_relation: edge offsets are not monotonic");
       if (!h->st_rel_off && (rc = h->dalloc(&h->st_rel_off, (size_t)h->cfg.max_batch + 1))) return rc;
       if (!h->st_rel_centres && (rc = h->dalloc(&h->st_rel_centres, (size_t)4 * h->cfg.n_bin))) return rc;
-      if ((size_t)ne > h->st_rel_cap) {  // (a grown buffer has a new address: graphs keyed on the old one miss)
+      if ((size_t)ne > h->st_rel_cap) {
+        // a grown buffer has a new address: graphs keyed on the old one can never hit again — drop them and release
+        // the old staging buffer (the stream was synchronised just above, nothing is reading it)
+        int32_t* old = h->st_rel_edges;
         const size_t cap = std::max<size_t>(1024, (size_t)ne * 2);
         if ((rc = h->dalloc(&h->st_rel_edges, 3 * cap))) return rc;
         h->st_rel_cap = cap;
+        if (old) {
+          for (size_t gi = h->graphs.size(); gi-- > 0;)
+            if (h->graphs[gi].key.rel_edges == old) {
+              h->graphs[gi].destroy();
+              h->graphs.erase(h->graphs.begin() + gi);
+            }
+          h->owned.erase(std::remove(h->owned.begin(), h->owned.end(), (void*)old), h->owned.end());
+          (void)hipFree(old);
+        }
       }
       for (auto& o : off) o -= e0;
       HIP_OK(h, hipMemcpyAsync(h->st_rel_off, off.data(), (size_t)(B + 1) * 4, hipMemcpyHostToDevice, st));

@@ -98,6 +98,9 @@ class FIDNetV3:
         pm = padding_mask.to(device=self.device, dtype=torch.uint8).contiguous()
         B, N = label.shape
         assert bbox.shape == (B, N, 4) and pm.shape == (B, N)
+        if B and (int(label.min()) < 0 or int(label.max()) >= self.num_label):
+            # nn.Embedding raises on such an index (fid/model.py:128); the kernel would clamp it silently
+            raise IndexError(f"label out of range [0, {self.num_label}): min {int(label.min())}, max {int(label.max())}")
         feat = torch.empty((B, self.d_model), dtype=torch.float32, device=self.device)
         self._check(self.lib.ldm_fid_features(self._h, bbox.data_ptr(), label.data_ptr(), pm.data_ptr(), B, N,
                                               feat.data_ptr(), _stream_ptr(self.device)), "ldm_fid_features")
@@ -116,7 +119,13 @@ def load_fidnet_v3(dataset, weight_dir: str, device=None) -> FIDNetV3:
     ckpt_path = os.path.join(weight_dir, prefix, "model_best.pth.tar")
     dev = device.index if isinstance(device, torch.device) else device
     model = FIDNetV3(num_label=dataset.num_classes, max_bbox=dataset.max_seq_length, device=dev)
-    x = torch.load(ckpt_path, map_location="cpu")
+    try:  # the reference opens the checkpoint through fsspec (model.py:187-189): gs:// and s3:// weight dirs work there
+        import fsspec
+
+        with fsspec.open(ckpt_path, "rb") as f:
+            x = torch.load(f, map_location="cpu", weights_only=False)
+    except ImportError:
+        x = torch.load(ckpt_path, map_location="cpu", weights_only=False)
     model.load_state_dict(x["state_dict"])
     return model.eval()
 
