@@ -81,7 +81,7 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&
 constexpr int F32_BK = 16;
 constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-free b128 reads
 
-__global__ __launch_bounds__(256) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
                                                         int lda, int ldw, int K, int tiles_n, EpiArgs e) {
   __shared__ __attribute__((aligned(16))) float As[2][128][F32_LD];
   __shared__ __attribute__((aligned(16))) float Ws[2][128][F32_LD];
