@@ -238,6 +238,38 @@ struct Draw {
 // (tests/test_hip_parity.py::test_strong_mask_shortcut_is_an_identity).
 LDM_PT_HD bool strong_shortcut(const TokenArgs& a) { return a.strong && a.cond_tok >= 0 && a.cond_tok < a.n_class; }
 
+// ---- top-k / top-p: walk the candidates o in class order; for the class of each slot j accumulate the probability
+// (and, RANK, the number) of the candidates that precede it in the descending stable order, itself included.
+// Branch-free on purpose: the 16 lanes of a group rarely agree, and selects cost a third of the divergent form.
+template <bool RANK, class M>
+LDM_PT_HD void order_walk(const M& m, const TokenArgs& a, const float (&lg)[M::NJ], const float* sc_lg,
+                          const float* sc_pr, int n_walk, bool cand_all, float (&cum)[M::NJ], int (&rank)[M::NJ]) {
+  constexpr int NJ = M::NJ;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int j = 0; j < NJ; ++j) {
+    cum[j] = 0.f;
+    rank[j] = -1;  // the class itself is counted below (slots without a class are never read)
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4  // (four candidates' scratch reads in flight: with one wavefront per SIMD nothing else hides their latency)
+#endif
+  for (int oi = 0; oi < n_walk; ++oi) {
+    const int o = (M::LIVE || cand_all) ? oi : live_id(a, oi);  // candidate (= scratch) index, increasing with class
+    const float ol = sc_lg[o];
+    const float op = sc_pr[o];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < NJ; ++j) {
+      const bool upto = (ol > lg[j]) | ((ol == lg[j]) & (o <= m.sidx(j)));  // o precedes slot j's class, or is it
+      cum[j] += upto ? op : 0.f;
+      if (RANK) rank[j] += upto ? 1 : 0;
+    }
+  }
+}
+
 // ---- categorical draw over the group's candidates (helpers/sampling.py:81-130).  lp is consumed.
 // sc_lg / sc_pr: scratch of n_cand floats each, private to the group (top-k / top-p only), indexed by candidate.
 // cand_all: the rank loop of top-k / top-p walks every candidate; else (full-vocabulary map on a posterior it computed
@@ -317,45 +349,30 @@ LDM_PT_HD Draw draw_token(const G& g, const M& m, const TokenArgs& a, float (&lp
         sc_pr[m.sidx(j)] = ex[j] / es;
       }
     g.sync();
-    // position in the descending (stable) order and the inclusive cumulative probability up to it
+    // inclusive cumulative probability of every class in the descending (stable) order, and for top-k its position
     float cum[NJ];
     int rank[NJ];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int j = 0; j < NJ; ++j) {
-      cum[j] = 0.f;
-      rank[j] = 0;
-    }
     const int n_walk = (M::LIVE || cand_all) ? m.n_cand(a) : a.count + 2;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 4  // (four candidates' scratch reads in flight: with one wavefront per SIMD nothing else hides their latency)
-#endif
-    for (int oi = 0; oi < n_walk; ++oi) {
-      const int o = (M::LIVE || cand_all) ? oi : live_id(a, oi);  // candidate (= scratch) index, increasing with class
-      const float ol = sc_lg[o];
-      const float op = sc_pr[o];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-      for (int j = 0; j < NJ; ++j) {
-        const int i = m.sidx(j);
-        const bool before = (ol > lg[j]) || (ol == lg[j] && o < i);
-        if (before) {
-          rank[j] += 1;
-          cum[j] += op;
-        } else if (o == i) {
-          cum[j] += op;  // inclusive
-        }
-      }
-    }
     if (a.kind == kTopP) {  // drop every class whose inclusive cumulative probability exceeds p, except the first
+      order_walk<false>(m, a, lg, sc_lg, sc_pr, n_walk, cand_all, cum, rank);
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
       for (int j = 0; j < NJ; ++j)
-        if (cum[j] > a.top_p && rank[j] > 0) lg[j] = -INFINITY;
+        if (m.valid(a, j) && lg[j] > bv) {
+          bv = lg[j];
+          bi = m.sidx(j);
+        }
+      g.gargmax(bv, bi);  // first maximum in class order = position 0
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int j = 0; j < NJ; ++j)
+        if (cum[j] > a.top_p && m.sidx(j) != bi) lg[j] = -INFINITY;
     } else {                // threshold = k-th largest value (sampling.py:73-78)
+      order_walk<true>(m, a, lg, sc_lg, sc_pr, n_walk, cand_all, cum, rank);
       float thr = INFINITY;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
