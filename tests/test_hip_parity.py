@@ -464,6 +464,49 @@ def test_loop_ragged_batches_fast_mode(cuda, B, sampler):
     assert torch.equal(full, torch.cat(parts))
 
 
+def test_fused_loop_t200_spans_two_launches_vs_oracle(cuda):
+    """BASELINE config 5's step count: a T = 200 schedule (alpha_schedule over 200 steps, AdaLN table of 200 timesteps).
+    The loop kernel takes its timesteps in the kernel arguments, 128 per launch (kStackLoopMaxSteps): 200 steps = two
+    launches, the second starting from the tokens of the first with the RNG counter word at 128.  Checked: the loop ==
+    the same steps one ldm_sample_step at a time (same kernel, same state: bit-exact, across the launch seam); the
+    fast loop and the exact-mode loop against the oracle's free-running loop on identical Philox uniforms."""
+    import dataclasses
+
+    from layout_dm_amd.binding import Engine
+
+    spec = dataclasses.replace(SP.RICO25, name="rico25_t200", n_step=200)
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    W = R.as_torch_weights(sd)
+    B = 3
+    steps = R.timestep_list(spec.n_step, 200)
+    assert len(steps) == 200
+    cfg = {"name": "random", "temperature": 1.0}
+    ref = torch.stack(R.sample_loop(W, spec, B, cfg, seed=31, first_layout=70, get_intermediate_results=True)).int()
+    assert ref.shape[0] == 200
+    for precision, bound in (("fast", 5e-3), ("exact", 1e-3)):
+        e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+                   n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision=precision,
+                   max_batch=8)
+        e.load_state_dict(sd)
+        tok = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+        out, inter = e.sample_loop(tok, steps, steps, cfg, seed=31, first_layout=70, intermediates=True, use_graph=True)
+        inter = inter.cpu()
+        assert torch.equal(inter[-1], out.cpu())
+        if precision == "fast":
+            cur = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+            for i, t in enumerate(steps):
+                cur = e.sample_step(cur, t, cfg, seed=31, first_layout=70, step=i)
+                if i in (0, 1, 126, 127, 128, 129, 198, 199):
+                    assert torch.equal(cur.cpu(), inter[i]), i
+        e.close()
+        diff = inter != ref
+        frac = diff.float().mean().item()
+        print(f"[T=200 loop / {precision}] tokens differing from the oracle on identical uniforms: {int(diff.sum())}/"
+              f"{diff.numel()} = {frac:.2e}; first 130 steps: {int(diff[:130].sum())}")
+        assert frac <= bound, frac
+        assert (out.cpu() != spec.mask_id).all()
+
+
 @pytest.mark.parametrize("sampler", ["deterministic", "random", "top_p", "top_k", "gumbel"])
 def test_fused_loop_equals_per_step_path(cuda, monkeypatch, sampler):
     """The shipping fast path — the whole reverse loop of a layout in ONE launch (kernels_stack.hip HEAD == 2: tokens in
