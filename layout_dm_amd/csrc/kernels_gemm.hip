@@ -81,15 +81,20 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&
 constexpr int F32_BK = 16;
 constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-free b128 reads
 
+// Persistent over tiles: the grid is min(tiles, 4 per CU) workgroups and workgroup w walks tiles w, w + grid, ... (the
+// same XCD: grid is a multiple of 8).  A workgroup that moves on to its next tile leaves its 64 epilogue stores to drain
+// from L2 while the next main loop runs, and pays the launch / first-load ramp once instead of once per tile:
+// tools/microbench/gemm32.hip, in_proj 444 -> 364 us, FFN1 507 -> 485 us per chunk (profiles/r03_gemm32_microbench.txt).
 __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
-                                                        int lda, int ldw, int K, int tiles_n, EpiArgs e) {
+                                                        int lda, int ldw, int K, int tiles_n, int n_tiles, EpiArgs e) {
   __shared__ __attribute__((aligned(16))) float As[2][128][F32_LD];
   __shared__ __attribute__((aligned(16))) float Ws[2][128][F32_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  const int tile = xcd_remap(t, n_tiles);
   const int m0 = (tile / tiles_n) * 128;
   const int n0 = (tile % tiles_n) * 128;
 
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
 
   const int nk = K / F32_BK;
   gload(0);
+  if (t != (int)blockIdx.x) __syncthreads();  // the previous tile's last fragment reads of buffer 0
   lstore(0);
   __syncthreads();
   const int frow = lane & 31;
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
     __syncthreads();
   }
   epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  }
 }
 
 // N = 464 (attn-out, FFN2: 45 % of the exact-mode step): 128-wide N tiles cover it with 4 tiles = 512 columns (10 % of the
@@ -383,8 +390,15 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
                          g.ldw, g.K, t160, e);
       return;
     }
-    hipLaunchKernelGGL(gemm_f32_128x128, grid, block, 0, st, (const float*)g.A, (const float*)g.W, g.lda, g.ldw, g.K,
-                       tiles_n, e);
+    static const int resident = [] {  // 4 workgroups per CU (40 KB of LDS, 115 VGPRs)
+      int dev = 0, cus = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      return (4 * cus) & ~7;  // (a multiple of 8: tile t stays on XCD t % 8)
+    }();
+    const int n_tiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL(gemm_f32_128x128, dim3(n_tiles < resident ? n_tiles : resident), block, 0, st, (const float*)g.A,
+                       (const float*)g.W, g.lda, g.ldw, g.K, tiles_n, n_tiles, e);
   } else if (g.precision == 1) {
     hipLaunchKernelGGL(gemm_f16_128x128<1>, grid, block, 0, st, (const __half*)g.A, (const __half*)nullptr,
                        (const __half*)g.W, (const __half*)nullptr, g.lda, g.ldw, g.K, tiles_n, e);
