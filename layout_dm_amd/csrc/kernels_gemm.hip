@@ -81,85 +81,99 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&
 constexpr int F32_BK = 16;
 constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-free b128 reads
 
+// Operands by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VGPR round trip.  One wave
+// instruction fills 1 KiB of LDS linearly, and WHICH (row, 16-byte k segment) lands in a slot is the lane's choice of
+// global address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) makes the ds_read_b128 of 8
+// consecutive rows at one segment hit 8 distinct 16-byte bank groups without padding (32 KB of LDS per workgroup).
 // Persistent over tiles: the grid is min(tiles, 4 per CU) workgroups and workgroup w walks tiles w, w + grid, ... (the
-// same XCD: grid is a multiple of 8).  A workgroup that moves on to its next tile leaves its 64 epilogue stores to drain
-// from L2 while the next main loop runs, and pays the launch / first-load ramp once instead of once per tile:
-// tools/microbench/gemm32.hip, in_proj 444 -> 364 us, FFN1 507 -> 485 us per chunk (profiles/r03_gemm32_microbench.txt).
+// same XCD: grid is a multiple of 8); a workgroup that moves on leaves its 64 epilogue stores to drain from L2 under the
+// next main loop and pays the launch / first-load ramp once.  tools/microbench/gemm32.hip on the four shapes of a layer
+// (M = 32 000): register-staged, one workgroup per tile 414 / 161 / 507 / 527 us -> 334 / 155 / 446 / 475 us, bit-identical
+// (profiles/r03_gemm32_microbench.txt).
 __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
                                                         int lda, int ldw, int K, int tiles_n, int n_tiles, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) float As[2][128][F32_LD];
-  __shared__ __attribute__((aligned(16))) float Ws[2][128][F32_LD];
+  __shared__ __attribute__((aligned(1024))) float L[2][2][128 * F32_BK];  // [buffer][A | W][slot]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-  const int tile = xcd_remap(t, n_tiles);
-  const int m0 = (tile / tiles_n) * 128;
-  const int n0 = (tile % tiles_n) * 128;
-
-  // staging: each thread moves 2 float4 of A and 2 of W per K-tile
-  const int lrow = tid >> 2;  // 0..63
-  const int lc4 = (tid & 3) * 4;
-  float4 ra[2], rw[2];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + lrow + i * 64;
-      const int n = n0 + lrow + i * 64;
-      ra[i] = (m < e.M) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + kt * F32_BK + lc4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-      rw[i] = (n < e.N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + kt * F32_BK + lc4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&As[buf][lrow + i * 64][lc4]) = ra[i];
-      *reinterpret_cast<float4*>(&Ws[buf][lrow + i * 64][lc4]) = rw[i];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
+  const int frow = lane & 31, hi = lane >> 5;
   const int nk = K / F32_BK;
-  gload(0);
-  if (t != (int)blockIdx.x) __syncthreads();  // the previous tile's last fragment reads of buffer 0
-  lstore(0);
-  __syncthreads();
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  const unsigned lds0 = (unsigned)(size_t)&L[0][0][0];
+  // fragment read offsets (bytes inside a [128 x 16] operand image): row base + swizzled segment of k group 0 / 1
+  const int xr = (frow >> 1) & 3;
+  const unsigned fa0 = (unsigned)((wm * 64 + frow) * 64 + 16 * (hi ^ xr)), fa1 = fa0 ^ 32u;
+  const unsigned fb0 = (unsigned)((wn * 64 + frow) * 64 + 16 * (hi ^ xr)), fb1 = fb0 ^ 32u;
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tile = xcd_remap(t, n_tiles);
+    const int m0 = (tile / tiles_n) * 128;
+    const int n0 = (tile % tiles_n) * 128;
+    const float* At = A + (size_t)m0 * lda;
+    const float* Wt = W + (size_t)n0 * ldw;
+    // DMA source offsets (bytes from the tile's first row) of this wave's two instructions per operand: LDS slot
+    // 64 i + lane <- (row, segment).  Rows past M / N are clamped to the last one: their products are never stored.
+    unsigned va[2], vw[2];
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      f32x4 a[2], b[2];
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave + 4 * j, r = 16 * i + (lane >> 2), sg = (lane & 3) ^ ((r >> 1) & 3);
+      va[j] = (unsigned)((min(r, e.M - 1 - m0) * lda + sg * 4) * 4);
+      vw[j] = (unsigned)((min(r, e.N - 1 - n0) * ldw + sg * 4) * 4);
+    }
+    auto dma = [&](int kt, int buf) {
+      const char* ga = reinterpret_cast<const char*>(At + kt * F32_BK);
+      const char* gw = reinterpret_cast<const char*>(Wt + kt * F32_BK);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        a[mi] = *reinterpret_cast<const f32x4*>(&As[buf][wm * 64 + mi * 32 + frow][kg * 8 + fk]);
+      for (int j = 0; j < 2; ++j) {
+        const unsigned la = lds0 + (unsigned)(buf * 2 * 128 * F32_BK * 4) + (unsigned)((wave + 4 * j) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw),
+                     "s"(la + 128 * F32_BK * 4)
+                     : "memory");
+      }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
-        b[ni] = *reinterpret_cast<const f32x4*>(&Ws[buf][wn * 64 + ni * 32 + frow][kg * 8 + fk]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-    if (kt + 1 < nk) lstore(buf ^ 1);
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // (the previous tile's last iteration ended with a barrier: both buffers are free)
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count the DMA in its vmcnt bookkeeping
     __syncthreads();
-  }
-  epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    auto mfmas = [&](int buf) {
+      const char* la = reinterpret_cast<const char*>(&L[buf][0][0]);
+      const char* lb = reinterpret_cast<const char*>(&L[buf][1][0]);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(la + (kg ? fa1 : fa0) + mi * 32 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(lb + (kg ? fb1 : fb0) + ni * 32 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {  // (two iterations per trip: the buffer index is static)
+      if (kt + 1 < nk) dma(kt + 1, 1);
+      mfmas(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) dma(kt + 2, 0);
+        mfmas(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
   }
 }
 
@@ -390,11 +404,13 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
                          g.ldw, g.K, t160, e);
       return;
     }
-    static const int resident = [] {  // 4 workgroups per CU (40 KB of LDS, 115 VGPRs)
-      int dev = 0, cus = 256;
+    static const int resident = [] {  // as many workgroups as the chip holds at once (32 KB of LDS, < 100 VGPRs: 5 per CU)
+      int dev = 0, cus = 256, per_cu = 4;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      return (4 * cus) & ~7;  // (a multiple of 8: tile t stays on XCD t % 8)
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_f32_128x128, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+      if (const char* v = getenv("LDM_GEMM32_SLOTS")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (A/B timing)
+      return (per_cu * cus) & ~7;  // (a multiple of 8: tile t stays on XCD t % 8)
     }();
     const int n_tiles = tiles_m * tiles_n;
     hipLaunchKernelGGL(gemm_f32_128x128, dim3(n_tiles < resident ? n_tiles : resident), block, 0, st, (const float*)g.A,

@@ -9,8 +9,10 @@
 //               a CU reach their epilogues at different times
 //   noepi       base without the epilogue's memory traffic (ablation)      k1: base with ONE k-tile (prologue + epilogue)
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -150,6 +152,207 @@ __global__ __launch_bounds__(256, 4) void g32(const float* __restrict__ A, const
   }
 }
 
+// Distance-2 operand prefetch: the global loads of k-tile kt + 2 are issued at the top of iteration kt into a second
+// register set, the set that arrived during iteration kt - 1 goes to LDS right away (its ds_writes overlap the MFMAs),
+// and the iteration ends with the barrier alone.  +16 VGPRs: OCC workgroups per CU.
+template <int OCC, int PERS>
+__global__ __launch_bounds__(256, OCC) void g32_d2(const float* __restrict__ A, const float* __restrict__ W, int lda, int ldw,
+                                                   int K, int tiles_n, int n_tiles, Epi e) {
+  __shared__ __attribute__((aligned(16))) float As[2][128][LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][128][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 2, lc4 = (tid & 3) * 4;
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const int nk = K / BK;
+  for (int t = blockIdx.x; t < n_tiles; t += PERS ? gridDim.x : n_tiles) {
+    const int tile = xcd_remap(t, n_tiles);
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    f32x4 ra0_0, ra0_1, rw0_0, rw0_1, ra1_0, ra1_1, rw1_0, rw1_1;
+    // rows past M / N are clamped: their products are never stored
+    const float* ap0 = A + (size_t)min(m0 + lrow, e.M - 1) * lda + lc4;
+    const float* ap1 = A + (size_t)min(m0 + lrow + 64, e.M - 1) * lda + lc4;
+    const float* wp0 = W + (size_t)min(n0 + lrow, e.N - 1) * ldw + lc4;
+    const float* wp1 = W + (size_t)min(n0 + lrow + 64, e.N - 1) * ldw + lc4;
+#define G32_GLOAD(kt, RA, RW)                                        \
+  do {                                                               \
+    RA##_0 = *reinterpret_cast<const f32x4*>(ap0 + (kt) * BK);       \
+    RA##_1 = *reinterpret_cast<const f32x4*>(ap1 + (kt) * BK);       \
+    RW##_0 = *reinterpret_cast<const f32x4*>(wp0 + (kt) * BK);       \
+    RW##_1 = *reinterpret_cast<const f32x4*>(wp1 + (kt) * BK);       \
+  } while (0)
+#define G32_LSTORE(buf, RA, RW)                                            \
+  do {                                                                     \
+    *reinterpret_cast<f32x4*>(&As[buf][lrow][lc4]) = RA##_0;               \
+    *reinterpret_cast<f32x4*>(&As[buf][lrow + 64][lc4]) = RA##_1;          \
+    *reinterpret_cast<f32x4*>(&Ws[buf][lrow][lc4]) = RW##_0;               \
+    *reinterpret_cast<f32x4*>(&Ws[buf][lrow + 64][lc4]) = RW##_1;          \
+  } while (0)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    G32_GLOAD(0, ra0, rw0);
+    if (nk > 1) G32_GLOAD(1, ra1, rw1);
+    if (PERS) __syncthreads();
+    G32_LSTORE(0, ra0, rw0);
+    __syncthreads();
+    auto mfmas = [&](int buf) {
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(&As[buf][wm * 64 + mi * 32 + frow][kg * 8 + fk]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(&Ws[buf][wn * 64 + ni * 32 + frow][kg * 8 + fk]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      // even iteration: LDS buffer 0 holds tile kt; set 1 holds tile kt + 1 (arrived during the previous iteration)
+      if (kt + 1 < nk) G32_LSTORE(1, ra1, rw1);
+      if (kt + 2 < nk) G32_GLOAD(kt + 2, ra0, rw0);
+      mfmas(0);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) G32_LSTORE(0, ra0, rw0);
+        if (kt + 3 < nk) G32_GLOAD(kt + 3, ra1, rw1);
+        mfmas(1);
+        __syncthreads();
+      }
+    }
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + col_in;
+        if (n >= e.N) continue;
+        const float bv = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+          if (m >= e.M) continue;
+          float v = acc[mi][ni][r] + bv;
+          if (e.relu) v = fmaxf(v, 0.f);
+          if (e.res) v += e.res[(size_t)m * e.ldres + n];
+          e.C[(size_t)m * e.ldc + n] = v;
+        }
+      }
+  }
+}
+
+// Operands by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VGPR round trip.  One wave
+// instruction fills 1 KiB of LDS linearly; WHICH (row, 16-byte k segment) lands in a slot is the lane's choice of global
+// address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) makes the ds_read_b128 of 8 consecutive rows
+// at one segment hit 8 distinct 16-byte bank groups without padding (LDS 32 KB per workgroup).
+template <int PERS>
+__global__ __launch_bounds__(256, 4) void g32_dma(const float* __restrict__ A, const float* __restrict__ W, int lda, int ldw,
+                                                  int K, int tiles_n, int n_tiles, Epi e) {
+  __shared__ __attribute__((aligned(1024))) float L[2][2][128 * BK];  // [buffer][A | W][slots]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, hi = lane >> 5;
+  const int nk = K / BK;
+  const unsigned lds0 = (unsigned)(size_t)&L[0][0][0];
+  // fragment read offsets (bytes inside a [128 x 16] operand image): row base + swizzled segment of k group 0 / 1
+  const int xr = (frow >> 1) & 3;
+  const unsigned fa0 = (unsigned)((wm * 64 + frow) * 64 + 16 * (hi ^ xr)), fa1 = fa0 ^ 32u;
+  const unsigned fb0 = (unsigned)((wn * 64 + frow) * 64 + 16 * (hi ^ xr)), fb1 = fb0 ^ 32u;
+  for (int t = blockIdx.x; t < n_tiles; t += PERS ? gridDim.x : n_tiles) {
+    const int tile = xcd_remap(t, n_tiles);
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    // DMA source offsets of this wave's two instructions per operand: slot 64 i + lane -> (row, segment)
+    unsigned va[2], vw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave + 4 * j, r = 16 * i + (lane >> 2), sg = (lane & 3) ^ ((r >> 1) & 3);
+      va[j] = (unsigned)((min(m0 + r, e.M - 1) * lda + sg * 4) * 4);
+      vw[j] = (unsigned)((min(n0 + r, e.N - 1) * ldw + sg * 4) * 4);
+    }
+    auto dma = [&](int kt, int buf) {
+      const char* ga = reinterpret_cast<const char*>(A + kt * BK);
+      const char* gw = reinterpret_cast<const char*>(W + kt * BK);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned la = lds0 + (unsigned)(buf * 2 * 128 * BK * 4) + (unsigned)((wave + 4 * j) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw), "s"(la + 128 * BK * 4)
+                     : "memory");
+      }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto mfmas = [&](int buf) {
+      const char* la = reinterpret_cast<const char*>(&L[buf][0][0]);
+      const char* lb = reinterpret_cast<const char*>(&L[buf][1][0]);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(la + (kg ? fa1 : fa0) + mi * 32 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(lb + (kg ? fb1 : fb0) + ni * 32 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) dma(kt + 1, 1);
+      mfmas(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) dma(kt + 2, 0);
+        mfmas(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + col_in;
+        if (n >= e.N) continue;
+        const float bv = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+          if (m >= e.M) continue;
+          float v = acc[mi][ni][r] + bv;
+          if (e.relu) v = fmaxf(v, 0.f);
+          if (e.res) v += e.res[(size_t)m * e.ldres + n];
+          e.C[(size_t)m * e.ldc + n] = v;
+        }
+      }
+  }
+}
+
 #define CK(x)                                                                  \
   do {                                                                         \
     hipError_t err_ = (x);                                                     \
@@ -210,12 +413,18 @@ int main() {
           case 516: hipLaunchKernelGGL(g32<516>, dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, stag, e); break;
           case 512: hipLaunchKernelGGL(g32<512>, dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, stag, e); break;
           case 513: hipLaunchKernelGGL(g32<513>, dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, stag, e); break;
+          case 2003: hipLaunchKernelGGL((g32_d2<3, 0>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 2013: hipLaunchKernelGGL((g32_d2<3, 1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 2004: hipLaunchKernelGGL((g32_d2<4, 0>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 2014: hipLaunchKernelGGL((g32_d2<4, 1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 3000: hipLaunchKernelGGL((g32_dma<0>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 3001: hipLaunchKernelGGL((g32_dma<1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
           case 20: hipLaunchKernelGGL(g32<20>, dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, stag, e); break;
         }
       };
-      for (int i = 0; i < 3; ++i) launch();
+      for (int i = 0; i < 15; ++i) launch();
       CK(hipEventRecord(e0, 0));
-      const int it = 20;
+      const int it = 30;
       for (int i = 0; i < it; ++i) launch();
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
@@ -236,6 +445,29 @@ int main() {
     if (run("noepi, LDS writes mid-iteration", 516, n_tiles, sh.K, 0)) return 1;
     if (run("LDS writes mid-iteration", 512, n_tiles, sh.K, 0)) return 1;
     if (run("pers, LDS writes mid-iteration", 513, G, sh.K, 0)) return 1;
+    {  // the DMA form computes the same product (same k order per MFMA group: bit-identical)
+      std::vector<float> c0((size_t)M * sh.N), c1((size_t)M * sh.N);
+      Epi e{bias, sh.res ? R : nullptr, C, M, sh.N, sh.N, sh.N, sh.relu};
+      hipLaunchKernelGGL(g32<0>, dim3(n_tiles), dim3(256), 0, 0, A, W, sh.K, sh.K, sh.K, tiles_n, n_tiles, 0, e);
+      CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(C, 0, c0.size() * 4));
+      hipLaunchKernelGGL((g32_dma<1>), dim3(G), dim3(256), 0, 0, A, W, sh.K, sh.K, sh.K, tiles_n, n_tiles, e);
+      CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      double mx = 0;
+      for (size_t i = 0; i < c0.size(); ++i) {
+        const double d = fabs((double)c0[i] - (double)c1[i]);
+        if (d > mx) mx = d;
+        if (c0[i] != c1[i]) ++bad;
+      }
+      printf("   check: LDS-DMA (persistent) vs base: %zu of %zu elements differ, max |diff| %.3g\n", bad, c0.size(), mx);
+    }
+    if (run("LDS-DMA operands", 3000, n_tiles, sh.K, 0)) return 1;
+    if (run("LDS-DMA operands, pers", 3001, G, sh.K, 0)) return 1;
+    if (run("distance-2 prefetch, 3 per CU", 2003, n_tiles, sh.K, 0)) return 1;
+    if (run("distance-2 prefetch, 3 per CU, pers", 2013, 3 * prop.multiProcessorCount, sh.K, 0)) return 1;
+    if (run("distance-2 prefetch, 4 per CU (spills?)", 2004, n_tiles, sh.K, 0)) return 1;
+    if (run("distance-2 prefetch, 4 per CU, pers", 2014, G, sh.K, 0)) return 1;
     if (run("noepi, global loads, no LDS writes", 68, n_tiles, sh.K, 0)) return 1;
     if (run("noepi, LDS writes, no global loads", 132, n_tiles, sh.K, 0)) return 1;
     if (run("pers G=1024", 1, G, sh.K, 0)) return 1;
