@@ -177,105 +177,111 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
   }
 }
 
-// N = 464 (attn-out, FFN2: 45 % of the exact-mode step): 128-wide N tiles cover it with 4 tiles = 512 columns (10 % of the
-// MFMAs multiply padding) and 2 000 workgroups = 2.6 rounds on the chip's 768 resident slots.  This variant computes a
-// 128 x 160 tile (3 tiles = 480 columns: 3.4 % padding; 1 500 workgroups = 1.95 rounds): the four waves stack along M
-// (32 rows x 160 columns = 5 accumulator tiles each), one A fragment and five W fragments per 4-k group.
+// N = 464 (attn-out, FFN2: 43 % of the exact-mode step): 128-wide N tiles cover it with 4 tiles = 512 columns (10 % of the
+// MFMAs multiply padding).  This variant computes a 128 x 160 tile (3 tiles = 480 columns: 3.4 % padding; 750 workgroups,
+// one round): the four waves stack along M (32 rows x 160 columns = 5 accumulator tiles each), one A fragment and five W
+// fragments per 4-k group.  Operands by LDS-DMA exactly as above (A image 8 KB, W image 10 KB, two buffers: 36 KB).
 constexpr int F32_BN2 = 160;
 
-__global__ __launch_bounds__(256, 3) void gemm_f32_128x160(const float* __restrict__ A, const float* __restrict__ W,
-                                                        int lda, int ldw, int K, int tiles_n, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) float As[2][128][F32_LD];
-  __shared__ __attribute__((aligned(16))) float Ws[2][F32_BN2][F32_LD];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * 128;
-  const int n0 = (tile % tiles_n) * F32_BN2;
-
-  // staging: A tile = 128 x 4 float4 (2 per thread), W tile = 160 x 4 float4 (2.5 per thread: the third only for tid < 128)
-  float4 ra[2], rw[3];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 2, c4 = (idx & 3) * 4;
-      const int m = m0 + row;
-      ra[i] = (m < e.M) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + kt * F32_BK + c4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 2, c4 = (idx & 3) * 4;
-      const int n = n0 + row;
-      rw[i] = (idx < F32_BN2 * 4 && n < e.N) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + kt * F32_BK + c4)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&As[buf][idx >> 2][(idx & 3) * 4]) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < F32_BN2 * 4) *reinterpret_cast<float4*>(&Ws[buf][idx >> 2][(idx & 3) * 4]) = rw[i];
-    }
-  };
-
-  f32x16 acc[5];
-#pragma unroll
-  for (int ni = 0; ni < 5; ++ni)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
-
+__global__ __launch_bounds__(256, 4) void gemm_f32_128x160(const float* __restrict__ A, const float* __restrict__ W,
+                                                        int lda, int ldw, int K, int tiles_n, int n_tiles, EpiArgs e) {
+  constexpr int kImgA = 128 * F32_BK * 4, kImgW = F32_BN2 * F32_BK * 4;  // bytes
+  __shared__ __attribute__((aligned(1024))) char L[2][kImgA + kImgW];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nk = K / F32_BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  const unsigned lds0 = (unsigned)(size_t)&L[0][0];
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    // everything lane-derived is rebuilt per tile from the hardware lane id (80 accumulators + 24 fragment registers
+    // leave no room to carry it through the main loop at 4 workgroups per CU)
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const int frow = lane & 31, hi = lane >> 5;
+    const int xr = (frow >> 1) & 3;
+    const unsigned fb0 = (unsigned)(frow * 64 + 16 * (hi ^ xr));  // (A: + wave * 2048; W: + kImgA + ni * 2048; k group 1: ^ 32)
+    const int tile = xcd_remap(t, n_tiles);
+    const int m0 = (tile / tiles_n) * 128;
+    const int n0 = (tile % tiles_n) * F32_BN2;
+    const float* At = A + (size_t)m0 * lda;
+    const float* Wt = W + (size_t)n0 * ldw;
+    // A image: DMA instructions 0..7 (waves w, w + 4); W image: 0..9 (w, w + 4, and 8 + w for w < 2)
+    unsigned va[2], vw[3];
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[buf][wave * 32 + frow][kg * 8 + fk]);
-      // one W fragment at a time (4 dependent MFMAs per accumulator tile: the fp32 MFMA's dependent latency equals its
-      // issue interval): 4-8 fragment registers live instead of 20 — what keeps the kernel at 3 workgroups per CU
-      // without scratch (a scratch-using kernel between scratch-free ones made the graph-replayed step 7 % slower)
+    for (int j = 0; j < 3; ++j) {
+      const int i = wave + 4 * j, r = 16 * i + (lane >> 2), sg = (lane & 3) ^ ((r >> 1) & 3);
+      if (j < 2) va[j] = (unsigned)((min(r, e.M - 1 - m0) * lda + sg * 4) * 4);
+      vw[j] = (unsigned)((min(r, e.N - 1 - n0) * ldw + sg * 4) * 4);
+    }
+    auto dma = [&](int kt, int buf) {
+      const char* ga = reinterpret_cast<const char*>(At + kt * F32_BK);
+      const char* gw = reinterpret_cast<const char*>(Wt + kt * F32_BK);
+      const unsigned lb = lds0 + (unsigned)(buf * (kImgA + kImgW));
 #pragma unroll
-      for (int ni = 0; ni < 5; ++ni) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[buf][ni * 32 + frow][kg * 8 + fk]);
+      for (int j = 0; j < 2; ++j) {
+        const unsigned la = lb + (unsigned)((wave + 4 * j) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw), "s"(la + kImgA)
+                     : "memory");
+      }
+      if (wave < 2) {
+        const unsigned la = lb + (unsigned)(kImgA + (wave + 8) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[2]), "s"(gw), "s"(la) : "memory");
+      }
+    };
+    f32x16 acc[5];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[ni], 0, 0, 0);
+    for (int ni = 0; ni < 5; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto mfmas = [&](int buf) {
+      const char* lb = &L[buf][0];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const unsigned fo = kg ? (fb0 ^ 32u) : fb0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lb + fo + wave * 32 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 5; ++ni) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lb + fo + kImgA + ni * 32 * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[ni], 0, 0, 0);
+        }
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) dma(kt + 1, 1);
+      mfmas(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) dma(kt + 2, 0);
+        mfmas(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
       }
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue (same element order as epilogue_store: D[i = row][j = column])
-  const int col_in = lane & 31;
-  const int row_hi = (lane >> 5) * 4;
+    // epilogue (same element order as epilogue_store: D[i = row][j = column])
+    const int col_in = lane & 31;
+    const int row_hi = (lane >> 5) * 4;
 #pragma unroll
-  for (int ni = 0; ni < 5; ++ni) {
-    const int n = n0 + ni * 32 + col_in;
-    if (n >= e.N) continue;
-    const float bv = e.bias ? e.bias[n] : 0.f;
+    for (int ni = 0; ni < 5; ++ni) {
+      const int n = n0 + ni * 32 + col_in;
+      if (n >= e.N) continue;
+      const float bv = e.bias ? e.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
-      if (m >= e.M) continue;
-      float v = acc[ni][r] + bv;
-      if (e.relu) v = fmaxf(v, 0.f);
-      if (e.res) v += e.res[(size_t)m * e.ldres + n];
-      if (e.C32) e.C32[(size_t)m * e.ldc32 + n] = v;
-      if (e.C16) {
-        const __half h = __float2half_rn(v);
-        e.C16[(size_t)m * e.ldc16 + n] = h;
-        if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n] = __float2half_rn((v - __half2float(h)) * kLoScale);
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+        if (m >= e.M) continue;
+        float v = acc[ni][r] + bv;
+        if (e.relu) v = fmaxf(v, 0.f);
+        if (e.res) v += e.res[(size_t)m * e.ldres + n];
+        if (e.C32) e.C32[(size_t)m * e.ldc32 + n] = v;
+        if (e.C16) {
+          const __half h = __float2half_rn(v);
+          e.C16[(size_t)m * e.ldc16 + n] = h;
+          if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n] = __float2half_rn((v - __half2float(h)) * kLoScale);
+        }
       }
     }
   }
@@ -394,14 +400,22 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
   EpiArgs e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
   dim3 grid(tiles_m * tiles_n), block(256);
   if (g.precision == 0) {
-    // opt-in (LDM_GEMM32_WIDE=1): in a sequential run the 160-wide tiles cut FFN2 by 25 % and attn-out by 23 %, but the
-    // timed exact-mode loop runs two chunk pipelines concurrently, where the other lane already fills the idle rounds, and
-    // there the wide tiles are 1 % slower (profiles/r02_call35_37_*)
+    // opt-in (LDM_GEMM32_WIDE=1): run alone, the 160-wide tiles cut FFN2 by 4 % (366 vs 381 ms per 100 steps), but the
+    // timed exact-mode loop runs two chunk pipelines concurrently, where the other lane already fills the idle slots, and
+    // there they are 0.5 % slower (profiles/r03_call26_gemm32_wide_ab.txt; the same verdict as r02_call35_37_*)
     static const bool wide = getenv("LDM_GEMM32_WIDE") && atoi(getenv("LDM_GEMM32_WIDE")) != 0;
     const int t160 = (g.N + F32_BN2 - 1) / F32_BN2;
-    if (wide && t160 * F32_BN2 < tiles_n * 128) {  // fewer padded columns with 160-wide tiles (N = 464: 480 vs 512)
-      hipLaunchKernelGGL(gemm_f32_128x160, dim3(tiles_m * t160), block, 0, st, (const float*)g.A, (const float*)g.W, g.lda,
-                         g.ldw, g.K, t160, e);
+    if (wide && t160 * F32_BN2 < tiles_n * 128) {  // fewer padded columns (N = 464: 480 vs 512)
+      static const int resident160 = [] {
+        int dev = 0, cus = 256, per_cu = 4;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_f32_128x160, 256, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+        return (per_cu * cus) & ~7;
+      }();
+      const int n_tiles = tiles_m * t160;
+      hipLaunchKernelGGL(gemm_f32_128x160, dim3(n_tiles < resident160 ? n_tiles : resident160), block, 0, st, (const float*)g.A,
+                         (const float*)g.W, g.lda, g.ldw, g.K, t160, n_tiles, e);
       return;
     }
     static const int resident = [] {  // as many workgroups as the chip holds at once (32 KB of LDS, < 100 VGPRs: 5 per CU)
