@@ -1128,7 +1128,11 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
     p.t_post = t_post;
     p.step = step;
     p.layout_off = (int)(rng_layout_off + off);
-    if (!rel) {
+    // cond=relation adjusts the log-probabilities only while t >= 10 (logit_adjustment.py:107); the remaining steps are
+    // a plain constrained step with the [PAD] disable, i.e. the fused posterior + draw launch
+    const bool adjust = rel && t_model >= 10 && rel->num_update > 0;
+    if (!adjust) {
+      if (rel) p.pad_disable = 1;
       p.tokens_out = tout + (size_t)off * h->S;
       if (embed_next) {  // (one chunk per call: run_loop_body)
         p.x_next = h->P; p.emb = h->emb; p.pos = h->pos; p.D = h->D; p.ldx = h->D;
@@ -1150,7 +1154,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       ldm_handle::Scope sc(h, st, "posterior", 0, (double)Bc * h->S * (h->Cp * 4 + h->C * 4));
       launch_posterior_sample(q, st);
     }
-    if (t_model >= 10 && rel->num_update > 0) {  // logit_adjustment.py:107
+    {
       RelArgs a{};
       a.logp = h->rel_logp;
       a.cond_seq = cond->d_cond_seq + (size_t)off * h->S;
@@ -1168,6 +1172,9 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       q.tokens_out = tout + (size_t)off * h->S;
       q.step = step;
       q.layout_off = (int)(rng_layout_off + off);
+      if (embed_next) {  // the next step's embedding rows, as in the fused launch above
+        q.x_next = h->P; q.emb = h->emb; q.pos = h->pos; q.D = h->D; q.ldx = h->D;
+      }
       ldm_handle::Scope sc(h, st, "pad_disable_sample", 0, (double)Bc * h->S * (h->C * 4 + 8));
       launch_posterior_sample(q, st);
     }
@@ -1416,7 +1423,7 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation
     int32_t* nxt = h->tok_b + off * S;
     // the stack kernel takes raw rows and computes its own row statistics, so the posterior kernel of step i can write
     // step i + 1's embedding itself (no separate embedding launch inside the loop)
-    const bool fuse_embed = !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6;
+    const bool fuse_embed = h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6;
     for (int i = 0; i < n_steps; ++i) {
       int rc = step_all(h, cur, nxt, t_model[i], t_post[i], cond ? &cc : nullptr, rel, off, s, i, Bc, off, st,
                         fuse_embed && i > 0, fuse_embed && i + 1 < n_steps, i);
