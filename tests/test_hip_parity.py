@@ -103,7 +103,7 @@ def test_stack_kernel_agrees_with_generic_kernels(cuda, monkeypatch):
 
 
 @pytest.mark.parametrize("precision", ["exact", "fast"])
-@pytest.mark.parametrize("shape", ["short_sequence", "long_sequence", "small_backbone"])
+@pytest.mark.parametrize("shape", ["short_sequence", "mid_sequence", "long_sequence", "small_backbone"])
 def test_denoiser_other_geometries_take_the_generic_kernels(cuda, shape, precision):
     """The layout-resident kernels are built for the reference's one backbone (medium shrunk by 29/32: d_model 464,
     8 heads, d_ff 1856) at 96 < S <= 128 tokens.  Any other geometry must still give the reference's numbers through
@@ -114,6 +114,8 @@ def test_denoiser_other_geometries_take_the_generic_kernels(cuda, shape, precisi
 
     base = SP.SPECS["rico25"]
     spec = {"short_sequence": dataclasses.replace(base, name="short", max_elem=10),            # S = 50
+            # S = 105: still the layout-resident kernels (96 < S <= 128), with 23 padded rows / keys instead of 3
+            "mid_sequence": dataclasses.replace(base, name="mid", max_elem=21),
             "long_sequence": dataclasses.replace(base, name="long", max_elem=30, n_layer=2),   # S = 150 (exact only)
             "small_backbone": dataclasses.replace(base, name="small", d_model=256, n_head=4,   # head dim 64
                                                   d_ff=1024, n_layer=2, n_step=20)}[shape]
@@ -462,6 +464,42 @@ def test_loop_ragged_batches_fast_mode(cuda, B, sampler):
     if B > cut:
         parts.append(e.sample_loop(mk(B - cut), steps, steps, cfg, seed=11, first_layout=cut, use_graph=True)[0].clone())
     assert torch.equal(full, torch.cat(parts))
+
+
+def test_fused_loop_shorter_sequence_vs_oracle(cuda):
+    """The one-launch loop at S = 105 tokens (21 elements: 96 < S <= 128 keeps the layout-resident kernels, with 23 padded
+    rows / keys per layout instead of 3): free-running `random` and greedy loops against the oracle on identical Philox
+    uniforms, and cond=c with its strong mask."""
+    import dataclasses
+
+    from layout_dm_amd.binding import Engine
+
+    spec = dataclasses.replace(SP.RICO25, name="rico25_e21", max_elem=21, n_step=30)
+    assert spec.seq_len == 105
+    sd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True)
+    W = R.as_torch_weights(sd)
+    B = 5
+    steps = R.timestep_list(spec.n_step, spec.n_step)
+    e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
+               n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast", max_batch=8)
+    e.load_state_dict(sd)
+    for cfg, bound in (({"name": "random", "temperature": 1.0}, 5e-3), ({"name": "deterministic"}, 5e-3)):
+        tok = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+        out, inter = e.sample_loop(tok, steps, steps, cfg, seed=13, first_layout=21, intermediates=True, use_graph=True)
+        ref = torch.stack(R.sample_loop(W, spec, B, cfg, seed=13, first_layout=21, get_intermediate_results=True)).int()
+        frac = (inter.cpu() != ref).float().mean().item()
+        print(f"[S=105 loop / fast / {cfg['name']}] tokens differing from the oracle: {frac:.2e}")
+        assert frac <= bound, (cfg, frac)
+        assert (out.cpu() != spec.mask_id).all()
+    c = synth.synth_cond_c(spec, B, seed=4)
+    cond = {"seq": c["seq"], "mask": c["mask"], "type": "c"}
+    tok = torch.from_numpy(c["seq"]).int().to(cuda)
+    got = e.sample_loop(tok, steps, steps, {"name": "random", "temperature": 1.0}, cond=cond, seed=13, first_layout=21,
+                        use_graph=True)[0].cpu()
+    e.close()
+    m = torch.from_numpy(c["mask"])
+    assert torch.equal(got.long()[m], torch.from_numpy(c["seq"])[m]), "strong-masked tokens changed"
+    assert (got != spec.mask_id).all()
 
 
 def test_fused_loop_t200_spans_two_launches_vs_oracle(cuda):

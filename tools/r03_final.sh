@@ -11,4 +11,5 @@ bash tools/rocprof_stats.sh $O/rocprof_stats_config3.txt --config 3 --steps 3 --
 bash tools/rocprof_stats.sh $O/rocprof_stats_exact.txt --precision exact --steps 2 --warmup 1 $Q > /dev/null 2>&1
 bash tools/pmc_sq.sh $O/sq_counters_fast_loop.txt fast 100 > /dev/null 2>&1
 bash tools/pmc_sq.sh $O/sq_counters_exact.txt exact 4 > /dev/null 2>&1
+timeout 250 tools/microbench/gemm32 > $O/gemm32_microbench.txt 2>&1
 head -12 $O/rocprof_stats_config2.txt; head -8 $O/rocprof_stats_config3.txt; head -30 $O/sq_counters_fast_loop.txt
