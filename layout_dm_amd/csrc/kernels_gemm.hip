@@ -83,8 +83,11 @@ constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-fre
 
 // Operands by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VGPR round trip.  One wave
 // instruction fills 1 KiB of LDS linearly, and WHICH (row, 16-byte k segment) lands in a slot is the lane's choice of
-// global address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) makes the ds_read_b128 of 8
-// consecutive rows at one segment hit 8 distinct 16-byte bank groups without padding (32 KB of LDS per workgroup).
+// global address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) serves a fragment
+// ds_read_b128 in two passes without padding (32 KB of LDS per workgroup).  The XOR with (r >> 2) & 3 is conflict-free
+// under gfx950's 16-lane service groups (tests/test_lds_swizzle.py) and was measured: 0.5 % SLOWER in the timed loop, FFN1 and
+// in_proj 2-4 % slower run alone (profiles/r03_call29_30_gemm32_swizzle_ab.txt): the LDS is far from saturated by
+// this kernel (12 fragment reads per 32 MFMAs of 64 cycles), so the reads' pace is not what limits it.
 // Persistent over tiles: the grid is min(tiles, 4 per CU) workgroups and workgroup w walks tiles w, w + grid, ... (the
 // same XCD: grid is a multiple of 8); a workgroup that moves on leaves its 64 epilogue stores to drain from L2 under the
 // next main loop and pays the launch / first-load ramp once.  tools/microbench/gemm32.hip on the four shapes of a layer

@@ -88,3 +88,34 @@ def test_lds_budgets_fit_160k():
     attn = 2 * 32768 + 4 * 16384 + 3 * 8 * 64 * 4 + 2 * 512 * 4 + 512 * 4
     assert ffn <= 160 * 1024 and attn <= 160 * 1024
     assert (ffn, attn) == (142592, 143360)
+
+
+def test_fp32_gemm_operand_images():
+    """gemm_f32_128x128 / gemm_f32_128x160 (kernels_gemm.hip): operands arrive by LDS-DMA, one 1-KiB wave instruction =
+    64 consecutive 16-byte slots; lane l of instruction i fetches row 16 i + (l >> 2), segment (l & 3) ^ x(row), i.e.
+    slot(row, seg) = 4 row + (seg ^ x(row)).  For the XOR that ships (x = (row >> 1) & 3) and for the conflict-free
+    alternative (x = (row >> 2) & 3; measured 0.5 % slower, profiles/r03_call29_30_*): the image holds every (row, segment)
+    exactly once and the fragment reads — lane (frow, hi), k group kg: row base + frow, segment 2 kg + hi — address it."""
+    rows = 160
+    for shift, free in ((1, False), (2, True)):
+        x = lambda row: (row >> shift) & 3
+        seen = {}
+        for i in range(rows // 16):
+            for lane in range(64):
+                row = 16 * i + (lane >> 2)
+                seg = (lane & 3) ^ x(row)
+                slot = 64 * i + lane
+                assert slot == 4 * row + (seg ^ x(row))
+                seen[(row, seg)] = slot
+        assert len(seen) == rows * 4 and sorted(seen.values()) == list(range(rows * 4))
+        for base in (0, 32, 64, 96, 128):
+            for kg in range(2):
+                def addr(l, base=base, kg=kg):
+                    frow, hi = l & 31, l >> 5
+                    off = frow * 64 + 16 * (hi ^ x(frow))            # fa0 / fb0 of the kernel
+                    off = off ^ 32 if kg else off                     # k group 1: segment ^ 2
+                    return base * 64 + off
+                assert conflict_free(addr) == free
+                for l in range(64):  # the reads address the segment the MFMA group expects
+                    row, seg = base + (l & 31), 2 * kg + (l >> 5)
+                    assert addr(l) == 16 * seen[(row, seg)]

@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256, OCC) void g32_d2(const float* __restrict__ A, 
 
 // Operands by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VGPR round trip.  One wave
 // instruction fills 1 KiB of LDS linearly; WHICH (row, 16-byte k segment) lands in a slot is the lane's choice of global
-// address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) makes the ds_read_b128 of 8 consecutive rows
-// at one segment hit 8 distinct 16-byte bank groups without padding (LDS 32 KB per workgroup).
+// address, so the swizzle is free: slot(r, s) = 4 r + (s ^ ((r >> 1) & 3)) serves a fragment ds_read_b128 in
+// two passes without padding (LDS 32 KB per workgroup); the conflict-free XOR ((r >> 2) & 3) measured 0.5 % slower in the
+// product (profiles/r03_call29_30_gemm32_swizzle_ab.txt).
 template <int PERS>
 __global__ __launch_bounds__(256, 4) void g32_dma(const float* __restrict__ A, const float* __restrict__ W, int lda, int ldw,
                                                   int K, int tiles_n, int n_tiles, Epi e) {
