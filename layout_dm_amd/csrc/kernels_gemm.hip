@@ -48,12 +48,13 @@ struct EpiArgs {
   int M, N, ldres, ldc32, ldc16, relu;
 };
 
-__device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&acc)[2][2], int m_base, int n_base,
+template <int MI = 2>
+__device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&acc)[MI][2], int m_base, int n_base,
                                                int lane) {
   const int col_in = lane & 31;
   const int row_hi = (lane >> 5) * 4;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int n = n_base + ni * 32 + col_in;
@@ -79,7 +80,6 @@ __device__ __forceinline__ void epilogue_store(const EpiArgs& e, const f32x16 (&
 
 // ---------------------------------------------------------------- exact fp32
 constexpr int F32_BK = 16;
-constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-free b128 reads
 
 // Operands by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VGPR round trip.  One wave
 // instruction fills 1 KiB of LDS linearly, and WHICH (row, 16-byte k segment) lands in a slot is the lane's choice of
@@ -93,28 +93,35 @@ constexpr int F32_LD = F32_BK + 4;  // 20 floats = 80 B row stride: conflict-fre
 // next main loop and pays the launch / first-load ramp once.  tools/microbench/gemm32.hip on the four shapes of a layer
 // (M = 32 000): register-staged, one workgroup per tile 414 / 161 / 507 / 527 us -> 334 / 155 / 446 / 475 us, bit-identical
 // (profiles/r03_gemm32_microbench.txt).
-__global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restrict__ A, const float* __restrict__ W,
+// MI = 2: 128 x 128 tile (each wave 64 x 64).  MI = 1: 64 x 128 tile (each wave 32 x 64; 24 KB of LDS) for the GEMMs whose
+// 128-row tiles fit the chip in one round: with two half-height tiles per workgroup the stores of the first drain under the
+// main loop of the second (opt-in, LDM_GEMM32_BM64=1).
+template <int MI>
+__global__ __launch_bounds__(256, 4) void gemm_f32_tile(const float* __restrict__ A, const float* __restrict__ W,
                                                         int lda, int ldw, int K, int tiles_n, int n_tiles, EpiArgs e) {
-  __shared__ __attribute__((aligned(1024))) float L[2][2][128 * F32_BK];  // [buffer][A | W][slot]
+  constexpr int BM = 64 * MI;
+  constexpr int kImgA = BM * F32_BK * 4, kImgW = 128 * F32_BK * 4;  // bytes
+  __shared__ __attribute__((aligned(1024))) char L[2][kImgA + kImgW];  // [buffer][A image | W image]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 31, hi = lane >> 5;
   const int nk = K / F32_BK;
-  const unsigned lds0 = (unsigned)(size_t)&L[0][0][0];
-  // fragment read offsets (bytes inside a [128 x 16] operand image): row base + swizzled segment of k group 0 / 1
+  const unsigned lds0 = (unsigned)(size_t)&L[0][0];
+  // fragment read offsets (bytes inside a [rows x 16] operand image): row base + swizzled segment of k group 0 / 1
   const int xr = (frow >> 1) & 3;
-  const unsigned fa0 = (unsigned)((wm * 64 + frow) * 64 + 16 * (hi ^ xr)), fa1 = fa0 ^ 32u;
-  const unsigned fb0 = (unsigned)((wn * 64 + frow) * 64 + 16 * (hi ^ xr)), fb1 = fb0 ^ 32u;
+  const unsigned fa0 = (unsigned)((wm * 32 * MI + frow) * 64 + 16 * (hi ^ xr)), fa1 = fa0 ^ 32u;
+  const unsigned fb0 = (unsigned)(kImgA + (wn * 64 + frow) * 64 + 16 * (hi ^ xr)), fb1 = fb0 ^ 32u;
   for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const int tile = xcd_remap(t, n_tiles);
-    const int m0 = (tile / tiles_n) * 128;
+    const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * 128;
     const float* At = A + (size_t)m0 * lda;
     const float* Wt = W + (size_t)n0 * ldw;
-    // DMA source offsets (bytes from the tile's first row) of this wave's two instructions per operand: LDS slot
-    // 64 i + lane <- (row, segment).  Rows past M / N are clamped to the last one: their products are never stored.
+    // DMA source offsets (bytes from the tile's first row) of this wave's instructions: LDS slot 64 i + lane <- (row,
+    // segment); A image: instructions w (+ 4 for MI = 2), W image: w and w + 4.  Rows past M / N are clamped to the last
+    // one: their products are never stored.
     unsigned va[2], vw[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -127,16 +134,16 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
       const char* gw = reinterpret_cast<const char*>(Wt + kt * F32_BK);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const unsigned la = lds0 + (unsigned)(buf * 2 * 128 * F32_BK * 4) + (unsigned)((wave + 4 * j) * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw),
-                     "s"(la + 128 * F32_BK * 4)
+        const unsigned la = lds0 + (unsigned)(buf * (kImgA + kImgW)) + (unsigned)((wave + 4 * j) * 1024);
+        if (j < MI)
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw), "s"(la + kImgA)
                      : "memory");
       }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -146,19 +153,18 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc does not count the DMA in its vmcnt bookkeeping
     __syncthreads();
     auto mfmas = [&](int buf) {
-      const char* la = reinterpret_cast<const char*>(&L[buf][0][0]);
-      const char* lb = reinterpret_cast<const char*>(&L[buf][1][0]);
+      const char* lb = &L[buf][0];
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
-        f32x4 a[2], b[2];
+        f32x4 a[MI], b[2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(la + (kg ? fa1 : fa0) + mi * 32 * 64);
+        for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(lb + (kg ? fa1 : fa0) + mi * 32 * 64);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(lb + (kg ? fb1 : fb0) + ni * 32 * 64);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
+          for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_128x128(const float* __restri
         __syncthreads();
       }
     }
-    epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    epilogue_store<MI>(e, acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
   }
 }
 
@@ -421,16 +427,25 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
                          (const float*)g.W, g.lda, g.ldw, g.K, t160, n_tiles, e);
       return;
     }
-    static const int resident = [] {  // as many workgroups as the chip holds at once (32 KB of LDS, < 100 VGPRs: 5 per CU)
+    static const auto resident_of = [](const void* kern) {  // as many workgroups as the chip holds at once
       int dev = 0, cus = 256, per_cu = 4;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_f32_128x128, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
       if (const char* v = getenv("LDM_GEMM32_SLOTS")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (A/B timing)
       return (per_cu * cus) & ~7;  // (a multiple of 8: tile t stays on XCD t % 8)
-    }();
+    };
+    static const int resident = resident_of((const void*)gemm_f32_tile<2>);  // 32 KB of LDS, < 100 VGPRs: 5 per CU
     const int n_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL(gemm_f32_128x128, dim3(n_tiles < resident ? n_tiles : resident), block, 0, st, (const float*)g.A,
+    static const bool bm64 = getenv("LDM_GEMM32_BM64") && atoi(getenv("LDM_GEMM32_BM64")) != 0;
+    if (bm64 && n_tiles <= resident) {  // one round of 128-row tiles: two half-height tiles per workgroup instead
+      static const int resident64 = resident_of((const void*)gemm_f32_tile<1>);
+      const int n64 = ((g.M + 63) / 64) * tiles_n;
+      hipLaunchKernelGGL(gemm_f32_tile<1>, dim3(n64 < resident64 ? n64 : resident64), block, 0, st, (const float*)g.A,
+                         (const float*)g.W, g.lda, g.ldw, g.K, tiles_n, n64, e);
+      return;
+    }
+    hipLaunchKernelGGL(gemm_f32_tile<2>, dim3(n_tiles < resident ? n_tiles : resident), block, 0, st, (const float*)g.A,
                        (const float*)g.W, g.lda, g.ldw, g.K, tiles_n, n_tiles, e);
   } else if (g.precision == 1) {
     hipLaunchKernelGGL(gemm_f16_128x128<1>, grid, block, 0, st, (const __half*)g.A, (const __half*)nullptr,
