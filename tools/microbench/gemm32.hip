@@ -354,6 +354,107 @@ __global__ __launch_bounds__(256, 4) void g32_dma(const float* __restrict__ A, c
   }
 }
 
+// The DMA form with a ring of three operand buffers (48 KB: 3 workgroups per CU): k-tile kt + 2 is requested at the top
+// of iteration kt, and the iteration ends by waiting only for k-tile kt + 1 (vmcnt(4): this wave's four newer requests may
+// stay in flight).
+template <int PERS>
+__global__ __launch_bounds__(256, 3) void g32_dma3(const float* __restrict__ A, const float* __restrict__ W, int lda, int ldw,
+                                                   int K, int tiles_n, int n_tiles, Epi e) {
+  __shared__ __attribute__((aligned(1024))) float L[3][2][128 * BK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, hi = lane >> 5;
+  const int nk = K / BK;
+  const unsigned lds0 = (unsigned)(size_t)&L[0][0][0];
+  const int xr = (frow >> 1) & 3;
+  const unsigned fa0 = (unsigned)((wm * 64 + frow) * 64 + 16 * (hi ^ xr)), fa1 = fa0 ^ 32u;
+  const unsigned fb0 = (unsigned)((wn * 64 + frow) * 64 + 16 * (hi ^ xr)), fb1 = fb0 ^ 32u;
+  for (int t = blockIdx.x; t < n_tiles; t += PERS ? gridDim.x : n_tiles) {
+    const int tile = xcd_remap(t, n_tiles);
+    const int m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+    unsigned va[2], vw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave + 4 * j, r = 16 * i + (lane >> 2), sg = (lane & 3) ^ ((r >> 1) & 3);
+      va[j] = (unsigned)((min(m0 + r, e.M - 1) * lda + sg * 4) * 4);
+      vw[j] = (unsigned)((min(n0 + r, e.N - 1) * ldw + sg * 4) * 4);
+    }
+    auto dma = [&](int kt, int buf) {
+      const char* ga = reinterpret_cast<const char*>(A + kt * BK);
+      const char* gw = reinterpret_cast<const char*>(W + kt * BK);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned la = lds0 + (unsigned)(buf * 2 * 128 * BK * 4) + (unsigned)((wave + 4 * j) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(va[j]), "s"(ga), "s"(la) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vw[j]), "s"(gw), "s"(la + 128 * BK * 4)
+                     : "memory");
+      }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto mfmas = [&](int buf) {
+      const char* la = reinterpret_cast<const char*>(&L[buf][0][0]);
+      const char* lb = reinterpret_cast<const char*>(&L[buf][1][0]);
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(la + (kg ? fa1 : fa0) + mi * 32 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(lb + (kg ? fb1 : fb0) + ni * 32 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    // iteration kt: request tile kt + 2 into buffer (kt + 2) % 3 (last read in iteration kt - 1: free since its barrier),
+    // compute on buffer kt % 3, then wait for tile kt + 1 (all but this wave's 4 newest requests) and meet
+    auto step = [&](int kt, int b0, int b2) {
+      if (kt + 2 < nk) dma(kt + 2, b2);
+      mfmas(b0);
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 3) {
+      step(kt, 0, 2);
+      if (kt + 1 < nk) step(kt + 1, 1, 0);
+      if (kt + 2 < nk) step(kt + 2, 2, 1);
+    }
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + col_in;
+        if (n >= e.N) continue;
+        const float bv = e.bias ? e.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + row_hi;
+          if (m >= e.M) continue;
+          float v = acc[mi][ni][r] + bv;
+          if (e.relu) v = fmaxf(v, 0.f);
+          if (e.res) v += e.res[(size_t)m * e.ldres + n];
+          e.C[(size_t)m * e.ldc + n] = v;
+        }
+      }
+  }
+}
+
 #define CK(x)                                                                  \
   do {                                                                         \
     hipError_t err_ = (x);                                                     \
@@ -420,6 +521,8 @@ int main() {
           case 2014: hipLaunchKernelGGL((g32_d2<4, 1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
           case 3000: hipLaunchKernelGGL((g32_dma<0>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
           case 3001: hipLaunchKernelGGL((g32_dma<1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 3100: hipLaunchKernelGGL((g32_dma3<0>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
+          case 3101: hipLaunchKernelGGL((g32_dma3<1>), dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, e); break;
           case 20: hipLaunchKernelGGL(g32<20>, dim3(grid), dim3(256), 0, 0, A, W, sh.K, sh.K, Kx, tiles_n, n_tiles, stag, e); break;
         }
       };
@@ -465,6 +568,21 @@ int main() {
     }
     if (run("LDS-DMA operands", 3000, n_tiles, sh.K, 0)) return 1;
     if (run("LDS-DMA operands, pers", 3001, G, sh.K, 0)) return 1;
+    if (run("LDS-DMA operands, pers, 5 per CU", 3001, 5 * prop.multiProcessorCount, sh.K, 0)) return 1;
+    if (run("LDS-DMA ring of 3 buffers, 3 per CU", 3100, n_tiles, sh.K, 0)) return 1;
+    if (run("LDS-DMA ring of 3, pers, 3 per CU", 3101, 3 * prop.multiProcessorCount, sh.K, 0)) return 1;
+    {  // the ring computes the same product
+      std::vector<float> c0((size_t)M * sh.N), c1((size_t)M * sh.N);
+      Epi e{bias, sh.res ? R : nullptr, C, M, sh.N, sh.N, sh.N, sh.relu};
+      hipLaunchKernelGGL(g32<0>, dim3(n_tiles), dim3(256), 0, 0, A, W, sh.K, sh.K, sh.K, tiles_n, n_tiles, 0, e);
+      CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemset(C, 0, c0.size() * 4));
+      hipLaunchKernelGGL((g32_dma3<1>), dim3(3 * prop.multiProcessorCount), dim3(256), 0, 0, A, W, sh.K, sh.K, sh.K, tiles_n, n_tiles, e);
+      CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < c0.size(); ++i) bad += c0[i] != c1[i];
+      printf("   check: LDS-DMA ring of 3 (persistent) vs base: %zu of %zu elements differ\n", bad, c0.size());
+    }
     if (run("distance-2 prefetch, 3 per CU", 2003, n_tiles, sh.K, 0)) return 1;
     if (run("distance-2 prefetch, 3 per CU, pers", 2013, 3 * prop.multiProcessorCount, sh.K, 0)) return 1;
     if (run("distance-2 prefetch, 4 per CU (spills?)", 2004, n_tiles, sh.K, 0)) return 1;
