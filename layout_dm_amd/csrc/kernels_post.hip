@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
   if (p.logp_in) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      lp[j] = m.valid(a, j) ? p.logp_in[((size_t)b * C + m.cls(a, j)) * p.S + s] : -INFINITY;
+      lp[j] = m.valid(a, j) ? p.logp_in[p.logp_tm ? ((size_t)b * p.S + s) * C + m.cls(a, j) : ((size_t)b * C + m.cls(a, j)) * p.S + s]
+                            : -INFINITY;
     // disable [PAD] where the number of elements is known: for cond=relation the reference applies it AFTER the logit
     // adjustment, i.e. between ldm_relation_update and the draw
     ldm_post::pad_disable_only(m, a, lp);
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
   if (p.logp_out) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (m.valid(a, j)) p.logp_out[((size_t)b * C + m.cls(a, j)) * p.S + s] = lp[j];
+      if (m.valid(a, j))
+        p.logp_out[p.logp_tm ? ((size_t)b * p.S + s) * C + m.cls(a, j) : ((size_t)b * C + m.cls(a, j)) * p.S + s] = lp[j];
   }
   if (!p.tokens_out) return;
 

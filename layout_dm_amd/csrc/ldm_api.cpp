@@ -1150,6 +1150,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       PostArgs q = p;
       q.pad_disable = 0;  // applied after the adjustment, below
       q.logp_out = h->rel_logp;
+      q.logp_tm = 1;  // (the handle's own buffer: token-major, a token's classes contiguous)
       q.tokens_out = nullptr;
       ldm_handle::Scope sc(h, st, "posterior", 0, (double)Bc * h->S * (h->Cp * 4 + h->C * 4));
       launch_posterior_sample(q, st);
@@ -1157,6 +1158,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
     {
       RelArgs a{};
       a.logp = h->rel_logp;
+      a.logp_tm = 1;
       a.cond_seq = cond->d_cond_seq + (size_t)off * h->S;
       fill_rel(h, a, rel, rel_layout_off + off, Bc);
       ldm_handle::Scope sc(h, st, "relation_update", 0, (double)Bc * 4 * h->cfg.n_bin * h->cfg.max_elem * 8);
@@ -1169,6 +1171,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       q.weak = nullptr;
       q.pad_disable = 1;
       q.logp_in = h->rel_logp;
+      q.logp_tm = 1;
       q.tokens_out = tout + (size_t)off * h->S;
       q.step = step;
       q.layout_off = (int)(rng_layout_off + off);

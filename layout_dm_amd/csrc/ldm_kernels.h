@@ -140,6 +140,7 @@ struct RelArgs {
   int canvas_bins[4];       // bin of the canvas box (0.5, 0.5, 1, 1) per coordinate
   float step;               // relation_lambda / (14 * number of graphs in the call)
   int num_update, B, C, S, A, n_category, n_bin, pad_id;
+  int logp_tm;              // 0: logp is (B,C,S) (the API's layout); 1: (B,S,C), token-major (the handle's own buffer)
 };
 void launch_relation_update(const RelArgs& a, hipStream_t st);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
@@ -169,6 +170,8 @@ struct PostArgs {
   int32_t* tokens_out;     // [M] or nullptr
   float* logp_out;         // (B,C,S) or nullptr (parity hook)
   const float* logp_in;    // (B,C,S) or nullptr: skip the posterior, only sample (ldm_sample_tokens)
+  int logp_tm;             // 1: logp_out / logp_in are (B,S,C), token-major (a token's classes contiguous: the handle's own
+                           // cond=relation buffer); 0: the API's (B,C,S)
   const float* sched;      // device [8][n_attr][T+1] schedule buffers, see ScheduleRow
   int T;                   // n_step
   int t_post;              // timestep of q_posterior
