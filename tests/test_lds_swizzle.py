@@ -91,7 +91,7 @@ def test_lds_budgets_fit_160k():
 
 
 def test_fp32_gemm_operand_images():
-    """gemm_f32_128x128 / gemm_f32_128x160 (kernels_gemm.hip): operands arrive by LDS-DMA, one 1-KiB wave instruction =
+    """gemm_f32_tile / gemm_f32_128x160 (kernels_gemm.hip): operands arrive by LDS-DMA, one 1-KiB wave instruction =
     64 consecutive 16-byte slots; lane l of instruction i fetches row 16 i + (l >> 2), segment (l & 3) ^ x(row), i.e.
     slot(row, seg) = 4 row + (seg ^ x(row)).  For the XOR that ships (x = (row >> 1) & 3) and for the conflict-free
     alternative (x = (row >> 2) & 3; measured 0.5 % slower, profiles/r03_call29_30_*): the image holds every (row, segment)
