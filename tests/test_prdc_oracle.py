@@ -25,3 +25,26 @@ def test_prdc_known_answers():
     # real radii: 1, 1, 2; fake radii: 2.2, 2.2, 7.4; d(r, f) = [[.4, 2.6, 10], [.6, 1.6, 9], [2.6, .4, 7]]
     assert out["precision"] == 2 / 3 and out["coverage"] == 1.0 and out["recall"] == 1.0
     assert abs(out["density"] - (2 + 1 + 0) / 3) < 1e-12
+
+
+def test_prdc_against_an_independent_neighbour_search():
+    """The same four numbers from scikit-learn's exact k-NN search (radii) and a plain double loop over thresholded
+    distances — nothing shared with the restatement's pairwise-matrix / partition route (Naeem et al. 2020, eqs. 3-5:
+    precision / recall = share of samples inside at least one k-NN ball of the other set, density = mean number of real
+    balls a fake sample falls into / k, coverage = share of real samples whose ball holds a fake sample)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(3)
+    for nr, nf, d, k in ((120, 90, 8, 5), (64, 333, 48, 3), (257, 257, 24, 7)):
+        real = rng.standard_normal((nr, d))
+        fake = 0.8 * rng.standard_normal((nf, d)) + 0.3
+        rad_r = NearestNeighbors(n_neighbors=k + 1, algorithm="brute").fit(real).kneighbors(real)[0][:, k]
+        rad_f = NearestNeighbors(n_neighbors=k + 1, algorithm="brute").fit(fake).kneighbors(fake)[0][:, k]
+        dist = np.sqrt(((real[:, None, :] - fake[None, :, :]) ** 2).sum(-1))
+        in_real = dist < rad_r[:, None]   # fake j inside the ball of real i
+        in_fake = dist < rad_f[None, :]   # real i inside the ball of fake j
+        want = {"precision": in_real.any(0).mean(), "recall": in_fake.any(1).mean(),
+                "density": in_real.sum(0).mean() / k, "coverage": (dist.min(1) < rad_r).mean()}
+        got = OF.compute_prdc(real, fake, nearest_k=k)
+        for key in want:
+            assert abs(got[key] - want[key]) < 1e-12, (key, got[key], want[key])
