@@ -1,0 +1,49 @@
+"""CPU: the bench line the GPU box last produced (profiles/r03_final2_bench.json, written by `python bench.py` with no
+flags) against the driver's contract — the keys, their types and the arithmetic that ties them together.  A change of
+bench.py that breaks the contract shows up here as soon as a new line is committed."""
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_final*_bench.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r0*_final_bench.json")))
+    if not files:
+        pytest.skip("no committed bench line")
+    lines = [l for l in open(files[-1]).read().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py must print ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _latest()
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), key
+    assert "vs_baseline" in d and d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"].split(",")[0] in base["metric"] and d["unit"] == "layouts/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["scaling"] in ("weak", "strong") and "synthetic" in d["data"]
+    assert isinstance(d["config"]["workload"], str) and "model" not in d["config"]
+    # value = layouts of one step / time of one step (512 layouts per GPU on config 2)
+    assert "batch=512" in d["config"]["workload"]
+    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic work per launch / that kernel's average launch duration
+    assert abs(r["achieved"] - r["algorithmic_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 2e-3 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["unit"] == "layouts/s" and c["value"] > 0 and c["cores"] >= 1
+    assert isinstance(c["sample"], str) and c["sample"]
+    # the extras of the N = 1 line
+    assert set(d["modes"]) >= {"exact", "fast", "fast_verified"} and d["modes"]["fast_verified"]["tokens_equal_exact_mode"]
+    assert set(d["configs"]) >= {"3", "4", "refinement", "relation"}
+    assert len(d["tokens_sha256"]["sha256"]) == 64
