@@ -12,8 +12,8 @@
 //    i.e. MFMA j of a group contracts k = {k0+j, k0+4+j} — a permutation of the K order that is
 //    applied to A and W alike, so the product is unchanged.
 //  * fp16 modes: v_mfma_f32_32x32x16_f16, lane l supplies 8 consecutive k (ds_read_b128).
-//  * LDS rows are padded (+4 floats / +8 halfs) so the 16-lane ds_read_b128 groups hit 16 distinct
-//    4-bank slots (conflict-free), global->register->LDS staging is double-buffered.
+//  * exact mode operands arrive by LDS-DMA into unpadded, XOR-swizzled images (see gemm_f32_tile); the fp16 kernels of the
+//    generic path stage global -> register -> LDS, double-buffered, with rows padded by 8 halfs.
 //  * workgroup -> tile mapping is XCD-aware: the 8 XCDs have private L2s and the dispatcher places
 //    block b on XCD b%8, so consecutive tile ids (same A row-panel, neighbouring W panels) are
 //    remapped onto the same XCD.
