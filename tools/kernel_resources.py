@@ -14,10 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
+    asm = "/dev/null"
+    if "--asm" in argv:  # --asm <file>: keep the assembly
+        i = argv.index("--asm")
+        asm = argv[i + 1]
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
     src = os.path.join(ROOT, "layout_dm_amd", "csrc", args[0])
     flt = args[1] if len(args) > 1 else ""
-    asm = sys.argv[sys.argv.index("--asm") + 1] if "--asm" in sys.argv else "/dev/null"
     cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
            "-o", asm, src, "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
