@@ -131,3 +131,29 @@ def test_step_tail_kernels_use_no_scratch(tmp_path):
             for sym, body in blocks:
                 m = re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", body)
                 assert m and int(m.group(1)) == 0, (sym, m and m.group(1))
+
+
+def test_exact_mode_kernels_resources(tmp_path):
+    """The exact mode's fp32 kernels: no scratch, and the register / LDS footprints their schedules were measured at —
+    the 128 x 128 GEMM tile at <= 102 VGPRs and 32 KB of LDS (5 workgroups per CU), its 64-row and 160-wide variants and the
+    fp32 attention (K alone in LDS: 30 KB, <= 170 VGPRs: 3 workgroups per CU).  The GEMMs' operands arrive by LDS-DMA."""
+    want = {
+        "gemm_f32_tileILi2E": dict(src="kernels_gemm.hip", vgpr=102, lds=32 * 1024),
+        "gemm_f32_tileILi1E": dict(src="kernels_gemm.hip", vgpr=85, lds=24 * 1024),
+        "gemm_f32_128x160": dict(src="kernels_gemm.hip", vgpr=128, lds=36 * 1024),
+        "attn32_direct_kILi29E": dict(src="kernels_attn.hip", vgpr=170, lds=0),  # (dynamic LDS: 128 x 59 floats at launch)
+    }
+    asm_of = {}
+    for key, w in want.items():
+        asm = asm_of.setdefault(w["src"], _compile(w["src"], tmp_path))
+        blocks = re.findall(r"\.amdhsa_kernel\s+(\S*%s\S*)(.*?)\.end_amdhsa_kernel" % key, asm, flags=re.S)
+        assert len(blocks) == 1, (key, [b[0] for b in blocks])
+        sym, body = blocks[0]
+        get = lambda field: int(re.search(r"\.amdhsa_%s\s+(\d+)" % field, body).group(1))
+        assert get("private_segment_fixed_size") == 0, sym
+        assert get("next_free_vgpr") <= w["vgpr"], (sym, get("next_free_vgpr"))
+        assert get("group_segment_fixed_size") == w["lds"], (sym, get("group_segment_fixed_size"))
+        if "gemm_f32" in key:
+            ins = _kernels(asm)[sym]
+            assert sum("global_load_lds_dwordx4" in i for i in ins) >= 3, sym
+            assert not any(i.startswith("ds_write") for i in ins), sym  # no register staging left
