@@ -1,5 +1,5 @@
-"""CPU: the bench line the GPU box last produced (profiles/r03_final2_bench.json, written by `python bench.py` with no
-flags) against the driver's contract — the keys, their types and the arithmetic that ties them together.  A change of
+"""CPU: the bench lines the GPU box produced in the evidence runs (profiles/r03_final*_bench.json, written by `python bench.py`
+with no flags) against the driver's contract — the keys, their types and the arithmetic that ties them together.  A change of
 bench.py that breaks the contract shows up here as soon as a new line is committed."""
 import glob
 import json
@@ -10,18 +10,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _latest():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_final*_bench.json")) +
-                   glob.glob(os.path.join(ROOT, "profiles", "r0*_final_bench.json")))
+def _lines():
+    files = sorted(set(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_final*_bench.json"))))
     if not files:
         pytest.skip("no committed bench line")
-    lines = [l for l in open(files[-1]).read().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, "bench.py must print ONE JSON line"
-    return json.loads(lines[0])
+    out = []
+    for f in files:
+        lines = [l for l in open(f).read().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, f"{f}: bench.py must print ONE JSON line"
+        out.append(pytest.param(json.loads(lines[0]), id=os.path.basename(f)))
+    return out
 
 
-def test_bench_line_contract():
-    d = _latest()
+@pytest.mark.parametrize("d", _lines() if glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_final*_bench.json")) else [])
+def test_bench_line_contract(d):
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
