@@ -312,6 +312,133 @@ def relation_cases(spec, B=2, seed=7):
     return out
 
 
+def _relation_cond(spec, B, seed, edge_ratio=0.5):
+    """cond=relation inputs as the reference builds them: random layouts -> AddCanvasElement + AddRelationConstraints
+    (data/util.py:111-177) -> graph batch; seq / mask as helpers/task.py:94-114 (categories given, [PAD] beyond)."""
+    from trainer.data.util import AddCanvasElement, AddRelationConstraints
+
+    g = torch.Generator().manual_seed(seed)
+    rel = AddRelationConstraints(seed=seed, edge_ratio=edge_ratio)
+    ys, eis, eas, bts, seqs, off = [], [], [], [], [], 0
+    for b in range(B):
+        n = int(torch.randint(3, 9, (1,), generator=g))
+        box = torch.rand(n, 4, generator=g) * torch.tensor([0.8, 0.8, 0.5, 0.5]) + torch.tensor([0.1, 0.1, 0.05, 0.05])
+        lab = torch.randint(0, spec.n_category, (n,), generator=g)
+        data = type("Data", (), {})()
+        data.x, data.y, data.attr = box, lab, {"has_canvas_element": torch.tensor([False])}
+        data = rel(AddCanvasElement()(data))
+        ys.append(data.y)
+        eis.append(data.edge_index.view(2, -1) + off)
+        eas.append(data.edge_attr)
+        bts.append(torch.full((n + 1,), b, dtype=torch.long))
+        off += n + 1
+        seq = torch.full((spec.seq_len,), spec.pad_id, dtype=torch.long)
+        seq[: n * spec.n_attr] = spec.mask_id
+        seq[0: n * spec.n_attr: spec.n_attr] = lab
+        seqs.append(seq)
+    graph = rh.GraphBatch(torch.cat(ys), torch.cat(eis, dim=1), torch.cat(eas), torch.cat(bts))
+    seq = torch.stack(seqs)
+    return graph, seq, seq != spec.mask_id
+
+
+def trained_like_cases(spec, B=2):
+    """VERDICT r3 next #1a: the reference itself on weight distributions other than its init (oracle/synth.py
+    TRAINED_LIKE): teacher-forced denoiser logits / posterior at three timesteps, the reference's own float32 noise floor
+    at each (its float32 forward against its own float64 forward: what "bit-exact greedy tokens" and "logits <= 2e-5" can
+    mean at that point), the largest attention score, and a stochastic trajectory with the reference's greedy next
+    tokens and top-2 margins at every step."""
+    m, _ = rh.build_reference_model("rico25", seed=0)               # (installs the import stubs)
+    from trainer.models.categorical_diffusion.util import index_to_log_onehot
+
+    out = {"points": np.array(list(synth.TRAINED_LIKE))}
+    g = torch.Generator().manual_seed(77)
+    ts = [90, 50, 5]
+    out["ts"] = np.array(ts, np.int32)
+    for point in synth.TRAINED_LIKE:
+        ssd = synth.trained_like_state_dict(spec, point, seed=2, prefix="")
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+        floor, smax = 0.0, 0.0
+        for t in ts:
+            tokens = random_valid_tokens(spec, B, t / (spec.n_step - 1), g)
+            tt = torch.full((B,), t, dtype=torch.long)
+            with torch.no_grad():
+                logits = m.transformer(tokens, timestep=tt)["logits"]
+                lz = index_to_log_onehot(tokens, spec.n_class)
+                post = m.q_posterior(m.predict_start(lz, tt), lz, tt)
+                m.double()
+                logits64 = m.transformer(tokens, timestep=tt)["logits"]
+                m.float()
+            floor = max(floor, ((logits.double() - logits64).abs().max() / logits64.abs().max()).item())
+            out[f"{point}_tokens_{t}"] = tokens.numpy().astype(np.int16)
+            out[f"{point}_logits_{t}"] = logits.numpy()
+            out[f"{point}_post_{t}"] = post.numpy()
+        # m.double()/m.float() round-trips the float32 parameters exactly; reload anyway so the trajectory below starts
+        # from the checkpoint as loaded
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+        out[f"{point}_f32_noise_floor"] = np.float64(floor)
+        tr = trajectory(m, spec, B, rh.sampling_cfg("random"), None, seed=11)
+        for k, v in tr.items():
+            out[f"{point}_{k}"] = v
+    return out
+
+
+def config5_cases(B=2):
+    """BASELINE config 5's shape (VERDICT r3 next #1b): a T = 200 model (schedule buffers and AdaLN tables of 200
+    timesteps; base.py:310-311 rejects num_timesteps > the model's) sampled with cond=refinement and with cond=relation —
+    the reference's own sample() on reference-built inputs (helpers/task.py:154-224 prior, data/util.py:111-177 graphs),
+    all 200 steps, with the reference's greedy next tokens and top-2 margins at every visited state."""
+    import dataclasses
+
+    spec = dataclasses.replace(SP.SPECS["rico25"], name="rico25_t200", n_step=200)
+    m, tok = rh.build_reference_model("rico25", seed=0, n_step=200)
+    ssd = synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True, prefix="")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
+    out = {}
+    # refinement (helpers/task.py:126-138, LayoutDM branch)
+    c = synth.synth_cond_c(spec, B, seed=15)
+    g = torch.Generator().manual_seed(19)
+    seq_orig = torch.from_numpy(c["seq"]).clone()
+    for a in range(1, spec.n_attr):
+        ids = torch.as_tensor(spec.full_ids(a))
+        valid = torch.from_numpy(c["seq"][:, a::spec.n_attr] == spec.mask_id)
+        rnd = ids[torch.randint(0, spec.n_bin, (B, spec.max_elem), generator=g)]
+        seq_orig[:, a::spec.n_attr] = torch.where(valid, rnd, seq_orig[:, a::spec.n_attr])
+    cond = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": "refinement",
+            "seq_orig": seq_orig}
+    cfg = rh.sampling_cfg("random", num_timesteps=200, refine_mode="uniform", refine_offset_ratio=0.1,
+                          refine_lambda=3.0)
+    tr = trajectory(m, spec, B, cfg, cond, seed=23)
+    assert len(tr["steps"]) == 200
+    for k, v in tr.items():
+        out["ref_" + k] = v
+    out["ref_cond_seq"] = c["seq"].astype(np.int16)
+    out["ref_cond_mask"] = c["mask"]
+    out["ref_seq_orig"] = seq_orig.numpy().astype(np.int16)
+    from trainer.helpers.task import _index_to_smoothed_log_onehot
+
+    table = _index_to_smoothed_log_onehot(torch.arange(spec.n_class)[None], tok, mode="uniform",
+                                          offset_ratio=0.1)[0].T.contiguous() * 3.0
+    out["ref_weak_table"] = table.numpy()
+    # relation (logit_adjustment.py:88-126 inside _sample_single_step, base.py:261-269)
+    graph, seq, mask = _relation_cond(spec, B, seed=29)
+    cond = {"seq": seq, "mask": mask, "type": "relation", "batch_w_canvas": graph}
+    cfg = rh.sampling_cfg("random", num_timesteps=200, relation_lambda=3e6, relation_mode="average", relation_tau=1.0,
+                          relation_num_update=3)
+    tr = trajectory(m, spec, B, cfg, cond, seed=31)
+    for k, v in tr.items():
+        out["rel_" + k] = v
+    bt = tok.bbox_tokenizer
+    out["rel_cond_seq"] = seq.numpy().astype(np.int16)
+    out["rel_cond_mask"] = mask.numpy()
+    out["rel_y"], out["rel_edge_index"] = graph.y.numpy(), graph.edge_index.numpy()
+    out["rel_edge_attr"], out["rel_batch"] = graph.edge_attr.numpy(), graph.batch.numpy()
+    out["rel_centres"] = np.stack([np.asarray(bt.clustering_models[f"{k}-{spec.n_bin}"].cluster_centers_,
+                                              np.float64).reshape(-1) for k in ("x", "y", "w", "h")])
+    canvas_ids = bt.encode(torch.tensor([[[0.5, 0.5, 1.0, 1.0]]])).long().view(-1)
+    out["rel_canvas_bins"] = (canvas_ids - torch.arange(4) * spec.n_bin).numpy().astype(np.int32)
+    return out
+
+
 def fid_cases(num_label=25, B=6, N=25):
     """FIDNetV3.extract_features (trainer/fid/model.py:147-152) of the REAL reference class on the synthetic
     checkpoint of oracle/fid.py (decoder-half parameters keep their torch init: they do not enter the features)."""
@@ -358,12 +485,20 @@ def main(out_dir=None, only=None):
     if only == "fid":
         np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
         return
+    if only == "trained_like":
+        np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
+        return
+    if only == "config5":
+        np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
+        return
     if only == "decode":
         for ds in ("rico25", "publaynet"):
             _, tok = rh.build_reference_model(ds, seed=0)
             np.savez_compressed(os.path.join(OUT, f"{ds}_decode.npz"), **decode_cases(tok, SP.SPECS[ds]))
         return
     np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
+    np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
+    np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
     for ds in ("rico25", "publaynet"):
         spec = SP.SPECS[ds]
         m, tok = rh.build_reference_model(ds, seed=0)

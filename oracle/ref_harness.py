@@ -225,7 +225,7 @@ DATASETS = {
 }
 
 
-def make_cfgs(dataset: str = "rico25"):
+def make_cfgs(dataset: str = "rico25", n_step: int = 100):
     data_cfg = DictConfig(
         num_bin_bboxes=32,
         pad_until_max=True,
@@ -246,7 +246,7 @@ def make_cfgs(dataset: str = "rico25"):
             batch_first=True,
             norm_first=True,
             timestep_type="adalayernorm",
-            diffusion_step=100,
+            diffusion_step=n_step,
         ),
         num_layers=4,
     )
@@ -254,7 +254,7 @@ def make_cfgs(dataset: str = "rico25"):
 
 
 def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool = False,
-                          q_type: str = "constrained"):
+                          q_type: str = "constrained", n_step: int = 100):
     """Instantiate the reference diffusion module with the reference's own init.
 
     perturb=True additionally randomises every bias / LayerNorm affine parameter so
@@ -270,7 +270,7 @@ def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool 
     )
     from trainer.models.common.util import shrink
 
-    data_cfg, dataset_cfg, backbone_cfg = make_cfgs(dataset)
+    data_cfg, dataset_cfg, backbone_cfg = make_cfgs(dataset, n_step)
     torch.manual_seed(seed)
     tok = LayoutSequenceTokenizer(data_cfg, dataset_cfg)
     cls = ConstrainedMaskAndReplaceDiffusion
@@ -280,7 +280,7 @@ def build_reference_model(dataset: str = "rico25", seed: int = 0, perturb: bool 
         backbone_cfg=shrink(backbone_cfg, 29 / 32),
         num_classes=tok.N_total,
         max_token_length=tok.max_token_length,
-        num_timesteps=100,
+        num_timesteps=n_step,  # BASELINE config 5 samples with T = 200: base.py:310-311 needs a T >= 200 model
         pos_emb="elem_attr",
         transformer_type="flattened",
         auxiliary_loss_weight=0.1,

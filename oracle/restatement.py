@@ -195,9 +195,11 @@ def q_posterior(W, spec: ModelSpec, log_x_start: torch.Tensor, tokens: torch.Ten
     return out
 
 
-def apply_cond(spec: ModelSpec, logp: torch.Tensor, cond: Optional[dict]) -> torch.Tensor:
-    """Constraint injection of _sample_single_step (categorical_diffusion/base.py:243-284),
-    except cond=relation's gradient update (logit_adjustment.py) which stays in PyTorch."""
+def apply_cond(spec: ModelSpec, logp: torch.Tensor, cond: Optional[dict], t: Optional[int] = None) -> torch.Tensor:
+    """Constraint injection of _sample_single_step (categorical_diffusion/base.py:243-284).  cond=relation's gradient
+    update (logit_adjustment.py:88-126, between the refinement prior and the [PAD] disable) runs when the cond dict
+    carries its inputs under "relation" = {graph, centres, canvas_bins, lr, num_update} and the model timestep `t` is
+    given; without them the relation step is skipped (the update then belongs to the caller)."""
     if not cond:
         return logp
     B, C, S = logp.shape
@@ -208,6 +210,10 @@ def apply_cond(spec: ModelSpec, logp: torch.Tensor, cond: Optional[dict]) -> tor
     if cond.get("type") == "refinement":
         wm = torch.as_tensor(cond["weak_mask"])
         logp = torch.where(wm, logp + torch.as_tensor(cond["weak_logits"]), logp)
+    if cond.get("type") == "relation" and cond.get("relation") is not None and t is not None:
+        r = cond["relation"]
+        logp = relation_update(spec, logp, seq, r["graph"], r["centres"], r["canvas_bins"], float(r["lr"]),
+                               int(r["num_update"]), int(t))
     if cond.get("type") in ("c", "cwh", "refinement", "relation"):
         pos = torch.arange(S).view(1, S)
         pad_mask = (pos % spec.n_attr != 0) & (seq != spec.pad_id)  # (B,S)
@@ -334,7 +340,7 @@ def single_step(W, spec, tokens, t, cfg, cond=None, skip_step: int = 0, uniforms
     if skip_step > 0 and noise_t > skip_step:
         noise_t = noise_t - skip_step
     logp = q_posterior(W, spec, log_x0, tokens, noise_t, q_type=q_type)
-    logp = apply_cond(spec, logp, cond)
+    logp = apply_cond(spec, logp, cond, t)          # the relation update sees the MODEL timestep (base.py:262)
     nxt = sample_tokens(logp, cfg, uniforms=uniforms, generator=generator)
     if return_all:
         return nxt, logits, logp
