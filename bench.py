@@ -24,8 +24,14 @@ The ONE JSON line carries the headline numerics mode (--precision, default `fast
   "tokens_sha256" of the first 512 layouts of a fixed-seed Rico25 unconditional run: independent of N by construction
               (Philox keyed by global layout index), so a scaling run can prove it.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run (one rank
-per GPU).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launch it under torch.distributed.run (one
+rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or call it plainly — `python bench.py
+--gpus N` then re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1` on a free port.  Every N > 1 run uses the SAME per-GPU workload (config 4: 1024 layouts per GPU); the N = 1
+line keeps config 2 as the headline and carries the config-4 figure under "scaling_point".  Rank 0 prints ONE JSON
+line (with n_gpus, the RCCL world size actually seen, per-rank layouts/s min / max, tokens_sha256).
+`--dry-run`: the same launch, shard, gather, barrier and reporting path on the gloo backend with a fake sampler (no
+GPU): what tests/test_bench_spawn.py runs at world size 2.
 """
 from __future__ import annotations
 
@@ -88,7 +94,108 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes")
     ap.add_argument("--cpu-budget", type=float, default=22.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / shard / gather / report path only: gloo backend, fake sampler, no GPU")
     return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------- self-spawn (N > 1)
+def maybe_spawn(a):
+    """`python bench.py --gpus N` outside a torch.distributed.run launch: re-execute under it (one rank per GPU)."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def _fake_tokens(first, count, seed, S=125):
+    """Deterministic function of the GLOBAL layout index (what the Philox-keyed sampler guarantees on the GPU)."""
+    import torch
+
+    i = torch.arange(first, first + count, dtype=torch.int64)[:, None]
+    s = torch.arange(S, dtype=torch.int64)[None, :]
+    return ((((i * 2654435761 + s * 40503 + seed * 7919) & 0xFFFFFFFF) >> 7) % 150).to(torch.int32)
+
+
+def dry_run_main(a, world, rank, local_rank):
+    """The N-rank launch path without a GPU: gloo, fake sampler through distributed.sample_sharded, the same barrier +
+    max-over-ranks timing, per-rank statistics and tokens_sha256 as the real run."""
+    import hashlib
+
+    import torch
+
+    from layout_dm_amd.distributed import sample_sharded, shard_range
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+    config = a.config or (2 if world == 1 else 4)
+    B = a.batch or CONFIGS[config]["batch"]
+    n_global = a.total if a.total else world * B
+    lo, hi = shard_range(n_global, rank, world) if a.total else (rank * B, (rank + 1) * B)
+    seed_box, local_s = [0], [0.0]
+
+    def sample_fn(first, count):
+        assert world == 1 or (first == lo and count == hi - lo)
+        t = time.perf_counter()
+        out = _fake_tokens(first, count, seed_box[0])
+        local_s[0] += time.perf_counter() - t
+        return out
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+
+    final = None
+    for i in range(a.warmup):
+        seed_box[0] = i
+        final = sample_sharded(sample_fn, n_global)
+    sync()
+    local_s[0] = 0.0
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        seed_box[0] = a.warmup + i
+        final = sample_sharded(sample_fn, n_global)
+    sync()
+    dt = time.perf_counter() - t0
+    rates = [(hi - lo) * a.steps / max(local_s[0], 1e-9)]
+    seen_world = 1
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        allr = [None] * world
+        dist.all_gather_object(allr, rates[0])
+        rates, seen_world = allr, dist.get_world_size()
+    assert final.shape[0] == n_global and torch.equal(final, _fake_tokens(0, n_global, a.warmup + a.steps - 1))
+    sha = hashlib.sha256(sample_sharded(lambda f, c: _fake_tokens(f, c, SHA_SEED), max(SHA_LAYOUTS, world))
+                         [:SHA_LAYOUTS].contiguous().numpy().tobytes()).hexdigest()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "layouts/sec (whole node), Rico25 uncond T=100", "value": round(n_global * a.steps / dt, 2),
+            "unit": "layouts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "strong" if a.total else "weak", "vs_baseline": None, "dtype": "none (dry run)",
+            "data": "synthetic", "dry_run": True,
+            "config": {"workload": f"DRY RUN (fake sampler, gloo): BASELINE config {config} shape, batch={B}/GPU",
+                       "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
+            "world_size_seen": seen_world,
+            "per_rank_layouts_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1), "ranks": len(rates)},
+            "tokens_sha256": {"sha256": sha, "of": "fake sampler; must not depend on n_gpus"}}), flush=True)
 
 
 # ----------------------------------------------------------------------------------------- CPU baseline
@@ -236,15 +343,25 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
     seed_box = [0]
     my_lo = shard_range(total, rank, world)[0] if total else rank * B
 
+    ev_pairs = []
+
     def sample_fn(first_layout, count):  # this rank's shard: `count` layouts starting at global index `first_layout`
         assert count == B and (world == 1 or first_layout == my_lo)
         tokens.copy_(init)  # inputs resident in HBM
+        if world > 1:       # this rank's own device time, without the gather / barrier (per-rank layouts/s)
+            ev_pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+            ev_pairs[-1][0].record()
+        _sample(first_layout)
+        if world > 1:
+            ev_pairs[-1][1].record()
+        return tokens
+
+    def _sample(first_layout):
         if verified:
             model.verified.sample_loop(tokens, t_model, t_post, cond=None)
         else:
             eng.sample_loop(tokens, t_model, t_post, cfg, seed=seed_box[0], first_layout=first_layout,
                             use_graph=not a.no_graph, lc_keep=lc_keep, relation=relation)
-        return tokens
 
     n_global = total if total else world * B
 
@@ -261,15 +378,23 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
     for i in range(warmup):
         final = one_step(i)
     sync()
+    del ev_pairs[:]
     t0 = time.perf_counter()
     for i in range(steps):
         final = one_step(warmup + i)
     sync()
     dt = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        mine = torch.tensor([B * len(ev_pairs) / max(sum(x.elapsed_time(y) for x, y in ev_pairs) * 1e-3, 1e-9)],
+                            dtype=torch.float64, device=dev)
+        allr = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = {"min": round(float(allr.min()), 1), "max": round(float(allr.max()), 1), "ranks": int(allr.numel()),
+                    "what": "layouts/s of each rank's own sampling launches (HIP events, no gather / barrier)"}
     fin = final.cpu()
     assert fin.shape[0] == n_global
     assert (fin != eng.mask_id).all(), "sampling left [MASK] tokens"
@@ -285,8 +410,11 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
            "sampling": sampling,
            "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
            "frac_of_mfma_peak_whole_job": round(value * flop_layout / 1e12 / (world * PEAK_TFLOPS[precision]), 4)}
+    if per_rank is not None:
+        res["per_rank_layouts_per_s"] = per_rank
     if verified:
-        res["verification"] = dict(model.verified.last_stats, tie_rel=model.verified.tie_rel)
+        res["verification"] = dict(model.verified.last_stats)
+        res["calibration"] = dict(model.verified.calibration)
     if with_roofline and rank == 0 and not verified:
         # per-kernel durations: HIP events around every launch, on the stream the kernels run on, over one more step of
         # the same workload (eager launches — events cannot bracket graph nodes; the one-launch loop of the fast mode is
@@ -357,6 +485,7 @@ def tokens_sha256(a, sd, spec, rank, world, local_rank, dist):
 
 def main():
     a = parse()
+    maybe_spawn(a)          # `python bench.py --gpus N>1` re-executes itself under torch.distributed.run (does not return)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -364,8 +493,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if a.dry_run:
+        return dry_run_main(a, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -412,6 +541,7 @@ def main():
 
     res, eng, tokens = run_mode(a, spec, sd, a.precision, B, a.steps, a.warmup, cond_local, rank, world, local_rank,
                                 dist, with_roofline=not a.no_roofline, total=a.total)
+    desc = eng.describe()
     per_gpu = f"{B}/GPU" if not a.total else f"{a.total} total ({B} on rank 0)"
     workload = (f"BASELINE config {config}: {a.dataset} cond={a.cond} T={a.timesteps} batch={per_gpu} "
                 f"sampling={a.sampling}" + (" top_p=0.9" if a.sampling == "top_p" else ""))
@@ -434,13 +564,22 @@ def main():
                    "cond=c sequences built as helpers/task.py:94-110, n~U{1..25} elements per layout)"),
         "config": {"workload": workload, "precision_mode": a.precision,
                    "launch": "one launch per sampling call (reverse loop resident in the layout's workgroup)"
-                   if (a.precision == "fast" and os.environ.get("LDM_STACK_LOOP", "1") != "0") else
+                   if desc.get("loop") == "one_launch" else
                    ("per-step launches in hipGraphs" if not a.no_graph else "per-step launches, eager"),
                    "chunk_layouts": eng.chunk, "lanes": eng.lanes,
-                   "env_overrides": {k: v for k, v in os.environ.items() if k.startswith("LDM_") and k != "LDM_BENCH_PRECISION"},
+                   # what the LIBRARY says it runs (ldm_describe), incl. the development knobs it honoured (LDM_DEV=1
+                   # only; ldm_create refuses a stray knob) — not what os.environ happens to hold
+                   "library": desc,
+                   "cpu_baseline_kind": "port",
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
         "algorithmic_tflops": res["algorithmic_tflops"],
+        "world_size_seen": dist.get_world_size() if dist is not None else 1,
     }
+    if "per_rank_layouts_per_s" in res:
+        out["per_rank_layouts_per_s"] = res["per_rank_layouts_per_s"]
+    if world > 1 and config == 4 and not a.total and not a.batch:
+        out["scaling_point"] = {"workload": "BASELINE config 4 shard: rico25 uncond T=100 1024 layouts/GPU sampling=random",
+                                "layouts_per_s_per_gpu": round(res["value"] / world, 2)}
     for k in ("roofline", "kernel_breakdown_ms", "gemm_mfma_utilisation"):
         if k in res:
             out[k] = res[k]
@@ -473,10 +612,11 @@ def main():
                 # BASELINE config 2 verbatim: GREEDY decoding; fast + exact re-decision == the exact engine's tokens
                 if a.cond != "unconditional":
                     continue
-                r, e2, tk = run_mode(a, spec, sd, "fast", B, min(a.steps, 3), 1, None, rank, world, local_rank, dist,
+                kv = max(a.steps, 10)
+                r, e2, tk = run_mode(a, spec, sd, "fast", B, kv, 1, None, rank, world, local_rank, dist,
                                      with_roofline=False, sampling="deterministic", verified=True)
                 e2.close()
-                g, e3, _ = run_mode(a, spec, sd, "fast", B, min(a.steps, 3), 1, None, rank, world, local_rank, dist,
+                g, e3, _ = run_mode(a, spec, sd, "fast", B, kv, 1, None, rank, world, local_rank, dist,
                                     with_roofline=False, sampling="deterministic")
                 e3.close()
                 x, e4, tx = run_mode(a, spec, sd, "exact", B, 1, 0, None, rank, world, local_rank, dist,
@@ -484,8 +624,21 @@ def main():
                 r["tokens_equal_exact_mode"] = bool(torch.equal(tk, tx))
                 e4.close()
                 r["plain_fast_greedy_layouts_per_s"] = g["value"]
+                if config == 2 and B == 512 and a.timesteps == 100:
+                    # BASELINE config 2 as written: greedy decode with the bit-exact check.  Greedy decoding of THIS
+                    # diffusion keeps every token [MASK] until t <= 2 on ANY checkpoint (the posterior's mass on
+                    # [MASK] is ~ (t-1)/t: SURVEY App. G), so the near-ties — and the exact re-checks — sit in the
+                    # last steps; `nondegenerate` below starts the greedy loops from mid-trajectory states instead
+                    out["config2_verbatim"] = {
+                        "workload": "BASELINE config 2 verbatim: rico25 cond=unconditional T=100 batch=512 greedy decode",
+                        "mode": "fast_verified", "value": r["value"], "unit": "layouts/s", "steps": kv,
+                        "ms_per_step": r["ms_per_step"], "tokens_equal_exact_mode": r["tokens_equal_exact_mode"],
+                        "exact_fraction": r["verification"]["exact_fraction"],
+                        "relaunched_fraction": r["verification"]["relaunched_fraction"]}
+                    if not a.no_extras:
+                        r["nondegenerate"] = verified_nondegenerate(a, spec, sd, B, local_rank)
             else:
-                k = a.steps if m == "fast" else min(a.steps, 5)  # exact steps take ~1.5 s each
+                k = a.steps if m == "fast" else 10  # exact steps take ~1.2 s each; >= 10 timed steps whatever --steps says
                 r, e2, _ = run_mode(a, spec, sd, m, B, k, 1, cond_local, rank, world, local_rank, dist,
                                     with_roofline=not a.no_roofline)
                 e2.close()
@@ -495,6 +648,19 @@ def main():
     if world == 1 and not a.no_extras and not a.total and not a.batch:
         out["configs"] = extras(a, SP, config, rank, world, local_rank, dist)
         out["fid_features"] = fid_timing(SP, local_rank)
+        if "4" in out["configs"]:   # the per-GPU workload of every N > 1 run, under the same key there
+            out["scaling_point"] = {"workload": "BASELINE config 4 shard: rico25 uncond T=100 1024 layouts/GPU sampling=random",
+                                    "layouts_per_s_per_gpu": out["configs"]["4"]["value"]}
+        if config == 2 and a.cond == "unconditional":
+            # a power-bound kernel's clock depends on operand statistics: the headline workload once more on the
+            # "wide" trained-like weights (sigma 0.15, LayerNorm gains 1 +- 0.5, outlier channels, AdaLN x5)
+            sdw = SP.trained_like_state_dict(spec, "wide", seed=2)
+            rw, ew, _ = run_mode(a, spec, sdw, a.precision, B, min(a.steps, 5), 1, None, rank, world, local_rank, dist,
+                                 with_roofline=False)
+            ew.close()
+            out["weight_sensitivity"] = {"weights": "trained_like 'wide' (layout_dm_amd/synthetic.py)", "value": rw["value"],
+                                         "unit": "layouts/s", "steps": rw["steps"],
+                                         "ratio_to_headline": round(rw["value"] / res["value"], 4)}
     if not a.no_extras:
         out["tokens_sha256"] = {"sha256": tokens_sha256(a, SP.synth_state_dict(SP.SPECS["rico25"], seed=0), SP.SPECS["rico25"],
                                                         rank, world, local_rank, dist),
@@ -519,16 +685,88 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def verified_nondegenerate(a, spec, sd, B, local_rank):
+    """fast_verified where the marks are NOT confined to a greedy run's last steps by construction: greedy free-running
+    loops started from the states a stochastic (`random`) run visits at step 20 / 50 / 80, B layouts; each checked
+    token for token against the exact engine's greedy loop from the same state."""
+    import torch
+
+    from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion, timestep_schedule
+
+    m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
+                                   d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
+                                   num_timesteps=spec.n_step, precision="fast_verified", max_batch=B, device=local_rank)
+    m.load_state_dict(sd)
+    vg, fa, ex = m.verified, m.verified.fast, m.verified.exact
+    t_model, t_post = timestep_schedule(spec.n_step, a.timesteps)
+    n = len(t_model)
+    greedy = {"name": "deterministic"}
+    tok = torch.full((B, fa.S), fa.mask_id, dtype=torch.int32, device=fa.device)
+    _, inter = fa.sample_loop(tok, t_model, t_post, {"name": "random", "temperature": 1.0}, seed=77, intermediates=True)
+    inter = inter.clone()
+    out = {"what": f"greedy loops from the states of a `random` run (seed 77) at step i0, {B} layouts; layouts/s-equivalent "
+                   f"= {B} x (steps run) / {n} / time", "calibration": dict(vg.calibration)}
+    reps = 3
+    for i0 in (20, 50, 80):
+        start = inter[i0 - 1].clone()
+        want = ex.sample_loop(start.clone(), t_model[i0:], t_post[i0:], greedy)[0].clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ex.sample_loop(start.clone(), t_model[i0:], t_post[i0:], greedy)
+        torch.cuda.synchronize()
+        dt_exact = time.perf_counter() - t0
+        vg.sample_loop(start.clone(), t_model[i0:], t_post[i0:])       # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            got = vg.sample_loop(start.clone(), t_model[i0:], t_post[i0:])[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        st = vg.last_stats
+        out[f"from_step_{i0}"] = {
+            "value": round(B * (n - i0) / n / dt, 1), "unit": "layouts/s-equivalent", "steps_run": n - i0, "reps": reps,
+            "exact_engine_layouts_per_s_equivalent": round(B * (n - i0) / n / dt_exact, 1),
+            "tokens_equal_exact_mode": bool(torch.equal(got, want)),
+            "exact_fraction": round(st["exact_fraction"], 5), "relaunched_fraction": round(st["relaunched_fraction"], 6),
+            "marked_layout_steps": st["marked_layout_steps"], "mismatch_layout_steps": st["mismatch_layout_steps"],
+            "fast_passes": st["fast_passes"]}
+    fa.close()
+    ex.close()
+    return out
+
+
 def extras(a, SP, headline_config, rank, world, local_rank, dist):
     """The other BASELINE configurations and SURVEY section 8f's rows, a few steps each (N = 1)."""
     import copy
+    import dataclasses
 
     out = {}
-    for key in ("3", "4", "refinement", "relation"):
+    for key in ("3", "4", "refinement", "relation", "5_refinement_T200", "5_relation_T200"):
         if key == str(headline_config):
             continue
         b = copy.copy(a)
         graph = None
+        if key.startswith("5_"):
+            # BASELINE config 5's shape: a T = 200 model (schedule buffers / AdaLN tables of 200 timesteps; base.py:310-311
+            # needs num_timesteps <= the model's) sampled for 200 steps with cond=refinement / cond=relation, 512 layouts
+            b.dataset, b.sampling, b.timesteps, B = "rico25", "random", 200, 512
+            spec = dataclasses.replace(SP.SPECS["rico25"], n_step=200)
+            if key == "5_refinement_T200":
+                cond = SP.synth_cond_refinement(spec, B, seed=0)
+            else:
+                cond, graph = SP.synth_cond_relation(spec, B, seed=0)
+            what = (f"BASELINE config 5 shape: rico25 cond={'refinement' if graph is None else 'relation'} T=200 (T=200 "
+                    f"model, random-init weights) batch={B} sampling=random")
+            sd = SP.synth_state_dict(spec, seed=0, perturb=False)
+            r, e, _ = run_mode(b, spec, sd, a.precision, B, 3, 1, cond, rank, world, local_rank, dist,
+                               with_roofline=not a.no_roofline, relation_graph=graph)
+            e.close()
+            entry = {"workload": what, "value": r["value"], "unit": "layouts/s", "ms_per_step": r["ms_per_step"], "steps": 3,
+                     "algorithmic_tflops": r["algorithmic_tflops"]}
+            if "roofline" in r:
+                entry["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "frac", "avg_launch_ms", "share_of_step")}
+            out[key] = entry
+            continue
         if key in ("3", "4"):
             base = CONFIGS[int(key)]
             b.dataset, b.cond, b.sampling, B = base["dataset"], base["cond"], base["sampling"], base["batch"]

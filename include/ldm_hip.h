@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 4
+#define LDM_ABI_VERSION 5
 
 typedef struct ldm_handle ldm_handle;
 
@@ -162,15 +162,18 @@ int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm_cond* cond
                     uint64_t seed, uint64_t first_layout, int B, int32_t* d_intermediates, int use_graph,
                     void* stream);
 
-/* ---- near-tie report of deterministic decoding (ABI 4) ---------------------------------------
- * north star: "token indices bit-exact under greedy/argmax decoding".  LDM_PREC_FAST_F16 carries <= 1e-3 relative logits
- * error, so its argmax (sampling.py:88-90) can differ from the reference's where two classes are closer than that error
- * can move them.  tie_rel > 0 enables the report: every deterministic ldm_sample_step / ldm_sample_loop then marks, per
- * (step, layout), whether some token of the layout was decided with a log-probability lead over the runner-up below
- * tie_rel * max |logit of that token| (6 x the mode's relative logits error bounds the lead's error: DESIGN.md section 3.5).
- * Unmarked layouts carry the reference's own greedy tokens; the caller re-decides the marked ones in LDM_PREC_EXACT_F32
- * from the state before their first marked step (layout_dm_amd/verified.py).  tie_rel = 0 disables. */
-int ldm_set_tie_report(ldm_handle* h, float tie_rel);
+/* ---- near-tie report of deterministic decoding (ABI 4; tie_abs: ABI 5) ------------------------
+ * north star: "token indices bit-exact under greedy/argmax decoding".  LDM_PREC_FAST_F16's logits carry an error that
+ * depends on the checkpoint (3e-4 of max |logit| on the reference's init, 1e-3 on wider weights, more once attention rows
+ * saturate: DESIGN.md section 3.5), so its argmax (sampling.py:88-90) can differ from the reference's where two classes
+ * are closer than that error can move them.  With the report enabled every deterministic ldm_sample_step /
+ * ldm_sample_loop marks, per (step, layout), whether some token of the layout was decided with a log-probability lead
+ * over the runner-up below  max(tie_rel * max |logit of that token|, tie_abs).  The lead moves by at most 6 x the largest
+ * absolute logits error of the token: with tie_abs = 6 x a bound on that error — MEASURED on the
+ * checkpoint by the caller, layout_dm_amd/verified.py calibrate() — an unmarked token is the exact mode's token; the
+ * caller re-checks the marked (step, layout) pairs in LDM_PREC_EXACT_F32.  tie_rel = tie_abs = 0 disables.  Not defined
+ * for cond=relation (the draw follows an SGD on the log-probabilities): such calls fail while the report is enabled. */
+int ldm_set_tie_report(ldm_handle* h, float tie_rel, float tie_abs);
 /* flags of the most recent deterministic call: d_flags (n_steps, B) uint8, row i = i-th step of that call */
 int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, int B, void* stream);
 
@@ -230,6 +233,12 @@ int ldm_profile_get(ldm_handle* h, int idx, const char** name, double* total_ms,
                     double* flops, double* bytes);
 int ldm_profile_reset(ldm_handle* h);
 int ldm_abi_version(void);
+/* "key=value;..." description of what the handle runs — numerics mode, kernel family, one-launch loop or per-step
+ * graphs, chunk / lanes, near-tie thresholds — and the development knobs the library honoured in this process.
+ * Environment knobs (LDM_STACK_LOOP, LDM_FUSED_ATTN, ...: INTEGRATION.md section 5) select development / ablation paths;
+ * they are honoured only together with LDM_DEV=1, and ldm_create fails while one is set without it.
+ * Writes at most cap - 1 characters + NUL; returns the length needed (ABI 5). */
+int ldm_describe(const ldm_handle* h, char* buf, int cap);
 /* layouts per chunk and number of concurrent lanes the handle was created with (after the 0 = auto defaults) */
 int ldm_get_layout(const ldm_handle* h, int* chunk, int* lanes);
 

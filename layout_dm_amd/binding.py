@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16 = 0, 1, 2
 PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16,
@@ -27,7 +27,7 @@ EXPORTS = (
     "ldm_denoise_logits", "ldm_posterior", "ldm_sample_tokens", "ldm_sample_step", "ldm_sample_loop",
     "ldm_decode_layouts", "ldm_relation_update", "ldm_set_tie_report", "ldm_get_tie_flags",
     "ldm_last_loop_ms", "ldm_set_profiling", "ldm_profile_count", "ldm_profile_get", "ldm_profile_reset",
-    "ldm_abi_version", "ldm_get_layout",
+    "ldm_abi_version", "ldm_get_layout", "ldm_describe",
     # FID feature extractor (bound in layout_dm_amd/fid.py)
     "ldm_fid_create", "ldm_fid_destroy", "ldm_fid_last_error", "ldm_fid_load_weight", "ldm_fid_finalize",
     "ldm_fid_features", "ldm_prdc",
@@ -90,7 +90,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                     C.POINTER(C.c_int32), i32, C.POINTER(LdmSampler), u64, u64, i32, vp, i32, vp]
     lib.ldm_decode_layouts.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.ldm_relation_update.argtypes = [vp, vp, vp, C.POINTER(LdmRelation), i32, i32, vp]
-    lib.ldm_set_tie_report.argtypes = [vp, C.c_float]
+    lib.ldm_set_tie_report.argtypes = [vp, C.c_float, C.c_float]
     lib.ldm_get_tie_flags.argtypes = [vp, vp, i32, i32, vp]
     lib.ldm_last_loop_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ldm_set_profiling.argtypes = [vp, i32]
@@ -99,6 +99,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ldm_profile_reset.argtypes = [vp]
     lib.ldm_get_layout.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ldm_describe.argtypes = [vp, C.c_char_p, i32]
     for name in EXPORTS:
         if name not in ("ldm_destroy", "ldm_last_error") and not name.startswith("ldm_fid_"):
             getattr(lib, name).restype = C.c_int
@@ -296,10 +297,10 @@ class Engine:
         return tokens, inter
 
     # ------------------------------------------------------------------ near-tie report (deterministic decoding)
-    def set_tie_report(self, tie_rel: float):
-        """tie_rel > 0: deterministic steps / loops mark, per (step, layout), whether some token was decided with a lead
-        over the runner-up below tie_rel * max |logit| (include/ldm_hip.h); 0 disables."""
-        self._check(self.lib.ldm_set_tie_report(self._h, float(tie_rel)), "ldm_set_tie_report")
+    def set_tie_report(self, tie_rel: float, tie_abs: float = 0.0):
+        """Deterministic steps / loops mark, per (step, layout), whether some token was decided with a lead over the
+        runner-up below max(tie_rel * max |logit of the token|, tie_abs) (include/ldm_hip.h); 0, 0 disables."""
+        self._check(self.lib.ldm_set_tie_report(self._h, float(tie_rel), float(tie_abs)), "ldm_set_tie_report")
 
     def tie_flags(self, n_steps: int, B: int) -> torch.Tensor:
         """(n_steps, B) uint8 flags of the most recent deterministic call."""
@@ -360,6 +361,22 @@ class Engine:
         return {"bbox": bbox, "label": label, "mask": mask.bool()}
 
     # ------------------------------------------------------------------ introspection
+    def describe(self) -> Dict[str, str]:
+        """What this handle runs (ldm_describe): numerics mode, kernel family, loop structure, chunk / lanes, near-tie
+        thresholds and the development knobs the LIBRARY honoured (LDM_DEV=1 only) — not what os.environ says."""
+        buf = C.create_string_buffer(1024)
+        n = self.lib.ldm_describe(self._h, buf, 1024)
+        if n < 0:
+            raise RuntimeError("ldm_describe failed")
+        out = {}
+        for kv in buf.value.decode().split(";"):
+            k, _, v = kv.partition("=")
+            if k == "knobs":
+                out[k] = buf.value.decode().split("knobs=", 1)[1]
+                break
+            out[k] = v
+        return out
+
     def last_loop_ms(self) -> float:
         ms = C.c_float()
         self._check(self.lib.ldm_last_loop_ms(self._h, C.byref(ms)), "ldm_last_loop_ms")

@@ -423,8 +423,9 @@ static void launch_rows(const AttnArgs& a, hipStream_t st) {
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
   // LDM_ATTN32=rows selects the r01 VALU kernel for A/B timing
-  static const bool use_rows = getenv("LDM_ATTN32") && std::string(getenv("LDM_ATTN32")) == "rows";
-  static const bool use_staged = getenv("LDM_ATTN32") && std::string(getenv("LDM_ATTN32")) == "staged";  // A/B timing
+  static const std::string attn32_knob = knob_env("LDM_ATTN32") ? knob_env("LDM_ATTN32") : "";
+  static const bool use_rows = attn32_knob == "rows";
+  static const bool use_staged = attn32_knob == "staged";  // A/B timing
   if (!a.in_f16 && !use_rows && !use_staged && a.S <= 128 && a.S > 96 && a.dh == 58 && a.D % 2 == 0 && a.ld % 2 == 0 &&
       a.ldo32 % 2 == 0 && a.ldo16 % 2 == 0) {
     constexpr int DH2 = 29;

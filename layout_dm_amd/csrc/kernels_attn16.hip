@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
 
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st) {
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
-  static const int abl = getenv("LDM_ATTN_ABL") ? atoi(getenv("LDM_ATTN_ABL")) : 0;
+  static const int abl = knob_int("LDM_ATTN_ABL", 0);  // (dev mode only: ldm_knobs.h)
   auto kern = abl == 1 ? attn_mfma_k<1> : abl == 2 ? attn_mfma_k<2> : abl == 3 ? attn_mfma_k<3> : attn_mfma_k<0>;
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), 0, st, qkv, out, S, H, ldq, ldo, scale_log2e);
 }

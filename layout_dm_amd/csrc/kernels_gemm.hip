@@ -412,7 +412,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
     // opt-in (LDM_GEMM32_WIDE=1): run alone, the 160-wide tiles cut FFN2 by 4 % (366 vs 381 ms per 100 steps), but the
     // timed exact-mode loop runs two chunk pipelines concurrently, where the other lane already fills the idle slots, and
     // there they are 0.5 % slower (profiles/r03_call26_gemm32_wide_ab.txt; the same verdict as r02_call35_37_*)
-    static const bool wide = getenv("LDM_GEMM32_WIDE") && atoi(getenv("LDM_GEMM32_WIDE")) != 0;
+    static const bool wide = knob_int("LDM_GEMM32_WIDE", 0) != 0;
     const int t160 = (g.N + F32_BN2 - 1) / F32_BN2;
     if (wide && t160 * F32_BN2 < tiles_n * 128) {  // fewer padded columns (N = 464: 480 vs 512)
       static const int resident160 = [] {
@@ -432,12 +432,12 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-      if (const char* v = getenv("LDM_GEMM32_SLOTS")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (A/B timing)
+      if (const char* v = knob_env("LDM_GEMM32_SLOTS")) per_cu = atoi(v) > 0 ? atoi(v) : per_cu;  // (A/B timing)
       return (per_cu * cus) & ~7;  // (a multiple of 8: tile t stays on XCD t % 8)
     };
     static const int resident = resident_of((const void*)gemm_f32_tile<2>);  // 32 KB of LDS, < 100 VGPRs: 5 per CU
     const int n_tiles = tiles_m * tiles_n;
-    static const bool bm64 = getenv("LDM_GEMM32_BM64") && atoi(getenv("LDM_GEMM32_BM64")) != 0;
+    static const bool bm64 = knob_int("LDM_GEMM32_BM64", 0) != 0;
     if (bm64 && n_tiles <= resident) {  // one round of 128-row tiles: two half-height tiles per workgroup instead
       static const int resident64 = resident_of((const void*)gemm_f32_tile<1>);
       const int n64 = ((g.M + 63) / 64) * tiles_n;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
     p.tokens_out[row] = d.token;
     // near-tie report (deterministic decoding): the winner's lead over the runner-up is inside what the mode's logits
     // error can move — the caller re-decides this layout in the exact mode (ldm_tie_flags_*)
-    if (p.tie_flags && !p.logp_in && d.gap < p.tie_rel * absmax) p.tie_flags[b] = 1;
+    if (p.tie_flags && !p.logp_in && d.gap < fmaxf(p.tie_rel * absmax, p.tie_abs)) p.tie_flags[b] = 1;
   }
   if (p.x_next) {
     // the group that drew the token also writes the row the next reverse step starts from (a separate embedding
@@ -181,7 +181,7 @@ void launch_posterior_sample(const PostArgs& p, hipStream_t st) {
   const int M = p.B * p.S;
   int live_max = 0;
   for (int a = 0; a < p.v.n_attr; ++a) live_max = live_max > p.v.count[a] + 2 ? live_max : p.v.count[a] + 2;
-  const char* fw = getenv("LDM_POST_WAVE");  // A/B aid and test hook (read per launch: tests toggle it)
+  const char* fw = knob_env("LDM_POST_WAVE");  // A/B aid and test hook (read per launch: tests toggle it)
   const bool force_wave = fw && atoi(fw) != 0;
   const bool wave = p.logp_in || p.logp_out || live_max > 48 || force_wave;
   auto kern = wave ? (p.f32_lse ? posterior_sample_k<64, false, true> : posterior_sample_k<64, false, false>)

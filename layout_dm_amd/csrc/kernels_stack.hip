@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
               toks[s] = d.token;
               if (kp->inter) kp->inter[((size_t)it * kp->inter_ld + b) * S + s] = d.token;
               if (last) p.tokens_out[(size_t)b * S + s] = d.token;
-              if (p.tie_flags && d.gap < p.tie_rel * rs.z) p.tie_flags[(size_t)it * kp->tie_ld + b] = 1;
+              if (p.tie_flags && d.gap < fmaxf(p.tie_rel * rs.z, p.tie_abs)) p.tie_flags[(size_t)it * kp->tie_ld + b] = 1;
             }
           }
         }
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
 void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int B, int S, int H, int dh,
                          const StackHead& head, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + F + 2 * LN_DP + 512) * 4;
-  static const bool tm = getenv("LDM_ATTN_TM") && atoi(getenv("LDM_ATTN_TM")) != 0;
+  static const bool tm = knob_int("LDM_ATTN_TM", 0) != 0;
   auto kern = tm ? stack_stream_k<true, 1> : stack_stream_k<false, 1>;
   allow_big_lds((const void*)kern);
   StackArgs a{};

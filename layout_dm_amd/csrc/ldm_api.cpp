@@ -88,7 +88,7 @@ struct PendingEvent {
 struct GraphKey {
   int B, n_steps, kind, top_k, has_cond, has_strong, has_weak, pad_disable, has_inter;
   int has_rel = 0, rel_num_update = 0, rel_n_graph = 0, rel_bins[4] = {0, 0, 0, 0};
-  float tie_rel = 0.f;
+  float tie_rel = 0.f, tie_abs = 0.f;
   float rel_lambda = 0.f;
   const void* rel_edges = nullptr;
   float temperature, top_p;
@@ -97,7 +97,7 @@ struct GraphKey {
   bool operator==(const GraphKey& o) const {
     return B == o.B && n_steps == o.n_steps && kind == o.kind && top_k == o.top_k && has_cond == o.has_cond &&
            has_strong == o.has_strong && has_weak == o.has_weak && pad_disable == o.pad_disable &&
-           has_inter == o.has_inter && tie_rel == o.tie_rel && has_rel == o.has_rel && rel_num_update == o.rel_num_update &&
+           has_inter == o.has_inter && tie_rel == o.tie_rel && tie_abs == o.tie_abs && has_rel == o.has_rel && rel_num_update == o.rel_num_update &&
            rel_n_graph == o.rel_n_graph && rel_lambda == o.rel_lambda && rel_edges == o.rel_edges &&
            rel_bins[0] == o.rel_bins[0] && rel_bins[1] == o.rel_bins[1] && rel_bins[2] == o.rel_bins[2] &&
            rel_bins[3] == o.rel_bins[3] && temperature == o.temperature && top_p == o.top_p && tokens == o.tokens &&
@@ -197,7 +197,7 @@ struct ldm_handle {
                        // sampling call, the step's tail behind the vocabulary head (LDM_STACK_LOOP=0: one stack launch +
                        // one posterior launch per step, captured in per-lane hipGraphs — the r02 path)
   // near-tie report of deterministic decoding (ldm_set_tie_report): flags [tie_steps][max_batch]
-  float tie_rel = 0.f;
+  float tie_rel = 0.f, tie_abs = 0.f;
   uint8_t* tie_flags = nullptr;
   int tie_steps = 0;
   // cond staging (handle-owned, fixed addresses) so a captured graph does not depend on caller pointers
@@ -323,6 +323,14 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   if (cfg->d_model / cfg->n_head > 64) return bad("head_dim > 64 not supported");
   if (cfg->precision < 0 || cfg->precision > 2) return bad("unknown precision mode");
   if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
+  {  // development knobs are refused outside dev mode (ldm_knobs.h): no stray variable changes the shipped path
+    static std::string msg;
+    const std::string k = knob_refused();
+    if (!k.empty()) {
+      msg = "environment knob " + k + " is set but LDM_DEV=1 is not: development / ablation paths are refused";
+      return bad(msg.c_str());
+    }
+  }
   {
     // sequence length: the fp16 attention kernels hold a layout's scores in ONE 128 x 128 tile; the fp32 row kernel
     // keeps K and V of a (layout, head) in LDS (2 x S x head_dim floats <= 160 KiB).  The reference's datasets: S = 125.
@@ -374,7 +382,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   // chunk: layouts per pass. auto = keep (x, qkv, hidden ...) of one chunk well inside the 256 MiB MALL
   int chunk = cfg->chunk;
-  if (const char* ce = getenv("LDM_CHUNK")) chunk = atoi(ce);  // experiments
+  if (const char* ce = knob_env("LDM_CHUNK")) chunk = atoi(ce);  // experiments
   // auto: 256 layouts (M = 32 000 rows = 250 row blocks / 256 per-layout workgroups: one full round of the 256 CUs;
   // P + Q of a chunk = 119 MB stay inside the 256 MiB Infinity Cache) and two lanes (see Workspace)
   if (chunk <= 0) chunk = 256;
@@ -383,10 +391,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
 
   // lanes: LDM_LANES / LDM_LANE_OFFSET_US override cfg->lanes (experiments); more lanes than chunks make no sense
   h->n_lanes = cfg->lanes > 0 ? cfg->lanes : 2;
-  if (const char* le = getenv("LDM_LANES")) h->n_lanes = std::max(1, atoi(le));
+  if (const char* le = knob_env("LDM_LANES")) h->n_lanes = std::max(1, atoi(le));
   h->n_lanes = std::min(h->n_lanes, std::max(1, (cfg->max_batch + chunk - 1) / chunk));
   h->lane_offset_us = 50;
-  if (const char* lo = getenv("LDM_LANE_OFFSET_US")) h->lane_offset_us = std::max(0, atoi(lo));
+  if (const char* lo = knob_env("LDM_LANE_OFFSET_US")) h->lane_offset_us = std::max(0, atoi(lo));
   h->ws.resize(h->n_lanes);
   const size_t Mc = (size_t)chunk * h->S;
   int rc = 0;
@@ -411,12 +419,12 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->Fq = round_up(h->F, 64);
     h->Mpad = round_up((int)Mc, 256);
     const size_t Mp = h->Mpad;
-    const char* env = getenv("LDM_GEMM_CFG");  // "q,o,1,2,h" tile-config ids (tuning override)
+    const char* env = knob_env("LDM_GEMM_CFG");  // "q,o,1,2,h" tile-config ids (tuning override)
     int defaults[5] = {5, 5, 5, 5, 5};
     for (int i = 0; i < 5; ++i) h->gemm_cfg[i] = defaults[i];
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
-    if (const char* fa = getenv("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa) == 0 ? 0 : 6;
-    if (const char* sp = getenv("LDM_STACK_LOOP")) h->stack_loop = atoi(sp);
+    if (const char* fa = knob_env("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa) == 0 ? 0 : 6;
+    if (const char* sp = knob_env("LDM_STACK_LOOP")) h->stack_loop = atoi(sp);
     // stack kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row (its
     // exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128; d_model 464 in 8 heads, K padded to 512
     if (h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464 || h->Dq != 512 || h->HD != 512 || h->H != 8 ||
@@ -1140,6 +1148,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       if (tie_row >= 0 && h->tie_rel > 0.f && h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) {
         p.tie_flags = h->tie_flags + (size_t)tie_row * h->cfg.max_batch + rng_layout_off + off;
         p.tie_rel = h->tie_rel;
+        p.tie_abs = h->tie_abs;
       }
       ldm_handle::Scope sc(h, st, "posterior_sample", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
       launch_posterior_sample(p, st);
@@ -1225,6 +1234,7 @@ static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, cons
     if (tie_row0 >= 0 && h->tie_rel > 0.f && h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) {
       p.tie_flags = h->tie_flags + (size_t)(tie_row0 + i0) * h->cfg.max_batch;
       p.tie_rel = h->tie_rel;
+      p.tie_abs = h->tie_abs;
     }
     StackLoop lp{};
     lp.tables = StackTables{h->tbl_att_static, h->tbl_att_dyn, h->tbl_ffn, h->tbl_head};
@@ -1344,20 +1354,25 @@ extern "C" int ldm_decode_layouts(ldm_handle* h, const int32_t* d_tokens, int B,
 // runner-up by more than the mode's logits error can move.  With the report enabled every deterministic step marks
 // the layouts in which some token was decided inside that band; the caller re-decides exactly those in the exact
 // mode (layout_dm_amd.verified: greedy decoding is RNG-free and layouts are independent).
-extern "C" int ldm_set_tie_report(ldm_handle* h, float tie_rel) {
+extern "C" int ldm_set_tie_report(ldm_handle* h, float tie_rel, float tie_abs) {
   if (!h) return -1;
-  if (!(tie_rel >= 0.f)) return h->fail(-1, "tie_rel must be >= 0");
+  if (!(tie_rel >= 0.f) || !(tie_abs >= 0.f)) return h->fail(-1, "tie_rel / tie_abs must be >= 0");
+  if (tie_abs > 0.f && !(tie_rel > 0.f)) tie_rel = 1e-30f;  // (the report is keyed on tie_rel > 0)
   ON_DEVICE(h);
   if (tie_rel > 0.f && !h->tie_flags) {
     h->tie_steps = std::max(h->T, 1);
     int rc = h->dalloc(&h->tie_flags, (size_t)h->tie_steps * h->cfg.max_batch);
     if (rc) return rc;
   }
-  if (tie_rel != h->tie_rel) {  // captured graphs carry the flag pointers / threshold of their capture
+  if ((tie_rel != h->tie_rel || tie_abs != h->tie_abs) && !h->graphs.empty()) {
+    // captured graphs carry the flag pointers / thresholds of their capture; a replay on another stream may still be
+    // executing one of them
+    HIP_OK(h, hipDeviceSynchronize());
     for (auto& g : h->graphs) g.destroy();
     h->graphs.clear();
   }
   h->tie_rel = tie_rel;
+  h->tie_abs = tie_abs;
   return 0;
 }
 extern "C" int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, int B, void* stream) {
@@ -1370,9 +1385,12 @@ extern "C" int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, i
   return 0;
 }
 // clears the rows a deterministic call is about to fill
-static int tie_begin(ldm_handle* h, const ldm_sampler* s, int n_steps, int B, hipStream_t st) {
+static int tie_begin(ldm_handle* h, const ldm_sampler* s, const ldm_relation* rel, int n_steps, int B, hipStream_t st) {
   (void)B;
   if (!(h->tie_rel > 0.f) || !h->tie_flags || s->kind != LDM_SAMPLE_DETERMINISTIC) return 0;
+  // the adjusted steps of cond=relation draw from the SGD's output, where the lead of the winner is no longer a
+  // function of the logits with a known Lipschitz bound: no report exists for them, so none may be assumed
+  if (rel) return h->fail(-1, "near-tie report is not defined for cond=relation: decode in LDM_PREC_EXACT_F32 instead");
   if (n_steps > h->tie_steps) return h->fail(-1, "near-tie report: at most %d steps per call", h->tie_steps);
   HIP_OK(h, hipMemsetAsync(h->tie_flags, 0, (size_t)n_steps * h->cfg.max_batch, st));
   return 0;
@@ -1392,7 +1410,7 @@ extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
   if (t_model < 0 || t_model >= h->T || t_post < 0 || t_post >= h->T)
     return h->fail(-1, "timestep out of range [0,%d)", h->T);  // constrained.py:139
-  if ((rc = tie_begin(h, s, 1, B, st))) return rc;
+  if ((rc = tie_begin(h, s, rel, 1, B, st))) return rc;
   if (loop_fusable(h, rel)) {
     const int32_t tm = t_model, tp = t_post;
     if ((rc = run_loop_fused(h, d_tokens_in, d_tokens_out, cond, &tm, &tp, 1, s, step, B, nullptr, 0, st))) return rc;
@@ -1459,7 +1477,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
   const size_t nbytes = (size_t)B * h->S * 4;
   HIP_OK(h, hipEventRecord(h->loop_a, st));
   if ((rc = set_rng(h, seed, first_layout, st))) return rc;
-  if ((rc = tie_begin(h, s, n_steps, B, st))) return rc;
+  if ((rc = tie_begin(h, s, rel, n_steps, B, st))) return rc;
   if (loop_fusable(h, rel)) {
     // one launch: every layout's workgroup runs all its steps in place on the caller's tokens (no staging, no graph)
     if ((rc = run_loop_fused(h, d_tokens_inout, d_tokens_inout, cond, h_t_model, h_t_post, n_steps, s, 0, B,
@@ -1506,8 +1524,10 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
       if (!h->st_rel_centres && (rc = h->dalloc(&h->st_rel_centres, (size_t)4 * h->cfg.n_bin))) return rc;
       if ((size_t)ne > h->st_rel_cap) {
         // a grown buffer has a new address: graphs keyed on the old one can never hit again — drop them and release
-        // the old staging buffer (the stream was synchronised just above, nothing is reading it)
+        // the old staging buffer, once NOTHING on the device can still be reading it (an earlier replay may run on
+        // another stream than the one synchronised above)
         int32_t* old = h->st_rel_edges;
+        if (old) HIP_OK(h, hipDeviceSynchronize());
         const size_t cap = std::max<size_t>(1024, (size_t)ne * 2);
         if ((rc = h->dalloc(&h->st_rel_edges, 3 * cap))) return rc;
         h->st_rel_cap = cap;
@@ -1556,6 +1576,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
     }
     key.has_inter = inter_dst != nullptr;
     key.tie_rel = (h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) ? h->tie_rel : 0.f;
+    key.tie_abs = (h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) ? h->tie_abs : 0.f;
     if (rel) {
       key.has_rel = 1;
       key.rel_num_update = rel->num_update;
@@ -1629,6 +1650,26 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
 }
 
 // ------------------------------------------------------------------------------------------ introspection
+// "key=value;..." description of what this handle runs: numerics mode, kernel family, chunk / lanes, near-tie thresholds
+// and the development knobs the library has honoured in this process (ldm_knobs.h).  Returns the length needed.
+extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
+  if (!h) return -1;
+  static const char* prec[3] = {"exact_f32", "fast_f16", "split_f16"};
+  const bool loop = loop_fusable(h, nullptr);
+  char tmp[768];
+  const int n = snprintf(tmp, sizeof(tmp),
+                         "abi=%d;precision=%s;kernels=%s;loop=%s;chunk=%d;lanes=%d;lane_offset_us=%d;tie_rel=%g;tie_abs=%g;knobs=%s",
+                         LDM_ABI_VERSION, prec[h->cfg.precision],
+                         h->cfg.precision != LDM_PREC_FAST_F16 ? "tiled_gemm+attn" : h->fused_attn == 6 ? "stack" : "generic16",
+                         loop ? "one_launch" : "per_step_graph", h->chunk, h->n_lanes, h->lane_offset_us, (double)h->tie_rel,
+                         (double)h->tie_abs, knobs_honoured().c_str());
+  if (buf && cap > 0) {
+    strncpy(buf, tmp, (size_t)cap - 1);
+    buf[cap - 1] = 0;
+  }
+  return n;
+}
+
 extern "C" int ldm_last_loop_ms(ldm_handle* h, float* ms) {
   if (!h || !ms) return -1;
   if (!h->loop_timed) return h->fail(-1, "no loop has run yet");

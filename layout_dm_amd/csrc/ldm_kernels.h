@@ -10,6 +10,8 @@
 #include <set>
 #include <utility>
 
+#include "ldm_knobs.h"
+
 namespace ldm {
 
 // Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once
@@ -194,8 +196,10 @@ struct PostArgs {
   int D, ldx;
   // near-tie report of deterministic decoding: tie_flags[b] = 1 when some token of layout b was decided with a lead over
   // the runner-up below tie_rel * max |logit of the token| (what the fp16 mode's logits error can move), or nullptr
+  // ... or below the absolute floor tie_abs (6 x a bound on the ABSOLUTE logits error of the checkpoint, measured by the
+  // caller: the error of a small-magnitude row does not shrink with that row's own max |logit|)
   uint8_t* tie_flags;
-  float tie_rel;
+  float tie_rel, tie_abs;
 };
 enum ScheduleRow { kLogAt = 0, kLogBt, kLogCt, kLogCumAt, kLogCumBt, kLogCumCt, kLog1mCt, kLog1mCumCt, kNumSched };
 void launch_posterior_sample(const PostArgs& p, hipStream_t st);

@@ -63,12 +63,20 @@ class HipMaskAndReplaceDiffusion:
         # precision "fast_verified": the fp16 engine for every sampler, plus an exact (fp32) engine of the same weights
         # that re-decides the near-tie layouts of DETERMINISTIC decoding (layout_dm_amd/verified.py): greedy tokens are
         # then the exact mode's, i.e. the reference's, bit for bit
+        # precision "auto" (r04): both engines are built; load_state_dict measures the fp16 engine's logits error against the
+        # fp32 engine ON THE CHECKPOINT (verified.measure_fast_error: probe states over the whole timestep range) and keeps
+        # the fast engine only if it is inside the north star's 1e-3 relative tolerance — otherwise every call runs exact.
+        # (The fp16 mode's error is a property of the weights: 3e-4 on the reference's init, ~1e-3 at sigma = 0.06,
+        # percents once attention rows saturate: DESIGN.md section 3.5.)
         self.verified = None
+        self.auto = precision == "auto"
+        self.auto_tolerance = 1e-3
+        self.selected_precision = None if self.auto else precision
         mk = lambda prec: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
                                  d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
                                  precision=prec, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type,
                                  lanes=lanes)
-        if precision == "fast_verified":
+        if precision in ("fast_verified", "auto"):
             from .verified import VerifiedGreedy
 
             self.engine = mk("fast")
@@ -96,10 +104,23 @@ class HipMaskAndReplaceDiffusion:
         return self
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        if self.verified is not None:
+            self.engine = self.verified.fast                    # (auto may have switched to the exact engine before)
         self.engine.load_state_dict(state_dict)
         if self.verified is not None:
             self.verified.exact.load_state_dict(state_dict)
+            cal = self.verified.calibrate()                     # tie_abs <- 6 x safety x measured |logits error|
+            if self.auto:
+                ok = cal["err_rel"] <= self.auto_tolerance
+                self.selected_precision = "fast_verified" if ok else "exact"
+                if not ok:
+                    self.engine = self.verified.exact
         return self
+
+    @property
+    def calibration(self) -> Dict[str, float]:
+        """fast-vs-exact logits error measured at load time (precision fast_verified / auto), else {}."""
+        return dict(self.verified.calibration) if self.verified is not None else {}
 
     # -- the hot path ----------------------------------------------------------------------------
     @torch.no_grad()
@@ -151,7 +172,8 @@ class HipMaskAndReplaceDiffusion:
             if cond:
                 sub = {k: (v[off:off + n] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B else v)
                        for k, v in cond.items()}
-            if self.verified is not None and _cfg_get(sampling_cfg, "name") == "deterministic":
+            if (self.verified is not None and self.engine is self.verified.fast
+                    and _cfg_get(sampling_cfg, "name") == "deterministic"):
                 tk, inter = self.verified.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, cond=sub,
                                                       intermediates=get_intermediate_results)
             else:

@@ -101,6 +101,10 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
                          seed: Optional[int] = None, first_layout: int = 0, return_device_tensor: bool = False, **_kw):
     """BaseMaskAndReplaceDiffusion.sample for cond["type"] == "relation" (base.py:293-371)."""
     eng = inner.engine
+    if getattr(inner, "verified", None) is not None and str(_cfg_get(sampling_cfg, "name")) == "deterministic":
+        # fast_verified promises the exact mode's greedy tokens; the near-tie report does not exist for the adjusted
+        # steps (ldm_sample_loop refuses it), so greedy cond=relation decoding runs on the exact engine
+        eng = inner.verified.exact
     T = inner.num_timesteps
     t_model, t_post = timestep_schedule(T, int(_cfg_get(sampling_cfg, "num_timesteps", T)),
                                         float(_cfg_get(sampling_cfg, "time_difference", 0.0) or 0.0))

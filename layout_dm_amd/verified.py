@@ -1,46 +1,112 @@
 """`fast_verified`: greedy decoding at (almost) the fp16 mode's speed with the EXACT mode's tokens.
 
 north star: "token indices bit-exact under greedy/argmax decoding".  The fast numerics mode (fp16 operands, fp32
-accumulate) carries <= 1e-3 relative logits error, so its argmax (helpers/sampling.py:88-90) can differ from the
-reference's where two classes are closer than that error can move them — 1 token in ~30 000 on the reference's own
-trajectories.  Those places are detectable from inside the fast pass: with the near-tie report enabled
-(`ldm_set_tie_report`, include/ldm_hip.h) every deterministic step marks, per (step, layout), whether some token was decided
-with a log-probability lead over the runner-up below `tie_rel * max |logit|`.  The lead's error is bounded by 6x the
-largest logit error (2 from the difference of two log-softmax values, the rest from the posterior's
-log-sum-exp terms with derivative <= 1), so with tie_rel = 6 x the mode's relative logits tolerance an UNMARKED token is the
-exact mode's token.  Greedy decoding is RNG-free and layouts are independent, so a marked layout is simply re-decided in
-the exact mode from its state before its first marked step, and spliced in.
+accumulate) carries a logits error that depends on the checkpoint (3e-4 of max |logit| on the reference's init, 1e-3 on
+wider weights, percents once attention rows saturate — DESIGN.md section 3.5), so its argmax (helpers/sampling.py:88-90) can
+differ from the reference's where two classes are closer than that error can move them.  Those places are detectable
+from inside the fast pass: with the near-tie report enabled (`ldm_set_tie_report`, include/ldm_hip.h) every
+deterministic step marks, per (step, layout), whether some token was decided with a log-probability lead over the
+runner-up below max(tie_rel * max |logit of the token|, tie_abs).  The lead's error is bounded by 6x the largest ABSOLUTE
+logits error of the token (2 from the difference of two log-softmax values, the rest from the
+posterior's log-sum-exp terms with derivative <= 1), so with tie_abs = 6 x a bound on that error an UNMARKED token is the
+exact mode's token.  The bound is MEASURED on the checkpoint (`calibrate`: fast vs exact logits on probe states over the
+whole timestep range, times a safety factor) — it is an observation on this checkpoint, not a theorem; `audit` re-checks
+a random sample of unmarked (step, layout) pairs in the exact mode and reports what it finds.
 
-The reference-side contract (base.py:205-291,293-371) is unchanged: tokens in, tokens out.  Cost = the fast loop + the
-exact mode on (layouts marked) x (steps after their first mark).
+r04 algorithm — the cost is what the marks cost, not what the tail of the loop costs:
+
+  1. run the fast loop with the intermediates of every step and the near-tie flags;
+  2. every marked (step, layout) is re-decided by ONE exact `ldm_sample_step` from the state before that step (all marks
+     of a step in one call) and compared with the fast result;
+  3. only layouts whose exact tokens DIFFER (measured: ~0.3 % of the marked pairs) are re-launched — in the fast mode —
+     from the corrected state, for the remaining steps, and the procedure repeats on their remainder.
+
+Greedy decoding is RNG-free and layouts are independent, so splicing is exact.  By induction over the steps the result is
+the exact engine's greedy trajectory wherever the report is sound.  The reference-side contract (base.py:205-291,293-371)
+is unchanged: tokens in, tokens out.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from .binding import Engine
 
-# 6 x (1e-3 relative logits tolerance of LDM_PREC_FAST_F16, tests/test_hip_parity.py LOGIT_REL_TOL); the measured logits
-# error is 3.6e-4 .. 4.6e-4, and the largest reference top-2 margin ever seen among the fast mode's mismatches is 3.4e-4
-# of log-probability on logits of magnitude ~2
+# 6 x (1e-3 relative logits tolerance of LDM_PREC_FAST_F16, tests/test_hip_parity.py LOGIT_REL_TOL) on the token's own
+# max |logit|: the r03 criterion, kept as a second, scale-following term beside the calibrated absolute floor
 DEFAULT_TIE_REL = 6e-3
+LEAD_LIPSCHITZ = 6.0     # |delta lead| <= 6 x max |delta logit|
 GREEDY = {"name": "deterministic"}
+
+
+def probe_states(eng: Engine, n_layouts: int = 8, ts: Optional[Sequence[int]] = None, seed: int = 0):
+    """[(tokens (n,S) int32 cpu, t)] covering the timestep range: valid tokens of each attribute's sub-vocabulary
+    ([PAD] included), masked with probability t / (T - 1) — what states of a reverse trajectory look like at step t."""
+    T = eng.T
+    if ts is None:
+        ts = sorted({T - 1, (3 * T) // 4, T // 2, T // 4, min(2, T - 1), min(1, T - 1), 0}, reverse=True)
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for t in ts:
+        tok = torch.empty((n_layouts, eng.S), dtype=torch.int64)
+        for a in range(eng.n_attr):
+            if eng.q_type == "vanilla":
+                lo, cnt = 0, eng.C - 2
+            else:
+                lo, cnt = (0, eng.n_category) if a == 0 else (eng.n_category + (a - 1) * eng.n_bin, eng.n_bin)
+            r = torch.randint(0, cnt + 1, (n_layouts, eng.S // eng.n_attr), generator=g)
+            tok[:, a::eng.n_attr] = torch.where(r == cnt, torch.full_like(r, eng.pad_id), lo + r)
+        tok[torch.rand((n_layouts, eng.S), generator=g) < t / max(T - 1, 1)] = eng.mask_id
+        out.append((tok.int(), int(t)))
+    return out
+
+
+def measure_fast_error(fast: Engine, exact: Engine, states=None) -> Dict[str, float]:
+    """Largest logits error of the fast engine against the exact engine of the same weights on `states` (default:
+    probe_states): absolute, relative to the largest |logit| of the probe, and relative per row."""
+    states = states if states is not None else probe_states(fast)
+    e_abs = e_rel = e_row = absmax = 0.0
+    for tok, t in states:
+        lf, le = fast.denoise_logits(tok, t), exact.denoise_logits(tok, t)
+        d = (lf - le).abs()
+        m = le.abs().max().item()
+        e_abs = max(e_abs, d.max().item())
+        e_rel = max(e_rel, d.max().item() / max(m, 1e-30))
+        e_row = max(e_row, (d.amax(-1) / le.abs().amax(-1).clamp_min(1e-30)).max().item())
+        absmax = max(absmax, m)
+    return {"err_abs": e_abs, "err_rel": e_rel, "err_rel_row": e_row, "absmax": absmax, "n_states": len(states)}
 
 
 class VerifiedGreedy:
     """A fast-mode engine and an exact-mode engine of the same model; deterministic decoding only."""
 
-    def __init__(self, fast: Engine, exact: Engine, tie_rel: float = DEFAULT_TIE_REL):
+    def __init__(self, fast: Engine, exact: Engine, tie_rel: float = DEFAULT_TIE_REL, tie_abs: float = 0.0,
+                 safety: float = 2.0, audit: float = 0.0):
         assert fast.S == exact.S and fast.C == exact.C and fast.device == exact.device
-        self.fast, self.exact, self.tie_rel = fast, exact, float(tie_rel)
+        self.fast, self.exact = fast, exact
+        self.tie_rel, self.tie_abs, self.safety, self.audit = float(tie_rel), float(tie_abs), float(safety), float(audit)
+        self.calibration: Dict[str, float] = {}
         self.last_stats: Dict[str, float] = {}
+        self._audit_gen = torch.Generator().manual_seed(0)
+
+    # ------------------------------------------------------------------ the measured error bound
+    def calibrate(self, states=None) -> Dict[str, float]:
+        """tie_abs <- 6 x safety x (largest absolute fast-vs-exact logits error on the probe states).  Call after the
+        weights are loaded (HipMaskAndReplaceDiffusion.load_state_dict does)."""
+        c = measure_fast_error(self.fast, self.exact, states)
+        self.tie_abs = LEAD_LIPSCHITZ * self.safety * c["err_abs"]
+        c["tie_abs"], c["tie_rel"], c["safety"] = self.tie_abs, self.tie_rel, self.safety
+        self.calibration = c
+        return c
 
     @staticmethod
     def _sub(cond: Optional[dict], idx: torch.Tensor, B: int) -> Optional[dict]:
         if not cond:
             return None
+        if cond.get("type") == "relation":
+            raise NotImplementedError("fast_verified: cond=relation has no near-tie report (its draw follows an SGD on the "
+                                      "log-probabilities); decode it with the exact engine")
         out = {}
         for k, v in cond.items():
             if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B:
@@ -51,44 +117,91 @@ class VerifiedGreedy:
                 out[k] = v
         return out
 
+    def _audit_mask(self, flags: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.audit <= 0.0:
+            return None
+        pick = torch.rand(flags.shape, generator=self._audit_gen) < self.audit
+        return pick.to(flags.device) & ~flags
+
     def sample_step(self, tokens: torch.Tensor, t_model: int, t_post: Optional[int] = None, cond: Optional[dict] = None,
                     step: int = 0) -> torch.Tensor:
         """One greedy reverse step (_sample_single_step, base.py:205-291): fast everywhere, exact on the marked layouts."""
         f = self.fast
         tokens = f._tok(tokens)
         B = tokens.shape[0]
-        f.set_tie_report(self.tie_rel)
+        f.set_tie_report(self.tie_rel, self.tie_abs)
         out = f.sample_step(tokens, t_model, GREEDY, t_post=t_post, cond=cond, step=step)
         idx = f.tie_flags(1, B)[0].nonzero().flatten()
+        changed = 0
         if idx.numel():
-            out[idx] = self.exact.sample_step(tokens[idx].contiguous(), t_model, GREEDY, t_post=t_post,
-                                              cond=self._sub(cond, idx, B), step=step)
-        self.last_stats = {"layouts": B, "marked_layout_steps": int(idx.numel()), "steps": 1}
+            ex = self.exact.sample_step(tokens[idx].contiguous(), t_model, GREEDY, t_post=t_post,
+                                        cond=self._sub(cond, idx, B), step=step)
+            changed = int((ex != out[idx]).any(dim=1).sum())
+            out[idx] = ex
+        self.last_stats = {"layouts": B, "steps": 1, "marked_layout_steps": int(idx.numel()),
+                           "exact_layout_steps": int(idx.numel()), "mismatch_layout_steps": changed}
         return out
 
     def sample_loop(self, tokens: torch.Tensor, t_model: Sequence[int], t_post: Sequence[int], cond: Optional[dict] = None,
                     intermediates: bool = False):
         """The greedy T-step loop (base.py:293-371), in place on `tokens` (B,S) int32 cuda -> (tokens, intermediates|None)."""
-        f = self.fast
+        f, e = self.fast, self.exact
         tokens = f._tok(tokens)
-        B, n = tokens.shape[0], len(t_model)
-        init = tokens.clone()
-        f.set_tie_report(self.tie_rel)
-        out, inter = f.sample_loop(tokens, t_model, t_post, GREEDY, cond=cond, intermediates=True)
-        flags = f.tie_flags(n, B).bool()                         # (n, B)
-        marked = flags.any(dim=0)
-        first = torch.where(marked, flags.to(torch.int32).argmax(dim=0), torch.full_like(flags[0], n, dtype=torch.int64))
-        redo_steps = 0
-        for i0 in torch.unique(first[marked]).tolist():          # one exact call per distinct first marked step
-            idx = (first == i0).nonzero().flatten()
-            start = (init if i0 == 0 else inter[i0 - 1])[idx].contiguous()
-            tk, it = self.exact.sample_loop(start, list(t_model[i0:]), list(t_post[i0:]), GREEDY,
-                                            cond=self._sub(cond, idx, B), intermediates=intermediates)
-            out[idx] = tk
-            if intermediates:
-                inter[i0:, idx] = it
-            redo_steps += int(idx.numel()) * (n - i0)
-        self.last_stats = {"layouts": B, "steps": n, "marked_layouts": int(marked.sum()),
-                           "marked_layout_steps": int(flags.sum()), "exact_layout_steps": redo_steps,
-                           "exact_fraction": redo_steps / float(max(B * n, 1))}
-        return out, (inter if intermediates else None)
+        B, n, S = tokens.shape[0], len(t_model), f.S
+        t_model, t_post = [int(x) for x in t_model], [int(x) for x in t_post]
+        f.set_tie_report(self.tie_rel, self.tie_abs)
+        inter_all = torch.empty((n, B, S), dtype=torch.int32, device=f.device) if intermediates else None
+        final = torch.empty_like(tokens)
+        st = {"marked": 0, "checked": 0, "mismatch": 0, "relaunched": 0, "passes": 0, "audited": 0, "audit_mismatch": 0}
+        # work item: (global layout ids, index of its first step, state before that step)
+        work: List = [(torch.arange(B, device=f.device), 0, tokens.clone())]
+        while work:
+            idx, i0, start = work.pop()
+            b, m = int(idx.numel()), n - i0
+            sub = cond if b == B else self._sub(cond, idx, B)
+            out, inter = f.sample_loop(start.clone(), t_model[i0:], t_post[i0:], GREEDY, cond=sub, intermediates=True)
+            flags = f.tie_flags(m, b).bool()                                  # (m, b)
+            aud = self._audit_mask(flags)
+            check = flags if aud is None else (flags | aud)
+            st["marked"] += int(flags.sum())
+            st["passes"] += 1
+            bad_at = torch.full((b,), m, dtype=torch.int64, device=f.device)     # first step whose fast tokens are wrong
+            for s in check.any(dim=1).nonzero().flatten().tolist():           # steps with something to check, ascending
+                j = (check[s] & (bad_at > s)).nonzero().flatten()             # (a layout is void behind its first wrong step)
+                if not j.numel():
+                    continue
+                prev = (start if s == 0 else inter[s - 1])[j].contiguous()
+                ex = e.sample_step(prev, t_model[i0 + s], GREEDY, t_post=t_post[i0 + s],
+                                   cond=self._sub(sub, j, b) if sub else None, step=i0 + s)
+                st["checked"] += int(j.numel())
+                diff = (ex != inter[s][j]).any(dim=1)
+                if aud is not None:
+                    st["audited"] += int(aud[s][j].sum())
+                    st["audit_mismatch"] += int((diff & aud[s][j]).sum())
+                if bool(diff.any()):
+                    jd = j[diff]
+                    bad_at[jd] = s
+                    inter[s][jd] = ex[diff]                                   # the corrected state after step s
+                    st["mismatch"] += int(jd.numel())
+            if inter_all is not None:
+                inter_all[i0:, idx] = inter        # (rows behind a layout's bad_at are overwritten by its re-launch)
+            final[idx] = out
+            redo = (bad_at < m).nonzero().flatten()
+            if redo.numel():
+                for s in torch.unique(bad_at[redo]).tolist():
+                    jd = (bad_at == s).nonzero().flatten()
+                    fixed = inter[s][jd].contiguous()
+                    if s == m - 1:                                            # wrong only at the last step: spliced, done
+                        final[idx[jd]] = fixed
+                    else:
+                        work.append((idx[jd], i0 + s + 1, fixed.clone()))
+                        st["relaunched"] += int(jd.numel()) * (m - s - 1)
+        tokens.copy_(final)
+        tot = float(max(B * n, 1))
+        self.last_stats = {"layouts": B, "steps": n, "marked_layout_steps": st["marked"],
+                           "exact_layout_steps": st["checked"], "mismatch_layout_steps": st["mismatch"],
+                           "relaunched_layout_steps": st["relaunched"], "fast_passes": st["passes"],
+                           "exact_fraction": st["checked"] / tot, "relaunched_fraction": st["relaunched"] / tot,
+                           "audited_layout_steps": st["audited"], "audit_mismatch_layout_steps": st["audit_mismatch"],
+                           "tie_rel": self.tie_rel, "tie_abs": self.tie_abs}
+        return tokens, inter_all

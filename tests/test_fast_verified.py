@@ -27,6 +27,8 @@ def verified(ds):
 
     if ds not in _VG:
         _VG[ds] = VerifiedGreedy(engine(ds, "fast"), engine(ds, "exact"))
+        cal = _VG[ds].calibrate()
+        print(f"[fast_verified/{ds}] calibration: {cal}")
     return _VG[ds]
 
 
@@ -100,6 +102,7 @@ def test_tie_report_is_sound_at_benchmark_batch(cuda):  # noqa: F811
 
     fa, ex = engine("rico25", "fast", max_batch=B), engine("rico25", "exact", max_batch=B)
     vg = VerifiedGreedy(fa, ex)
+    vg.calibrate()
     steps = R.timestep_list(spec.n_step, 100)
     tok = torch.full((B, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
     _, inter = ex.sample_loop(tok, steps, steps, {"name": "random", "temperature": 1.0}, seed=3, intermediates=True)
@@ -109,7 +112,7 @@ def test_tie_report_is_sound_at_benchmark_batch(cuda):  # noqa: F811
         before = inter[i - 1]
         t = steps[i]
         e_out = ex.sample_step(before, t, {"name": "deterministic"}, step=i)
-        fa.set_tie_report(vg.tie_rel)
+        fa.set_tie_report(vg.tie_rel, vg.tie_abs)
         f_out = fa.sample_step(before, t, {"name": "deterministic"}, step=i)
         flags = fa.tie_flags(1, B)[0].bool()
         diff = (f_out != e_out).any(dim=1)
@@ -120,4 +123,4 @@ def test_tie_report_is_sound_at_benchmark_batch(cuda):  # noqa: F811
         n_diff += int(diff.sum())
     print(f"[tie report, B=512, 7 steps] marked layout-steps {n_marked}/{7 * B}; layouts whose fast tokens differ from "
           f"the exact mode's {n_diff} (all marked)")
-    fa.set_tie_report(0.0)
+    fa.set_tie_report(0.0, 0.0)

@@ -85,6 +85,7 @@ def test_stack_kernel_agrees_with_generic_kernels(cuda, monkeypatch):
     ref = R.denoiser_logits(W, spec, tokens.long(), 23)
     outs = {}
     for gen in ("6", "0"):
+        monkeypatch.setenv("LDM_DEV", "1")  # development knobs are honoured in dev mode only (csrc/ldm_knobs.h)
         monkeypatch.setenv("LDM_FUSED_ATTN", gen)
         e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
                    n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
@@ -563,6 +564,7 @@ def test_fused_loop_equals_per_step_path(cuda, monkeypatch, sampler):
     c = synth.synth_cond_c(spec, 300, seed=3)
     outs = {}
     for loop in ("0", "1"):
+        monkeypatch.setenv("LDM_DEV", "1")
         monkeypatch.setenv("LDM_STACK_LOOP", loop)
         e = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model,
                    n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="fast",
@@ -608,6 +610,7 @@ def test_strong_mask_shortcut_is_an_identity(cuda, monkeypatch, sampler):
     cfg = {"name": sampler, "temperature": 1.0, "top_p": 0.9, "top_k": 5}
     outs = []
     for wave in ("0", "1"):
+        monkeypatch.setenv("LDM_DEV", "1")
         monkeypatch.setenv("LDM_POST_WAVE", wave)
         tok = torch.from_numpy(c["seq"]).int().to(cuda)
         outs.append(e.sample_loop(tok, steps, steps, cfg, cond=cond, seed=4, first_layout=2, intermediates=True,

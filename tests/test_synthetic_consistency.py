@@ -19,6 +19,15 @@ def test_same_checkpoint(ds):
         assert np.array_equal(P.SPECS[ds].full_ids(at), OS.SPECS[ds].full_ids(at))
 
 
+@pytest.mark.parametrize("point", ["init", "mid", "wide"])
+def test_same_trained_like_checkpoint(point):
+    a = P.trained_like_state_dict(P.SPECS["rico25"], point, seed=2)
+    b = O.trained_like_state_dict(OS.SPECS["rico25"], point, seed=2)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_same_synthetic_cond_c():
     for ds in ("rico25", "publaynet"):
         a = P.synth_cond_c(P.SPECS[ds], 37, seed=4)
