@@ -139,7 +139,15 @@ def dry_run_main(a, world, rank, local_rank):
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("gloo")
+        sys.stdout.flush()
+        saved = os.dup(1)       # gloo announces its connections on stdout: keep the ONE-line contract
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     config = a.config or (2 if world == 1 else 4)
     B = a.batch or CONFIGS[config]["batch"]
     n_global = a.total if a.total else world * B
