@@ -1,38 +1,40 @@
-// cond=relation: the logit adjustment of the reference's sampler as ONE kernel with the analytic gradient.
+// cond=relation: the logit adjustment of the reference's sampler, one workgroup per layout, the
+// layout's log-probabilities in LDS for all SGD iterations (arithmetic: ldm_relation_core.h).
 //
-// Reference: update() in trainer/models/categorical_diffusion/logit_adjustment.py:88-126 runs `relation_num_update`
-// plain-SGD steps (lr = relation_lambda, t >= 10 only) on  mean_{graph, f} cost_f  w.r.t. the (B,C,S) log-probability
-// tensor, where the 14 costs f (trainer/models/clg/const.py:221-236) are hinge losses on the EXPECTED boxes
-//     bbox[node, x] = sum_n softmax_n(logp[node, bins of x]) * centre_x[n]        (_stochastic_convert, l.16-85,
-//                                                                                  mode = "average")
-// of the canvas node (fixed) and of every element whose conditioned category is not PAD.  Autograd there; here
-//     d mean / d logit[node,n,x] = 1/(14 B) * p_n (c_n - bbox_x) * G[node,x],   G = sum over the node's edges of the
-// hinge sub-gradients (relu'(z) = [z > 0]) of the area / centre-y / left-top-right-bottom terms.
-// One workgroup per layout: 25 elements x 4 coordinates x 32 bins of logits live in LDS for all iterations.
-// Edge sums run in edge order (deterministic); results agree with the autograd reference to fp32 rounding.
+//   relation_update_k   the split-step hook (ldm_relation_update): (B,C,S) tensor in, adjusted in place
+//   relation_step_k     the per-step path's fused tail of an ADJUSTED step (t >= 10): predict_start tail + q_posterior +
+//                       strong mask (ldm_post_token.h) -> SGD -> [PAD] disable -> draw, logits in, tokens (and the next
+//                       step's embedding rows) out — ONE launch per chunk-step where r03 had three around a 19.8 MB
+//                       (chunk, S, C) log-probability tensor.  Reference order: base.py:243-291.
 #include "ldm_kernels.h"
+#include "ldm_relation_core.h"
 
 namespace ldm {
 
-constexpr int REL_MAX_ELEM = 32;
-constexpr int REL_MAX_EDGE = 512;
+static __device__ __forceinline__ RelGraph rel_graph(const RelArgs& a) {
+  RelGraph gph;
+  gph.edge_off = a.edge_off; gph.edge_src = a.edge_src; gph.edge_dst = a.edge_dst; gph.edge_attr = a.edge_attr;
+  gph.centres = a.centres;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) gph.canvas_bins[x] = a.canvas_bins[x];
+  gph.step = a.step;
+  gph.num_update = a.num_update;
+  return gph;
+}
 
 __global__ __launch_bounds__(256) void relation_update_k(RelArgs a) {
-  __shared__ float lg[REL_MAX_ELEM * 4 * 32];   // logits of the bbox sub-vocabularies
-  __shared__ float pr[REL_MAX_ELEM * 4 * 32];   // their softmax
-  __shared__ float bbox[(REL_MAX_ELEM + 1) * 4];
-  __shared__ float grad[(REL_MAX_ELEM + 1) * 4];
-  __shared__ float eg[REL_MAX_EDGE * 8];        // per-edge gradient wrt (x,y,w,h) of src and dst
-  __shared__ int node_of[REL_MAX_ELEM];         // element -> node index (1..), -1 = not in the graph
+  __shared__ float lgs[REL_MAX_ELEM * 4 * 32];   // logits of the bbox sub-vocabularies
+  __shared__ float prs[REL_MAX_ELEM * 4 * 32];   // their softmax
+  __shared__ float scratch[kRelScratchFloats];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int E = a.S / a.A, NB = a.n_bin;
   const int e0 = a.edge_off[b], ne = a.edge_off[b + 1] - e0;
-  if (tid == 0) {
-    int k = 1;  // node 0 = canvas
-    for (int e = 0; e < E; ++e) node_of[e] = (a.cond_seq[(size_t)b * a.S + e * a.A] != a.pad_id) ? k++ : -1;
-  }
+  const RelGraph gph = rel_graph(a);
+  relation_nodes(scratch, tid, E, a.pad_id, NB, a.centres, a.canvas_bins,
+                 [&](int e) { return a.cond_seq[(size_t)b * a.S + e * a.A]; });
   __syncthreads();
+  const int* node_of = reinterpret_cast<const int*>(scratch + kRelNodeOff);
   const int n_item = E * 4 * NB;
   // the lanes run along the contiguous axis of the log-probabilities: the ELEMENT index for the API's (B, C, S) layout
   // (25 reads inside one 500-byte class row instead of 64 rows per wave instruction), the bin index for (B, S, C)
@@ -43,121 +45,168 @@ __global__ __launch_bounds__(256) void relation_update_k(RelArgs a) {
   for (int i = tid; i < n_item; i += 256) {
     int e, x, n;
     if (a.logp_tm) { e = i / (4 * NB); x = (i / NB) % 4; n = i % NB; } else { e = i % E; x = (i / E) / NB; n = (i / E) % NB; }
-    lg[(e * 4 + x) * NB + n] = node_of[e] > 0 ? a.logp[at(e, x, n)] : 0.f;
+    lgs[(e * 4 + x) * NB + n] = node_of[e] > 0 ? a.logp[at(e, x, n)] : 0.f;
   }
-  if (tid < 4) bbox[tid] = a.centres[tid * NB + a.canvas_bins[tid]];  // canvas: one-hot expectation
   __syncthreads();
-  const int half = tid >> 5, ln = tid & 31;  // 8 groups of 32 lanes: one (element, coordinate) softmax each
-  for (int it = 0; it < a.num_update; ++it) {
-    for (int pidx = half; pidx < E * 4; pidx += 8) {
-      const int e = pidx >> 2, x = pidx & 3;
-      if (node_of[e] < 0) continue;  // (uniform per 32-lane group)
-      const float v = ln < NB ? lg[pidx * NB + ln] : -INFINITY;
-      float mx = v;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
-      const float ex = ln < NB ? expf(v - mx) : 0.f;
-      float sm = ex;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 32);
-      const float p = ex / sm;
-      if (ln < NB) pr[pidx * NB + ln] = p;
-      float bb = ln < NB ? p * a.centres[x * NB + ln] : 0.f;
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) bb += __shfl_xor(bb, o, 32);
-      if (ln == 0) bbox[node_of[e] * 4 + x] = bb;
-    }
-    __syncthreads();
-    // ---- per-edge hinge sub-gradients (clg/const.py), REL_MAX_EDGE edges at a time
-    if (tid < (E + 1) * 4) grad[tid] = 0.f;
-    for (int eb = 0; eb < ne; eb += REL_MAX_EDGE) {
-    const int nb = min(REL_MAX_EDGE, ne - eb);
-    for (int k = tid; k < nb; k += 256) {
-      const int s = a.edge_src[e0 + eb + k], d = a.edge_dst[e0 + eb + k], at = a.edge_attr[e0 + eb + k];
-      const float xs = bbox[s * 4], ys = bbox[s * 4 + 1], ws = bbox[s * 4 + 2], hs = bbox[s * 4 + 3];
-      const float xd = bbox[d * 4], yd = bbox[d * 4 + 1], wd = bbox[d * 4 + 2], hd = bbox[d * 4 + 3];
-      const float eps = 1e-8f;
-      float gs[4] = {0.f, 0.f, 0.f, 0.f}, gd[4] = {0.f, 0.f, 0.f, 0.f};
-      {  // relative size (const.py:56-106): a = w*h ; both canvas variants share the formula
-        const float as = ws * hs, ad = wd * hd;
-        const float sm = 0.9f * as, lgv = 1.1f * as;  // (1 -/+ REL_SIZE_ALPHA) * a1
-        float gas = 0.f, gad = 0.f;
-        if (at & (1 << 1)) { if (ad - sm > 0.f) { gad += 1.f; gas -= 0.9f; } }
-        if (at & (1 << 2)) {
-          if ((sm - ad) + eps > 0.f) { gas += 0.9f; gad -= 1.f; }
-          if ((ad - lgv) + eps > 0.f) { gad += 1.f; gas -= 1.1f; }
-        }
-        if (at & (1 << 3)) { if (lgv - ad > 0.f) { gas += 1.1f; gad -= 1.f; } }
-        gs[2] += gas * hs; gs[3] += gas * ws;
-        gd[2] += gad * hd; gd[3] += gad * wd;
-      }
-      if (s == 0) {  // location w.r.t. the canvas (const.py:109-157): centre-y thirds of the dst element
-        const float y_sm = (float)(1.0 / 3), y_lg = (float)(2.0 / 3);
-        if (at & (1 << 6)) { if (yd - y_sm > 0.f) gd[1] += 1.f; }
-        if (at & (1 << 9)) {
-          if ((y_sm - yd) + eps > 0.f) gd[1] -= 1.f;
-          if ((yd - y_lg) + eps > 0.f) gd[1] += 1.f;
-        }
-        if (at & (1 << 8)) { if (y_lg - yd > 0.f) gd[1] -= 1.f; }
-      } else {  // pairwise location (const.py:160-218) on l,t,r,b = xc -/+ w/2, yc -/+ h/2
-        const float l1 = xs - ws / 2, t1 = ys - hs / 2, r1 = xs + ws / 2, b1 = ys + hs / 2;
-        const float l2 = xd - wd / 2, t2 = yd - hd / 2, r2 = xd + wd / 2, b2 = yd + hd / 2;
-        float gl1 = 0.f, gt1 = 0.f, gr1 = 0.f, gb1 = 0.f, gl2 = 0.f, gt2 = 0.f, gr2 = 0.f, gb2 = 0.f;
-        if (at & (1 << 6)) { if (b2 - t1 > 0.f) { gb2 += 1.f; gt1 -= 1.f; } }
-        if (at & (1 << 8)) { if (b1 - t2 > 0.f) { gb1 += 1.f; gt2 -= 1.f; } }
-        if (at & (1 << 5)) { if (r2 - l1 > 0.f) { gr2 += 1.f; gl1 -= 1.f; } }
-        if (at & (1 << 7)) { if (r1 - l2 > 0.f) { gr1 += 1.f; gl2 -= 1.f; } }
-        if (at & (1 << 9)) {
-          if ((l1 - r2) + eps > 0.f) { gl1 += 1.f; gr2 -= 1.f; }
-          if ((l2 - r1) + eps > 0.f) { gl2 += 1.f; gr1 -= 1.f; }
-        }
-        const float nx = (float)(((at >> 5) & 1) + ((at >> 7) & 1) + ((at >> 9) & 1));  // LEFT / RIGHT / CENTER add t1<b2, t2<b1
-        if (nx > 0.f) {
-          if ((t1 - b2) + eps > 0.f) { gt1 += nx; gb2 -= nx; }
-          if ((t2 - b1) + eps > 0.f) { gt2 += nx; gb1 -= nx; }
-        }
-        gs[0] += gl1 + gr1; gs[2] += (gr1 - gl1) * 0.5f; gs[1] += gt1 + gb1; gs[3] += (gb1 - gt1) * 0.5f;
-        gd[0] += gl2 + gr2; gd[2] += (gr2 - gl2) * 0.5f; gd[1] += gt2 + gb2; gd[3] += (gb2 - gt2) * 0.5f;
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        eg[k * 8 + x] = gs[x];
-        eg[k * 8 + 4 + x] = gd[x];
-      }
-    }
-    __syncthreads();
-    // ---- node gradients: deterministic sum in edge order
-    if (tid < (E + 1) * 4) {
-      const int node = tid >> 2, x = tid & 3;
-      float g = grad[tid];
-      for (int k = 0; k < nb; ++k) {
-        if (a.edge_src[e0 + eb + k] == node) g += eg[k * 8 + x];
-        if (a.edge_dst[e0 + eb + k] == node) g += eg[k * 8 + 4 + x];
-      }
-      grad[tid] = g;
-    }
-    __syncthreads();
-    }  // edge blocks
-    __syncthreads();
-    // ---- SGD step through the softmax expectation
-    for (int i = tid; i < n_item; i += 256) {
-      const int e = i / (4 * NB), x = (i / NB) % 4, n = i % NB;
-      const int node = node_of[e];
-      if (node < 0) continue;
-      lg[i] -= a.step * (pr[i] * (a.centres[x * NB + n] - bbox[node * 4 + x]) * grad[node * 4 + x]);
-    }
-    __syncthreads();
-  }
+  relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return lgs + (e * 4 + x) * NB; },
+               [&](int e, int x) { return prs + (e * 4 + x) * NB; }, scratch, [] { __syncthreads(); });
   for (int i = tid; i < n_item; i += 256) {
     int e, x, n;
     if (a.logp_tm) { e = i / (4 * NB); x = (i / NB) % 4; n = i % NB; } else { e = i % E; x = (i / E) / NB; n = (i / E) % NB; }
-    if (node_of[e] > 0) a.logp[at(e, x, n)] = lg[(e * 4 + x) * NB + n];
+    if (node_of[e] > 0) a.logp[at(e, x, n)] = lgs[(e * 4 + x) * NB + n];
   }
 }
 
 void launch_relation_update(const RelArgs& a, hipStream_t st) {
   if (a.B <= 0 || a.num_update <= 0) return;
   hipLaunchKernelGGL(relation_update_k, dim3(a.B), dim3(256), 0, st, a);
+}
+
+// ---- the fused tail of an adjusted step.  LDS: per token a row of kRelRowLd floats — [0, 48) the log-probabilities of its
+// live classes in slot order (body bins first: the SGD's 32 logits of a bbox token are the row's first 32 floats), [48, 80)
+// the softmax scratch of the SGD — then the SGD's scratch, then the samplers' scratch (2 x 48 floats per 16-lane group).
+constexpr int kRelRowLd = 80;
+constexpr int kRelStepMaxS = 128;
+constexpr int kRelStepLds = (kRelStepMaxS * kRelRowLd + kRelScratchFloats + 16 * 96) * 4;
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  float* rows = rsm;
+  float* scratch = rsm + kRelStepMaxS * kRelRowLd;
+  float* samp = scratch + kRelScratchFloats;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int S = p.S, C = p.v.n_class, A = p.v.n_attr;
+  const int E = S / A, NB = a.n_bin;
+  const int grp = tid >> 4;
+  const ldm_post::DppGroup<16, FAST> g{tid & 15};
+  const ldm_post::SlotMap<16, 3, true> m{tid & 15};
+  const RelGraph gph = rel_graph(a);
+  const int e0 = a.edge_off[b], ne = a.edge_off[b + 1] - e0;
+  relation_nodes(scratch, tid, E, p.v.pad_id, NB, a.centres, a.canvas_bins,
+                 [&](int e) { return p.cond_seq[(size_t)b * S + e * A]; });
+  __syncthreads();
+  const int* node_of = reinterpret_cast<const int*>(scratch + kRelNodeOff);
+  // a conditioned (strong-masked) token takes its conditioned value without posterior or draw (ldm_post_token.h
+  // strong_shortcut) — unless it is a bbox token of a graph node: the reference's SGD then moves that one-hot row like any
+  // other (update() runs on the whole tensor AFTER the strong mask, base.py:245-269), so it goes the long way
+  auto shortcut = [&](const ldm_post::TokenArgs& ta, int s) {
+    return ldm_post::strong_shortcut(ta) && !(s % A != 0 && node_of[s / A] > 0);
+  };
+
+  auto token_args = [&](int s) {
+    const int row = b * S + s, attr = s % A;
+    ldm_post::TokenArgs ta{};
+    ta.tok = p.tokens[row];
+    ta.start = p.v.start[attr];
+    ta.count = p.v.count[attr];
+    ta.pad_id = p.v.pad_id;
+    ta.mask_id = p.v.mask_id;
+    ta.n_class = C;
+    ta.cond_tok = p.cond_seq[row];
+    ta.strong = p.strong && p.strong[row];
+    ta.weak = nullptr;          // (the refinement prior belongs to another cond type)
+    ta.weak_stride = S;
+    ta.pad_disable = false;     // applied AFTER the adjustment (base.py:272-284), in the draw phase below
+    ta.kind = p.kind;
+    ta.temperature = p.temperature;
+    ta.top_p = p.top_p;
+    ta.top_k = p.top_k;
+    ta.pos = (uint32_t)s;
+    ta.step = (uint32_t)p.step;
+    return ta;
+  };
+  // ---- phase A: log p(x_{t-1} | x_t) of every free token -> LDS
+  for (int s = grp; s < S; s += 16) {
+    const ldm_post::TokenArgs ta = token_args(s);
+    if (shortcut(ta, s)) continue;   // conditioned token: its row is never read
+    const int attr = s % A;
+    const float* lrow = p.logits + (size_t)(b * S + s) * p.ldl;
+    float mx = -INFINITY;
+    for (int c = g.lane(); c < C - 1; c += 16) mx = fmaxf(mx, lrow[c]);
+    mx = g.gmax(mx);
+    float l0[3], lp[3];
+    if (FAST) {
+      float se = 0.f;
+      for (int c = g.lane(); c < C - 1; c += 16) se += g.exp(lrow[c] - mx);
+      const float lse0 = g.log(g.gsum(se));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int c = m.cls(ta, j);
+        l0[j] = (m.valid(ta, j) && c < C - 1) ? ldm_post::l0_f32(lrow[c], mx, lse0) : -70.0f;
+      }
+    } else {
+      double se = 0.0;
+      for (int c = g.lane(); c < C - 1; c += 16) se += exp((double)lrow[c] - (double)mx);
+      const double lse0 = log(g.gsumd(se));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int c = m.cls(ta, j);
+        l0[j] = (m.valid(ta, j) && c < C - 1) ? ldm_post::l0_f64(lrow[c], mx, lse0) : -70.0f;
+      }
+    }
+    const int T1 = p.T + 1, t = p.t_post, u = (t - 1 + T1) % T1;  // constrained.py:114
+    auto sch = [&](int kind, int idx) { return p.sched[((size_t)kind * A + attr) * T1 + idx]; };
+    const ldm_post::StepSchedule sc{sch(kLogAt, t),    sch(kLogBt, t),    sch(kLogCt, t),    sch(kLogCumAt, t),
+                                    sch(kLogCumBt, t), sch(kLogCumCt, t), sch(kLogCumAt, u), sch(kLogCumBt, u),
+                                    sch(kLogCumCt, u), sch(kLog1mCumCt, u)};
+    ldm_post::token_log_probs(g, m, ta, sc, l0, lp);
+    float* r = rows + s * kRelRowLd;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (m.valid(ta, j)) r[m.sidx(j)] = lp[j];
+  }
+  __syncthreads();
+  // ---- phase B: the SGD on the bbox tokens of the graph's nodes (element e, coordinate x = token e A + 1 + x)
+  relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd; },
+               [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd + 48; }, scratch, [] { __syncthreads(); });
+  // ---- phase C: [PAD] disable + draw (+ the next step's embedding row)
+  for (int s = grp; s < S; s += 16) {
+    ldm_post::TokenArgs ta = token_args(s);
+    const int row = b * S + s, attr = s % A;
+    int token;
+    if (shortcut(ta, s)) {
+      token = ta.cond_tok;
+    } else {
+      ta.pad_disable = attr != 0 && ta.cond_tok != p.v.pad_id;
+      if (p.kind != 0) {
+        ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
+        ta.seed = p.rng[0];
+      }
+      const float* r = rows + s * kRelRowLd;
+      float lp[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) lp[j] = m.valid(ta, j) ? r[m.sidx(j)] : -INFINITY;
+      ldm_post::pad_disable_only(m, ta, lp);
+      float* sc_lg = samp + grp * 96;
+      token = ldm_post::draw_token(g, m, ta, lp, sc_lg, sc_lg + 48, true).token;
+    }
+    if (g.lane() == 0) p.tokens_out[row] = token;
+    if (p.x_next) {
+      const float4* e = reinterpret_cast<const float4*>(p.emb + (size_t)token * p.D);
+      const float4* ps = reinterpret_cast<const float4*>(p.pos + (size_t)s * p.D);
+      float4* o = reinterpret_cast<float4*>(p.x_next + (size_t)row * p.ldx);
+      for (int c = g.lane(); c < (p.D >> 2); c += 16) {
+        const float4 x = e[c], y = ps[c];
+        o[c] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+    }
+  }
+}
+
+// p: the step's PostArgs (logits, tokens in / out, cond_seq + strong mask, schedule, sampler, RNG, x_next); a: the graph.
+// Requires S <= 128, live sub-vocabularies <= 48 classes (the caller checks and falls back to the three-launch form).
+void launch_relation_step(const PostArgs& p, const RelArgs& a, hipStream_t st) {
+  if (p.B <= 0) return;
+  auto kern = p.f32_lse ? relation_step_k<true> : relation_step_k<false>;
+  allow_big_lds((const void*)kern);
+  hipLaunchKernelGGL(kern, dim3(p.B), dim3(256), kRelStepLds, st, p, a);
+}
+bool relation_step_supported(const PostArgs& p) {
+  int live_max = 0;
+  for (int at = 0; at < p.v.n_attr; ++at) live_max = live_max > p.v.count[at] + 2 ? live_max : p.v.count[at] + 2;
+  return p.S <= kRelStepMaxS && live_max <= 48 && p.v.n_attr <= kMaxAttr;
 }
 
 }  // namespace ldm

@@ -30,6 +30,7 @@
 #include "ldm_dma.h"
 #include "ldm_pipes.h"
 #include "ldm_post_dpp.h"
+#include "ldm_relation_core.h"
 
 namespace ldm {
 
@@ -51,6 +52,9 @@ struct StackArgs {
   int32_t* inter;            // [n_steps][inter_ld][S] tokens after every step, or nullptr (get_intermediate_results)
   int n_steps, inter_ld, tie_ld;
   int16_t t_model[kStackLoopMaxSteps], t_post[kStackLoopMaxSteps];  // the denoiser's timestep and q_posterior's (base.py:218-240)
+  // REL: cond=relation (base.py:261-269) — the graph of the launch's layouts (edge_off + workgroup index) and its n_bin
+  RelGraph rel;
+  int rel_n_bin;
 };
 // HEAD == 2 reads its loop parameters from the kernel-argument segment AT THE POINT OF USE, through a pointer hipcc
 // cannot see through: hoisted out of the step loop they would occupy ~60 SGPRs for the whole kernel, which already
@@ -64,7 +68,7 @@ __device__ __forceinline__ stack_kargs_ptr stack_kargs() {
 constexpr int kPostLd = 161;   // floats per token row of the logits in LDS (odd: the 16-lane groups of a wavefront hit distinct banks)
 constexpr int kPostRows = 128 * kPostLd * 4;  // bytes of the logits rows; behind them one float4 (max, lse, max |x|, -) per row
 constexpr int kStackLoopB1 = 2048;            // HEAD == 2: the linear1 bias table is padded to whole 1-KiB DMA pieces
-constexpr int kStackLoopLds = 1024;           // HEAD == 2: tokens [128] | cond token + strong bit [128] behind the tables
+constexpr int kStackLoopLds = 1024 + 128;     // HEAD == 2: tokens [128] | cond token + strong bit [128] | REL: element -> graph node [32]
 
 __device__ unsigned long long g_stack_phase[16];
 
@@ -83,8 +87,12 @@ __device__ __forceinline__ float stack_xor32_swap(float v) {
 #define LDM_XOR32(v) (HEAD == 2 ? stack_xor32_swap(v) : __shfl_xor(v, 32, 64))
 
 // HEAD: 1 = one denoiser pass: rows in, logits out (parity hook + per-step path); 2 = the whole reverse loop: tokens in, tokens out
-template <bool TM, int HEAD>
+// REL (HEAD == 2 only): cond=relation — steps with t >= 10 run posterior (+ strong mask) -> SGD on the layout's log-probabilities
+// in LDS (ldm_relation_core.h; the 25 elements of the layout couple, so all four wavefronts cooperate between two barriers)
+// -> [PAD] disable -> draw, the reference's order (base.py:243-291).  Its own instantiation: the plain loop kernel is untouched.
+template <bool TM, int HEAD, bool REL = false>
 __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
+  static_assert(!REL || HEAD == 2, "the relation tail belongs to the loop kernel");
   constexpr int KS = 29, STAGE = TILE_STAGE, NT2 = 15, NGV = 58;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid_o = threadIdx.x;
@@ -109,6 +117,14 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       int cc = -1;
       if (kp->post.cond_seq) cc = kp->post.cond_seq[row] | ((kp->post.strong && kp->post.strong[row]) ? (1 << 30) : 0);
       toks[128 + tid_o] = cc;
+    }
+    if constexpr (REL) {  // element -> node of the layout's relation graph (node 0 = canvas), -1 = [PAD] element
+      if (tid_o == 0) {
+        int k = 1;
+        const int A5 = kp->post.v.n_attr;
+        for (int e = 0; e < S / A5; ++e)
+          toks[256 + e] = ((kp->post.cond_seq[(size_t)b_o * S + e * A5]) != kp->post.v.pad_id) ? k++ : -1;
+      }
     }
     __syncthreads();
   }
@@ -748,6 +764,11 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
         const ldm_post::DppGroup<16, true> g{lane4 & 15};
         const ldm_post::SlotMap<16, 3, true> m{lane4 & 15};
         const bool last = it + 1 == n_iter;
+        // REL: this step adjusts the log-probabilities (t >= 10, logit_adjustment.py:107)?  If so the loop below stops at the
+        // posterior (log-probabilities -> the token's own LDS row, slot order) and the draw follows the SGD further down
+        bool adjust = false;
+        if constexpr (REL) adjust = kp->t_model[it] >= 10 && kp->rel.num_update > 0;
+        [[maybe_unused]] const int* node_of = condc + 128;
 #pragma unroll 2
         for (int rd = 0; rd < 8; ++rd) {
           const int s = wave * 32 + rd * 4 + grp;
@@ -768,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             ta.strong = cc >= 0 && (cc >> 30) != 0;
             ta.weak = p.weak ? p.weak + (size_t)b * p.v.n_class * S + s : nullptr;  // (B, C, S)
             ta.weak_stride = S;
-            ta.pad_disable = p.pad_disable && cc >= 0 && attr != 0 && ta.cond_tok != p.v.pad_id;  // base.py:272-284
+            ta.pad_disable = !adjust && p.pad_disable && cc >= 0 && attr != 0 && ta.cond_tok != p.v.pad_id;  // base.py:272-284
             ta.kind = p.kind;
             ta.temperature = p.temperature;
             ta.top_p = p.top_p;
@@ -777,7 +798,10 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             ta.step = (uint32_t)(p.step + it);
             ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
             ta.seed = p.rng[0];
-            if (ldm_post::strong_shortcut(ta)) {  // conditioned token: every sampler returns it (ldm_post_token.h)
+            bool shortcut = ldm_post::strong_shortcut(ta);  // conditioned token: every sampler returns it (ldm_post_token.h)
+            // (... unless the SGD moves its row: a strong-masked bbox token of a graph node, kernels_relation.hip)
+            if constexpr (REL) shortcut = shortcut && !(adjust && attr != 0 && node_of[s / p.v.n_attr] > 0);
+            if (shortcut) {
               if (g.lane() == 0) {
                 toks[s] = ta.cond_tok;
                 if (kp->inter) kp->inter[((size_t)it * kp->inter_ld + b) * S + s] = ta.cond_tok;
@@ -798,6 +822,14 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "+v"(k4));  // (registers, not a private array hipcc indexes)
             const ldm_post::QTerms k{k0, k1, k2, k3, k4};
             ldm_post::token_log_probs(g, m, ta, sc, k, l0, lp);
+            if constexpr (REL) {
+              if (adjust) {  // (the row's logits are in registers by now: every lane of the group has read its l0)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                  if (m.valid(ta, j)) lrow_s[m.sidx(j)] = lp[j];
+                continue;
+              }
+            }
             // (scratch of top-k / top-p: the token's own row — its logits are in registers by now)
             const ldm_post::Draw d = ldm_post::draw_token(g, m, ta, lp, lrow_s, lrow_s + 48, false);
             if (g.lane() == 0) {
@@ -806,6 +838,63 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
               if (last) p.tokens_out[(size_t)b * S + s] = d.token;
               if (p.tie_flags && d.gap < fmaxf(p.tie_rel * rs.z, p.tie_abs)) p.tie_flags[(size_t)it * kp->tie_ld + b] = 1;
             }
+          }
+        }
+        if constexpr (REL) {
+          if (adjust) {
+            // ---- the SGD of logit_adjustment.update on the layout's bbox tokens: element e, coordinate x = token e A + 1 + x,
+            // whose 32 body bins are the first 32 floats of its row (slot order); softmax scratch at + 96 (behind the
+            // samplers' 2 x 48); the SGD's own scratch in the K / V buffers, dead until the next step's first head
+            const int A5 = p.v.n_attr;
+            float* rscr = reinterpret_cast<float*>(smem + 3 * STAGE);
+            const int tid5 = wave * 64 + stack_lane_id();
+            if (tid5 < 4) rscr[kRelBboxOff + tid5] = kp->rel.centres[tid5 * kp->rel_n_bin + kp->rel.canvas_bins[tid5]];
+            if (tid5 < 32) reinterpret_cast<int*>(rscr + kRelNodeOff)[tid5] = node_of[tid5];
+            __syncthreads();  // every wavefront's posterior rows are in LDS
+            const int e0 = kp->rel.edge_off[b], ne = kp->rel.edge_off[b + 1] - e0;
+            relation_sgd(kp->rel, e0, ne, tid5, S / A5, kp->rel_n_bin,
+                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd; },
+                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; }, rscr, [] { __syncthreads(); });
+            // ---- [PAD] disable + draw from the adjusted rows (base.py:272-291)
+#pragma unroll 1
+            for (int rd = 0; rd < 8; ++rd) {
+              const int s = wave * 32 + rd * 4 + grp;
+              if (s >= S) continue;
+              const int attr = s % A5;
+              const int cc = condc[s];
+              ldm_post::TokenArgs ta{};
+              ta.tok = toks[s];
+              ta.start = reinterpret_cast<const int*>(ssch)[100 + 2 * attr];
+              ta.count = reinterpret_cast<const int*>(ssch)[101 + 2 * attr];
+              ta.pad_id = p.v.pad_id;
+              ta.mask_id = p.v.mask_id;
+              ta.n_class = p.v.n_class;
+              ta.cond_tok = cc < 0 ? -1 : (cc & 0x3fffffff);
+              ta.strong = cc >= 0 && (cc >> 30) != 0;
+              ta.pad_disable = p.pad_disable && cc >= 0 && attr != 0 && ta.cond_tok != p.v.pad_id;
+              ta.kind = p.kind;
+              ta.temperature = p.temperature;
+              ta.top_p = p.top_p;
+              ta.top_k = p.top_k;
+              ta.pos = (uint32_t)s;
+              ta.step = (uint32_t)(p.step + it);
+              ta.layout = p.rng[1] + (uint64_t)p.layout_off + (uint64_t)b;
+              ta.seed = p.rng[0];
+              if (ldm_post::strong_shortcut(ta) && !(attr != 0 && node_of[s / A5] > 0)) continue;  // stored above
+              float* lrow_s = lgs + s * kPostLd;
+              float lp[3];
+#pragma unroll
+              for (int j = 0; j < 3; ++j) lp[j] = m.valid(ta, j) ? lrow_s[m.sidx(j)] : -INFINITY;
+              ldm_post::pad_disable_only(m, ta, lp);
+              g.sync();  // (the row is about to become the samplers' scratch)
+              const ldm_post::Draw d = ldm_post::draw_token(g, m, ta, lp, lrow_s, lrow_s + 48, false);
+              if (g.lane() == 0) {
+                toks[s] = d.token;
+                if (kp->inter) kp->inter[((size_t)it * kp->inter_ld + b) * S + s] = d.token;
+                if (last) p.tokens_out[(size_t)b * S + s] = d.token;
+              }
+            }
+            __syncthreads();  // the K / V buffers and the rows go back to the next step
           }
         }
       }
@@ -874,9 +963,16 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int 
 void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
                        const StackLoop& lp, hipStream_t st) {
   const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + kStackLoopB1 + 2 * LN_DP + 512) * 4 + kStackLoopLds;
-  auto kern = stack_stream_k<false, 2>;
+  auto kern = lp.rel ? stack_stream_k<false, 2, true> : stack_stream_k<false, 2, false>;
   allow_big_lds((const void*)kern);
   StackArgs a{};
+  if (lp.rel) {
+    a.rel.edge_off = lp.rel->edge_off; a.rel.edge_src = lp.rel->edge_src; a.rel.edge_dst = lp.rel->edge_dst;
+    a.rel.edge_attr = lp.rel->edge_attr; a.rel.centres = lp.rel->centres;
+    for (int x = 0; x < 4; ++x) a.rel.canvas_bins[x] = lp.rel->canvas_bins[x];
+    a.rel.step = lp.rel->step; a.rel.num_update = lp.rel->num_update;
+    a.rel_n_bin = lp.rel->n_bin;
+  }
   a.ls = ls; a.ldx = N; a.N = N; a.S = S; a.H = H; a.n_chunks = F / 32;
   a.scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   a.head_img = (const char*)head.img; a.head_g = head.g; a.head_b = head.b; a.n_head_tiles = head.n_tiles;

@@ -193,6 +193,7 @@ struct ldm_handle {
                        //    geometry (and as an A/B / cross-check of the stack kernel: LDM_FUSED_ATTN=0)
   // parameter-table LDS images of the loop kernel (ldm_kernels.h StackTables), built by build_loop_tables
   float *tbl_att_static = nullptr, *tbl_att_dyn = nullptr, *tbl_ffn = nullptr, *tbl_head = nullptr;
+  int rel_loop = 1;    // cond=relation inside the one-launch loop (LDM_REL_LOOP=0: the per-step path)
   int stack_loop = 1;  // the WHOLE reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): one launch per
                        // sampling call, the step's tail behind the vocabulary head (LDM_STACK_LOOP=0: one stack launch +
                        // one posterior launch per step, captured in per-lane hipGraphs — the r02 path)
@@ -425,6 +426,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     if (env) sscanf(env, "%d,%d,%d,%d,%d", &h->gemm_cfg[0], &h->gemm_cfg[1], &h->gemm_cfg[2], &h->gemm_cfg[3], &h->gemm_cfg[4]);
     if (const char* fa = knob_env("LDM_FUSED_ATTN")) h->fused_attn = atoi(fa) == 0 ? 0 : 6;
     if (const char* sp = knob_env("LDM_STACK_LOOP")) h->stack_loop = atoi(sp);
+    h->rel_loop = knob_int("LDM_REL_LOOP", 1);
     // stack kernel: one 128-row tile per layout, and every one of its 4 waves must own at least one real row (its
     // exec-masked stores are counted by the vmcnt waits) => 96 < S <= 128; d_model 464 in 8 heads, K padded to 512
     if (h->S > 128 || h->S <= 96 || h->dh > 64 || h->D != 464 || h->Dq != 512 || h->HD != 512 || h->H != 8 ||
@@ -1155,6 +1157,20 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       continue;
     }
     // cond=relation (base.py:243-291): posterior + strong mask -> logit adjustment -> [PAD] disable -> draw
+    if (relation_step_supported(p) && knob_int("LDM_REL_FUSED", 1) != 0) {  // ... in ONE launch (r04)
+      PostArgs q = p;
+      q.pad_disable = 1;
+      q.tokens_out = tout + (size_t)off * h->S;
+      if (embed_next) {
+        q.x_next = h->P; q.emb = h->emb; q.pos = h->pos; q.D = h->D; q.ldx = h->D;
+      }
+      RelArgs a{};
+      a.cond_seq = cond->d_cond_seq + (size_t)off * h->S;
+      fill_rel(h, a, rel, rel_layout_off + off, Bc);
+      ldm_handle::Scope sc(h, st, "relation_step", 0, (double)Bc * h->S * (h->Cp * 4 + 8));
+      launch_relation_step(q, a, st);
+      continue;
+    }
     {
       PostArgs q = p;
       q.pad_disable = 0;  // applied after the adjustment, below
@@ -1196,21 +1212,26 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
 
 // ---- the whole reverse loop in one launch (kernels_stack.hip HEAD == 2) -----------------------------------------
 // Eligible: fast numerics on the layout-resident kernels (the reference's backbone, S <= 128), a vocabulary of 5 head
-// tiles whose attribute sub-vocabularies fit the fused tail, no cond=relation (its logit adjustment couples the
-// elements of a layout through an SGD on the full log-probability tensor: it keeps the per-step path).
+// tiles whose attribute sub-vocabularies fit the fused tail.  cond=relation (r04): its logit adjustment couples the
+// elements of a layout through an SGD on the log-probabilities — the layout's workgroup holds them in LDS behind the
+// vocabulary head, so the adjusted steps run posterior -> SGD -> [PAD] disable -> draw in the same launch
+// (stack_stream_k<., 2, true>); needs the constrained vocabulary with <= 32 bins and <= 32 elements.
 static bool loop_fusable(const ldm_handle* h, const ldm_relation* rel) {
   int live_max = 0;
   for (int a = 0; a < h->cfg.n_attr; ++a) live_max = std::max(live_max, h->vocab.count[a] + 2);
-  return h->stack_loop && !rel && h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6 && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
+  if (rel && (h->rel_loop == 0 || h->cfg.q_type != LDM_Q_CONSTRAINED || h->cfg.n_bin > 32 || h->cfg.max_elem > 32 ||
+              h->cfg.n_attr != 5))
+    return false;
+  return h->stack_loop && h->cfg.precision == LDM_PREC_FAST_F16 && h->fused_attn == 6 && h->head_img_ks && h->Cp == 160 && live_max <= kStackPostMaxLive && h->S <= 128 &&
          h->T < 32768 && !h->fast.empty() && h->tbl_att_dyn && h->D == 464 && h->F <= 2048;
 }
 
 // tokens_in -> tokens_out (may alias) through n_steps reverse steps; step0 = loop index of the first one (RNG counter
 // word); cond pointers describe layout 0..B of this call; d_inter (n_steps, B, S) or nullptr; tie_row0 >= 0: near-tie
 // flags of step i go to row tie_row0 + i of h->tie_flags
-static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, const ldm_cond* cond, const int32_t* t_model,
-                          const int32_t* t_post, int n_steps, const ldm_sampler* s, int step0, int B, int32_t* d_inter,
-                          int tie_row0, hipStream_t st) {
+static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, const ldm_cond* cond, const ldm_relation* rel,
+                          const int32_t* t_model, const int32_t* t_post, int n_steps, const ldm_sampler* s, int step0, int B,
+                          int32_t* d_inter, int tie_row0, hipStream_t st) {
   const int D = h->D, F = h->F, M = B * h->S;
   FusedLayerSet ls{};
   ls.n_layer = h->L;
@@ -1231,6 +1252,11 @@ static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, cons
     p.step = step0 + i0;
     p.layout_off = 0;
     p.emb = h->emb; p.pos = h->pos; p.D = D;
+    RelArgs ra{};
+    if (rel) {
+      p.pad_disable = 1;  // cond type relation (base.py:272)
+      fill_rel(h, ra, rel, 0, B);
+    }
     if (tie_row0 >= 0 && h->tie_rel > 0.f && h->tie_flags && s->kind == LDM_SAMPLE_DETERMINISTIC) {
       p.tie_flags = h->tie_flags + (size_t)(tie_row0 + i0) * h->cfg.max_batch;
       p.tie_rel = h->tie_rel;
@@ -1241,6 +1267,7 @@ static int run_loop_fused(ldm_handle* h, const int32_t* tin, int32_t* tout, cons
     lp.post = &p; lp.adaln = h->adaln; lp.t_model = t_model + i0; lp.t_post = t_post + i0;
     lp.inter = d_inter ? d_inter + (size_t)i0 * B * h->S : nullptr;
     lp.n_steps = n; lp.inter_ld = B; lp.tie_ld = h->cfg.max_batch;
+    lp.rel = rel ? &ra : nullptr;
     ldm_handle::Scope sc(h, st, "layers_fused_loop", n * step_flops, (double)B * h->S * 8);
     launch_stack_loop(ls, F, D, B, h->S, h->H, h->dh, hd, lp, st);
   }
@@ -1413,7 +1440,7 @@ extern "C" int ldm_sample_step(ldm_handle* h, const int32_t* d_tokens_in, int32_
   if ((rc = tie_begin(h, s, rel, 1, B, st))) return rc;
   if (loop_fusable(h, rel)) {
     const int32_t tm = t_model, tp = t_post;
-    if ((rc = run_loop_fused(h, d_tokens_in, d_tokens_out, cond, &tm, &tp, 1, s, step, B, nullptr, 0, st))) return rc;
+    if ((rc = run_loop_fused(h, d_tokens_in, d_tokens_out, cond, rel, &tm, &tp, 1, s, step, B, nullptr, 0, st))) return rc;
   } else if ((rc = step_all(h, d_tokens_in, d_tokens_out, t_model, t_post, cond, rel, 0, s, step, B, 0, st, false, false, 0))) {
     return rc;
   }
@@ -1480,7 +1507,7 @@ extern "C" int ldm_sample_loop(ldm_handle* h, int32_t* d_tokens_inout, const ldm
   if ((rc = tie_begin(h, s, rel, n_steps, B, st))) return rc;
   if (loop_fusable(h, rel)) {
     // one launch: every layout's workgroup runs all its steps in place on the caller's tokens (no staging, no graph)
-    if ((rc = run_loop_fused(h, d_tokens_inout, d_tokens_inout, cond, h_t_model, h_t_post, n_steps, s, 0, B,
+    if ((rc = run_loop_fused(h, d_tokens_inout, d_tokens_inout, cond, rel, h_t_model, h_t_post, n_steps, s, 0, B,
                              d_intermediates, 0, st)))
       return rc;
     HIP_OK(h, hipEventRecord(h->loop_b, st));

@@ -122,6 +122,7 @@ struct StackLoop {
   int32_t* inter;            // [n_steps][inter_ld][S] or nullptr
   int n_steps, inter_ld;
   int tie_ld;                // post->tie_flags of step i at + i * tie_ld (per layout of this launch)
+  const struct RelArgs* rel; // cond=relation: the graph of the launch's layouts (edge_off advanced to its first layout), or nullptr
 };
 // largest sub-vocabulary (body + [PAD] + [MASK]) the fused tail takes: 3 class slots on each of a group's 16 lanes
 constexpr int kStackPostMaxLive = 48;
@@ -145,6 +146,12 @@ struct RelArgs {
   int logp_tm;              // 0: logp is (B,C,S) (the API's layout); 1: (B,S,C), token-major (the handle's own buffer)
 };
 void launch_relation_update(const RelArgs& a, hipStream_t st);
+// the fused tail of an adjusted cond=relation step of the per-step path (kernels_relation.hip relation_step_k): posterior
+// (+ strong mask) -> SGD -> [PAD] disable -> draw in ONE launch; p = the step's PostArgs (logits in, tokens out, x_next),
+// a = the graph (a.logp unused).  relation_step_supported: S <= 128 and live sub-vocabularies <= 48 classes.
+struct PostArgs;
+void launch_relation_step(const PostArgs& p, const RelArgs& a, hipStream_t st);
+bool relation_step_supported(const PostArgs& p);
 // MFMA attention on the head-padded fp16 layout (kernels_attn16.hip)
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st);
 

@@ -30,7 +30,8 @@ inline const std::map<std::string, const char*>& knob_table() {
       {"LDM_GEMM32_SLOTS", "resident fp32 GEMM workgroups per CU"},
       {"LDM_GEMM32_BM64", "64-row fp32 GEMM tiles for one-round shapes"},
       {"LDM_EXACT_LN", "0 = separate LayerNorm launches in the exact mode (pre-r04 structure)"},
-      {"LDM_REL_FUSED", "0 = three launches per cond=relation step (pre-r04 structure)"},
+      {"LDM_REL_FUSED", "0 = three launches per cond=relation step of the per-step path (pre-r04 structure)"},
+      {"LDM_REL_LOOP", "0 = cond=relation on the per-step path instead of inside the one-launch loop (fast mode)"},
   };
   return t;
 }

@@ -321,6 +321,59 @@ def test_config5_T200_loops_equal_their_steps(cuda, golden_dir):
         torch.cuda.synchronize()
 
 
+def test_relation_in_the_loop_kernel_equals_the_per_step_path(cuda, monkeypatch):
+    """r04: cond=relation inside the one-launch loop (stack_stream_k<., 2, true>: posterior -> SGD -> [PAD] disable -> draw behind
+    the vocabulary head, ldm_relation_core.h) against the per-step path (LDM_DEV=1 LDM_REL_LOOP=0: stack launch +
+    relation_step_k per chunk-step, hipGraph), B = 300 random graphs, T = 100, three samplers.  One source for the SGD and
+    for the step's tail; what differs is the summation order of the log-softmax (as for the plain loop:
+    test_fused_loop_equals_per_step_path), so tokens may differ only where that moves a tie or a CDF edge — and, behind
+    an SGD with steps of O(1e4), where it moves a hinge.  Conditioned categories survive; no [MASK] / [PAD] in free slots."""
+    from layout_dm_amd.binding import Engine
+    from layout_dm_amd.synthetic import linear_bin_centres, synth_cond_relation
+    from layout_dm_amd import synthetic as PS
+
+    spec = SP.RICO25
+    sd = synth.synth_state_dict(spec, seed=1, perturb=True)
+    B = 300
+    cond_np, graph = synth_cond_relation(PS.SPECS["rico25"], B, seed=3, edge_ratio=0.3)
+    steps = R.timestep_list(spec.n_step, 100)
+    outs = {}
+    for loop in ("1", "0"):
+        monkeypatch.setenv("LDM_DEV", "1")
+        monkeypatch.setenv("LDM_REL_LOOP", loop)
+        e = Engine(n_category=spec.n_category, precision="fast", max_batch=512)
+        e.load_state_dict(sd)
+        assert e.describe()["loop"] == "one_launch"
+        cond = {"seq": cond_np["seq"], "mask": cond_np["mask"], "type": "relation"}
+        plan = e.make_relation(graph, linear_bin_centres(spec.n_bin), [16, 16, 31, 31], 3e6, 3, B)
+        res = {}
+        for name in ("deterministic", "random", "top_p"):
+            cfg = {"name": name, "temperature": 1.0, "top_p": 0.9}
+            tok = torch.from_numpy(cond_np["seq"]).int().to(cuda)
+            out, inter = e.sample_loop(tok, steps, steps, cfg, cond=cond, seed=7, first_layout=11, intermediates=True,
+                                       relation=plan)
+            res[name] = (out.cpu().clone(), inter.cpu().clone())
+            if loop == "1" and name == "random":   # the loop == the same steps one launch at a time (same kernel, same state)
+                cur = torch.from_numpy(cond_np["seq"]).int().to(cuda)
+                for i, t in enumerate(steps[:14]):
+                    cur = e.sample_step(cur, t, cfg, cond=cond, seed=7, first_layout=11, step=i, relation=plan)
+                    assert torch.equal(cur.cpu(), res[name][1][i]), i
+        torch.cuda.synchronize()
+        e.close()
+        outs[loop] = res
+    m = torch.from_numpy(cond_np["mask"])
+    seq = torch.from_numpy(cond_np["seq"])
+    for name in ("deterministic", "random", "top_p"):
+        a, b = outs["1"][name], outs["0"][name]
+        final = (a[0] != b[0]).float().mean().item()
+        early = (a[1][:10] != b[1][:10]).float().mean().item()
+        print(f"[relation in the loop kernel vs per-step path / {name}] tokens differing: first 10 steps {early:.2e}, final {final:.2e}")
+        assert early <= 5e-4 and final <= 5e-3, (name, early, final)
+        assert torch.equal(a[0].long()[m], seq[m]), "conditioned tokens changed"
+        free = ~m
+        assert (a[0].long()[free] != spec.mask_id).all() and (a[0].long()[free] != spec.pad_id).all()
+
+
 # ----------------------------------------------------------------------------- fast_verified where it hurts (B = 512)
 def test_fast_verified_free_running_from_mid_trajectory_b512(cuda):
     """greedy free-running loops at B = 512 started from the states a stochastic run visits at step 20,

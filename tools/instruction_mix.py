@@ -1,4 +1,4 @@
-"""Dev tool (no GPU needed): the DYNAMIC instruction mix of the one-launch loop kernel `stack_stream_k<false, 2>`, per phase
+"""Dev tool (no GPU needed): the DYNAMIC instruction mix of the one-launch loop kernel `stack_stream_k<false, 2, false>`, per phase
 and per instruction class, from its gfx950 assembly (VERDICT r3 next #6 i).
 
     python tools/instruction_mix.py [--asm stack.s] > profiles/r04_instruction_mix_fast_loop.txt
@@ -21,7 +21,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN3ldm14stack_stream_kILb0ELi2EEEvNS_9StackArgsE"
+KERNEL = "_ZN3ldm14stack_stream_kILb0ELi2ELb0EEEvNS_9StackArgsE"
 N_LAYER, N_HEAD, N_CHUNK_IT, TAIL_ROUNDS = 4, 8, 59, 8
 
 CLASSES = ["mfma", "valu_fp", "valu_pk", "valu_trans", "valu_cvt", "valu_acc_move", "valu_move_perm", "valu_lane_id",
