@@ -4,7 +4,7 @@
 // so there is no online-softmax loop — a workgroup of 4 waves handles one (layout, head), wave w
 // owning query rows 32w..32w+31.
 //
-// Layout contract (set up by the host, see ldm_api.cpp): qkv is [M, 3*H*64] fp16 with every head's
+// Layout contract (set up by the host, see ldm_weights.cpp): qkv is [M, 3*H*64] fp16 with every head's
 // q/k/v slice padded 58 -> 64 columns (exact zeros: the padded in_proj rows/bias are zero), so each
 // head row is one aligned 128-byte line; the output is [M, H*64] in the same head-padded layout and
 // the out-projection weight has matching zero columns.

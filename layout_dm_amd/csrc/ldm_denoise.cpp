@@ -1,0 +1,226 @@
+// Host side of libldm_hip.so: the launch sequence of ONE denoiser pass over a chunk of layouts, per numerics mode
+// (CategoricalTransformer.forward, nn_lib.py:191-237 + transformer_utils.py:165-246).
+#include "ldm_handle.h"
+
+using namespace ldm_host;
+
+// ------------------------------------------------------------------------------------------ one pass
+double ldm_host::gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
+
+// fast mode on the reference's backbone: the stack kernel (kernels_stack.hip) — ONE launch for all layers and the
+// vocabulary head, a layout's rows in its workgroup's out-projection accumulators from the embedding output to the
+// logits.  Normalisation is deferred into the kernel (no LayerNorm launch, no LN output tensor): the embedding writes raw
+// rows, the kernel computes its own row statistics.  (The one-launch reverse loop, run_loop_fused, does not come here: it
+// gathers the embedding itself.)
+static int denoise_chunk_stack(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
+  const int M = Bc * h->S, D = h->D, F = h->F;
+  if (!skip_embed) {  // x0 = emb[token] + pos -> P (raw)   (skipped when the previous step's posterior wrote P)
+    LnArgs a{};
+    a.tokens = d_tokens; a.emb = h->emb; a.pos = h->pos; a.y32 = h->P; a.stats_out = h->stats_a; a.raw = 1;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = h->Dq;
+    ldm_handle::Scope sc(h, st, "embed_stats", 0, (double)M * D * 8);
+    launch_layernorm(a, st);
+  }
+  FusedLayerSet ls{};
+  ls.n_layer = h->L;
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    ls.w[i] = FusedLayerW{h->fast[i].attn_head_img_ks, h->fast[i].b_in, ss, ss + D, h->fast[i].b_out_v,
+                          h->fast[i].ffn_img_pipe, w.b1, w.b2, w.g2, w.be2};
+  }
+  const StackHead hd{h->head_img_ks, h->head_g, h->head_b, h->logits, h->Cp, h->Cp / 32};
+  ldm_handle::Scope sc(h, st, "layers_fused",
+                       h->L * (gemm_flops(M, 3 * D, D) + 4.0 * Bc * h->H * (double)h->S * h->S * h->dh +
+                               gemm_flops(M, D, D) + 2 * gemm_flops(M, F, D)) + gemm_flops(M, h->C, D),
+                       (double)M * (D * 4 + h->Cp * 4));
+  launch_stack_stream(ls, F, h->P, D, Bc, h->S, h->H, h->dh, hd, st);
+  return 0;
+}
+
+// fast mode, every other accepted geometry: fp16 LDS-DMA GEMMs + MFMA attention on the head-padded layout
+static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st,
+                              bool skip_embed = false) {
+  if (h->fused_attn == 6) return denoise_chunk_stack(h, d_tokens, t, Bc, st, skip_embed);
+  const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dq = h->Dq, HD = h->HD, Fq = h->Fq;
+  auto gemm = [&](const char* name, int tag, const __half* A, int lda, int K, const __half* W, int ldw, int N,
+                  const float* bias, int relu, const float* res, float* C32, int ldc32, __half* C16, int ldc16,
+                  double flops, double bytes) {
+    GemmArgs g{};
+    g.A = A; g.W = W; g.bias = bias; g.relu = relu; g.res = res; g.ldres = D;
+    g.C32 = C32; g.ldc32 = ldc32; g.C16 = C16; g.ldc16 = ldc16;
+    const int cfg = h->gemm_cfg[tag];
+    g.M = M; g.N = N; g.K = round_up(K, gemm16_block_k(cfg)); g.lda = lda; g.ldw = ldw; g.precision = 1;
+    ldm_handle::Scope sc(h, st, name, flops, bytes);
+    launch_gemm16(g, cfg, tag, st);
+  };
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const ldm_handle::FastLayer& f = h->fast[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    {
+      LnArgs a{};
+      a.x = h->P; a.tokens = (i == 0) ? d_tokens : nullptr; a.emb = h->emb; a.pos = h->pos;
+      a.p0 = ss; a.p1 = ss + D; a.y32 = h->P; a.y16 = h->a16;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 1;
+      ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * 10);
+      launch_layernorm(a, st);
+    }
+    gemm("gemm_qkv", 0, h->a16, Dq, D, f.w_in, Dq, 3 * HD, f.b_in, 0, nullptr, nullptr, 0, h->qkv16,
+         3 * HD, gemm_flops(M, 3 * D, D), (double)M * (D * 2 + 3 * HD * 2));
+    {
+      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh, (double)M * (3 * HD + HD) * 2);
+      launch_attention16(h->qkv16, h->att16, Bc, h->S, h->H, h->dh, 3 * HD, HD, st);
+    }
+    gemm("gemm_attn_out", 1, h->att16, HD, HD, f.w_out, HD, D, w.b_out, 0, h->P, h->Q, D, nullptr, 0,
+         gemm_flops(M, D, D), (double)M * (HD * 2 + D * 8));
+    {
+      LnArgs a{};
+      a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2; a.y16 = h->h16;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 0;
+      ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * 6);
+      launch_layernorm(a, st);
+    }
+    gemm("gemm_ffn1", 2, h->h16, Dq, D, f.w1, Dq, F, w.b1, 1, nullptr, nullptr, 0, h->hid16, Fq,
+         gemm_flops(M, F, D), (double)M * (D * 2 + F * 2));
+    gemm("gemm_ffn2", 3, h->hid16, Fq, F, f.w2, Fq, D, w.b2, 0, h->Q, h->P, D, nullptr, 0,
+         gemm_flops(M, D, F), (double)M * (F * 2 + D * 8));
+  }
+  {
+    LnArgs a{};
+    a.x = h->P; a.p0 = h->head_g; a.p1 = h->head_b; a.y16 = h->h16;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dq; a.ada = 0;
+    ldm_handle::Scope sc(h, st, "layernorm_head", 0, (double)M * D * 6);
+    launch_layernorm(a, st);
+  }
+  gemm("gemm_head", 4, h->h16, Dq, D, h->fast_head, Dq, h->Cp, nullptr, 0, nullptr, h->logits, h->Cp,
+       nullptr, 0, gemm_flops(M, C, D), (double)M * (D * 2 + C * 4));
+  return 0;
+}
+
+// denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
+int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
+  if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed);
+  const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
+  const int prec = h->cfg.precision;
+  const bool f16 = prec != LDM_PREC_EXACT_F32;
+  const bool split = prec == LDM_PREC_SPLIT_F16;
+  const size_t esz = f16 ? 2 : 4;
+  for (int i = 0; i < h->L; ++i) {
+    const LayerW& w = h->layers[i];
+    const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
+    {  // AdaLN (layer 0: fused with the embedding gather); P <- normed x (the residual base)
+      LnArgs a{};
+      a.x = h->P;
+      a.tokens = (i == 0) ? d_tokens : nullptr;
+      a.emb = h->emb;
+      a.pos = h->pos;
+      a.p0 = ss;
+      a.p1 = ss + D;
+      a.y32 = h->P;
+      a.y16 = f16 ? h->a16 : nullptr;
+      a.y16lo = split ? h->a16lo : nullptr;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 1;
+      ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * (4 + 4 + (f16 ? 2 : 0)));
+      launch_layernorm(a, st);
+    }
+    {  // QKV projection
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->a16 : (const void*)h->P;
+      g.Alo = h->a16lo;
+      g.W = f16 ? (const void*)w.w_in16 : (const void*)w.w_in;
+      g.Wlo = w.w_in16lo;
+      g.bias = w.b_in;
+      g.C32 = (prec == LDM_PREC_FAST_F16) ? nullptr : h->qkv32;
+      g.C16 = (prec == LDM_PREC_FAST_F16) ? h->qkv16 : nullptr;
+      g.M = M; g.N = 3 * D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D;
+      g.ldc32 = 3 * D; g.ldc16 = 3 * D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * D * esz + (double)M * 3 * D * (prec == 1 ? 2 : 4));
+      launch_gemm(g, st);
+    }
+    {  // attention
+      AttnArgs a{};
+      a.in_f16 = (prec == LDM_PREC_FAST_F16);
+      a.qkv = a.in_f16 ? (const void*)h->qkv16 : (const void*)h->qkv32;
+      a.out32 = f16 ? nullptr : h->att32;
+      a.out16 = f16 ? h->att16 : nullptr;
+      a.out16lo = split ? h->att16lo : nullptr;
+      a.B = Bc; a.S = h->S; a.H = h->H; a.dh = h->dh; a.D = D; a.ld = 3 * D; a.ldo32 = D; a.ldo16 = Dp;
+      ldm_handle::Scope sc(h, st, "attention", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh,
+                           (double)M * 3 * D * (a.in_f16 ? 2 : 4) + (double)M * D * esz);
+      launch_attention(a, st);
+    }
+    {  // out-proj + residual onto the normed x:  Q = P + att·Wo^T + bo
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->att16 : (const void*)h->att32;
+      g.Alo = h->att16lo;
+      g.W = f16 ? (const void*)w.w_out16 : (const void*)w.w_out;
+      g.Wlo = w.w_out16lo;
+      g.bias = w.b_out;
+      g.res = h->P; g.ldres = D;
+      g.C32 = h->Q; g.ldc32 = D;
+      g.M = M; g.N = D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * D * (esz + 8));
+      launch_gemm(g, st);
+    }
+    {  // LayerNorm 2
+      LnArgs a{};
+      a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2;
+      a.y32 = f16 ? nullptr : h->h32;
+      a.y16 = f16 ? h->h16 : nullptr;
+      a.y16lo = split ? h->h16lo : nullptr;
+      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
+      ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * (4 + esz));
+      launch_layernorm(a, st);
+    }
+    {  // FFN1 + ReLU
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
+      g.Alo = h->h16lo;
+      g.W = f16 ? (const void*)w.w1_16 : (const void*)w.w1;
+      g.Wlo = w.w1_16lo;
+      g.bias = w.b1; g.relu = 1;
+      g.C32 = f16 ? nullptr : h->hid32; g.ldc32 = F;
+      g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
+      g.M = M; g.N = F; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_ffn1", gemm_flops(M, F, D), (double)M * D * esz + (double)M * F * esz);
+      launch_gemm(g, st);
+    }
+    {  // FFN2 + residual:  P = Q + hid·W2^T + b2
+      GemmArgs g{};
+      g.A = f16 ? (const void*)h->hid16 : (const void*)h->hid32;
+      g.Alo = h->hid16lo;
+      g.W = f16 ? (const void*)w.w2_16 : (const void*)w.w2;
+      g.Wlo = w.w2_16lo;
+      g.bias = w.b2;
+      g.res = h->Q; g.ldres = D;
+      g.C32 = h->P; g.ldc32 = D;
+      g.M = M; g.N = D; g.K = f16 ? Fp : F; g.lda = f16 ? Fp : F; g.ldw = f16 ? Fp : F; g.precision = prec;
+      ldm_handle::Scope sc(h, st, "gemm_ffn2", gemm_flops(M, D, F), (double)M * F * esz + (double)M * D * 8);
+      launch_gemm(g, st);
+    }
+  }
+  {  // head: LayerNorm + vocab projection (no bias)
+    LnArgs a{};
+    a.x = h->P; a.p0 = h->head_g; a.p1 = h->head_b;
+    a.y32 = f16 ? nullptr : h->h32;
+    a.y16 = f16 ? h->h16 : nullptr;
+    a.y16lo = split ? h->h16lo : nullptr;
+    a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
+    {
+      ldm_handle::Scope sc(h, st, "layernorm_head", 0, (double)M * D * (4 + esz));
+      launch_layernorm(a, st);
+    }
+    GemmArgs g{};
+    g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
+    g.Alo = h->h16lo;
+    g.W = f16 ? (const void*)h->head_w16 : (const void*)h->head_w;
+    g.Wlo = h->head_w16lo;
+    g.C32 = h->logits; g.ldc32 = h->Cp;
+    g.M = M; g.N = C; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+    ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, C, D), (double)M * D * esz + (double)M * C * 4);
+    launch_gemm(g, st);
+  }
+  return 0;
+}
+

@@ -1,4 +1,4 @@
-// Internal launch interface between the C-ABI host layer (ldm_api.cpp) and the gfx950 kernels.
+// Internal launch interface between the C-ABI host layer (ldm_api.cpp, ldm_loop.cpp) and the gfx950 kernels.
 // Everything here is CDNA4-only (wave64, MFMA); there is no other backend.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -104,7 +104,7 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int 
 // ... and the whole reverse loop of a layout in its workgroup (kernels_stack.hip HEAD == 2): tokens in / out through
 // post->tokens / post->tokens_out, the step's tail (ldm_post_token.h) behind the vocabulary head on the logits in LDS.
 // ls.w[i].ada_scale / ada_shift are ignored: the AdaLN rows of step i come from adaln[t_model[i]].
-// parameter tables of the loop kernel as LDS images (floats; built on the host by ldm_api.cpp build_loop_tables)
+// parameter tables of the loop kernel as LDS images (floats; built on the host by ldm_weights.cpp build_loop_tables)
 constexpr int kStackTblAttStatic = 1536;  // in_proj bias [3 * 8 heads * 64]
 constexpr int kStackTblAttDyn = 1536;     // 1 + AdaLN scale [512] | shift [512] | b_out + W_out b_v + shift [512]
 constexpr int kStackTblFfn = 3584;        // linear1 bias [2048] | norm2 gamma [512] | beta [512] | linear2 bias [512]

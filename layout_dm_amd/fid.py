@@ -195,3 +195,26 @@ def compute_fid(feats_real, feats_fake) -> float:
 
     fr, ff = arr(feats_real), arr(feats_fake)
     return frechet_distance(np.mean(fr, axis=0), np.cov(fr, rowvar=False), np.mean(ff, axis=0), np.cov(ff, rowvar=False))
+
+
+def token_set_features(engine, fid_model: FIDNetV3, tokens, batch: int = 512) -> torch.Tensor:
+    """(n, S) token ids -> (n, 256) FIDNetV3 features, all on the device: ids -> {bbox, label, mask} through
+    ldm_decode_layouts (what LayoutDM.sample returns, models/layoutdm.py:77-88) -> extract_features on (bbox, label,
+    ~mask), i.e. the path trainer/eval.py:203-220 takes from a saved result pickle to its feature list."""
+    tokens = torch.as_tensor(tokens)
+    feats = []
+    for i in range(0, tokens.shape[0], batch):
+        dec = engine.decode(tokens[i:i + batch].to(torch.int32))
+        feats.append(fid_model.extract_features(dec["bbox"].float(), dec["label"], ~dec["mask"]))
+    return torch.cat(feats)
+
+
+def scores_vs_reference_samples(engine, fid_model: FIDNetV3, tokens_ref_a, tokens_ref_b, tokens_ours) -> dict:
+    """BASELINE config 5's acceptance metric ("FID vs reference") as one call: the generative-model scores
+    (helpers/metric.py:37-59) of OUR sample set against a reference sample set, next to the same scores between two
+    independent reference sample sets — the seed-to-seed spread that says what "the same distribution" measures as at
+    this sample size."""
+    fa, fb, fo = (token_set_features(engine, fid_model, t) for t in (tokens_ref_a, tokens_ref_b, tokens_ours))
+    return {"ref_b_vs_ref_a": compute_generative_model_scores(fa, fb), "ref_a_vs_ref_b": compute_generative_model_scores(fb, fa),
+            "ours_vs_ref_a": compute_generative_model_scores(fa, fo), "ours_vs_ref_b": compute_generative_model_scores(fb, fo),
+            "n": {"ref_a": int(fa.shape[0]), "ref_b": int(fb.shape[0]), "ours": int(fo.shape[0])}}
