@@ -421,7 +421,7 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
     if per_rank is not None:
         res["per_rank_layouts_per_s"] = per_rank
     if verified:
-        res["verification"] = dict(model.verified.last_stats)
+        res["verification"] = dict(model.verified.last_stats, verifier_engine=model.verifier)
         res["calibration"] = dict(model.verified.calibration)
     if with_roofline and rank == 0 and not verified:
         # per-kernel durations: HIP events around every launch, on the stream the kernels run on, over one more step of
@@ -609,7 +609,7 @@ def main():
     eng.close()
 
     # every numerics mode in the one line (N=1): the bit-exact mode's throughput next to the headline's
-    modes = a.modes if a.modes is not None else ("exact,fast,fast_verified" if world == 1 else "")
+    modes = a.modes if a.modes is not None else ("exact,split,fast,fast_verified" if world == 1 else "")
     modes = [m for m in modes.split(",") if m and m != "none"]
     if modes:
         out["modes"] = {}
@@ -705,7 +705,13 @@ def verified_nondegenerate(a, spec, sd, B, local_rank):
                                    d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
                                    num_timesteps=spec.n_step, precision="fast_verified", max_batch=B, device=local_rank)
     m.load_state_dict(sd)
-    vg, fa, ex = m.verified, m.verified.fast, m.verified.exact
+    vg, fa = m.verified, m.verified.fast
+    # the yardstick is the fp32-MFMA engine, whatever engine the verifier itself uses (default: split)
+    mx = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
+                                    d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
+                                    num_timesteps=spec.n_step, precision="exact", max_batch=B, device=local_rank)
+    mx.load_state_dict(sd)
+    ex = mx.engine
     t_model, t_post = timestep_schedule(spec.n_step, a.timesteps)
     n = len(t_model)
     greedy = {"name": "deterministic"}
@@ -713,7 +719,7 @@ def verified_nondegenerate(a, spec, sd, B, local_rank):
     _, inter = fa.sample_loop(tok, t_model, t_post, {"name": "random", "temperature": 1.0}, seed=77, intermediates=True)
     inter = inter.clone()
     out = {"what": f"greedy loops from the states of a `random` run (seed 77) at step i0, {B} layouts; layouts/s-equivalent "
-                   f"= {B} x (steps run) / {n} / time", "calibration": dict(vg.calibration)}
+                   f"= {B} x (steps run) / {n} / time", "verifier_engine": m.verifier, "calibration": dict(vg.calibration)}
     reps = 3
     for i0 in (20, 50, 80):
         start = inter[i0 - 1].clone()
@@ -739,6 +745,7 @@ def verified_nondegenerate(a, spec, sd, B, local_rank):
             "marked_layout_steps": st["marked_layout_steps"], "mismatch_layout_steps": st["mismatch_layout_steps"],
             "fast_passes": st["fast_passes"]}
     fa.close()
+    m.verified.exact.close()
     ex.close()
     return out
 

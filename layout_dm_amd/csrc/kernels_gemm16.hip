@@ -241,6 +241,237 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16_k(const __half* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16 x 3 SPLIT GEMM (LDM_PREC_SPLIT_F16): fp32-grade products on the fp16 matrix pipe.
+//     x = hi + 2^-11 lo',   hi = fp16(x),  lo' = fp16((x - hi) 2^11)            (both operands, prepared by their producers)
+//     A W^T = Ahi Whi^T + 2^-11 (Alo' Whi^T + Ahi Wlo'^T)   (+ 2^-22 Alo' Wlo'^T, dropped: below fp32 rounding)
+// Same structure as gemm16_k — operands by LDS-DMA through an NSTAGE ring, one barrier per K tile, swapped-operand MFMAs so a
+// lane owns one output row — with a stage holding four images (A hi | W hi | A lo | W lo) and three MFMAs per fragment
+// pair on two accumulators (main, correction).  Why: gfx950's fp32 MFMA peaks at 157 TFLOP/s, its fp16 MFMA at 2 500: three
+// fp16 passes have a 5.3 x higher ceiling than one fp32 pass at the same (measured: better, 7e-7 vs 9e-7) logits error, and
+// 4 fragment reads feed 3 MFMAs instead of 2 feeding 1.  r03's split GEMM (gemm_f16_128x128<3>, register-staged, 221
+// layouts/s) was a numerics cross-check; this one makes the split mode the fast reference-precision mode.
+struct Epi16x {
+  const float* bias;
+  const float* res;
+  float* C32;
+  __half *C16, *C16lo;
+  int M, N, ldres, ldc32, ldc16, relu;
+};
+constexpr float kLoScale16 = 2048.0f, kLoScaleInv16 = 1.0f / 2048.0f;
+
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
+__global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restrict__ A, const __half* __restrict__ Alo,
+                                                           const __half* __restrict__ W, const __half* __restrict__ Wlo,
+                                                           int lda, int ldw, int K, int tiles_n, int grp, Epi16x e) {
+  constexpr int NW = WM * WN;
+  constexpr int RB = BK * 2;          // bytes per tile row
+  constexpr int CPR = RB / 16;        // 16-B chunks per row (4 or 8)
+  constexpr int RPI = 64 / CPR;       // rows per 1-KiB DMA instruction
+  constexpr int NINST = (BM + BN) / RPI;  // per half (hi / lo)
+  constexpr int LPT = NINST / NW;     // DMA instructions per wave per half
+  static_assert(NINST % NW == 0, "tile does not split evenly over the waves");
+  constexpr int HALF_BYTES = (BM + BN) * RB;
+  constexpr int STAGE_BYTES = 2 * HALF_BYTES;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap16(blockIdx.x, gridDim.x);
+  // tile order inside an XCD's contiguous range.  grp = 0: row-major (all column tiles of a row tile, then the next row
+  // tile).  grp = G: column groups of G tiles, row tiles inside a group — the G x (BN x K) weight slabs of a group stay
+  // in the XCD's 4-MiB L2 while the activation row tiles stream through it once per group instead of once per column tile
+  int tm_i, tn_i;
+  if (grp <= 0) {
+    tm_i = tile / tiles_n; tn_i = tile % tiles_n;
+  } else {
+    const int tiles_m = gridDim.x / tiles_n;
+    const int full = tiles_m * grp;                 // tiles of one full column group
+    const int g = tile / full;
+    const int gw = min(grp, tiles_n - g * grp);     // (the last group may be narrower)
+    const int r = tile - g * full;
+    tm_i = r / gw; tn_i = g * grp + r % gw;
+  }
+  const int m0 = tm_i * BM;
+  const int n0 = tn_i * BN;
+
+  const int lrow = lane / CPR;
+  const int lchunk = lane % CPR;
+  const __half *src_hi[LPT], *src_lo[LPT];
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int inst = wave + j * NW;
+    const int R = inst * RPI + lrow;  // row in the concatenated [A rows ; W rows] image
+    const bool isA = (inst * RPI) < BM;
+    const int rt = isA ? R : R - BM;
+    const int sw = (CPR == 8) ? ((rt >> 1) & 7) : ((rt >> 2) & 3);
+    const int c = lchunk ^ sw;
+    const size_t off = isA ? (size_t)(m0 + rt) * lda + c * 8 : (size_t)(n0 + rt) * ldw + c * 8;
+    src_hi[j] = (isA ? A : W) + off;
+    src_lo[j] = (isA ? Alo : Wlo) + off;
+  }
+  auto issue = [&](int kt, int stage) {
+    char* sbase = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int inst = wave + j * NW;
+      __builtin_amdgcn_global_load_lds((gas_ptr)(src_hi[j] + (size_t)kt * BK), (las_ptr)(sbase + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)(src_lo[j] + (size_t)kt * BK), (las_ptr)(sbase + HALF_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+
+  const int frow = lane & 31;
+  const int hi = lane >> 5;
+  const int fsw = (CPR == 8) ? ((frow >> 1) & 7) : ((frow >> 2) & 3);
+  int offA[BK / 16], offW[BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    const int phys = (ks * 2 + hi) ^ fsw;
+    offA[ks] = (wm * (BM / WM) + frow) * RB + phys * 16;
+    offW[ks] = BM * RB + (wn * (BN / WN) + frow) * RB + phys * 16;
+  }
+
+  f32x16 acc[TM][TN], cor[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; cor[mi][ni][r] = 0.f; }
+
+  const int nk = K / BK;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = min(NSTAGE - 2, nk - 1 - kt);  // tiles issued after kt that may stay in flight
+    if (NSTAGE >= 4 && rem >= 2) wait_vmcnt<4 * LPT>();
+    else if (rem >= 1) wait_vmcnt<2 * LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    const char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f16x8 a[TM], al[TM], w[TN], wl[TN];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        a[mi] = *reinterpret_cast<const f16x8*>(sbase + offA[ks] + mi * 32 * RB);
+        al[mi] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offA[ks] + mi * 32 * RB);
+      }
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        w[ni] = *reinterpret_cast<const f16x8*>(sbase + offW[ks] + ni * 32 * RB);
+        wl[ni] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offW[ks] + ni * 32 * RB);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+          cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], cor[mi][ni], 0, 0, 0);
+          cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], cor[mi][ni], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: lane (frow, hi) owns row m and, per 32-column tile, the columns 8 rq + 4 hi + (0..3)
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int m = m0 + wm * (BM / WM) + mi * 32 + frow;
+    if (m >= e.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n0 + wn * (BN / WN) + ni * 32 + rq * 8 + hi * 4;
+        if (n >= e.N) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][rq * 4 + i] + cor[mi][ni][rq * 4 + i] * kLoScaleInv16;
+        if (n + 3 < e.N && (e.N & 3) == 0) {
+          if (e.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+          if (e.relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          if (e.res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          }
+          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (e.C16) {
+            __half h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h[i] = __float2half_rn(v[i]);
+              l[i] = __float2half_rn((v[i] - __half2float(h[i])) * kLoScale16);
+            }
+            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(h);
+            if (e.C16lo) *reinterpret_cast<uint2*>(e.C16lo + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(l);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (n + i >= e.N) continue;
+            float x = v[i] + (e.bias ? e.bias[n + i] : 0.f);
+            if (e.relu) x = fmaxf(x, 0.f);
+            if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
+            if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
+            if (e.C16) {
+              const __half hh = __float2half_rn(x);
+              e.C16[(size_t)m * e.ldc16 + n + i] = hh;
+              if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n + i] = __float2half_rn((x - __half2float(hh)) * kLoScale16);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
+static void launch_x3(const GemmArgs& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  constexpr int lds = NSTAGE * 2 * (BM + BN) * BK * 2;
+  auto kern = gemm16x3_k<BM, BN, BK, NSTAGE, WM, WN, TAG>;
+  allow_big_lds((const void*)kern);
+  static const int grp = knob_int("LDM_X3_GRP", 0);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A, (const __half*)g.Alo,
+                     (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, grp, e);
+}
+
+// Split-mode GEMM.  Requires: K a multiple of 32 (the host pads: Dp / Fp), A / Alo with >= ceil(M / 256) * 256 rows and
+// W / Wlo with >= ceil(N / 256) * 256 rows allocated (rows past M / N feed products that are never stored).
+// tag names the Linear class for rocprofv3 (0 qkv, 1 attn_out, 2 ffn1, 3 ffn2, 4 head).
+void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st) {
+  // 256 x 128 tiles on 8 waves (two per SIMD), 3-stage ring of 48-KiB stages: +14 % over 128 x 128 on 4 waves; a 4-stage
+  // ring, 128 x 256 tiles and column-grouped tile orders change nothing (profiles/r04_call6_*, r04_call7_*)
+  static const int cfg = knob_int("LDM_X3_CFG", 2);  // (dev: tile-shape A/B)
+  if (cfg == 0) { launch_x3<128, 128, 32, 3, 2, 2, 5>(g, st); return; }
+  if (cfg == 1) { launch_x3<128, 128, 32, 4, 2, 2, 5>(g, st); return; }
+  if (cfg == 3) { launch_x3<128, 256, 32, 3, 2, 4, 5>(g, st); return; }
+  if (cfg == 4) { launch_x3<256, 128, 32, 2, 4, 2, 5>(g, st); return; }
+  if (cfg == 5 && g.K % 64 == 0) { launch_x3<128, 128, 64, 2, 2, 2, 5>(g, st); return; }
+  switch (tag) {
+    case 0: launch_x3<256, 128, 32, 3, 4, 2, 0>(g, st); return;
+    case 1: launch_x3<256, 128, 32, 3, 4, 2, 1>(g, st); return;
+    case 2: launch_x3<256, 128, 32, 3, 4, 2, 2>(g, st); return;
+    case 3: launch_x3<256, 128, 32, 3, 4, 2, 3>(g, st); return;
+    default: launch_x3<256, 128, 32, 3, 4, 2, 4>(g, st); return;
+  }
+}
+
 template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG = 0>
 static void launch_cfg(const GemmArgs& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;

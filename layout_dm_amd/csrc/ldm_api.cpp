@@ -75,8 +75,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   h->dh = h->D / h->H;
   h->L = cfg->n_layer;
   h->T = cfg->n_step;
-  h->Dp = round_up(h->D, 32);
-  h->Fp = round_up(h->F, 32);
+  // K axes of the fp16 operand copies: whole 128-byte rows per 64-wide K tile in the split mode (the LDS-DMA split GEMM reads
+  // operand rows one K tile at a time: a 64-byte row segment is half a cache line and doubles the L2 traffic)
+  h->Dp = round_up(h->D, cfg->precision == LDM_PREC_SPLIT_F16 ? 64 : 32);
+  h->Fp = round_up(h->F, cfg->precision == LDM_PREC_SPLIT_F16 ? 64 : 32);
   h->Cp = round_up(h->C, 32);
   // vocabulary geometry: helpers/layout_tokenizer.py:79-82,429-467
   h->vocab.n_class = h->C;
@@ -157,16 +159,18 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
       A(&h->hid16, Mp * h->Fq);
     }
   } else {
-    A(&h->a16, Mc * h->Dp);
-    A(&h->att16, Mc * h->Dp);
-    A(&h->h16, Mc * h->Dp);
-    A(&h->hid16, Mc * h->Fp);
+    // (whole 128-row tiles: the LDS-DMA split GEMM loads its operands without bounds checks)
+    const size_t Mt = (size_t)round_up((int)Mc, 256);
+    A(&h->a16, Mt * h->Dp);
+    A(&h->att16, Mt * h->Dp);
+    A(&h->h16, Mt * h->Dp);
+    A(&h->hid16, Mt * h->Fp);
     {
       A(&h->qkv32, Mc * 3 * h->D);
-      A(&h->a16lo, Mc * h->Dp);
-      A(&h->att16lo, Mc * h->Dp);
-      A(&h->h16lo, Mc * h->Dp);
-      A(&h->hid16lo, Mc * h->Fp);
+      A(&h->a16lo, Mt * h->Dp);
+      A(&h->att16lo, Mt * h->Dp);
+      A(&h->h16lo, Mt * h->Dp);
+      A(&h->hid16lo, Mt * h->Fp);
     }
   }
   h->save_ws(lane);

@@ -99,6 +99,14 @@ static int denoise_chunk_fast(ldm_handle* h, const int32_t* d_tokens, int t, int
 }
 
 // denoiser forward for `Bc` layouts whose tokens start at d_tokens -> h->logits [Bc*S, Cp]
+// exact: fp32 MFMA tiles; split: the fp16 x 3 LDS-DMA GEMM (kernels_gemm16.hip gemm16x3_k; LDM_DEV=1 LDM_SPLIT_GEMM=old: the
+// register-staged r03 kernel, kept as a cross-check)
+static void launch_gemm_mode(const GemmArgs& g, int tag, hipStream_t st) {
+  static const bool old_split = knob_env("LDM_SPLIT_GEMM") && std::string(knob_env("LDM_SPLIT_GEMM")) == "old";
+  if (g.precision == LDM_PREC_SPLIT_F16 && !old_split && g.K % 32 == 0) launch_gemm16x3(g, tag, st);
+  else launch_gemm(g, st);
+}
+
 int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
   if (h->cfg.precision == LDM_PREC_FAST_F16) return denoise_chunk_fast(h, d_tokens, t, Bc, st, skip_embed);
   const int M = Bc * h->S, D = h->D, F = h->F, C = h->C, Dp = h->Dp, Fp = h->Fp;
@@ -136,7 +144,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.M = M; g.N = 3 * D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D;
       g.ldc32 = 3 * D; g.ldc16 = 3 * D; g.precision = prec;
       ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * D * esz + (double)M * 3 * D * (prec == 1 ? 2 : 4));
-      launch_gemm(g, st);
+      launch_gemm_mode(g, 0, st);
     }
     {  // attention
       AttnArgs a{};
@@ -161,7 +169,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.C32 = h->Q; g.ldc32 = D;
       g.M = M; g.N = D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
       ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * D * (esz + 8));
-      launch_gemm(g, st);
+      launch_gemm_mode(g, 1, st);
     }
     {  // LayerNorm 2
       LnArgs a{};
@@ -184,7 +192,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
       g.M = M; g.N = F; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
       ldm_handle::Scope sc(h, st, "gemm_ffn1", gemm_flops(M, F, D), (double)M * D * esz + (double)M * F * esz);
-      launch_gemm(g, st);
+      launch_gemm_mode(g, 2, st);
     }
     {  // FFN2 + residual:  P = Q + hid·W2^T + b2
       GemmArgs g{};
@@ -197,7 +205,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.C32 = h->P; g.ldc32 = D;
       g.M = M; g.N = D; g.K = f16 ? Fp : F; g.lda = f16 ? Fp : F; g.ldw = f16 ? Fp : F; g.precision = prec;
       ldm_handle::Scope sc(h, st, "gemm_ffn2", gemm_flops(M, D, F), (double)M * F * esz + (double)M * D * 8);
-      launch_gemm(g, st);
+      launch_gemm_mode(g, 3, st);
     }
   }
   {  // head: LayerNorm + vocab projection (no bias)
@@ -219,7 +227,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     g.C32 = h->logits; g.ldc32 = h->Cp;
     g.M = M; g.N = C; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
     ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, C, D), (double)M * D * esz + (double)M * C * 4);
-    launch_gemm(g, st);
+    launch_gemm_mode(g, 4, st);
   }
   return 0;
 }

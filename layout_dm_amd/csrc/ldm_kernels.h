@@ -75,6 +75,9 @@ void launch_gemm(const GemmArgs& g, hipStream_t st);
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);
+// fp16 x 3 split GEMM on the same pipeline (kernels_gemm16.hip gemm16x3_k): A / Alo / W / Wlo, K % 32 == 0, operand
+// buffers allocated to whole 128-row tiles
+void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st);
 // per-layer weights of the stack kernel (all device pointers)
 struct FusedLayerW {
   const void* img;        // ldm_pack::pack_attn_head_image (in_proj K axis in k-slot order)

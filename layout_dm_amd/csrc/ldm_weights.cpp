@@ -55,9 +55,11 @@ static int need(ldm_handle* h, const std::string& key, std::initializer_list<int
 // fp16 (and split-lo) copy of a [N,K] weight with the K axis zero-padded to Kp
 static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half** hi, __half** lo) {
   const bool split = h->cfg.precision == LDM_PREC_SPLIT_F16;
-  int rc = h->dalloc(hi, (size_t)N * Kp);
+  // (rows padded with zeros to whole 128-row tiles: the LDS-DMA GEMMs load W without bounds checks)
+  const size_t Nt = (size_t)round_up(N, 256);
+  int rc = h->dalloc(hi, Nt * Kp);
   if (rc) return rc;
-  if (split && (rc = h->dalloc(lo, (size_t)N * Kp))) return rc;
+  if (split && (rc = h->dalloc(lo, Nt * Kp))) return rc;
   if (K == Kp) {
     launch_f32_to_f16(w, *hi, split ? *lo : nullptr, (int64_t)N * K, 0);
   } else {

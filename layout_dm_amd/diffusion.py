@@ -58,7 +58,8 @@ class HipMaskAndReplaceDiffusion:
     def __init__(self, *, n_category: int, n_bin: int = 32, max_elem: int = 25, n_attr: int = 5,
                  d_model: int = 464, n_head: int = 8, d_ff: int = 1856, n_layer: int = 4,
                  num_timesteps: int = 100, precision: str = "exact", max_batch: int = 512, chunk: int = 0,
-                 device: Optional[int] = None, use_graph: bool = True, q_type: str = "constrained", lanes: int = 0):
+                 device: Optional[int] = None, use_graph: bool = True, q_type: str = "constrained", lanes: int = 0,
+                 verifier: str = "split"):
         # q_type: Q_TYPES of models/layoutdm.py:20-23 — "constrained" (constrained.py) or "vanilla" (vanilla.py)
         # precision "fast_verified": the fp16 engine for every sampler, plus an exact (fp32) engine of the same weights
         # that re-decides the near-tie layouts of DETERMINISTIC decoding (layout_dm_amd/verified.py): greedy tokens are
@@ -69,6 +70,7 @@ class HipMaskAndReplaceDiffusion:
         # (The fp16 mode's error is a property of the weights: 3e-4 on the reference's init, ~1e-3 at sigma = 0.06,
         # percents once attention rows saturate: DESIGN.md section 3.5.)
         self.verified = None
+        self.verifier = verifier
         self.auto = precision == "auto"
         self.auto_tolerance = 1e-3
         self.selected_precision = None if self.auto else precision
@@ -79,8 +81,11 @@ class HipMaskAndReplaceDiffusion:
         if precision in ("fast_verified", "auto"):
             from .verified import VerifiedGreedy
 
+            # the reference-precision engine behind fast_verified / auto: "split" (fp16 x 3 on the fp16 matrix pipe: the
+            # exact mode's logits error at 1.7 x its speed, r04) or "exact" (fp32 MFMA)
+            assert verifier in ("split", "exact")
             self.engine = mk("fast")
-            self.verified = VerifiedGreedy(self.engine, mk("exact"))
+            self.verified = VerifiedGreedy(self.engine, mk(verifier))
         else:
             self.engine = mk(precision)
         self.q_type = q_type
@@ -112,7 +117,7 @@ class HipMaskAndReplaceDiffusion:
             cal = self.verified.calibrate()                     # tie_abs <- 6 x safety x measured |logits error|
             if self.auto:
                 ok = cal["err_rel"] <= self.auto_tolerance
-                self.selected_precision = "fast_verified" if ok else "exact"
+                self.selected_precision = "fast_verified" if ok else self.verifier
                 if not ok:
                     self.engine = self.verified.exact
         return self

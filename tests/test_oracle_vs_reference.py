@@ -19,7 +19,8 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
 
     out = str(tmp_path / "golden")
     make_golden.main(out_dir=out)
-    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz"))
+    # (rico25_mid_reference_samples.npz has its own generator and its own regeneration test below)
+    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz") and f != "rico25_mid_reference_samples.npz")
     assert names == sorted(f for f in os.listdir(out) if f.endswith(".npz"))
     for n in names:
         a, b = np.load(os.path.join(golden_dir, n)), np.load(os.path.join(out, n))
@@ -69,3 +70,18 @@ def test_restatement_matches_live_reference_on_fresh_states():
             assert (post - ref_post).abs().max().item() == 0.0
             nxt = R.single_step(W, spec, tokens, t, {"name": "deterministic"})
             assert torch.equal(nxt, ref_next)
+
+
+def test_reference_sample_sets_regenerate(golden_dir):
+    """tests/golden/rico25_mid_reference_samples.npz (the two 1 024-layout sample sets of the reference's own sample() behind
+    tests/test_fid_vs_reference.py) is what the real reference draws today: the first chunk of 64 layouts of each seed,
+    re-generated here, equals the committed tokens bit for bit (the whole file takes ~40 min of CPU: python -m
+    oracle.make_reference_samples)."""
+    from oracle import make_reference_samples as mrs
+
+    g = np.load(os.path.join(golden_dir, "rico25_mid_reference_samples.npz"))
+    new = mrs.generate(n_chunk=1)
+    assert g["tokens"].shape == (2, mrs.N_CHUNK * mrs.CHUNK, 125) and tuple(g["seeds"]) == mrs.SEEDS
+    assert np.array_equal(new["tokens"], g["tokens"][:, :mrs.CHUNK])
+    # two independent draws of a non-degenerate distribution: no [MASK] left, the sets differ
+    assert (g["tokens"] != 154).all() and not np.array_equal(g["tokens"][0], g["tokens"][1])

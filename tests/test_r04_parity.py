@@ -145,9 +145,9 @@ def test_trained_like_logits_fast_mode_and_auto_selection(cuda, golden_dir, poin
         assert worst <= 1e-3                                    # the north star's bound where the mode claims it
     # the probe's verdict agrees with the error against the reference (within the spread between probe and fixture states)
     assert 0.4 * worst <= cal["err_rel"] <= 2.5 * worst, (worst, cal)
-    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "exact")
+    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "split")
     if point == "wide":
-        assert m.selected_precision == "exact" and m.engine is m.verified.exact
+        assert m.selected_precision == "split" and m.engine is m.verified.exact   # (the reference-precision engine: split)
         out = m.sample(batch_size=2, sampling_cfg={"name": "deterministic", "num_timesteps": 5})
         ref = R.sample_loop(R.as_torch_weights(synth.trained_like_state_dict(spec, point, seed=2)), spec, 2,
                             {"name": "deterministic", "num_timesteps": 5})
