@@ -26,11 +26,14 @@ __global__ __launch_bounds__(256) void relation_update_k(RelArgs a) {
   __shared__ float lgs[REL_MAX_ELEM * 4 * 32];   // logits of the bbox sub-vocabularies
   __shared__ float prs[REL_MAX_ELEM * 4 * 32];   // their softmax
   __shared__ float scratch[kRelScratchFloats];
+  __shared__ int inc_off[kRelIncOffInts];
+  __shared__ unsigned short inc[2 * REL_MAX_EDGE];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int E = a.S / a.A, NB = a.n_bin;
   const int e0 = a.edge_off[b], ne = a.edge_off[b + 1] - e0;
   const RelGraph gph = rel_graph(a);
+  relation_incidence(gph, e0, ne, tid, E, scratch, inc_off, inc, [] { __syncthreads(); });
   relation_nodes(scratch, tid, E, a.pad_id, NB, a.centres, a.canvas_bins,
                  [&](int e) { return a.cond_seq[(size_t)b * a.S + e * a.A]; });
   __syncthreads();
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void relation_update_k(RelArgs a) {
   }
   __syncthreads();
   relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return lgs + (e * 4 + x) * NB; },
-               [&](int e, int x) { return prs + (e * 4 + x) * NB; }, scratch, [] { __syncthreads(); });
+               [&](int e, int x) { return prs + (e * 4 + x) * NB; }, scratch, inc_off, inc, [] { __syncthreads(); });
   for (int i = tid; i < n_item; i += 256) {
     int e, x, n;
     if (a.logp_tm) { e = i / (4 * NB); x = (i / NB) % 4; n = i % NB; } else { e = i % E; x = (i / E) / NB; n = (i / E) % NB; }
@@ -67,7 +70,7 @@ void launch_relation_update(const RelArgs& a, hipStream_t st) {
 // the softmax scratch of the SGD — then the SGD's scratch, then the samplers' scratch (2 x 48 floats per 16-lane group).
 constexpr int kRelRowLd = 80;
 constexpr int kRelStepMaxS = 128;
-constexpr int kRelStepLds = (kRelStepMaxS * kRelRowLd + kRelScratchFloats + 16 * 96) * 4;
+constexpr int kRelStepLds = (kRelStepMaxS * kRelRowLd + kRelScratchFloats + 16 * 96) * 4 + kRelIncBytes;
 
 template <bool FAST>
 __global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
@@ -75,6 +78,8 @@ __global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
   float* rows = rsm;
   float* scratch = rsm + kRelStepMaxS * kRelRowLd;
   float* samp = scratch + kRelScratchFloats;
+  int* inc_off = reinterpret_cast<int*>(samp + 16 * 96);
+  unsigned short* inc = reinterpret_cast<unsigned short*>(inc_off + kRelIncOffInts);
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
   const int S = p.S, C = p.v.n_class, A = p.v.n_attr;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
   const ldm_post::SlotMap<16, 3, true> m{tid & 15};
   const RelGraph gph = rel_graph(a);
   const int e0 = a.edge_off[b], ne = a.edge_off[b + 1] - e0;
+  relation_incidence(gph, e0, ne, tid, E, scratch, inc_off, inc, [] { __syncthreads(); });
   relation_nodes(scratch, tid, E, p.v.pad_id, NB, a.centres, a.canvas_bins,
                  [&](int e) { return p.cond_seq[(size_t)b * S + e * A]; });
   __syncthreads();
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
   __syncthreads();
   // ---- phase B: the SGD on the bbox tokens of the graph's nodes (element e, coordinate x = token e A + 1 + x)
   relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd; },
-               [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd + 48; }, scratch, [] { __syncthreads(); });
+               [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd + 48; }, scratch, inc_off, inc,
+               [] { __syncthreads(); });
   // ---- phase C: [PAD] disable + draw (+ the next step's embedding row)
   for (int s = grp; s < S; s += 16) {
     ldm_post::TokenArgs ta = token_args(s);

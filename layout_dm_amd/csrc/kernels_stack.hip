@@ -68,7 +68,9 @@ __device__ __forceinline__ stack_kargs_ptr stack_kargs() {
 constexpr int kPostLd = 161;   // floats per token row of the logits in LDS (odd: the 16-lane groups of a wavefront hit distinct banks)
 constexpr int kPostRows = 128 * kPostLd * 4;  // bytes of the logits rows; behind them one float4 (max, lse, max |x|, -) per row
 constexpr int kStackLoopB1 = 2048;            // HEAD == 2: the linear1 bias table is padded to whole 1-KiB DMA pieces
-constexpr int kStackLoopLds = 1024 + 128;     // HEAD == 2: tokens [128] | cond token + strong bit [128] | REL: element -> graph node [32]
+constexpr int kStackLoopLds = 1024 + 128 + 2304;  // HEAD == 2: tokens [128] | cond token + strong bit [128] | REL: element -> graph
+                                                  // node [32] | incidence lists of the graph's nodes (ldm_relation_core.h kRelIncBytes)
+static_assert(kRelIncBytes <= 2304, "incidence lists outgrow their LDS slot");
 
 __device__ unsigned long long g_stack_phase[16];
 
@@ -125,6 +127,10 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
         for (int e = 0; e < S / A5; ++e)
           toks[256 + e] = ((kp->post.cond_seq[(size_t)b_o * S + e * A5]) != kp->post.v.pad_id) ? k++ : -1;
       }
+      // which edges touch which node, in edge order: once per launch (the K / V buffers serve as scratch)
+      const int e0 = kp->rel.edge_off[b_o], ne = kp->rel.edge_off[b_o + 1] - e0;
+      relation_incidence(kp->rel, e0, ne, tid_o, S / kp->post.v.n_attr, reinterpret_cast<float*>(smem + 3 * STAGE), toks + 288,
+                         reinterpret_cast<unsigned short*>(toks + 288 + kRelIncOffInts), [] { __syncthreads(); });
     }
     __syncthreads();
   }
@@ -854,7 +860,8 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             const int e0 = kp->rel.edge_off[b], ne = kp->rel.edge_off[b + 1] - e0;
             relation_sgd(kp->rel, e0, ne, tid5, S / A5, kp->rel_n_bin,
                          [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd; },
-                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; }, rscr, [] { __syncthreads(); });
+                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; }, rscr, node_of + 32,
+                         reinterpret_cast<const unsigned short*>(node_of + 32 + kRelIncOffInts), [] { __syncthreads(); });
             // ---- [PAD] disable + draw from the adjusted rows (base.py:272-291)
 #pragma unroll 1
             for (int rd = 0; rd < 8; ++rd) {

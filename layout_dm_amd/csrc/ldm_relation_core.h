@@ -37,7 +37,14 @@ constexpr int kRelGradOff = kRelBboxOff + (REL_MAX_ELEM + 1) * 4;
 constexpr int kRelEgOff = kRelGradOff + (REL_MAX_ELEM + 1) * 4;
 constexpr int kRelNodeOff = kRelEgOff + REL_MAX_EDGE * 8;
 constexpr int kRelEdgeOff = kRelNodeOff + REL_MAX_ELEM;
-constexpr int kRelScratchFloats = kRelEdgeOff + 3 * REL_MAX_EDGE;
+constexpr int kRelCentreOff = kRelEdgeOff + 3 * REL_MAX_EDGE;   // the cluster centres, [4][32] (r04: were re-read from global
+                                                                // memory by every softmax round: ~11 of the SGD's 44 us)
+constexpr int kRelScratchFloats = kRelCentreOff + 4 * 32;
+// incidence lists of the layout's graph nodes (which edges touch a node, in EDGE ORDER: the order the node gradients are
+// summed in), built once per launch: offsets [REL_MAX_ELEM + 2] ints, entries [2 REL_MAX_EDGE] = edge << 1 | (node is dst).
+// r03 scanned all edges per node, per iteration (a chain of dependent LDS reads: ~12 us per step).
+constexpr int kRelIncOffInts = REL_MAX_ELEM + 2;
+constexpr int kRelIncBytes = kRelIncOffInts * 4 + 2 * REL_MAX_EDGE * 2;
 
 // the graph and the hyper-parameters of one call (device pointers; edge offsets are absolute positions in the edge arrays)
 struct RelGraph {
@@ -62,12 +69,55 @@ __device__ __forceinline__ void relation_nodes(float* scratch, int tid, int E, i
   if (tid < 4) scratch[kRelBboxOff + tid] = centres[tid * n_bin + canvas_bins[tid]];  // canvas: one-hot expectation
 }
 
+// Fills inc_off / inc for the layout's graph (inc_off[0] = -1: more than REL_MAX_EDGE edges, relation_sgd then scans).
+// Uses the edge and gradient areas of `scratch`; ends with a barrier.
+template <class Graph, class Barrier>
+__device__ __forceinline__ void relation_incidence(const Graph& a, int e0, int ne, int tid, int E, float* scratch, int* inc_off,
+                                                   unsigned short* inc, Barrier barrier) {
+  if (ne > REL_MAX_EDGE) {
+    if (tid == 0) inc_off[0] = -1;
+    barrier();
+    return;
+  }
+  int* es = reinterpret_cast<int*>(scratch + kRelEdgeOff);
+  int* ed = es + REL_MAX_EDGE;
+  int* deg = reinterpret_cast<int*>(scratch + kRelGradOff);
+  for (int k = tid; k < ne; k += 256) {
+    es[k] = a.edge_src[e0 + k];
+    ed[k] = a.edge_dst[e0 + k];
+  }
+  barrier();
+  if (tid <= E) {
+    int c = 0;
+    for (int k = 0; k < ne; ++k) c += (es[k] == tid) + (ed[k] == tid);
+    deg[tid] = c;
+  }
+  barrier();
+  if (tid == 0) {
+    int o = 0;
+    for (int n = 0; n <= E; ++n) {
+      inc_off[n] = o;
+      o += deg[n];
+    }
+    inc_off[E + 1] = o;
+  }
+  barrier();
+  if (tid <= E) {
+    int o = inc_off[tid];
+    for (int k = 0; k < ne; ++k) {
+      if (es[k] == tid) inc[o++] = (unsigned short)(k << 1);
+      if (ed[k] == tid) inc[o++] = (unsigned short)((k << 1) | 1);
+    }
+  }
+  barrier();
+}
+
 // lg(e, x) -> the n_bin body-bin logits of element e, coordinate x (LDS, updated in place);
 // pr(e, x) -> n_bin floats of LDS scratch for their softmax;  barrier() -> workgroup barrier.
 // Graph: RelGraph, possibly in the kernel-argument address space (the loop kernel reads it there at the point of use).
 template <class Graph, class LgAt, class PrAt, class Barrier>
 __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int tid, int E, int NB, LgAt lg, PrAt pr,
-                                             float* scratch, Barrier barrier) {
+                                             float* scratch, const int* inc_off, const unsigned short* inc, Barrier barrier) {
   float* bbox = scratch + kRelBboxOff;
   float* grad = scratch + kRelGradOff;
   float* eg = scratch + kRelEgOff;
@@ -84,33 +134,49 @@ __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int
   };
   const bool one_block = ne <= REL_MAX_EDGE;
   if (one_block) stage_edges(0, ne);  // (visible behind the first barrier below)
+  float* cen = scratch + kRelCentreOff;
+  if (tid < 4 * 32) cen[tid] = (tid & 31) < NB ? a.centres[(tid >> 5) * NB + (tid & 31)] : 0.f;
+  barrier();
+  const bool by_node = one_block && inc_off[0] >= 0;
   const int grp = tid >> 4, l16 = tid & 15;
   const ldm_post::DppGroup<16, false> g{l16};
-  for (int it = 0; it < a.num_update; ++it) {
+  const bool ok0 = l16 < NB, ok1 = l16 + 16 < NB;
+  // One pass per iteration over the (element, coordinate) pairs, a 16-lane row each (two bins per lane): the SGD step of
+  // the PREVIOUS iteration on the pair's logits (its softmax, its expected coordinate and the node gradient are still in
+  // LDS), then the softmax / expectation of the updated logits.  A row reads and writes only its own pair's entries, so the
+  // update needs no barrier of its own (r04: 3 barriers per iteration instead of 5, no integer divisions).
+  for (int it = 0; it <= a.num_update; ++it) {
     for (int pidx = grp; pidx < E * 4; pidx += 16) {
       const int e = pidx >> 2, x = pidx & 3;
       const int node = node_of[e];
       if (node < 0) continue;  // (uniform per 16-lane row: DPP rows may diverge from each other)
-      const float* L = lg(e, x);
-      const bool ok0 = l16 < NB, ok1 = l16 + 16 < NB;
-      const float v0 = ok0 ? L[l16] : -INFINITY, v1 = ok1 ? L[l16 + 16] : -INFINITY;
+      float* L = lg(e, x);
+      float* P = pr(e, x);
+      const float c0 = cen[x * 32 + l16], c1 = cen[x * 32 + l16 + 16];
+      float v0 = ok0 ? L[l16] : -INFINITY, v1 = ok1 ? L[l16 + 16] : -INFINITY;
+      if (it > 0) {  // ---- SGD step through the softmax expectation (iteration it - 1)
+        const float bb_old = bbox[node * 4 + x], gr = grad[node * 4 + x];
+        if (ok0) { v0 -= a.step * (P[l16] * (c0 - bb_old) * gr); L[l16] = v0; }
+        if (ok1) { v1 -= a.step * (P[l16 + 16] * (c1 - bb_old) * gr); L[l16 + 16] = v1; }
+      }
+      if (it == a.num_update) continue;
       const float mx = g.gmax(fmaxf(v0, v1));
       const float x0 = ok0 ? expf(v0 - mx) : 0.f, x1 = ok1 ? expf(v1 - mx) : 0.f;
       const float sm = g.gsum(x0 + x1);
       const float p0 = x0 / sm, p1 = x1 / sm;
-      float* P = pr(e, x);
       if (ok0) P[l16] = p0;
       if (ok1) P[l16 + 16] = p1;
-      const float* c = a.centres + x * NB;
-      const float bb = g.gsum((ok0 ? p0 * c[l16] : 0.f) + (ok1 ? p1 * c[l16 + 16] : 0.f));
+      const float bb = g.gsum(p0 * c0 + p1 * c1);
       if (l16 == 0) bbox[node * 4 + x] = bb;
     }
+    if (it == a.num_update) break;
     barrier();
     // ---- per-edge hinge sub-gradients (clg/const.py), REL_MAX_EDGE edges at a time
     if (tid < (E + 1) * 4) grad[tid] = 0.f;
     for (int eb = 0; eb < ne; eb += REL_MAX_EDGE) {
       const int nb = min(REL_MAX_EDGE, ne - eb);
       if (!one_block) {
+        if (eb > 0) barrier();  // (the previous block's node sums have read es / ed / eg)
         stage_edges(eb, nb);
         barrier();
       }
@@ -172,24 +238,23 @@ __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int
       if (tid < (E + 1) * 4) {
         const int node = tid >> 2, x = tid & 3;
         float gsum = grad[tid];
-        for (int k = 0; k < nb; ++k) {
-          if (es[k] == node) gsum += eg[k * 8 + x];
-          if (ed[k] == node) gsum += eg[k * 8 + 4 + x];
+        if (by_node) {
+          for (int j = inc_off[node]; j < inc_off[node + 1]; ++j) {
+            const int ent = inc[j];
+            gsum += eg[(ent >> 1) * 8 + (ent & 1) * 4 + x];
+          }
+        } else {
+          for (int k = 0; k < nb; ++k) {
+            if (es[k] == node) gsum += eg[k * 8 + x];
+            if (ed[k] == node) gsum += eg[k * 8 + 4 + x];
+          }
         }
         grad[tid] = gsum;
       }
-      barrier();
     }  // edge blocks
     barrier();
-    // ---- SGD step through the softmax expectation
-    for (int i = tid; i < E * 4 * NB; i += 256) {
-      const int e = i / (4 * NB), x = (i / NB) % 4, n = i % NB;
-      const int node = node_of[e];
-      if (node < 0) continue;
-      lg(e, x)[n] -= a.step * (pr(e, x)[n] * (a.centres[x * NB + n] - bbox[node * 4 + x]) * grad[node * 4 + x]);
-    }
-    barrier();
   }
+  barrier();  // (the last SGD step's writes: the caller reads the rows next)
 }
 
 }  // namespace ldm
