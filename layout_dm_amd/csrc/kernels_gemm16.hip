@@ -261,6 +261,93 @@ struct Epi16x {
 };
 constexpr float kLoScale16 = 2048.0f, kLoScaleInv16 = 1.0f / 2048.0f;
 
+// Epilogue through an LDS transpose.  In the accumulator layout lane (frow, hi) owns ONE row and four 4-column runs of it, so a
+// direct store is 32 rows x 8 (fp16) or 16 (fp32) bytes per wave instruction: FFN1 issued 3.0e7 such write requests per
+// launch beside the 2.1e7 read requests of its operands, and these GEMMs are bound by the L2's REQUEST rate (0.66 requests
+// per channel-clock in TCC_REQ, matrix pipes busy 0.28: profiles/r04_call8_*, r04_call15_*).  Here every wave parks its
+// 64 x 64 tile in the (now dead) operand ring, reads it back along the rows and stores whole 128 / 256-byte row segments;
+// bias / ReLU / residual are applied on the way out, the residual read is coalesced the same way.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const f32x16 (&cor)[TM][TN], const Epi16x& e, int m0,
+                                            int n0, int wm, int wn, int frow, int hi, char* smem, int wave, int lane) {
+  constexpr int WR = TM * 32, WC = TN * 32, LD = WC + 4;
+  float* t = reinterpret_cast<float*>(smem) + wave * (WR * LD);
+  __syncthreads();  // every wave is done with the operand stages
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float4 v;
+        v.x = acc[mi][ni][rq * 4 + 0] + cor[mi][ni][rq * 4 + 0] * kLoScaleInv16;
+        v.y = acc[mi][ni][rq * 4 + 1] + cor[mi][ni][rq * 4 + 1] * kLoScaleInv16;
+        v.z = acc[mi][ni][rq * 4 + 2] + cor[mi][ni][rq * 4 + 2] * kLoScaleInv16;
+        v.w = acc[mi][ni][rq * 4 + 3] + cor[mi][ni][rq * 4 + 3] * kLoScaleInv16;
+        *reinterpret_cast<float4*>(t + (mi * 32 + frow) * LD + ni * 32 + rq * 8 + hi * 4) = v;
+      }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // the tile is this wave's own: LDS operations of a wavefront complete in order
+  __builtin_amdgcn_wave_barrier();
+  constexpr int LPR = WC / 4;   // lanes per row
+  constexpr int RPI = 64 / LPR; // rows per wave instruction
+  const int lr = lane / LPR, lc = (lane % LPR) * 4;
+  const int n = n0 + wn * WC + lc;
+  if (n >= e.N) return;
+  const bool vec = (n + 3 < e.N) && ((e.N & 3) == 0);
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e.bias) {
+    if (vec) bv = *reinterpret_cast<const float4*>(e.bias + n);
+    else {
+      bv.x = e.bias[n];
+      if (n + 1 < e.N) bv.y = e.bias[n + 1];
+      if (n + 2 < e.N) bv.z = e.bias[n + 2];
+      if (n + 3 < e.N) bv.w = e.bias[n + 3];
+    }
+  }
+#pragma unroll 4
+  for (int it = 0; it < WR / RPI; ++it) {
+    const int r = it * RPI + lr;
+    const int m = m0 + wm * WR + r;
+    if (m >= e.M) continue;
+    const float4 tv = *reinterpret_cast<const float4*>(t + r * LD + lc);
+    float v[4] = {tv.x + bv.x, tv.y + bv.y, tv.z + bv.z, tv.w + bv.w};
+    if (e.relu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (vec) {
+      if (e.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      }
+      if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (e.C16) {
+        __half h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          h[i] = __float2half_rn(v[i]);
+          l[i] = __float2half_rn((v[i] - __half2float(h[i])) * kLoScale16);
+        }
+        *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(h);
+        if (e.C16lo) *reinterpret_cast<uint2*>(e.C16lo + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(l);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (n + i >= e.N) continue;
+        float x = v[i];
+        if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
+        if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
+        if (e.C16) {
+          const __half hh = __float2half_rn(x);
+          e.C16[(size_t)m * e.ldc16 + n + i] = hh;
+          if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n + i] = __float2half_rn((x - __half2float(hh)) * kLoScale16);
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
 __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restrict__ A, const __half* __restrict__ Alo,
                                                            const __half* __restrict__ W, const __half* __restrict__ Wlo,
@@ -381,62 +468,146 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
     }
   }
 
-  // ---- epilogue: lane (frow, hi) owns row m and, per 32-column tile, the columns 8 rq + 4 hi + (0..3)
+  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, cor, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
+}
+
+// The same GEMM with the operands staged through REGISTERS (global_load_dwordx4 -> VGPRs -> ds_write_b128) instead of the LDS-DMA.
+// Why: the DMA path of the chip sustains ~6.4 TB/s (MI355X_MICROARCH.md "ldsdma-fill"), and gemm16x3_k sits on it — 5-6.5 TB/s of
+// operand fills, matrix pipes busy 0.28-0.36, half of the wave cycles in s_waitcnt (profiles/r04_call8_*) — while the vector
+// memory path reads the L2 at several times that.  Three-stage LDS ring, ONE register stage: iteration kt computes stage kt,
+// stores the registers (stage kt + 2, loaded during iteration kt - 1) and issues the loads of stage kt + 3.
+// BK = 32: a 64-byte row segment per (row, stage) = four 16-byte chunks; thread t owns chunk (t & 3) of rows (t >> 2) + i * NT / 4.
+template <int BM, int BN, int WM, int WN, int TAG>
+__global__ __launch_bounds__(WM* WN * 64) void gemm16x3r_k(const __half* __restrict__ A, const __half* __restrict__ Alo,
+                                                            const __half* __restrict__ W, const __half* __restrict__ Wlo,
+                                                            int lda, int ldw, int K, int tiles_n, Epi16x e) {
+  constexpr int BK = 32, NSTAGE = 3;
+  constexpr int NT = WM * WN * 64;
+  constexpr int RB = BK * 2;                       // 64 bytes per tile row
+  constexpr int HALF_BYTES = (BM + BN) * RB;       // [A rows | W rows] of one half (hi / lo)
+  constexpr int STAGE_BYTES = 2 * HALF_BYTES;
+  constexpr int RPP = NT / 4;                      // rows covered by one pass of the workgroup (4 chunks per row)
+  constexpr int NPA = BM / RPP, NPW = BN / RPP;    // passes over the A rows / W rows, per half
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must split evenly over the threads");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap16(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+
+  // ---- staging: global chunk (row r, chunk c) -> LDS slot r * RB + ((c ^ sw(r)) << 4), sw(r) = (r >> 2) & 3 (the read side below)
+  const int srow = tid >> 2, sc = tid & 3;
+  const __half* gA = A + (size_t)(m0 + srow) * lda + sc * 8;
+  const __half* gAl = Alo + (size_t)(m0 + srow) * lda + sc * 8;
+  const __half* gW = W + (size_t)(n0 + srow) * ldw + sc * 8;
+  const __half* gWl = Wlo + (size_t)(n0 + srow) * ldw + sc * 8;
+  static_assert(NPA >= 1 && NPA <= 2 && NPW >= 1 && NPW <= 2, "one or two passes per operand");
+  // (named registers, not arrays: hipcc keeps lambda-captured private arrays in scratch)
+  uint4 ra0, ra1, ral0, ral1, rw0, rw1, rwl0, rwl1;
+  ra1 = ral1 = rw1 = rwl1 = make_uint4(0, 0, 0, 0);
+  auto gload = [&](int kt) {
+    const size_t ko = (size_t)kt * BK;
+    ra0 = *reinterpret_cast<const uint4*>(gA + ko);
+    ral0 = *reinterpret_cast<const uint4*>(gAl + ko);
+    if constexpr (NPA > 1) {
+      ra1 = *reinterpret_cast<const uint4*>(gA + (size_t)RPP * lda + ko);
+      ral1 = *reinterpret_cast<const uint4*>(gAl + (size_t)RPP * lda + ko);
+    }
+    rw0 = *reinterpret_cast<const uint4*>(gW + ko);
+    rwl0 = *reinterpret_cast<const uint4*>(gWl + ko);
+    if constexpr (NPW > 1) {
+      rw1 = *reinterpret_cast<const uint4*>(gW + (size_t)RPP * ldw + ko);
+      rwl1 = *reinterpret_cast<const uint4*>(gWl + (size_t)RPP * ldw + ko);
+    }
+  };
+  const int soff0 = srow * RB + ((sc ^ ((srow >> 2) & 3)) << 4);                   // rows srow and srow + RPP share the
+  const int soff1 = (srow + RPP) * RB + ((sc ^ (((srow + RPP) >> 2) & 3)) << 4);   // swizzle when RPP % 16 == 0
+  auto sstore = [&](int stage) {
+    char* sb = smem + stage * STAGE_BYTES;
+    *reinterpret_cast<uint4*>(sb + soff0) = ra0;
+    *reinterpret_cast<uint4*>(sb + HALF_BYTES + soff0) = ral0;
+    if constexpr (NPA > 1) {
+      *reinterpret_cast<uint4*>(sb + soff1) = ra1;
+      *reinterpret_cast<uint4*>(sb + HALF_BYTES + soff1) = ral1;
+    }
+    *reinterpret_cast<uint4*>(sb + BM * RB + soff0) = rw0;
+    *reinterpret_cast<uint4*>(sb + HALF_BYTES + BM * RB + soff0) = rwl0;
+    if constexpr (NPW > 1) {
+      *reinterpret_cast<uint4*>(sb + BM * RB + soff1) = rw1;
+      *reinterpret_cast<uint4*>(sb + HALF_BYTES + BM * RB + soff1) = rwl1;
+    }
+  };
+
+  const int frow = lane & 31;
+  const int hi = lane >> 5;
+  const int fsw = (frow >> 2) & 3;
+  int offA[2], offW[2];
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const int m = m0 + wm * (BM / WM) + mi * 32 + frow;
-    if (m >= e.M) continue;
+  for (int ks = 0; ks < 2; ++ks) {
+    const int phys = (ks * 2 + hi) ^ fsw;
+    offA[ks] = (wm * (BM / WM) + frow) * RB + phys * 16;
+    offW[ks] = BM * RB + (wn * (BN / WN) + frow) * RB + phys * 16;
+  }
+  f32x16 acc[TM][TN], cor[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; cor[mi][ni][r] = 0.f; }
+
+  const int nk = K / BK;
+  gload(0);
+  sstore(0);
+  if (nk > 1) { gload(1); sstore(1); }
+  if (nk > 2) gload(2);
+  auto mfmas = [&](const char* sbase, int ks) {
+    f16x8 a[TM], al[TM], w[TN], wl[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      a[mi] = *reinterpret_cast<const f16x8*>(sbase + offA[ks] + mi * 32 * RB);
+      al[mi] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offA[ks] + mi * 32 * RB);
+    }
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int n = n0 + wn * (BN / WN) + ni * 32 + rq * 8 + hi * 4;
-        if (n >= e.N) continue;
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[mi][ni][rq * 4 + i] + cor[mi][ni][rq * 4 + i] * kLoScaleInv16;
-        if (n + 3 < e.N && (e.N & 3) == 0) {
-          if (e.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          }
-          if (e.relu) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-          }
-          if (e.res) {
-            const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          }
-          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-          if (e.C16) {
-            __half h[4], l[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              h[i] = __float2half_rn(v[i]);
-              l[i] = __float2half_rn((v[i] - __half2float(h[i])) * kLoScale16);
-            }
-            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(h);
-            if (e.C16lo) *reinterpret_cast<uint2*>(e.C16lo + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(l);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (n + i >= e.N) continue;
-            float x = v[i] + (e.bias ? e.bias[n + i] : 0.f);
-            if (e.relu) x = fmaxf(x, 0.f);
-            if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
-            if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
-            if (e.C16) {
-              const __half hh = __float2half_rn(x);
-              e.C16[(size_t)m * e.ldc16 + n + i] = hh;
-              if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n + i] = __float2half_rn((x - __half2float(hh)) * kLoScale16);
-            }
-          }
-        }
-      }
+      w[ni] = *reinterpret_cast<const f16x8*>(sbase + offW[ks] + ni * 32 * RB);
+      wl[ni] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offW[ks] + ni * 32 * RB);
     }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], cor[mi][ni], 0, 0, 0);
+        cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], cor[mi][ni], 0, 0, 0);
+      }
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // stage kt is visible; nobody reads stage kt - 1 (= the slot of stage kt + 2) any more
+    const char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+    mfmas(sbase, 0);
+    if (kt + 2 < nk) {
+      sstore((kt + 2) % NSTAGE);          // (the compiler waits for the loads of stage kt + 2 here: issued one iteration ago)
+      if (kt + 3 < nk) gload(kt + 3);
+    }
+    mfmas(sbase, 1);
   }
+  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, cor, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
+}
+
+template <int BM, int BN, int WM, int WN, int TAG>
+static void launch_x3r(const GemmArgs& g, hipStream_t st) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  constexpr int lds = 3 * 2 * (BM + BN) * 32 * 2;
+  auto kern = gemm16x3r_k<BM, BN, WM, WN, TAG>;
+  allow_big_lds((const void*)kern);
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A, (const __half*)g.Alo,
+                     (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, e);
 }
 
 template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
@@ -461,8 +632,9 @@ void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st) {
   if (cfg == 0) { launch_x3<128, 128, 32, 3, 2, 2, 5>(g, st); return; }
   if (cfg == 1) { launch_x3<128, 128, 32, 4, 2, 2, 5>(g, st); return; }
   if (cfg == 3) { launch_x3<128, 256, 32, 3, 2, 4, 5>(g, st); return; }
-  if (cfg == 4) { launch_x3<256, 128, 32, 2, 4, 2, 5>(g, st); return; }
   if (cfg == 5 && g.K % 64 == 0) { launch_x3<128, 128, 64, 2, 2, 2, 5>(g, st); return; }
+  if (cfg == 6) { launch_x3r<256, 128, 4, 2, 5>(g, st); return; }   // operands through registers
+  if (cfg == 7) { launch_x3r<128, 128, 2, 2, 5>(g, st); return; }
   switch (tag) {
     case 0: launch_x3<256, 128, 32, 3, 4, 2, 0>(g, st); return;
     case 1: launch_x3<256, 128, 32, 3, 4, 2, 1>(g, st); return;
