@@ -217,7 +217,7 @@ int ldm_fid_features(ldm_fid* h, const float* d_bbox, const int64_t* d_label, co
  * helpers/metric.py:37-59, which the reference takes from prdc.compute_prdc(real_features, fake_features, nearest_k=5)):
  * d_real (n_real, dim), d_fake (n_fake, dim) float32 device; h_out4 = {precision, recall, density, coverage} on the HOST
  * (the call synchronises `stream`); 1 <= nearest_k <= 7.  Uses the current device; workspace is allocated and freed
- * inside the call (max(n_real, n_fake)^2 floats). */
+ * inside the call (max(n_real, n_fake)^2 floats; at most 65 536 features per set, -6 beyond). */
 int ldm_prdc(const float* d_real, int n_real, const float* d_fake, int n_fake, int dim, int nearest_k, float* h_out4,
              void* stream);
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void prdc_kth_k(const float* __restrict__ D, i
 
 // per real row i: recall_i (some fake inside that fake's radius) and coverage_i (nearest fake inside real_i's radius)
 __global__ __launch_bounds__(256) void prdc_rows_k(const float* __restrict__ Drf, int n, int m, const float* __restrict__ r2_real,
-                                                   const float* __restrict__ r2_fake, unsigned* __restrict__ counts) {
+                                                   const float* __restrict__ r2_fake, unsigned long long* __restrict__ counts) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   bool rec = false;
@@ -95,19 +95,19 @@ __global__ __launch_bounds__(256) void prdc_rows_k(const float* __restrict__ Drf
   for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off, 64));
   const bool any_rec = __ballot(rec) != 0ull;
   if (lane == 0) {
-    if (any_rec) atomicAdd(&counts[1], 1u);
-    if (mn < r2_real[row]) atomicAdd(&counts[3], 1u);
+    if (any_rec) atomicAdd(&counts[1], 1ull);
+    if (mn < r2_real[row]) atomicAdd(&counts[3], 1ull);
   }
 }
 // per fake column j: precision_j (inside some real's radius) and its density count
 __global__ __launch_bounds__(256) void prdc_cols_k(const float* __restrict__ Drf, int n, int m, const float* __restrict__ r2_real,
-                                                   unsigned* __restrict__ counts) {
+                                                   unsigned long long* __restrict__ counts) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   unsigned inside = 0;
   for (int i = 0; i < n; ++i) inside += Drf[(size_t)i * m + j] < r2_real[i] ? 1u : 0u;
-  if (inside) atomicAdd(&counts[0], 1u);
-  atomicAdd(&counts[2], inside);
+  if (inside) atomicAdd(&counts[0], 1ull);
+  atomicAdd(&counts[2], (unsigned long long)inside);  // (density sums up to n_real x n_fake: 64-bit)
 }
 
 void launch_prdc_pdist2(const float* A, int n, const float* B, int m, int dim, float* D, hipStream_t st) {
@@ -116,7 +116,7 @@ void launch_prdc_pdist2(const float* A, int n, const float* B, int m, int dim, f
 void launch_prdc_kth(const float* D, int n, int m, int k1, float* r2, hipStream_t st) {
   hipLaunchKernelGGL(prdc_kth_k, dim3((n + 3) / 4), dim3(256), 0, st, D, n, m, k1, r2);
 }
-void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, const float* r2_fake, unsigned* counts,
+void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, const float* r2_fake, unsigned long long* counts,
                         hipStream_t st) {
   hipLaunchKernelGGL(prdc_rows_k, dim3((n + 3) / 4), dim3(256), 0, st, Drf, n, m, r2_real, r2_fake, counts);
   hipLaunchKernelGGL(prdc_cols_k, dim3((m + 255) / 256), dim3(256), 0, st, Drf, n, m, r2_real, counts);

@@ -189,8 +189,11 @@ extern "C" int ldm_prdc(const float* d_real, int n_real, const float* d_fake, in
   if (nearest_k < 1 || nearest_k > 7 || nearest_k + 1 > n_real || nearest_k + 1 > n_fake) return -1;
   hipStream_t st = (hipStream_t)stream;
   const size_t nmax = (size_t)std::max(n_real, n_fake);
+  // the pairwise-distance workspace is nmax^2 floats (prdc itself builds the same matrices): refuse sets whose matrix would
+  // not fit comfortably (> 16 GiB: 65 536 features per set) instead of failing opaquely inside hipMalloc
+  if (nmax > 65536) return -6;
   float *D = nullptr, *r2r = nullptr, *r2f = nullptr;
-  unsigned* cnt = nullptr;
+  unsigned long long* cnt = nullptr;
   auto done = [&](int rc) {
     if (D) (void)hipFree(D);
     if (r2r) (void)hipFree(r2r);
@@ -201,20 +204,21 @@ extern "C" int ldm_prdc(const float* d_real, int n_real, const float* d_fake, in
   if (hipMalloc((void**)&D, nmax * nmax * sizeof(float)) != hipSuccess) return done(-3);
   if (hipMalloc((void**)&r2r, n_real * sizeof(float)) != hipSuccess) return done(-3);
   if (hipMalloc((void**)&r2f, n_fake * sizeof(float)) != hipSuccess) return done(-3);
-  if (hipMalloc((void**)&cnt, 4 * sizeof(unsigned)) != hipSuccess) return done(-3);
-  if (hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned), st) != hipSuccess) return done(-2);
+  if (hipMalloc((void**)&cnt, 4 * sizeof(unsigned long long)) != hipSuccess) return done(-3);
+  if (hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return done(-2);
   launch_prdc_pdist2(d_real, n_real, d_real, n_real, dim, D, st);
   launch_prdc_kth(D, n_real, n_real, nearest_k + 1, r2r, st);
   launch_prdc_pdist2(d_fake, n_fake, d_fake, n_fake, dim, D, st);
   launch_prdc_kth(D, n_fake, n_fake, nearest_k + 1, r2f, st);
   launch_prdc_pdist2(d_real, n_real, d_fake, n_fake, dim, D, st);
   launch_prdc_counts(D, n_real, n_fake, r2r, r2f, cnt, st);
-  unsigned h[4];
+  unsigned long long h[4];
   if (hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return done(-2);
   if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return done(-2);
-  h_out4[0] = (float)h[0] / (float)n_fake;                            // precision
-  h_out4[1] = (float)h[1] / (float)n_real;                            // recall
-  h_out4[2] = (float)h[2] / ((float)nearest_k * (float)n_fake);       // density
-  h_out4[3] = (float)h[3] / (float)n_real;                            // coverage
+  // (the ratios in double like prdc, narrowed at the ABI)
+  h_out4[0] = (float)((double)h[0] / (double)n_fake);                           // precision
+  h_out4[1] = (float)((double)h[1] / (double)n_real);                           // recall
+  h_out4[2] = (float)((double)h[2] / ((double)nearest_k * (double)n_fake));     // density
+  h_out4[3] = (float)((double)h[3] / (double)n_real);                           // coverage
   return done(0);
 }

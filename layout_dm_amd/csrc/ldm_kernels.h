@@ -242,7 +242,7 @@ void launch_prdc_pdist2(const float* A, int n, const float* B, int m, int dim, f
 void launch_prdc_kth(const float* D, int n, int m, int k1, float* r2, hipStream_t st);
 // counts[4] (zeroed by the caller) += {fakes inside a real radius, reals with a fake inside that fake's radius,
 // sum over fakes of reals whose radius holds them, reals whose nearest fake is inside their radius}
-void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, const float* r2_fake, unsigned* counts,
+void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, const float* r2_fake, unsigned long long* counts,
                         hipStream_t st);
 
 // ---- small utilities ---------------------------------------------------------------------

@@ -174,7 +174,8 @@ def compute_prdc(real_features, fake_features, nearest_k: int = 5, device=None) 
         rc = lib.ldm_prdc(r.data_ptr(), r.shape[0], f.data_ptr(), f.shape[0], r.shape[1], int(nearest_k), out,
                           int(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
-        raise RuntimeError(f"ldm_prdc failed ({rc}): need 1 <= nearest_k <= 7 and more than nearest_k samples per set")
+        raise RuntimeError(f"ldm_prdc failed ({rc}): need 1 <= nearest_k <= 7, more than nearest_k and at most 65 536 samples "
+                           "per set (the pairwise-distance workspace is n^2 floats)")
     return {"precision": float(out[0]), "recall": float(out[1]), "density": float(out[2]), "coverage": float(out[3])}
 
 
