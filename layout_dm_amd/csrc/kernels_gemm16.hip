@@ -348,7 +348,10 @@ __device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const f
   }
 }
 
-template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
+// ABL (dev, tools/gemm_x3_probe.py): 0 the kernel; 1 no fragment reads / MFMAs (operand fills + barriers only); 2 no fills in the
+// steady state (fragment reads + MFMAs + barriers on whatever the prologue left in LDS); 3 MFMAs on constant fragments (fills +
+// MFMAs, no fragment reads).  Ablations produce wrong numbers by design and are reachable only through ldm_dev_bench_gemm_x3.
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restrict__ A, const __half* __restrict__ Alo,
                                                            const __half* __restrict__ W, const __half* __restrict__ Wlo,
                                                            int lda, int ldw, int K, int tiles_n, int grp, Epi16x e) {
@@ -442,18 +445,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    if (ABL != 2 && kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     const char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+    if constexpr (ABL == 1) continue;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       f16x8 a[TM], al[TM], w[TN], wl[TN];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
+        if constexpr (ABL == 3) {
+          a[mi] = al[mi] = f16x8{(_Float16)0.5f, (_Float16)0.25f, (_Float16)0.125f, (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)0.125f, (_Float16)1.f};
+          asm volatile("" : "+v"(a[mi]), "+v"(al[mi]));
+          continue;
+        }
         a[mi] = *reinterpret_cast<const f16x8*>(sbase + offA[ks] + mi * 32 * RB);
         al[mi] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offA[ks] + mi * 32 * RB);
       }
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
+        if constexpr (ABL == 3) {
+          w[ni] = wl[ni] = f16x8{(_Float16)0.5f, (_Float16)0.25f, (_Float16)0.125f, (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f, (_Float16)0.125f, (_Float16)1.f};
+          asm volatile("" : "+v"(w[ni]), "+v"(wl[ni]));
+          continue;
+        }
         w[ni] = *reinterpret_cast<const f16x8*>(sbase + offW[ks] + ni * 32 * RB);
         wl[ni] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offW[ks] + ni * 32 * RB);
       }
@@ -620,6 +634,26 @@ static void launch_x3(const GemmArgs& g, hipStream_t st) {
   static const int grp = knob_int("LDM_X3_GRP", 0);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A, (const __half*)g.Alo,
                      (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, grp, e);
+}
+
+// dev: the production tile shape with an ablation (see gemm16x3_k)
+void launch_gemm16x3_abl(const GemmArgs& g, int abl, hipStream_t st) {
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 127) / 128;
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  constexpr int lds = 3 * 2 * (256 + 128) * 32 * 2;
+  static const int grp = 0;
+#define LDM_X3_ABL(N_)                                                                                                   \
+  {                                                                                                                      \
+    auto kern = gemm16x3_k<256, 128, 32, 3, 4, 2, 6, N_>;                                                                \
+    allow_big_lds((const void*)kern);                                                                                    \
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, (const __half*)g.A, (const __half*)g.Alo,      \
+                       (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, grp, e);                    \
+  }
+  if (abl == 1) LDM_X3_ABL(1)
+  else if (abl == 2) LDM_X3_ABL(2)
+  else if (abl == 3) LDM_X3_ABL(3)
+  else LDM_X3_ABL(0)
+#undef LDM_X3_ABL
 }
 
 // Split-mode GEMM.  Requires: K a multiple of 32 (the host pads: Dp / Fp), A / Alo with >= ceil(M / 256) * 256 rows and

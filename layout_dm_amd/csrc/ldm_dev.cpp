@@ -80,6 +80,33 @@ extern "C" int ldm_dev_bench_gemm(int M, int N, int K, int cfg, int iters, float
   return ms >= 0.f ? 0 : -2;
 }
 
+// Split GEMM (gemm16x3_k, 256 x 128 tiles) on synthetic operands: abl = 0 the kernel, 1 operand fills only, 2 fragment reads +
+// MFMAs only, 3 fills + MFMAs without fragment reads (tools/gemm_x3_probe.py).  Average ms per launch.
+extern "C" int ldm_dev_bench_gemm_x3(int M, int N, int K, int abl, int c16, int iters, float* ms_out) {
+  const int Mp = round_up(M, 256), Np = round_up(N, 256), Kp = round_up(K, 64);
+  std::vector<uint16_t> ha((size_t)Mp * Kp), hw((size_t)Np * Kp);
+  uint32_t s = 4321u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return ((float)(s >> 8) / 8388608.0f) - 1.0f;
+  };
+  for (auto& x : ha) x = f2h_bits(rnd());
+  for (auto& x : hw) x = f2h_bits(rnd() * 0.05f);
+  DevScope d;
+  __half *A = nullptr, *Al = nullptr, *W = nullptr, *Wl = nullptr, *C16 = nullptr, *C16l = nullptr;
+  float *C32 = nullptr, *bias = nullptr;
+  if (!d.alloc(&A, ha.size() * 2, ha.data()) || !d.alloc(&Al, ha.size() * 2, ha.data()) || !d.alloc(&W, hw.size() * 2, hw.data()) ||
+      !d.alloc(&Wl, hw.size() * 2, hw.data()) || !d.alloc(&C32, (size_t)Mp * Np * 4) || !d.alloc(&C16, (size_t)Mp * Np * 2) ||
+      !d.alloc(&C16l, (size_t)Mp * Np * 2) || !d.alloc(&bias, (size_t)Np * 4) || !d.events())
+    return -3;
+  GemmArgs g{};
+  g.A = A; g.Alo = Al; g.W = W; g.Wlo = Wl; g.M = M; g.N = N; g.K = Kp; g.lda = Kp; g.ldw = Kp; g.precision = 2; g.bias = bias;
+  if (c16) { g.C16 = C16; g.C16lo = C16l; g.ldc16 = Np; g.relu = 1; } else { g.C32 = C32; g.ldc32 = Np; }
+  const float ms = d.time(iters, [&]() { launch_gemm16x3_abl(g, abl, 0); });
+  *ms_out = ms;
+  return ms >= 0.f ? 0 : -2;
+}
+
 // attention micro-benchmark: B layouts x 8 heads on random fp16 qkv (the stand-alone attn_mfma_k)
 extern "C" int ldm_dev_bench_attn(int B, int iters, float* ms_out) {
   const int S = 125, H = 8, ldq = 3 * H * 64, ldo = H * 64;

@@ -78,6 +78,7 @@ int gemm16_block_k(int cfg);
 // fp16 x 3 split GEMM on the same pipeline (kernels_gemm16.hip gemm16x3_k): A / Alo / W / Wlo, K % 32 == 0, operand
 // buffers allocated to whole 128-row tiles
 void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st);
+void launch_gemm16x3_abl(const GemmArgs& g, int abl, hipStream_t st);  // dev ablations (ldm_dev_bench_gemm_x3)
 // per-layer weights of the stack kernel (all device pointers)
 struct FusedLayerW {
   const void* img;        // ldm_pack::pack_attn_head_image (in_proj K axis in k-slot order)

@@ -49,3 +49,12 @@ def test_bench_line_contract(d):
     assert set(d["modes"]) >= {"exact", "fast", "fast_verified"} and d["modes"]["fast_verified"]["tokens_equal_exact_mode"]
     assert set(d["configs"]) >= {"3", "4", "refinement", "relation"}
     assert len(d["tokens_sha256"]["sha256"]) == 64
+    if "config2_verbatim" in d:   # r04 lines
+        v = d["config2_verbatim"]
+        assert v["tokens_equal_exact_mode"] is True and v["steps"] >= 10 and "greedy" in v["workload"]
+        assert "split" in d["modes"] and d["modes"]["exact"]["steps"] >= 10 and d["modes"]["split"]["steps"] >= 10
+        nd = d["modes"]["fast_verified"]["nondegenerate"]
+        assert all(nd[k]["tokens_equal_exact_mode"] for k in nd if k.startswith("from_step_"))
+        assert set(d["configs"]) >= {"5_refinement_T200", "5_relation_T200"}
+        assert d["config"]["cpu_baseline_kind"] == "port" and d["config"]["library"]["knobs"] == ""
+        assert d["world_size_seen"] == 1 and d["scaling_point"]["layouts_per_s_per_gpu"] == d["configs"]["4"]["value"]
