@@ -25,7 +25,7 @@ __device__ __forceinline__ float ldf<__half>(const __half* p) {
   return __half2float(*p);
 }
 
-constexpr float kLoScaleA = 2048.0f;
+constexpr float kLoScaleA = kSplitLoScale;
 
 template <typename TIn, int DHP>
 __global__ __launch_bounds__(128) void attn_rows(const TIn* __restrict__ qkv, float* __restrict__ out32,

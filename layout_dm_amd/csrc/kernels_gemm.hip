@@ -27,8 +27,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr float kLoScaleInv = 1.0f / 2048.0f;
-constexpr float kLoScale = 2048.0f;
+constexpr float kLoScaleInv = 1.0f / kSplitLoScale;
+constexpr float kLoScale = kSplitLoScale;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective for any nwg (cdna guide §5 "XCD swizzle must be bijective")
@@ -46,6 +46,7 @@ struct EpiArgs {
   __half* C16;
   __half* C16lo;
   int M, N, ldres, ldc32, ldc16, relu;
+  float out_scale = 1.0f;  // split mode: undoes the weight tensor's power-of-two pre-scale (applied to the accumulators)
 };
 
 template <int MI = 2>
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_f16_128x128(const __half* __restrict
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += acl[mi][ni][r] * kLoScaleInv;
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = (acc[mi][ni][r] + acl[mi][ni][r] * kLoScaleInv) * e.out_scale;
   }
   epilogue_store(e, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
@@ -407,6 +408,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t st) {
   const int tiles_m = (g.M + 127) / 128;
   const int tiles_n = (g.N + 127) / 128;
   EpiArgs e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  e.out_scale = g.out_scale > 0.f ? g.out_scale : 1.0f;
   dim3 grid(tiles_m * tiles_n), block(256);
   if (g.precision == 0) {
     // opt-in (LDM_GEMM32_WIDE=1): run alone, the 160-wide tiles cut FFN2 by 4 % (366 vs 381 ms per 100 steps), but the

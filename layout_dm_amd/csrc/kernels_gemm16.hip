@@ -244,11 +244,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16_k(const __half* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------------
 // fp16 x 3 SPLIT GEMM (LDM_PREC_SPLIT_F16): fp32-grade products on the fp16 matrix pipe.
-//     x = hi + 2^-11 lo',   hi = fp16(x),  lo' = fp16((x - hi) 2^11)            (both operands, prepared by their producers)
-//     A W^T = Ahi Whi^T + 2^-11 (Alo' Whi^T + Ahi Wlo'^T)   (+ 2^-22 Alo' Wlo'^T, dropped: below fp32 rounding)
+//     x = hi + lo,   hi = fp16(x),  lo = fp16(x - hi)                            (both operands, prepared by their producers)
+//     A W^T = Ahi Whi^T + Alo Whi^T + Ahi Wlo^T   (+ Alo Wlo^T ~ 2^-22 relative, dropped: below fp32 rounding)
 // Same structure as gemm16_k — operands by LDS-DMA through an NSTAGE ring, one barrier per K tile, swapped-operand MFMAs so a
 // lane owns one output row — with a stage holding four images (A hi | W hi | A lo | W lo) and three MFMAs per fragment
-// pair on two accumulators (main, correction).  Why: gfx950's fp32 MFMA peaks at 157 TFLOP/s, its fp16 MFMA at 2 500: three
+// pair on ONE accumulator (lo is unscaled: kSplitLoScale = 1, ldm_kernels.h; weights pre-scaled to magnitude ~1).  Why: gfx950's fp32 MFMA peaks at 157 TFLOP/s, its fp16 MFMA at 2 500: three
 // fp16 passes have a 5.3 x higher ceiling than one fp32 pass at the same (measured: better, 7e-7 vs 9e-7) logits error, and
 // 4 fragment reads feed 3 MFMAs instead of 2 feeding 1.  r03's split GEMM (gemm_f16_128x128<3>, register-staged, 221
 // layouts/s) was a numerics cross-check; this one makes the split mode the fast reference-precision mode.
@@ -258,8 +258,10 @@ struct Epi16x {
   float* C32;
   __half *C16, *C16lo;
   int M, N, ldres, ldc32, ldc16, relu;
+  float out_scale;  // undoes the weight tensor's power-of-two pre-scale
 };
-constexpr float kLoScale16 = 2048.0f, kLoScaleInv16 = 1.0f / 2048.0f;
+constexpr float kLoScale16 = kSplitLoScale;
+static_assert(kSplitLoScale == 1.0f, "gemm16x3 accumulates hi*hi, lo*hi and hi*lo into ONE accumulator: lo must be unscaled");
 
 // Epilogue through an LDS transpose.  In the accumulator layout lane (frow, hi) owns ONE row and four 4-column runs of it, so a
 // direct store is 32 rows x 8 (fp16) or 16 (fp32) bytes per wave instruction: FFN1 issued 3.0e7 such write requests per
@@ -268,34 +270,18 @@ constexpr float kLoScale16 = 2048.0f, kLoScaleInv16 = 1.0f / 2048.0f;
 // 64 x 64 tile in the (now dead) operand ring, reads it back along the rows and stores whole 128 / 256-byte row segments;
 // bias / ReLU / residual are applied on the way out, the residual read is coalesced the same way.
 template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const f32x16 (&cor)[TM][TN], const Epi16x& e, int m0,
+__device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const Epi16x& e, int m0,
                                             int n0, int wm, int wn, int frow, int hi, char* smem, int wave, int lane) {
   constexpr int WR = TM * 32, WC = TN * 32, LD = WC + 4;
-  float* t = reinterpret_cast<float*>(smem) + wave * (WR * LD);
+  float* t = reinterpret_cast<float*>(smem) + wave * (32 * LD);   // one 32-row slab of the wave's tile at a time
   __syncthreads();  // every wave is done with the operand stages
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        float4 v;
-        v.x = acc[mi][ni][rq * 4 + 0] + cor[mi][ni][rq * 4 + 0] * kLoScaleInv16;
-        v.y = acc[mi][ni][rq * 4 + 1] + cor[mi][ni][rq * 4 + 1] * kLoScaleInv16;
-        v.z = acc[mi][ni][rq * 4 + 2] + cor[mi][ni][rq * 4 + 2] * kLoScaleInv16;
-        v.w = acc[mi][ni][rq * 4 + 3] + cor[mi][ni][rq * 4 + 3] * kLoScaleInv16;
-        *reinterpret_cast<float4*>(t + (mi * 32 + frow) * LD + ni * 32 + rq * 8 + hi * 4) = v;
-      }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // the tile is this wave's own: LDS operations of a wavefront complete in order
-  __builtin_amdgcn_wave_barrier();
   constexpr int LPR = WC / 4;   // lanes per row
   constexpr int RPI = 64 / LPR; // rows per wave instruction
   const int lr = lane / LPR, lc = (lane % LPR) * 4;
   const int n = n0 + wn * WC + lc;
-  if (n >= e.N) return;
   const bool vec = (n + 3 < e.N) && ((e.N & 3) == 0);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e.bias) {
+  if (e.bias && n < e.N) {
     if (vec) bv = *reinterpret_cast<const float4*>(e.bias + n);
     else {
       bv.x = e.bias[n];
@@ -304,47 +290,67 @@ __device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const f
       if (n + 3 < e.N) bv.w = e.bias[n + 3];
     }
   }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        float4 v;
+        v.x = acc[mi][ni][rq * 4 + 0] * e.out_scale;
+        v.y = acc[mi][ni][rq * 4 + 1] * e.out_scale;
+        v.z = acc[mi][ni][rq * 4 + 2] * e.out_scale;
+        v.w = acc[mi][ni][rq * 4 + 3] * e.out_scale;
+        *reinterpret_cast<float4*>(t + frow * LD + ni * 32 + rq * 8 + hi * 4) = v;
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the slab is this wave's own: LDS operations of a wavefront complete in order
+    __builtin_amdgcn_wave_barrier();
+    if (n < e.N) {
 #pragma unroll 4
-  for (int it = 0; it < WR / RPI; ++it) {
-    const int r = it * RPI + lr;
-    const int m = m0 + wm * WR + r;
-    if (m >= e.M) continue;
-    const float4 tv = *reinterpret_cast<const float4*>(t + r * LD + lc);
-    float v[4] = {tv.x + bv.x, tv.y + bv.y, tv.z + bv.z, tv.w + bv.w};
-    if (e.relu) {
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int r = it * RPI + lr;
+        const int m = m0 + wm * WR + mi * 32 + r;
+        if (m >= e.M) continue;
+        const float4 tv = *reinterpret_cast<const float4*>(t + r * LD + lc);
+        float v[4] = {tv.x + bv.x, tv.y + bv.y, tv.z + bv.z, tv.w + bv.w};
+        if (e.relu) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-    if (vec) {
-      if (e.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
-      if (e.C16) {
-        __half h[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          h[i] = __float2half_rn(v[i]);
-          l[i] = __float2half_rn((v[i] - __half2float(h[i])) * kLoScale16);
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(h);
-        if (e.C16lo) *reinterpret_cast<uint2*>(e.C16lo + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(l);
-      }
-    } else {
+        if (vec) {
+          if (e.res) {
+            const float4 r4 = *reinterpret_cast<const float4*>(e.res + (size_t)m * e.ldres + n);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          }
+          if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)m * e.ldc32 + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (e.C16) {
+            __half h[4], l[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (n + i >= e.N) continue;
-        float x = v[i];
-        if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
-        if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
-        if (e.C16) {
-          const __half hh = __float2half_rn(x);
-          e.C16[(size_t)m * e.ldc16 + n + i] = hh;
-          if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n + i] = __float2half_rn((x - __half2float(hh)) * kLoScale16);
+            for (int i = 0; i < 4; ++i) {
+              h[i] = __float2half_rn(v[i]);
+              l[i] = __float2half_rn((v[i] - __half2float(h[i])) * kLoScale16);
+            }
+            *reinterpret_cast<uint2*>(e.C16 + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(h);
+            if (e.C16lo) *reinterpret_cast<uint2*>(e.C16lo + (size_t)m * e.ldc16 + n) = *reinterpret_cast<const uint2*>(l);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (n + i >= e.N) continue;
+            float x = v[i];
+            if (e.res) x += e.res[(size_t)m * e.ldres + n + i];
+            if (e.C32) e.C32[(size_t)m * e.ldc32 + n + i] = x;
+            if (e.C16) {
+              const __half hh = __float2half_rn(x);
+              e.C16[(size_t)m * e.ldc16 + n + i] = hh;
+              if (e.C16lo) e.C16lo[(size_t)m * e.ldc16 + n + i] = __float2half_rn((x - __half2float(hh)) * kLoScale16);
+            }
+          }
         }
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // (the slab is rewritten by the next pass)
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -425,13 +431,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
     offW[ks] = BM * RB + (wn * (BN / WN) + frow) * RB + phys * 16;
   }
 
-  f32x16 acc[TM][TN], cor[TM][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; cor[mi][ni][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int nk = K / BK;
 #pragma unroll
@@ -471,18 +477,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
         w[ni] = *reinterpret_cast<const f16x8*>(sbase + offW[ks] + ni * 32 * RB);
         wl[ni] = *reinterpret_cast<const f16x8*>(sbase + HALF_BYTES + offW[ks] + ni * 32 * RB);
       }
+      // three passes over the wave's tiles — the small cross terms first, so that they meet the running sum before the big
+      // term of this k step does — instead of three back-to-back MFMAs on one accumulator: consecutive MFMAs are independent
+      if constexpr (ABL != 4) {
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
-          cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], cor[mi][ni], 0, 0, 0);
-          cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], cor[mi][ni], 0, 0, 0);
-        }
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+      } else {  // (dev A/B: the dependent order)
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
+          }
+      }
     }
   }
 
-  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, cor, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
+  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
 }
 
 // The same GEMM with the operands staged through REGISTERS (global_load_dwordx4 -> VGPRs -> ds_write_b128) instead of the LDS-DMA.
@@ -566,13 +592,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3r_k(const __half* __restr
     offA[ks] = (wm * (BM / WM) + frow) * RB + phys * 16;
     offW[ks] = BM * RB + (wn * (BN / WN) + frow) * RB + phys * 16;
   }
-  f32x16 acc[TM][TN], cor[TM][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.f; cor[mi][ni][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int nk = K / BK;
   gload(0);
@@ -595,9 +621,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3r_k(const __half* __restr
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], acc[mi][ni], 0, 0, 0);
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], a[mi], acc[mi][ni], 0, 0, 0);
-        cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ni], a[mi], cor[mi][ni], 0, 0, 0);
-        cor[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ni], al[mi], cor[mi][ni], 0, 0, 0);
       }
   };
   for (int kt = 0; kt < nk; ++kt) {
@@ -610,13 +636,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3r_k(const __half* __restr
     }
     mfmas(sbase, 1);
   }
-  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, cor, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
+  x3_epilogue<BM, BN, WM, WN, TM, TN>(acc, e, m0, n0, wm, wn, frow, hi, smem, wave, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int TAG>
 static void launch_x3r(const GemmArgs& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu, g.out_scale > 0.f ? g.out_scale : 1.0f};
   constexpr int lds = 3 * 2 * (BM + BN) * 32 * 2;
   auto kern = gemm16x3r_k<BM, BN, WM, WN, TAG>;
   allow_big_lds((const void*)kern);
@@ -624,12 +650,12 @@ static void launch_x3r(const GemmArgs& g, hipStream_t st) {
                      (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, e);
 }
 
-template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG>
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0>
 static void launch_x3(const GemmArgs& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu, g.out_scale > 0.f ? g.out_scale : 1.0f};
   constexpr int lds = NSTAGE * 2 * (BM + BN) * BK * 2;
-  auto kern = gemm16x3_k<BM, BN, BK, NSTAGE, WM, WN, TAG>;
+  auto kern = gemm16x3_k<BM, BN, BK, NSTAGE, WM, WN, TAG, ABL>;
   allow_big_lds((const void*)kern);
   static const int grp = knob_int("LDM_X3_GRP", 0);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A, (const __half*)g.Alo,
@@ -639,7 +665,7 @@ static void launch_x3(const GemmArgs& g, hipStream_t st) {
 // dev: the production tile shape with an ablation (see gemm16x3_k)
 void launch_gemm16x3_abl(const GemmArgs& g, int abl, hipStream_t st) {
   const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 127) / 128;
-  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu};
+  Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu, g.out_scale > 0.f ? g.out_scale : 1.0f};
   constexpr int lds = 3 * 2 * (256 + 128) * 32 * 2;
   static const int grp = 0;
 #define LDM_X3_ABL(N_)                                                                                                   \
@@ -660,20 +686,25 @@ void launch_gemm16x3_abl(const GemmArgs& g, int abl, hipStream_t st) {
 // W / Wlo with >= ceil(N / 256) * 256 rows allocated (rows past M / N feed products that are never stored).
 // tag names the Linear class for rocprofv3 (0 qkv, 1 attn_out, 2 ffn1, 3 ffn2, 4 head).
 void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st) {
-  // 256 x 128 tiles on 8 waves (two per SIMD), 3-stage ring of 48-KiB stages: +14 % over 128 x 128 on 4 waves; a 4-stage
-  // ring, 128 x 256 tiles and column-grouped tile orders change nothing (profiles/r04_call6_*, r04_call7_*)
-  static const int cfg = knob_int("LDM_X3_CFG", 2);  // (dev: tile-shape A/B)
+  // 256 x 256 tiles on 8 waves (two per SIMD; each wave 128 x 64 = 8 accumulator tiles — possible since r04's one-accumulator
+  // numerics), 2-stage ring of 64-KiB stages; the vocabulary head (N = 155) keeps 256 x 128.  Same-box A/Bs
+  // (profiles/r04_call6_* ... r04_call19_*): 128 x 128 606 layouts/s -> 256 x 128 706 -> coalesced epilogue 745 -> one
+  // accumulator 754 -> 256 x 256 812; a 4-stage ring, 128 x 256, column-grouped tile orders, 128-byte operand rows (BK = 64),
+  // operands through registers and the order of the three MFMAs change nothing or lose.
+  static const int cfg = knob_int("LDM_X3_CFG", 8);  // (dev: tile-shape A/B)
   if (cfg == 0) { launch_x3<128, 128, 32, 3, 2, 2, 5>(g, st); return; }
   if (cfg == 1) { launch_x3<128, 128, 32, 4, 2, 2, 5>(g, st); return; }
+  if (cfg == 2) { launch_x3<256, 128, 32, 3, 4, 2, 5>(g, st); return; }
   if (cfg == 3) { launch_x3<128, 256, 32, 3, 2, 4, 5>(g, st); return; }
   if (cfg == 5 && g.K % 64 == 0) { launch_x3<128, 128, 64, 2, 2, 2, 5>(g, st); return; }
+  if (cfg == 9) { launch_x3<256, 256, 32, 2, 2, 4, 5, 4>(g, st); return; }   // the dependent MFMA order (A/B)
   if (cfg == 6) { launch_x3r<256, 128, 4, 2, 5>(g, st); return; }   // operands through registers
   if (cfg == 7) { launch_x3r<128, 128, 2, 2, 5>(g, st); return; }
   switch (tag) {
-    case 0: launch_x3<256, 128, 32, 3, 4, 2, 0>(g, st); return;
-    case 1: launch_x3<256, 128, 32, 3, 4, 2, 1>(g, st); return;
-    case 2: launch_x3<256, 128, 32, 3, 4, 2, 2>(g, st); return;
-    case 3: launch_x3<256, 128, 32, 3, 4, 2, 3>(g, st); return;
+    case 0: launch_x3<256, 256, 32, 2, 2, 4, 0>(g, st); return;
+    case 1: launch_x3<256, 256, 32, 2, 2, 4, 1>(g, st); return;
+    case 2: launch_x3<256, 256, 32, 2, 2, 4, 2>(g, st); return;
+    case 3: launch_x3<256, 256, 32, 2, 2, 4, 3>(g, st); return;
     default: launch_x3<256, 128, 32, 3, 4, 2, 4>(g, st); return;
   }
 }

@@ -16,7 +16,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-constexpr float kLoScale = 2048.0f;  // split mode: lo = (x - fp16(x)) * 2^11 keeps lo in fp16's normal range
+constexpr float kLoScale = kSplitLoScale;  // split mode: lo = (x - fp16(x)) * kSplitLoScale (ldm_kernels.h)
 
 // NV = float4 per lane (D <= 256*NV)
 template <int NV>
@@ -124,22 +124,22 @@ void launch_layernorm(const LnArgs& a, hipStream_t st) {
 
 // ------------------------------------------------------------------ casts
 __global__ __launch_bounds__(256) void cast_f32_f16(const float* __restrict__ src, __half* __restrict__ dst,
-                                                    __half* __restrict__ dstlo, int64_t n) {
+                                                    __half* __restrict__ dstlo, int64_t n, float scale) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n; i += stride) {
-    const float x = src[i];
+    const float x = src[i] * scale;  // (scale: an exact power of two — the split mode's weight pre-scale — or 1)
     const __half h = __float2half_rn(x);
     dst[i] = h;
     if (dstlo) dstlo[i] = __float2half_rn((x - __half2float(h)) * kLoScale);
   }
 }
 
-void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st) {
+void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st, float scale) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(cast_f32_f16, dim3(blocks), dim3(256), 0, st, src, dst, dstlo, n);
+  hipLaunchKernelGGL(cast_f32_f16, dim3(blocks), dim3(256), 0, st, src, dst, dstlo, n, scale);
 }
 
 // ------------------------------------------------------------------ load-time tables

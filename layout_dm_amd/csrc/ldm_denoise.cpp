@@ -137,7 +137,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.A = f16 ? (const void*)h->a16 : (const void*)h->P;
       g.Alo = h->a16lo;
       g.W = f16 ? (const void*)w.w_in16 : (const void*)w.w_in;
-      g.Wlo = w.w_in16lo;
+      g.Wlo = w.w_in16lo; g.out_scale = w.s_in;
       g.bias = w.b_in;
       g.C32 = (prec == LDM_PREC_FAST_F16) ? nullptr : h->qkv32;
       g.C16 = (prec == LDM_PREC_FAST_F16) ? h->qkv16 : nullptr;
@@ -163,7 +163,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.A = f16 ? (const void*)h->att16 : (const void*)h->att32;
       g.Alo = h->att16lo;
       g.W = f16 ? (const void*)w.w_out16 : (const void*)w.w_out;
-      g.Wlo = w.w_out16lo;
+      g.Wlo = w.w_out16lo; g.out_scale = w.s_out;
       g.bias = w.b_out;
       g.res = h->P; g.ldres = D;
       g.C32 = h->Q; g.ldc32 = D;
@@ -186,7 +186,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
       g.Alo = h->h16lo;
       g.W = f16 ? (const void*)w.w1_16 : (const void*)w.w1;
-      g.Wlo = w.w1_16lo;
+      g.Wlo = w.w1_16lo; g.out_scale = w.s1;
       g.bias = w.b1; g.relu = 1;
       g.C32 = f16 ? nullptr : h->hid32; g.ldc32 = F;
       g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
@@ -199,7 +199,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.A = f16 ? (const void*)h->hid16 : (const void*)h->hid32;
       g.Alo = h->hid16lo;
       g.W = f16 ? (const void*)w.w2_16 : (const void*)w.w2;
-      g.Wlo = w.w2_16lo;
+      g.Wlo = w.w2_16lo; g.out_scale = w.s2;
       g.bias = w.b2;
       g.res = h->Q; g.ldres = D;
       g.C32 = h->P; g.ldc32 = D;
@@ -223,7 +223,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
     g.Alo = h->h16lo;
     g.W = f16 ? (const void*)h->head_w16 : (const void*)h->head_w;
-    g.Wlo = h->head_w16lo;
+    g.Wlo = h->head_w16lo; g.out_scale = h->head_s;
     g.C32 = h->logits; g.ldc32 = h->Cp;
     g.M = M; g.N = C; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
     ldm_handle::Scope sc(h, st, "gemm_head", gemm_flops(M, C, D), (double)M * D * esz + (double)M * C * 4);

@@ -72,6 +72,7 @@ struct Raw {  // a checkpoint tensor as uploaded (fp32, device)
 struct LayerW {
   const float *w_in, *b_in, *w_out, *b_out, *w1, *b1, *w2, *b2, *g2, *be2;  // fp32 views
   __half *w_in16, *w_in16lo, *w_out16, *w_out16lo, *w1_16, *w1_16lo, *w2_16, *w2_16lo;
+  float s_in = 1.f, s_out = 1.f, s1 = 1.f, s2 = 1.f;  // split mode: 2^-k of each tensor's power-of-two pre-scale (GemmArgs.out_scale)
 };
 
 struct ProfEntry {
@@ -138,6 +139,7 @@ struct ldm_handle {
   float *pos = nullptr, *adaln = nullptr, *sched = nullptr;
   const float *emb = nullptr, *head_g = nullptr, *head_b = nullptr, *head_w = nullptr;
   __half *head_w16 = nullptr, *head_w16lo = nullptr;
+  float head_s = 1.f;
   std::vector<void*> owned;  // everything hipMalloc'ed by the handle
   // workspace of ONE chunk.  These are the pointers the launch sequences use; with several lanes (below) they are
   // switched to the lane's own buffers by activate() before its launches are recorded / issued.

@@ -33,6 +33,14 @@ inline void allow_big_lds(const void* kern) {
 }
 
 constexpr float kLogEps = -69.07755278982137f;  // log(1e-30): categorical_diffusion/util.py:8
+// Split mode (LDM_PREC_SPLIT_F16): x = hi + lo / kSplitLoScale with hi = fp16(x), lo = fp16((x - hi) * kSplitLoScale).
+// r04: 1 (was 2^11).  An unscaled lo lets the three products A_hi W_hi + A_lo W_hi + A_hi W_lo share ONE accumulator (the
+// 2^11 convention needed a second one for the cross terms: half the accumulator registers, i.e. half the tile).  fp16 keeps
+// denormals, so lo carries an absolute error <= 2^-25: negligible for operands of magnitude ~1 — LayerNorm outputs,
+// attention outputs, the FFN's hidden activations — and the WEIGHTS are brought there by an exact power-of-two pre-scale
+// per tensor (ldm_weights.cpp make_w16), undone in the GEMM's epilogue (GemmArgs.out_scale).  Logits error against the
+// float64 restatement, CPU emulation on three weight distributions: 6.0e-7 / 1.1e-6 / 1.0e-4 — the fp32 path's own.
+constexpr float kSplitLoScale = 1.0f;
 constexpr int kMaxAttr = 8;
 
 // ---- row kernels (kernels_norm.hip) -----------------------------------------------------
@@ -48,7 +56,7 @@ struct LnArgs {
   const float* p1;        // shift (ada) or beta    [D]
   float* y32;             // [M, D] or nullptr
   __half* y16;            // [M, ld16] or nullptr   (GEMM A operand, fp16 modes)
-  __half* y16lo;          // [M, ld16] or nullptr   (split mode: residual x - fp16(x), scaled by 2^11)
+  __half* y16lo;          // [M, ld16] or nullptr   (split mode: residual x - fp16(x), times kSplitLoScale)
   float2* stats_out;      // [M] (mean, rstd) or nullptr   (deferred normalisation, fast mode)
   int M, D, S, ld16, ada;
   int raw;                // 1: y32 receives the UN-normalised x (embedding only), stats_out the statistics
@@ -69,6 +77,7 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldres, ldc32, ldc16;
   int relu;
   int precision;  // LDM_PREC_*
+  float out_scale;  // split mode: 2^-k of the weight tensor's pre-scale 2^k (0 = 1)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
@@ -248,7 +257,8 @@ void launch_prdc_counts(const float* Drf, int n, int m, const float* r2_real, co
 
 // ---- small utilities ---------------------------------------------------------------------
 void launch_delay_us(int us, hipStream_t st);  // one wave spinning for `us` microseconds (lane phase offset)
-void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st);
+// dst = fp16(scale * src) (+ dstlo = the split-mode lo part)
+void launch_f32_to_f16(const float* src, __half* dst, __half* dstlo, int64_t n, hipStream_t st, float scale = 1.0f);
 // AdaLN table: out[t][l][2D] = Linear(SiLU(Emb[t])) (transformer_utils.py:67-69,80)
 void launch_adaln_table(const float* emb /*[T,D]*/, const float* w /*[2D,D]*/, const float* b /*[2D]*/,
                         float* out /*[T, L, 2D] at layer offset*/, int T, int D, int L, int layer, hipStream_t st);

@@ -53,20 +53,32 @@ static int need(ldm_handle* h, const std::string& key, std::initializer_list<int
 }
 
 // fp16 (and split-lo) copy of a [N,K] weight with the K axis zero-padded to Kp
-static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half** hi, __half** lo) {
+// out_scale (split mode): the weights are multiplied by the exact power of two 2^k that brings max |w| into [1, 2) before the hi / lo
+// split — lo is stored unscaled (kSplitLoScale = 1) and fp16's denormal spacing 2^-24 must be small against the weights — and
+// *out_scale = 2^-k goes to the GEMM's epilogue.
+static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half** hi, __half** lo, float* out_scale = nullptr) {
   const bool split = h->cfg.precision == LDM_PREC_SPLIT_F16;
+  float scale = 1.0f;
+  if (split) {
+    std::vector<float> host((size_t)N * K);
+    HIP_OK(h, hipMemcpy(host.data(), w, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (float x : host) mx = std::max(mx, std::fabs(x));
+    if (mx > 0.f && std::isfinite(mx)) scale = std::ldexp(1.0f, -(int)std::floor(std::log2(mx)));
+  }
+  if (out_scale) *out_scale = 1.0f / scale;
   // (rows padded with zeros to whole 128-row tiles: the LDS-DMA GEMMs load W without bounds checks)
   const size_t Nt = (size_t)round_up(N, 256);
   int rc = h->dalloc(hi, Nt * Kp);
   if (rc) return rc;
   if (split && (rc = h->dalloc(lo, Nt * Kp))) return rc;
   if (K == Kp) {
-    launch_f32_to_f16(w, *hi, split ? *lo : nullptr, (int64_t)N * K, 0);
+    launch_f32_to_f16(w, *hi, split ? *lo : nullptr, (int64_t)N * K, 0, scale);
   } else {
     __half *thi = nullptr, *tlo = nullptr;
     if ((rc = h->dalloc(&thi, (size_t)N * K))) return rc;
     if (split && (rc = h->dalloc(&tlo, (size_t)N * K))) return rc;
-    launch_f32_to_f16(w, thi, tlo, (int64_t)N * K, 0);
+    launch_f32_to_f16(w, thi, tlo, (int64_t)N * K, 0, scale);
     HIP_OK(h, hipMemcpy2DAsync(*hi, (size_t)Kp * 2, thi, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
     if (split)
       HIP_OK(h, hipMemcpy2DAsync(*lo, (size_t)Kp * 2, tlo, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
@@ -287,16 +299,16 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
     if ((rc = need(h, b + "norm2.bias", {D}, &w.be2))) return rc;
     launch_adaln_table(emb_t, lin_w, lin_b, h->adaln, T, D, L, i, 0);
     if (f16 && h->cfg.precision != LDM_PREC_FAST_F16) {
-      if ((rc = make_w16(h, w.w_in, 3 * D, D, h->Dp, &w.w_in16, &w.w_in16lo))) return rc;
-      if ((rc = make_w16(h, w.w_out, D, D, h->Dp, &w.w_out16, &w.w_out16lo))) return rc;
-      if ((rc = make_w16(h, w.w1, F, D, h->Dp, &w.w1_16, &w.w1_16lo))) return rc;
-      if ((rc = make_w16(h, w.w2, D, F, h->Fp, &w.w2_16, &w.w2_16lo))) return rc;
+      if ((rc = make_w16(h, w.w_in, 3 * D, D, h->Dp, &w.w_in16, &w.w_in16lo, &w.s_in))) return rc;
+      if ((rc = make_w16(h, w.w_out, D, D, h->Dp, &w.w_out16, &w.w_out16lo, &w.s_out))) return rc;
+      if ((rc = make_w16(h, w.w1, F, D, h->Dp, &w.w1_16, &w.w1_16lo, &w.s1))) return rc;
+      if ((rc = make_w16(h, w.w2, D, F, h->Fp, &w.w2_16, &w.w2_16lo, &w.s2))) return rc;
     }
   }
   if (h->cfg.precision == LDM_PREC_FAST_F16) {
     if ((rc = build_fast_weights(h))) return rc;
     if ((rc = build_loop_tables(h))) return rc;
-  } else if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo))) {
+  } else if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo, &h->head_s))) {
     return rc;
   }
   // schedule buffers are taken from the checkpoint, not recomputed

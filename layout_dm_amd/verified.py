@@ -101,12 +101,16 @@ class VerifiedGreedy:
         return c
 
     @staticmethod
+    def _refuse_relation(cond: Optional[dict]):
+        if cond and cond.get("type") == "relation":
+            raise NotImplementedError("fast_verified: cond=relation has no near-tie report (its draw follows an SGD on the "
+                                      "log-probabilities); decode it with the reference-precision engine "
+                                      "(relation.sample_with_relation does)")
+
+    @staticmethod
     def _sub(cond: Optional[dict], idx: torch.Tensor, B: int) -> Optional[dict]:
         if not cond:
             return None
-        if cond.get("type") == "relation":
-            raise NotImplementedError("fast_verified: cond=relation has no near-tie report (its draw follows an SGD on the "
-                                      "log-probabilities); decode it with the exact engine")
         out = {}
         for k, v in cond.items():
             if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B:
@@ -126,6 +130,7 @@ class VerifiedGreedy:
     def sample_step(self, tokens: torch.Tensor, t_model: int, t_post: Optional[int] = None, cond: Optional[dict] = None,
                     step: int = 0) -> torch.Tensor:
         """One greedy reverse step (_sample_single_step, base.py:205-291): fast everywhere, exact on the marked layouts."""
+        self._refuse_relation(cond)
         f = self.fast
         tokens = f._tok(tokens)
         B = tokens.shape[0]
@@ -145,6 +150,7 @@ class VerifiedGreedy:
     def sample_loop(self, tokens: torch.Tensor, t_model: Sequence[int], t_post: Sequence[int], cond: Optional[dict] = None,
                     intermediates: bool = False):
         """The greedy T-step loop (base.py:293-371), in place on `tokens` (B,S) int32 cuda -> (tokens, intermediates|None)."""
+        self._refuse_relation(cond)
         f, e = self.fast, self.exact
         tokens = f._tok(tokens)
         B, n, S = tokens.shape[0], len(t_model), f.S
