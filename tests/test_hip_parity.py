@@ -103,7 +103,7 @@ def test_stack_kernel_agrees_with_generic_kernels(cuda, monkeypatch):
     assert _rel(outs["6"], outs["0"]) <= 5e-4
 
 
-@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
 @pytest.mark.parametrize("shape", ["short_sequence", "mid_sequence", "long_sequence", "small_backbone"])
 def test_denoiser_other_geometries_take_the_generic_kernels(cuda, shape, precision):
     """The layout-resident kernels are built for the reference's one backbone (medium shrunk by 29/32: d_model 464,
@@ -139,7 +139,7 @@ def test_denoiser_other_geometries_take_the_generic_kernels(cuda, shape, precisi
     assert _rel(out, R.denoiser_logits(W, spec, tokens, t)) <= LOGIT_REL_TOL[precision]
 
 
-@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
 def test_denoiser_ragged_batch_and_chunks(cuda, precision):
     """B not a multiple of the chunk / of the 128-row GEMM tile; rows must not interact."""
     spec, W = weights("rico25")
@@ -443,6 +443,38 @@ def test_full_batch_512_properties(cuda):
     for a in range(spec.n_attr):
         ids = torch.as_tensor(spec.full_ids(a))[:-1]
         assert torch.isin(f[:, a::spec.n_attr], ids).all()
+
+
+def test_split_mode_loop_properties(cuda):
+    """The split mode (fp16 x 3 GEMMs on 256 x 256 tiles, r04) on a batch that does not fill its last chunk or its last
+    row tile (B = 300: chunks of 256 + 44 layouts = 32 000 + 5 500 rows): hipGraph replay == eager launches, the tokens of
+    layout i do not depend on how the batch is cut (rows past M feed products that are never stored), determinism, and a
+    teacher-forced greedy step == the exact engine's at B = 300."""
+    spec = SP.RICO25
+    B = 300
+    e = engine("rico25", "split", max_batch=512)
+    x = engine("rico25", "exact", max_batch=512)
+    steps = R.timestep_list(spec.n_step, 20)
+    tpost, prev = [], spec.n_step
+    for t in steps:  # base.py:227-235
+        skip = prev - t - 1
+        tpost.append(t - skip if (skip > 0 and t > skip) else t)
+        prev = t
+    cfg = {"name": "random", "temperature": 1.0}
+    mk = lambda n: torch.full((n, spec.seq_len), spec.mask_id, dtype=torch.int32, device=cuda)
+    full, inter = e.sample_loop(mk(B), steps, tpost, cfg, seed=21, first_layout=0, use_graph=True, intermediates=True)
+    full, inter = full.clone(), inter.clone()
+    eager = e.sample_loop(mk(B), steps, tpost, cfg, seed=21, first_layout=0, use_graph=False)[0]
+    assert torch.equal(full, eager)
+    again = e.sample_loop(mk(B), steps, tpost, cfg, seed=21, first_layout=0, use_graph=True)[0]
+    assert torch.equal(full, again)
+    lo = e.sample_loop(mk(100), steps, tpost, cfg, seed=21, first_layout=0, use_graph=False)[0]
+    hi = e.sample_loop(mk(200), steps, tpost, cfg, seed=21, first_layout=100, use_graph=False)[0]
+    assert torch.equal(full, torch.cat([lo, hi]))
+    assert (full != spec.mask_id).all()
+    state = inter[9]
+    assert torch.equal(e.sample_step(state, steps[10], {"name": "deterministic"}, t_post=tpost[10], step=10),
+                       x.sample_step(state, steps[10], {"name": "deterministic"}, t_post=tpost[10], step=10))
 
 
 @pytest.mark.parametrize("B,sampler", [(1, "random"), (257, "random"), (300, "top_p"), (511, "gumbel")])
