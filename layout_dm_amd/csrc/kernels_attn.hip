@@ -426,6 +426,12 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
   static const std::string attn32_knob = knob_env("LDM_ATTN32") ? knob_env("LDM_ATTN32") : "";
   static const bool use_rows = attn32_knob == "rows";
   static const bool use_staged = attn32_knob == "staged";  // A/B timing
+  // split mode: the fp16 x 3 kernel (LDM_ATTN32=direct keeps the fp32-MFMA kernel for A/B timing)
+  if (!a.in_f16 && a.out16 && a.out16lo && !a.out32 && attn32_knob.empty() &&
+      attention16x3_supported(a.S, a.dh, a.D, a.ld, a.ldo16)) {
+    launch_attention16x3((const float*)a.qkv, a.out16, a.out16lo, a.B, a.S, a.H, a.dh, a.D, a.ld, a.ldo16, st);
+    return;
+  }
   if (!a.in_f16 && !use_rows && !use_staged && a.S <= 128 && a.S > 96 && a.dh == 58 && a.D % 2 == 0 && a.ld % 2 == 0 &&
       a.ldo32 % 2 == 0 && a.ldo16 % 2 == 0) {
     constexpr int DH2 = 29;

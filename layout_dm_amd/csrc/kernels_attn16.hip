@@ -177,6 +177,234 @@ __global__ __launch_bounds__(256) void attn_mfma_k(const __half* __restrict__ qk
   }
 }
 
+// ---- split mode (r04): the same (layout, head) problem at reference precision on the fp16 pipe ------------------------
+// qkv arrives as fp32 (the split QKV GEMM's output); every operand is split into hi = fp16(x), lo = fp16(x - hi) on its way
+// into LDS / the operand registers and every product is three MFMAs into one accumulator (lo·hi, hi·lo, hi·hi; the dropped
+// lo·lo term is 2^-22 relative) — 96 MFMAs of 8 passes per wave instead of attn32_direct_k's 244 of 16 (3 072 against
+// 15 600 issue cycles), which leaves the kernel on its memory bound (qkv in, hi ‖ lo out: 237 MB per 256 layouts).
+//   K: float2 loads -> hi / lo images in the XOR-swizzled 128-B-row layout of attn_mfma_k (32 KB);
+//   Q: straight from global into fragment registers (lane = (query, k-group): four 32-byte runs of its own row);
+//   V: loaded into registers up front, written TRANSPOSED ([d][key], hi / lo) over the K images once the scores are done;
+//   P: softmax in fp32 (expf, as the exact kernel), scaled by 2^10 before the split so that the lo half of a small
+//      probability is not a denormal (absolute error 2^-35 of the row maximum instead of 2^-25); 1 / (2^10 sum) at the end;
+//   O: hi / lo through the V region, query-major, then whole 116-byte head rows to memory (as attn32_direct_k).
+// LDS 33 792 B, <= 170 VGPRs: three workgroups per CU.
+template <int DH>
+__global__ __launch_bounds__(256, 3) void attn16x3_k(const float* __restrict__ qkv, __half* __restrict__ out_hi,
+                                                    __half* __restrict__ out_lo, int S, int H, int D, int ld, int ldo,
+                                                    float scale) {
+  static_assert(DH % 2 == 0 && DH <= 64 && DH > 56, "one float2 grid of 32 columns per head row");
+  constexpr int C2 = DH / 2;
+  constexpr int O_LD = 66;  // halfs per O row (33 dwords: odd)
+  extern __shared__ __attribute__((aligned(16))) __half sm3[];
+  __half* Kh = sm3;
+  __half* Kl = sm3 + 128 * 64;
+  __half* Vh = sm3;  // after the scores
+  __half* Vl = sm3 + 64 * VT_LD;
+  __half* Oh = sm3;  // after P V
+  __half* Ol = sm3 + 128 * O_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t row0 = (size_t)b * S;
+  const float* qb = qkv + row0 * ld + h * DH;
+  const float* kb = qb + D;
+  const float* vb = qb + 2 * D;
+  const int j = lane & 31, hi = lane >> 5;
+  const int q = wave * 32 + j;
+  // (key, float2 column) of a head matrix, 0 outside [0, S) x [0, C2): the load itself goes to a clamped, valid address
+  auto ldz = [&](const float* base, int key, int c) {
+    const bool ok = key < S && c < C2;
+    const float2 x = *reinterpret_cast<const float2*>(base + (size_t)(key < S ? key : S - 1) * ld + 2 * (c < C2 ? c : C2 - 1));
+    return make_float2(ok ? x.x : 0.f, ok ? x.y : 0.f);
+  };
+  auto split2 = [](float2 x, __half2& hh, __half2& ll) {
+    const __half h0 = __float2half_rn(x.x), h1 = __float2half_rn(x.y);
+    hh = __halves2half2(h0, h1);
+    ll = __halves2half2(__float2half_rn(x.x - __half2float(h0)), __float2half_rn(x.y - __half2float(h1)));
+  };
+  // every global load of the problem is issued before the first use: K (for LDS), Q (fragments), V (held until the
+  // scores are done)
+  float2 rk[16], rv[16], rq[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + 256 * i, key = idx >> 5, c = idx & 31;
+    rk[i] = ldz(kb, key, c);
+  }
+  {
+    const float* qr = qb + (size_t)(q < S ? q : S - 1) * ld;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = (ks * 2 + hi) * 8 + 2 * e;
+        const float2 x = *reinterpret_cast<const float2*>(qr + (col < DH ? col : DH - 2));
+        rq[ks][e] = make_float2(col < DH ? x.x : 0.f, col < DH ? x.y : 0.f);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + 256 * i, key = idx >> 5, c = idx & 31;
+    rv[i] = ldz(vb, key, c);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + 256 * i, key = idx >> 5, c = idx & 31;
+    __half2 hh, ll;
+    split2(rk[i], hh, ll);
+    const int so = key * 64 + ((((2 * c) >> 3) ^ ((key >> 1) & 7)) << 3) + ((2 * c) & 7);
+    *reinterpret_cast<__half2*>(&Kh[so]) = hh;
+    *reinterpret_cast<__half2*>(&Kl[so]) = ll;
+  }
+  f16x8 qh[4], ql[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h0 = (_Float16)rq[ks][e].x, h1 = (_Float16)rq[ks][e].y;
+      qh[ks][2 * e] = h0;
+      qh[ks][2 * e + 1] = h1;
+      ql[ks][2 * e] = (_Float16)(rq[ks][e].x - (float)h0);
+      ql[ks][2 * e + 1] = (_Float16)(rq[ks][e].y - (float)h1);
+    }
+  const int ksw = (j >> 1) & 7;
+  __syncthreads();
+  // ---- scores^T (unscaled q·k): 4 key tiles x 4 k-steps x 3 products
+  f32x16 sc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = (kt * 32 + j) * 64 + (((ks * 2 + hi) ^ ksw) << 3);
+      const f16x8 kh = *reinterpret_cast<const f16x8*>(&Kh[off]);
+      const f16x8 kl = *reinterpret_cast<const f16x8*>(&Kl[off]);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc[kt], 0, 0, 0);
+      sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sc[kt], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with K: the region takes V^T
+  {
+    unsigned short* vh = reinterpret_cast<unsigned short*>(Vh);
+    unsigned short* vl = reinterpret_cast<unsigned short*>(Vl);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int idx = tid + 256 * i, key = idx >> 5, c = idx & 31;
+      __half2 hh, ll;
+      split2(rv[i], hh, ll);
+      const unsigned uh = *reinterpret_cast<const unsigned*>(&hh), ul = *reinterpret_cast<const unsigned*>(&ll);
+      vh[(2 * c) * VT_LD + key] = (unsigned short)(uh & 0xffffu);
+      vh[(2 * c + 1) * VT_LD + key] = (unsigned short)(uh >> 16);
+      vl[(2 * c) * VT_LD + key] = (unsigned short)(ul & 0xffffu);
+      vl[(2 * c + 1) * VT_LD + key] = (unsigned short)(ul >> 16);
+    }
+  }
+  // ---- softmax over the 128 keys of query j (64 here, 64 in lane^32), fp32
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (S < (kt + 1) * 32) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= S) sc[kt][r] = -INFINITY;
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf((sc[kt][r] - mx) * scale) * 1024.0f;
+      sc[kt][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  __syncthreads();  // V^T complete
+  // ---- O^T = V^T · P^T: 2 d tiles x 8 k-steps x 3 products (k-slot e of group hi <-> accumulator register 8 hf + e)
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      f16x8 ph, pl;
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) {
+        const float p = sc[kt][hf * 8 + e2];
+        const _Float16 p16 = (_Float16)p;
+        ph[e2] = p16;
+        pl[e2] = (_Float16)(p - (float)p16);
+      }
+      const int k0 = kt * 32 + hf * 16 + hi * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int vo = (dt * 32 + j) * VT_LD + k0;
+        const f16x4 h0 = *reinterpret_cast<const f16x4*>(&Vh[vo]), h1 = *reinterpret_cast<const f16x4*>(&Vh[vo + 8]);
+        const f16x4 l0 = *reinterpret_cast<const f16x4*>(&Vl[vo]), l1 = *reinterpret_cast<const f16x4*>(&Vl[vo + 8]);
+        f16x8 vh8, vl8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vh8[e] = h0[e]; vh8[4 + e] = h1[e];
+          vl8[e] = l0[e]; vl8[4 + e] = l1[e];
+        }
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // every wave is done with V^T: the region takes O (each wave its own 32 rows)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq4 = 0; rq4 < 4; ++rq4) {
+      const int d = dt * 32 + rq4 * 8 + hi * 4;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        __half2 hh, ll;
+        split2(make_float2(o[dt][rq4 * 4 + 2 * e] * inv, o[dt][rq4 * 4 + 2 * e + 1] * inv), hh, ll);
+        *reinterpret_cast<__half2*>(&Oh[q * O_LD + d + 2 * e]) = hh;
+        *reinterpret_cast<__half2*>(&Ol[q * O_LD + d + 2 * e]) = ll;
+      }
+    }
+  __syncthreads();
+  constexpr int NO = (32 * C2 + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < NO; ++i) {
+    const int idx = lane + 64 * i, qr = wave * 32 + idx / C2, c = idx % C2;
+    if (idx < 32 * C2 && qr < S) {
+      const size_t oo = (row0 + qr) * ldo + h * DH + 2 * c;
+      *reinterpret_cast<__half2*>(out_hi + oo) = *reinterpret_cast<const __half2*>(&Oh[qr * O_LD + 2 * c]);
+      *reinterpret_cast<__half2*>(out_lo + oo) = *reinterpret_cast<const __half2*>(&Ol[qr * O_LD + 2 * c]);
+    }
+  }
+}
+
+bool attention16x3_supported(int S, int dh, int D, int ld, int ldo) {
+  return S >= 1 && S <= 128 && dh == 58 && D % 2 == 0 && ld % 2 == 0 && ldo % 2 == 0;
+}
+
+void launch_attention16x3(const float* qkv, __half* out_hi, __half* out_lo, int B, int S, int H, int dh, int D, int ld,
+                          int ldo, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * 64 * VT_LD * sizeof(__half);
+  static_assert(lds >= (size_t)2 * 128 * 64 * sizeof(__half) && lds >= (size_t)2 * 128 * 66 * sizeof(__half), "one region, three uses");
+  hipLaunchKernelGGL((attn16x3_k<58>), dim3(B * H), dim3(256), lds, st, qkv, out_hi, out_lo, S, H, D, ld, ldo,
+                     1.0f / sqrtf((float)dh));
+}
+
 void launch_attention16(const __half* qkv, __half* out, int B, int S, int H, int dh, int ldq, int ldo, hipStream_t st) {
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)dh);
   static const int abl = knob_int("LDM_ATTN_ABL", 0);  // (dev mode only: ldm_knobs.h)

@@ -178,6 +178,10 @@ struct AttnArgs {
   int B, S, H, dh, D, ld, ldo32, ldo16;
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
+// split mode, the reference's head geometry (kernels_attn16.hip): fp32 qkv in, fp16 x 3 MFMAs, hi / lo fp16 out
+bool attention16x3_supported(int S, int dh, int D, int ld, int ldo);
+void launch_attention16x3(const float* qkv, __half* out_hi, __half* out_lo, int B, int S, int H, int dh, int D, int ld,
+                          int ldo, hipStream_t st);
 
 // ---- posterior + categorical draw (kernels_post.hip) ------------------------------------
 struct VocabTables {  // built on the host from the tokenizer geometry (layout_tokenizer.py:429-467)

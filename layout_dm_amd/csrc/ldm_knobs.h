@@ -23,7 +23,7 @@ inline const std::map<std::string, const char*>& knob_table() {
       {"LDM_FUSED_ATTN", "0 = generic tiled kernels instead of the layout-resident stack kernel"},
       {"LDM_STACK_LOOP", "0 = per-step launches instead of the one-launch reverse loop"},
       {"LDM_POST_WAVE", "wavefront-per-token step tail instead of the 16-lane groups"},
-      {"LDM_ATTN32", "rows|staged: older fp32 attention kernels"},
+      {"LDM_ATTN32", "rows|staged: older fp32 attention kernels; direct: the fp32-MFMA kernel in the split mode too"},
       {"LDM_ATTN_ABL", "fp16 attention timing ablations (WRONG NUMERICS)"},
       {"LDM_ATTN_TM", "stack kernel phase-timer instantiation"},
       {"LDM_GEMM32_WIDE", "160-wide fp32 GEMM tiles for N = 464"},
