@@ -357,7 +357,9 @@ __device__ __forceinline__ void x3_epilogue(const f32x16 (&acc)[TM][TN], const E
 // ABL (dev, tools/gemm_x3_probe.py): 0 the kernel; 1 no fragment reads / MFMAs (operand fills + barriers only); 2 no fills in the
 // steady state (fragment reads + MFMAs + barriers on whatever the prologue left in LDS); 3 MFMAs on constant fragments (fills +
 // MFMAs, no fragment reads).  Ablations produce wrong numbers by design and are reachable only through ldm_dev_bench_gemm_x3.
-template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0>
+// HINT (dev A/B, LDM_X3_CFG 10-12): bit 0 = the ACTIVATION fills carry the non-temporal policy (aux = 2: an operand that two column
+// tiles read and nobody else, straight from HBM / the Infinity Cache — FFN2's hidden activations, the out-projection's input).
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0, int HINT = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restrict__ A, const __half* __restrict__ Alo,
                                                            const __half* __restrict__ W, const __half* __restrict__ Wlo,
                                                            int lda, int ldw, int K, int tiles_n, int grp, Epi16x e) {
@@ -371,6 +373,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
   constexpr int HALF_BYTES = (BM + BN) * RB;
   constexpr int STAGE_BYTES = 2 * HALF_BYTES;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // 32x32 accumulators per wave
+  constexpr int JA = BM / (NW * RPI);  // instruction slots j < JA of every wave fill activation rows, the others weight rows
+  static_assert(HINT == 0 || BM % (NW * RPI) == 0, "operand of a fill slot must not depend on the wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -415,8 +419,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm16x3_k(const __half* __restri
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
       const int inst = wave + j * NW;
-      __builtin_amdgcn_global_load_lds((gas_ptr)(src_hi[j] + (size_t)kt * BK), (las_ptr)(sbase + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gas_ptr)(src_lo[j] + (size_t)kt * BK), (las_ptr)(sbase + HALF_BYTES + inst * 1024), 16, 0, 0);
+      if ((HINT & 1) && j < JA) {
+        __builtin_amdgcn_global_load_lds((gas_ptr)(src_hi[j] + (size_t)kt * BK), (las_ptr)(sbase + inst * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((gas_ptr)(src_lo[j] + (size_t)kt * BK), (las_ptr)(sbase + HALF_BYTES + inst * 1024), 16, 0, 2);
+      } else {
+        __builtin_amdgcn_global_load_lds((gas_ptr)(src_hi[j] + (size_t)kt * BK), (las_ptr)(sbase + inst * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gas_ptr)(src_lo[j] + (size_t)kt * BK), (las_ptr)(sbase + HALF_BYTES + inst * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -650,12 +659,12 @@ static void launch_x3r(const GemmArgs& g, hipStream_t st) {
                      (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, e);
 }
 
-template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0>
+template <int BM, int BN, int BK, int NSTAGE, int WM, int WN, int TAG, int ABL = 0, int HINT = 0>
 static void launch_x3(const GemmArgs& g, hipStream_t st) {
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu, g.out_scale > 0.f ? g.out_scale : 1.0f};
   constexpr int lds = NSTAGE * 2 * (BM + BN) * BK * 2;
-  auto kern = gemm16x3_k<BM, BN, BK, NSTAGE, WM, WN, TAG, ABL>;
+  auto kern = gemm16x3_k<BM, BN, BK, NSTAGE, WM, WN, TAG, ABL, HINT>;
   allow_big_lds((const void*)kern);
   static const int grp = knob_int("LDM_X3_GRP", 0);
   hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), lds, st, (const __half*)g.A, (const __half*)g.Alo,
@@ -664,13 +673,13 @@ static void launch_x3(const GemmArgs& g, hipStream_t st) {
 
 // dev: the production tile shape with an ablation (see gemm16x3_k)
 void launch_gemm16x3_abl(const GemmArgs& g, int abl, hipStream_t st) {
-  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 127) / 128;
+  const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
   Epi16x e{g.bias, g.res, g.C32, g.C16, g.C16lo, g.M, g.N, g.ldres, g.ldc32, g.ldc16, g.relu, g.out_scale > 0.f ? g.out_scale : 1.0f};
-  constexpr int lds = 3 * 2 * (256 + 128) * 32 * 2;
+  constexpr int lds = 2 * 2 * (256 + 256) * 32 * 2;
   static const int grp = 0;
 #define LDM_X3_ABL(N_)                                                                                                   \
   {                                                                                                                      \
-    auto kern = gemm16x3_k<256, 128, 32, 3, 4, 2, 6, N_>;                                                                \
+    auto kern = gemm16x3_k<256, 256, 32, 2, 2, 4, 6, N_>;                                                                \
     allow_big_lds((const void*)kern);                                                                                    \
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, st, (const __half*)g.A, (const __half*)g.Alo,      \
                        (const __half*)g.W, (const __half*)g.Wlo, g.lda, g.ldw, g.K, tiles_n, grp, e);                    \
@@ -700,6 +709,15 @@ void launch_gemm16x3(const GemmArgs& g, int tag, hipStream_t st) {
   if (cfg == 9) { launch_x3<256, 256, 32, 2, 2, 4, 5, 4>(g, st); return; }   // the dependent MFMA order (A/B)
   if (cfg == 6) { launch_x3r<256, 128, 4, 2, 5>(g, st); return; }   // operands through registers
   if (cfg == 7) { launch_x3r<128, 128, 2, 2, 5>(g, st); return; }
+  if (cfg == 10 || cfg == 11) {  // non-temporal activation fills: the two-reader operands (10), every GEMM (11)
+    switch (tag) {
+      case 0: if (cfg == 11) { launch_x3<256, 256, 32, 2, 2, 4, 0, 0, 1>(g, st); return; } break;
+      case 1: launch_x3<256, 256, 32, 2, 2, 4, 1, 0, 1>(g, st); return;
+      case 2: if (cfg == 11) { launch_x3<256, 256, 32, 2, 2, 4, 2, 0, 1>(g, st); return; } break;
+      case 3: launch_x3<256, 256, 32, 2, 2, 4, 3, 0, 1>(g, st); return;
+      default: break;
+    }
+  }
   switch (tag) {
     case 0: launch_x3<256, 256, 32, 2, 2, 4, 0>(g, st); return;
     case 1: launch_x3<256, 256, 32, 2, 2, 4, 1>(g, st); return;
