@@ -578,7 +578,17 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       // c - 1 on stage c = W1 tile c | W2 slab c - 1 (ldm_pack::pack_ffn_image_pipelined); n_chunks + 1 iterations
       const char* fimg = (const char*)w.ffn_img;
       for (int c = 0; c <= A.n_chunks; ++c) {
+#if !defined(LDM_ABL_FFN_WINDOW)
         F.gnext = fimg + (size_t)(c == A.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+#elif LDM_ABL_FFN_WINDOW == 1
+        // MEASUREMENT builds only (tools/build_ffn_window_variants.py, profiles/r04_call26_*; wrong numbers by design, never the
+        // shipped library): the FFN weight stream — 65 % of the 23.4 MB a workgroup-step pulls — re-reads stage 0 of the layer's
+        // image: a 64-KiB window that the XCD's L2 serves (no fabric / Infinity-Cache traffic) ...
+        F.gnext = fimg + wave * 16384;
+#else
+        // ... or one 16-KiB piece for all four waves, which the CU's vector L1 serves (no L2 -> CU traffic either)
+        F.gnext = fimg;
+#endif
         F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
         F.ab_next = relB + (c + 1 >= A.n_chunks ? 0 : c + 1) * 128;
         F.template step<0, true>();
