@@ -157,3 +157,30 @@ def test_exact_mode_kernels_resources(tmp_path):
             ins = _kernels(asm)[sym]
             assert sum("global_load_lds_dwordx4" in i for i in ins) >= 3, sym
             assert not any(i.startswith("ds_write") for i in ins), sym  # no register staging left
+
+
+def test_split_mode_kernels_resources(tmp_path):
+    """The split mode's kernels (r04): the production GEMM instantiations (256 x 256 tiles on 8 waves: 128 accumulator
+    registers per lane, <= 256 registers = two waves per SIMD, operands by LDS-DMA only, no scratch) and the fp16 x 3
+    attention (<= 170 VGPRs: three workgroups per CU; no scratch: a `cond ? *p : zero` load once compiled into a flat load
+    of a select between the global pointer and a STACK zero)."""
+    asm = _compile("kernels_gemm16.hip", tmp_path)
+    blocks = re.findall(r"\.amdhsa_kernel\s+(\S*gemm16x3_kILi256ELi256ELi32ELi2ELi2ELi4ELi[0-3]ELi0ELi0E\S*)(.*?)\.end_amdhsa_kernel", asm, flags=re.S)
+    assert len(blocks) == 4, [b[0] for b in blocks]
+    get = lambda body, field: int(re.search(r"\.amdhsa_%s\s+(\d+)" % field, body).group(1))
+    for sym, body in blocks:
+        assert get(body, "private_segment_fixed_size") == 0, sym
+        total = get(body, "next_free_vgpr")  # (unified register file: arch + accumulation registers)
+        assert total <= 256, (sym, total)
+        ins = _kernels(asm)[sym]
+        assert sum("global_load_lds_dwordx4" in i for i in ins) >= 8, sym
+        assert sum("v_mfma_f32_32x32x16_f16" in i or "v_mfma_f32_32x32x16f16" in i for i in ins) >= 48, sym
+    asm = _compile("kernels_attn16.hip", tmp_path)
+    blocks = re.findall(r"\.amdhsa_kernel\s+(\S*attn16x3_k\S*)(.*?)\.end_amdhsa_kernel", asm, flags=re.S)
+    assert len(blocks) == 1
+    sym, body = blocks[0]
+    assert get(body, "private_segment_fixed_size") == 0, sym
+    assert get(body, "next_free_vgpr") <= 170, (sym, get(body, "next_free_vgpr"))
+    ins = _kernels(asm)[sym]
+    assert not any(i.startswith(("flat_load", "scratch_")) for i in ins), sym
+    assert sum("v_mfma" in i for i in ins) == 96, sym  # 2 x (4 x 4 | 8 x 2) fragment pairs x 3 products

@@ -49,4 +49,5 @@ print(open(out).read()[:1200])
 PY
 bash tools/pmc_sq.sh $O/sq_counters_fast_loop.txt fast 100 > /dev/null 2>&1
 bash tools/pmc_sq.sh $O/sq_counters_exact.txt exact 4 > /dev/null 2>&1
+bash tools/pmc_sq.sh $O/sq_counters_split.txt split 4 > /dev/null 2>&1
 head -10 $O/rocprof_stats_config2.txt; head -8 $O/rocprof_stats_split.txt; head -26 $O/sq_counters_fast_loop.txt
