@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void relation_update_k(RelArgs a) {
     lgs[(e * 4 + x) * NB + n] = node_of[e] > 0 ? a.logp[at(e, x, n)] : 0.f;
   }
   __syncthreads();
-  relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return lgs + (e * 4 + x) * NB; },
-               [&](int e, int x) { return prs + (e * 4 + x) * NB; }, scratch, inc_off, inc, [] { __syncthreads(); });
+  relation_sgd<false>(gph, e0, ne, tid, E, NB, [&](int e, int x) { return lgs + (e * 4 + x) * NB; },
+                      [&](int e, int x) { return prs + (e * 4 + x) * NB; }, scratch, inc_off, inc, RelPersist{nullptr, nullptr},
+                      [] { __syncthreads(); });
   for (int i = tid; i < n_item; i += 256) {
     int e, x, n;
     if (a.logp_tm) { e = i / (4 * NB); x = (i / NB) % 4; n = i % NB; } else { e = i % E; x = (i / E) / NB; n = (i / E) % NB; }
@@ -165,9 +166,9 @@ __global__ __launch_bounds__(256) void relation_step_k(PostArgs p, RelArgs a) {
   }
   __syncthreads();
   // ---- phase B: the SGD on the bbox tokens of the graph's nodes (element e, coordinate x = token e A + 1 + x)
-  relation_sgd(gph, e0, ne, tid, E, NB, [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd; },
-               [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd + 48; }, scratch, inc_off, inc,
-               [] { __syncthreads(); });
+  relation_sgd<false>(gph, e0, ne, tid, E, NB, [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd; },
+                      [&](int e, int x) { return rows + (e * A + 1 + x) * kRelRowLd + 48; }, scratch, inc_off, inc,
+                      RelPersist{nullptr, nullptr}, [] { __syncthreads(); });
   // ---- phase C: [PAD] disable + draw (+ the next step's embedding row)
   for (int s = grp; s < S; s += 16) {
     ldm_post::TokenArgs ta = token_args(s);

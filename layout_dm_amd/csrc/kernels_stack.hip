@@ -68,6 +68,8 @@ __device__ __forceinline__ stack_kargs_ptr stack_kargs() {
 constexpr int kPostLd = 161;   // floats per token row of the logits in LDS (odd: the 16-lane groups of a wavefront hit distinct banks)
 constexpr int kPostRows = 128 * kPostLd * 4;  // bytes of the logits rows; behind them one float4 (max, lse, max |x|, -) per row
 constexpr int kStackLoopB1 = 2048;            // HEAD == 2: the linear1 bias table is padded to whole 1-KiB DMA pieces
+constexpr int kStackLoopRelLds = REL_MAX_EDGE * 4 + 4 * 32 * 4 + 16;  // REL: the layout's edges, packed | cluster centres [4][32] | edge count —
+                                                                     // staged once per launch (RelPersist), behind kStackLoopLds
 constexpr int kStackLoopLds = 1024 + 128 + 2304;  // HEAD == 2: tokens [128] | cond token + strong bit [128] | REL: element -> graph
                                                   // node [32] | incidence lists of the graph's nodes (ldm_relation_core.h kRelIncBytes)
 static_assert(kRelIncBytes <= 2304, "incidence lists outgrow their LDS slot");
@@ -131,6 +133,14 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       const int e0 = kp->rel.edge_off[b_o], ne = kp->rel.edge_off[b_o + 1] - e0;
       relation_incidence(kp->rel, e0, ne, tid_o, S / kp->post.v.n_attr, reinterpret_cast<float*>(smem + 3 * STAGE), toks + 288,
                          reinterpret_cast<unsigned short*>(toks + 288 + kRelIncOffInts), [] { __syncthreads(); });
+      // ... and the graph itself: r04's first loop form re-read the edges, the centres, the canvas box and the edge offsets from
+      // global memory in every adjusted step (three dependent round trips in front of the SGD)
+      unsigned* pke = reinterpret_cast<unsigned*>(toks + kStackLoopLds / 4);
+      float* pcen = reinterpret_cast<float*>(pke + REL_MAX_EDGE);
+      for (int k = tid_o; k < ne && k < REL_MAX_EDGE; k += 256)
+        pke[k] = (unsigned)kp->rel.edge_src[e0 + k] | ((unsigned)kp->rel.edge_dst[e0 + k] << 6) | ((unsigned)kp->rel.edge_attr[e0 + k] << 12);
+      if (tid_o < 128) pcen[tid_o] = (tid_o & 31) < kp->rel_n_bin ? kp->rel.centres[(tid_o >> 5) * kp->rel_n_bin + (tid_o & 31)] : 0.f;
+      if (tid_o == 0) reinterpret_cast<int*>(pcen + 128)[0] = ne;
     }
     __syncthreads();
   }
@@ -864,14 +874,22 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             const int A5 = p.v.n_attr;
             float* rscr = reinterpret_cast<float*>(smem + 3 * STAGE);
             const int tid5 = wave * 64 + stack_lane_id();
-            if (tid5 < 4) rscr[kRelBboxOff + tid5] = kp->rel.centres[tid5 * kp->rel_n_bin + kp->rel.canvas_bins[tid5]];
+            const unsigned* pke = reinterpret_cast<const unsigned*>(toks + kStackLoopLds / 4);
+            const float* pcen = reinterpret_cast<const float*>(pke + REL_MAX_EDGE);
+            if (tid5 < 4) rscr[kRelBboxOff + tid5] = pcen[tid5 * 32 + kp->rel.canvas_bins[tid5]];  // canvas: one-hot expectation
             if (tid5 < 32) reinterpret_cast<int*>(rscr + kRelNodeOff)[tid5] = node_of[tid5];
             __syncthreads();  // every wavefront's posterior rows are in LDS
-            const int e0 = kp->rel.edge_off[b], ne = kp->rel.edge_off[b + 1] - e0;
-            relation_sgd(kp->rel, e0, ne, tid5, S / A5, kp->rel_n_bin,
-                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd; },
-                         [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; }, rscr, node_of + 32,
-                         reinterpret_cast<const unsigned short*>(node_of + 32 + kRelIncOffInts), [] { __syncthreads(); });
+            const int ne = reinterpret_cast<const int*>(pcen + 128)[0];
+            auto lg_at = [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd; };
+            auto pr_at = [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; };
+            const int* inc_off = node_of + 32;
+            const unsigned short* inc = reinterpret_cast<const unsigned short*>(node_of + 32 + kRelIncOffInts);
+            if (ne <= REL_MAX_EDGE && inc_off[0] >= 0)
+              relation_sgd<true>(kp->rel, 0, ne, tid5, S / A5, kp->rel_n_bin, lg_at, pr_at, rscr, inc_off, inc, RelPersist{pke, pcen},
+                                 [] { __syncthreads(); });
+            else  // (more edges than the staged form holds: the general form, edges re-staged block by block)
+              relation_sgd<false>(kp->rel, kp->rel.edge_off[b], ne, tid5, S / A5, kp->rel_n_bin, lg_at, pr_at, rscr, inc_off, inc,
+                                  RelPersist{nullptr, nullptr}, [] { __syncthreads(); });
             // ---- [PAD] disable + draw from the adjusted rows (base.py:272-291)
 #pragma unroll 1
             for (int rd = 0; rd < 8; ++rd) {
@@ -979,7 +997,8 @@ void launch_stack_stream(const FusedLayerSet& ls, int F, float* x, int ldx, int 
 // spills).  The caller has checked: 5 head tiles, live sub-vocabularies <= 48 classes, S <= 128.
 void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
                        const StackLoop& lp, hipStream_t st) {
-  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + kStackLoopB1 + 2 * LN_DP + 512) * 4 + kStackLoopLds;
+  const int lds = 3 * TILE_STAGE + 2 * KV_BYTES + (3 * H * 64 + 2 * LN_DP + 512 + kStackLoopB1 + 2 * LN_DP + 512) * 4 + kStackLoopLds +
+                  (lp.rel ? kStackLoopRelLds : 0);
   auto kern = lp.rel ? stack_stream_k<false, 2, true> : stack_stream_k<false, 2, false>;
   allow_big_lds((const void*)kern);
   StackArgs a{};

@@ -39,7 +39,8 @@ constexpr int kRelNodeOff = kRelEgOff + REL_MAX_EDGE * 8;
 constexpr int kRelEdgeOff = kRelNodeOff + REL_MAX_ELEM;
 constexpr int kRelCentreOff = kRelEdgeOff + 3 * REL_MAX_EDGE;   // the cluster centres, [4][32] (r04: were re-read from global
                                                                 // memory by every softmax round: ~11 of the SGD's 44 us)
-constexpr int kRelScratchFloats = kRelCentreOff + 4 * 32;
+constexpr int kRelDummyOff = kRelCentreOff + 4 * 32;            // 32 logits | 32 softmax values | 1 box entry that nobody reads back
+constexpr int kRelScratchFloats = kRelDummyOff + 68;
 // incidence lists of the layout's graph nodes (which edges touch a node, in EDGE ORDER: the order the node gradients are
 // summed in), built once per launch: offsets [REL_MAX_ELEM + 2] ints, entries [2 REL_MAX_EDGE] = edge << 1 | (node is dst).
 // r03 scanned all edges per node, per iteration (a chain of dependent LDS reads: ~12 us per step).
@@ -112,12 +113,22 @@ __device__ __forceinline__ void relation_incidence(const Graph& a, int e0, int n
   barrier();
 }
 
-// lg(e, x) -> the n_bin body-bin logits of element e, coordinate x (LDS, updated in place);
-// pr(e, x) -> n_bin floats of LDS scratch for their softmax;  barrier() -> workgroup barrier.
+// What a kernel that keeps a layout for many steps (the loop kernel) stages ONCE per launch instead of once per step: the
+// layout's edges, packed src | dst << 6 | attr << 12 (<= REL_MAX_EDGE of them), and the cluster centres [4][32].  A per-step
+// kernel passes {nullptr, nullptr}: relation_sgd then stages both from global memory itself.
+struct RelPersist {
+  const unsigned* edges;
+  const float* centres;
+};
+constexpr int kRelPassBatch = 4;  // (element, coordinate) rows a 16-lane group has in flight at once
+
+// lg(e, x) -> the n_bin body-bin logits of element e, coordinate x (LDS, updated in place; 32 readable floats);
+// pr(e, x) -> n_bin floats of LDS scratch for their softmax (32 readable floats);  barrier() -> workgroup barrier.
 // Graph: RelGraph, possibly in the kernel-argument address space (the loop kernel reads it there at the point of use).
-template <class Graph, class LgAt, class PrAt, class Barrier>
+template <bool PACKED, class Graph, class LgAt, class PrAt, class Barrier>
 __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int tid, int E, int NB, LgAt lg, PrAt pr,
-                                             float* scratch, const int* inc_off, const unsigned short* inc, Barrier barrier) {
+                                             float* scratch, const int* inc_off, const unsigned short* inc, RelPersist pers,
+                                             Barrier barrier) {
   float* bbox = scratch + kRelBboxOff;
   float* grad = scratch + kRelGradOff;
   float* eg = scratch + kRelEgOff;
@@ -133,41 +144,99 @@ __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int
     }
   };
   const bool one_block = ne <= REL_MAX_EDGE;
-  if (one_block) stage_edges(0, ne);  // (visible behind the first barrier below)
-  float* cen = scratch + kRelCentreOff;
-  if (tid < 4 * 32) cen[tid] = (tid & 31) < NB ? a.centres[(tid >> 5) * NB + (tid & 31)] : 0.f;
-  barrier();
+  const float* cen = pers.centres;
+  if constexpr (!PACKED) {
+    if (one_block) stage_edges(0, ne);  // (visible behind the first barrier below)
+    float* cs = scratch + kRelCentreOff;
+    if (tid < 4 * 32) cs[tid] = (tid & 31) < NB ? a.centres[(tid >> 5) * NB + (tid & 31)] : 0.f;
+    cen = cs;
+    barrier();
+  }
   const bool by_node = one_block && inc_off[0] >= 0;
   const int grp = tid >> 4, l16 = tid & 15;
   const ldm_post::DppGroup<16, false> g{l16};
   const bool ok0 = l16 < NB, ok1 = l16 + 16 < NB;
+  // The rows of group grp: (element (grp >> 2) + 4 r, coordinate grp & 3), r = 0 .. — the coordinate, hence the centres, is the
+  // same for all of them.  A row that is not a graph node's (or past E) works on a dummy row of the scratch: no branch
+  // inside a batch, so the LDS reads, the three 16-lane reductions and the exp / divide chains of kRelPassBatch rows
+  // interleave (r04: one row at a time left ~8 000 cycles of a pass to LDS and DPP latency).
+  const int x = grp & 3;
+  const float c0 = cen[x * 32 + l16], c1 = cen[x * 32 + l16 + 16];
+  float* const dummy = scratch + kRelDummyOff;
+  constexpr int NR = REL_MAX_ELEM / 4;
   // One pass per iteration over the (element, coordinate) pairs, a 16-lane row each (two bins per lane): the SGD step of
   // the PREVIOUS iteration on the pair's logits (its softmax, its expected coordinate and the node gradient are still in
   // LDS), then the softmax / expectation of the updated logits.  A row reads and writes only its own pair's entries, so the
-  // update needs no barrier of its own (r04: 3 barriers per iteration instead of 5, no integer divisions).
+  // update needs no barrier of its own (3 barriers per iteration, no integer divisions).
   for (int it = 0; it <= a.num_update; ++it) {
-    for (int pidx = grp; pidx < E * 4; pidx += 16) {
-      const int e = pidx >> 2, x = pidx & 3;
-      const int node = node_of[e];
-      if (node < 0) continue;  // (uniform per 16-lane row: DPP rows may diverge from each other)
-      float* L = lg(e, x);
-      float* P = pr(e, x);
-      const float c0 = cen[x * 32 + l16], c1 = cen[x * 32 + l16 + 16];
-      float v0 = ok0 ? L[l16] : -INFINITY, v1 = ok1 ? L[l16 + 16] : -INFINITY;
-      if (it > 0) {  // ---- SGD step through the softmax expectation (iteration it - 1)
-        const float bb_old = bbox[node * 4 + x], gr = grad[node * 4 + x];
-        if (ok0) { v0 -= a.step * (P[l16] * (c0 - bb_old) * gr); L[l16] = v0; }
-        if (ok1) { v1 -= a.step * (P[l16 + 16] * (c1 - bb_old) * gr); L[l16 + 16] = v1; }
+    const bool upd = it > 0, soft = it < a.num_update;
+#pragma unroll 1
+    for (int rb = 0; rb < NR && (rb * 4 + (grp >> 2)) < E; rb += kRelPassBatch) {
+      float *L[kRelPassBatch], *P[kRelPassBatch], *BB[kRelPassBatch];
+      const float* GR[kRelPassBatch];
+      float v0[kRelPassBatch], v1[kRelPassBatch];
+#pragma unroll
+      for (int r = 0; r < kRelPassBatch; ++r) {
+        const int e = (grp >> 2) + 4 * (rb + r);
+        const int node = e < E ? node_of[e] : -1;
+        const bool valid = node >= 0;
+        L[r] = valid ? lg(e, x) : dummy;
+        P[r] = valid ? pr(e, x) : dummy + 32;
+        BB[r] = valid ? bbox + node * 4 + x : dummy + 64;
+        GR[r] = valid ? grad + node * 4 + x : dummy + 64;
       }
-      if (it == a.num_update) continue;
-      const float mx = g.gmax(fmaxf(v0, v1));
-      const float x0 = ok0 ? expf(v0 - mx) : 0.f, x1 = ok1 ? expf(v1 - mx) : 0.f;
-      const float sm = g.gsum(x0 + x1);
-      const float p0 = x0 / sm, p1 = x1 / sm;
-      if (ok0) P[l16] = p0;
-      if (ok1) P[l16 + 16] = p1;
-      const float bb = g.gsum(p0 * c0 + p1 * c1);
-      if (l16 == 0) bbox[node * 4 + x] = bb;
+#pragma unroll
+      for (int r = 0; r < kRelPassBatch; ++r) {
+        const float a0 = L[r][l16], a1 = L[r][l16 + 16];
+        v0[r] = ok0 ? a0 : -INFINITY;
+        v1[r] = ok1 ? a1 : -INFINITY;
+      }
+      if (upd) {  // ---- SGD step through the softmax expectation (iteration it - 1)
+        float q0[kRelPassBatch], q1[kRelPassBatch], bo[kRelPassBatch], go[kRelPassBatch];
+#pragma unroll
+        for (int r = 0; r < kRelPassBatch; ++r) {
+          q0[r] = P[r][l16];
+          q1[r] = P[r][l16 + 16];
+          bo[r] = *BB[r];
+          go[r] = *GR[r];
+        }
+#pragma unroll
+        for (int r = 0; r < kRelPassBatch; ++r) {
+          if (ok0) v0[r] -= a.step * (q0[r] * (c0 - bo[r]) * go[r]);
+          if (ok1) v1[r] -= a.step * (q1[r] * (c1 - bo[r]) * go[r]);
+        }
+        if (ok0) {
+#pragma unroll
+          for (int r = 0; r < kRelPassBatch; ++r) L[r][l16] = v0[r];
+        }
+        if (ok1) {
+#pragma unroll
+          for (int r = 0; r < kRelPassBatch; ++r) L[r][l16 + 16] = v1[r];
+        }
+      }
+      if (!soft) continue;
+      float p0[kRelPassBatch], p1[kRelPassBatch], bb[kRelPassBatch];
+#pragma unroll
+      for (int r = 0; r < kRelPassBatch; ++r) {
+        const float mx = g.gmax(fmaxf(v0[r], v1[r]));
+        const float x0 = ok0 ? expf(v0[r] - mx) : 0.f, x1 = ok1 ? expf(v1[r] - mx) : 0.f;
+        const float sm = g.gsum(x0 + x1);
+        p0[r] = x0 / sm;
+        p1[r] = x1 / sm;
+        bb[r] = g.gsum(p0[r] * c0 + p1[r] * c1);
+      }
+      if (ok0) {
+#pragma unroll
+        for (int r = 0; r < kRelPassBatch; ++r) P[r][l16] = p0[r];
+      }
+      if (ok1) {
+#pragma unroll
+        for (int r = 0; r < kRelPassBatch; ++r) P[r][l16 + 16] = p1[r];
+      }
+      if (l16 == 0) {
+#pragma unroll
+        for (int r = 0; r < kRelPassBatch; ++r) *BB[r] = bb[r];
+      }
     }
     if (it == a.num_update) break;
     barrier();
@@ -175,13 +244,19 @@ __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int
     if (tid < (E + 1) * 4) grad[tid] = 0.f;
     for (int eb = 0; eb < ne; eb += REL_MAX_EDGE) {
       const int nb = min(REL_MAX_EDGE, ne - eb);
-      if (!one_block) {
+      if (!PACKED && !one_block) {
         if (eb > 0) barrier();  // (the previous block's node sums have read es / ed / eg)
         stage_edges(eb, nb);
         barrier();
       }
       for (int k = tid; k < nb; k += 256) {
-        const int s = es[k], d = ed[k], at = ea[k];
+        int s, d, at;
+        if constexpr (PACKED) {
+          const unsigned pk = pers.edges[k];
+          s = (int)(pk & 63u); d = (int)((pk >> 6) & 63u); at = (int)(pk >> 12);
+        } else {
+          s = es[k]; d = ed[k]; at = ea[k];
+        }
         const float xs = bbox[s * 4], ys = bbox[s * 4 + 1], ws = bbox[s * 4 + 2], hs = bbox[s * 4 + 3];
         const float xd = bbox[d * 4], yd = bbox[d * 4 + 1], wd = bbox[d * 4 + 2], hd = bbox[d * 4 + 3];
         const float eps = 1e-8f;
@@ -239,6 +314,7 @@ __device__ __forceinline__ void relation_sgd(const Graph& a, int e0, int ne, int
         const int node = tid >> 2, x = tid & 3;
         float gsum = grad[tid];
         if (by_node) {
+#pragma unroll 4
           for (int j = inc_off[node]; j < inc_off[node + 1]; ++j) {
             const int ent = inc[j];
             gsum += eg[(ent >> 1) * 8 + (ent & 1) * 4 + x];
