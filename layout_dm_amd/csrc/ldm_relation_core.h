@@ -120,7 +120,7 @@ struct RelPersist {
   const unsigned* edges;
   const float* centres;
 };
-constexpr int kRelPassBatch = 4;  // (element, coordinate) rows a 16-lane group has in flight at once
+constexpr int kRelPassBatch = 8;  // (element, coordinate) rows a 16-lane group has in flight at once
 
 // lg(e, x) -> the n_bin body-bin logits of element e, coordinate x (LDS, updated in place; 32 readable floats);
 // pr(e, x) -> n_bin floats of LDS scratch for their softmax (32 readable floats);  barrier() -> workgroup barrier.
