@@ -73,6 +73,7 @@ constexpr int kStackLoopRelLds = REL_MAX_EDGE * 4 + 4 * 32 * 4 + 16;  // REL: th
 constexpr int kStackLoopLds = 1024 + 128 + 2304;  // HEAD == 2: tokens [128] | cond token + strong bit [128] | REL: element -> graph
                                                   // node [32] | incidence lists of the graph's nodes (ldm_relation_core.h kRelIncBytes)
 static_assert(kRelIncBytes <= 2304, "incidence lists outgrow their LDS slot");
+static_assert(kRelScratchFloats * 4 <= 2 * KV_BYTES, "the SGD's scratch lives in the K / V buffers");
 
 __device__ unsigned long long g_stack_phase[16];
 
@@ -137,10 +138,18 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
       // global memory in every adjusted step (three dependent round trips in front of the SGD)
       unsigned* pke = reinterpret_cast<unsigned*>(toks + kStackLoopLds / 4);
       float* pcen = reinterpret_cast<float*>(pke + REL_MAX_EDGE);
-      for (int k = tid_o; k < ne && k < REL_MAX_EDGE; k += 256)
-        pke[k] = (unsigned)kp->rel.edge_src[e0 + k] | ((unsigned)kp->rel.edge_dst[e0 + k] << 6) | ((unsigned)kp->rel.edge_attr[e0 + k] << 12);
+      int* pmeta = reinterpret_cast<int*>(pcen + 128);  // [0] edge count, [1] != 0: an edge does not fit the packed form
+      if (tid_o == 0) {
+        pmeta[0] = ne;
+        pmeta[1] = 0;
+      }
+      __syncthreads();
+      for (int k = tid_o; k < ne && k < REL_MAX_EDGE; k += 256) {
+        const unsigned es = (unsigned)kp->rel.edge_src[e0 + k], ed = (unsigned)kp->rel.edge_dst[e0 + k], ea = (unsigned)kp->rel.edge_attr[e0 + k];
+        if ((es | ed) >= 64u || ea >= (1u << 20)) atomicOr(&pmeta[1], 1);  // (the general form of the SGD takes such a graph)
+        pke[k] = es | (ed << 6) | (ea << 12);
+      }
       if (tid_o < 128) pcen[tid_o] = (tid_o & 31) < kp->rel_n_bin ? kp->rel.centres[(tid_o >> 5) * kp->rel_n_bin + (tid_o & 31)] : 0.f;
-      if (tid_o == 0) reinterpret_cast<int*>(pcen + 128)[0] = ne;
     }
     __syncthreads();
   }
@@ -879,12 +888,13 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
             if (tid5 < 4) rscr[kRelBboxOff + tid5] = pcen[tid5 * 32 + kp->rel.canvas_bins[tid5]];  // canvas: one-hot expectation
             if (tid5 < 32) reinterpret_cast<int*>(rscr + kRelNodeOff)[tid5] = node_of[tid5];
             __syncthreads();  // every wavefront's posterior rows are in LDS
-            const int ne = reinterpret_cast<const int*>(pcen + 128)[0];
+            const int* pmeta = reinterpret_cast<const int*>(pcen + 128);
+            const int ne = pmeta[0];
             auto lg_at = [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd; };
             auto pr_at = [&](int e, int x) { return lgs + (e * A5 + 1 + x) * kPostLd + 96; };
             const int* inc_off = node_of + 32;
             const unsigned short* inc = reinterpret_cast<const unsigned short*>(node_of + 32 + kRelIncOffInts);
-            if (ne <= REL_MAX_EDGE && inc_off[0] >= 0)
+            if (ne <= REL_MAX_EDGE && inc_off[0] >= 0 && pmeta[1] == 0)
               relation_sgd<true>(kp->rel, 0, ne, tid5, S / A5, kp->rel_n_bin, lg_at, pr_at, rscr, inc_off, inc, RelPersist{pke, pcen},
                                  [] { __syncthreads(); });
             else  // (more edges than the staged form holds: the general form, edges re-staged block by block)

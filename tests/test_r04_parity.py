@@ -321,6 +321,35 @@ def test_config5_T200_loops_equal_their_steps(cuda, golden_dir):
         torch.cuda.synchronize()
 
 
+def test_relation_loop_general_form_equals_the_packed_form(cuda):
+    """The loop kernel stages a layout's graph once per launch in a packed form (src | dst << 6 | attr << 12, ldm_relation_core.h
+    RelPersist); a graph that does not fit it takes the general form of the same SGD (edges re-staged from global memory).  An
+    attribute bit that no cost reads (1 << 20) forces that path without changing the arithmetic: tokens must be identical."""
+    from layout_dm_amd.binding import Engine
+    from layout_dm_amd.synthetic import linear_bin_centres, synth_cond_relation
+    from layout_dm_amd import synthetic as PS
+
+    spec = SP.RICO25
+    B = 96
+    e = Engine(n_category=spec.n_category, precision="fast", max_batch=128)
+    e.load_state_dict(synth.synth_state_dict(spec, seed=1, perturb=True))
+    cond_np, graph = synth_cond_relation(PS.SPECS["rico25"], B, seed=5, edge_ratio=0.3)
+    cond = {"seq": cond_np["seq"], "mask": cond_np["mask"], "type": "relation"}
+    steps = R.timestep_list(spec.n_step, 100)[:40]
+    outs = []
+    for high_bit in (False, True):
+        plan = e.make_relation(graph, linear_bin_centres(spec.n_bin), [16, 16, 31, 31], 3e6, 3, B)
+        if high_bit:
+            plan[1][3].bitwise_or_(1 << 20)
+        tok = torch.from_numpy(cond_np["seq"]).int().to(cuda)
+        out, inter = e.sample_loop(tok, steps, steps, {"name": "random", "temperature": 1.0}, cond=cond, seed=3, intermediates=True,
+                                   relation=plan)
+        outs.append((out.cpu().clone(), inter.cpu().clone()))
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    e.close()
+
+
 def test_relation_in_the_loop_kernel_equals_the_per_step_path(cuda, monkeypatch):
     """r04: cond=relation inside the one-launch loop (stack_stream_k<., 2, true>: posterior -> SGD -> [PAD] disable -> draw behind
     the vocabulary head, ldm_relation_core.h) against the per-step path (LDM_DEV=1 LDM_REL_LOOP=0: stack launch +
