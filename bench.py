@@ -356,12 +356,13 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
     def sample_fn(first_layout, count):  # this rank's shard: `count` layouts starting at global index `first_layout`
         assert count == B and (world == 1 or first_layout == my_lo)
         tokens.copy_(init)  # inputs resident in HBM
-        if world > 1:       # this rank's own device time, without the gather / barrier (per-rank layouts/s)
-            ev_pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
-            ev_pairs[-1][0].record()
+        # HIP events around this rank's own sampling launches of EVERY timed step, on the stream they run on (the engine
+        # launches on torch's current stream): the per-rank device time without the gather / barrier, and the launch
+        # durations the roofline is computed from
+        ev_pairs.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        ev_pairs[-1][0].record()
         _sample(first_layout)
-        if world > 1:
-            ev_pairs[-1][1].record()
+        ev_pairs[-1][1].record()
         return tokens
 
     def _sample(first_layout):
@@ -392,12 +393,13 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
         final = one_step(warmup + i)
     sync()
     dt = time.perf_counter() - t0
+    ev_ms = [x.elapsed_time(y) for x, y in ev_pairs]  # (everything is complete: sync() above)
     per_rank = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        mine = torch.tensor([B * len(ev_pairs) / max(sum(x.elapsed_time(y) for x, y in ev_pairs) * 1e-3, 1e-9)],
+        mine = torch.tensor([B * len(ev_ms) / max(sum(ev_ms) * 1e-3, 1e-9)],
                             dtype=torch.float64, device=dev)
         allr = torch.empty(dist.get_world_size(), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(allr, mine)
@@ -418,6 +420,11 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
            "sampling": sampling,
            "algorithmic_tflops": round(value * flop_layout / 1e12, 2),
            "frac_of_mfma_peak_whole_job": round(value * flop_layout / 1e12 / (world * PEAK_TFLOPS[precision]), 4)}
+    if ev_ms:
+        srt = sorted(ev_ms)
+        res["timed_region_step_ms_hip_events"] = {"avg": round(sum(ev_ms) / len(ev_ms), 4), "min": round(srt[0], 4),
+                                                  "median": round(srt[len(srt) // 2], 4), "max": round(srt[-1], 4),
+                                                  "n": len(ev_ms)}
     if per_rank is not None:
         res["per_rank_layouts_per_s"] = per_rank
     if verified:
@@ -457,6 +464,12 @@ def run_mode(a, spec, sd, precision, B, steps, warmup, cond_np, rank, world, loc
             # one launch = every layout's whole loop; per (layout, reverse step) of a workgroup:
             n_wg_rounds = -(-B // 256)
             roof["ms_per_workgroup_step"] = round(avg_ms / (a.timesteps * n_wg_rounds), 4)
+            if ev_ms and dom["launches"] == 1:
+                # the same figure from the TIMED region itself: a step there is this one launch (+ set_rng_k, 4 us)
+                t_avg = sum(ev_ms) / len(ev_ms)
+                roof["timed_region"] = {"avg_launch_ms": round(t_avg, 4), "achieved": round(dom["flops"] / (t_avg * 1e-3) / 1e12, 2),
+                                        "frac": round(dom["flops"] / (t_avg * 1e-3) / 1e12 / PEAK_TFLOPS[precision], 4),
+                                        "what": "HIP events around each of the timed steps' sampling launches"}
         res["roofline"] = roof
         res["kernel_breakdown_ms"] = {r["name"]: round(r["ms"], 3) for r in rows}
         gemm_ms = sum(r["ms"] for r in rows if r["name"].startswith(GEMM_CLASSES))
@@ -588,7 +601,7 @@ def main():
     if world > 1 and config == 4 and not a.total and not a.batch:
         out["scaling_point"] = {"workload": "BASELINE config 4 shard: rico25 uncond T=100 1024 layouts/GPU sampling=random",
                                 "layouts_per_s_per_gpu": round(res["value"] / world, 2)}
-    for k in ("roofline", "kernel_breakdown_ms", "gemm_mfma_utilisation"):
+    for k in ("roofline", "kernel_breakdown_ms", "gemm_mfma_utilisation", "timed_region_step_ms_hip_events"):
         if k in res:
             out[k] = res[k]
 
