@@ -341,20 +341,21 @@ def _relation_cond(spec, B, seed, edge_ratio=0.5):
     return graph, seq, seq != spec.mask_id
 
 
-def trained_like_cases(spec, B=2):
+def trained_like_cases(spec, B=2, points=None):
     """VERDICT r3 next #1a: the reference itself on weight distributions other than its init (oracle/synth.py
     TRAINED_LIKE): teacher-forced denoiser logits / posterior at three timesteps, the reference's own float32 noise floor
     at each (its float32 forward against its own float64 forward: what "bit-exact greedy tokens" and "logits <= 2e-5" can
     mean at that point), the largest attention score, and a stochastic trajectory with the reference's greedy next
     tokens and top-2 margins at every step."""
-    m, _ = rh.build_reference_model("rico25", seed=0)               # (installs the import stubs)
+    m, _ = rh.build_reference_model(spec.name, seed=0)               # (installs the import stubs)
     from trainer.models.categorical_diffusion.util import index_to_log_onehot
 
-    out = {"points": np.array(list(synth.TRAINED_LIKE))}
+    points = list(points or synth.TRAINED_LIKE)
+    out = {"points": np.array(points)}
     g = torch.Generator().manual_seed(77)
     ts = [90, 50, 5]
     out["ts"] = np.array(ts, np.int32)
-    for point in synth.TRAINED_LIKE:
+    for point in points:
         ssd = synth.trained_like_state_dict(spec, point, seed=2, prefix="")
         m.load_state_dict({k: torch.from_numpy(v) for k, v in ssd.items()})
         floor, smax = 0.0, 0.0
@@ -487,6 +488,7 @@ def main(out_dir=None, only=None):
         return
     if only == "trained_like":
         np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
+        np.savez_compressed(os.path.join(OUT, "publaynet_trained_like.npz"), **trained_like_cases(SP.SPECS["publaynet"], points=["mid"]))
         return
     if only == "config5":
         np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
@@ -498,6 +500,7 @@ def main(out_dir=None, only=None):
         return
     np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
     np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
+    np.savez_compressed(os.path.join(OUT, "publaynet_trained_like.npz"), **trained_like_cases(SP.SPECS["publaynet"], points=["mid"]))
     np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
     for ds in ("rico25", "publaynet"):
         spec = SP.SPECS[ds]

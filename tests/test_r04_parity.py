@@ -120,6 +120,38 @@ def test_trained_like_logits_exact_mode(cuda, golden_dir, point):
     assert worst <= max(2e-5, 3 * floor)
 
 
+@pytest.mark.parametrize("precision", ["exact", "split", "fast"])
+def test_trained_like_publaynet_mid(cuda, golden_dir, precision):
+    """The other vocabulary off the init distribution: PubLayNet (5 categories, C = 135) on the "mid" weights, fixture from the real
+    reference (tests/golden/publaynet_trained_like.npz).  Reference-precision modes: logits within max(2e-5, 3 x the reference's own
+    float32 noise floor), posterior, and the reference's greedy tokens on all 100 states of its stochastic trajectory; fast
+    mode: logits inside the envelope of the mid point, greedy tokens differ only where the reference's own top-2 margin is tiny."""
+    spec = SP.SPECS["publaynet"]
+    g = np.load(os.path.join(golden_dir, "publaynet_trained_like.npz"))
+    e = _engine(spec, "mid", lambda: synth.trained_like_state_dict(spec, "mid", seed=2), precision, 8)
+    floor = float(g["mid_f32_noise_floor"])
+    worst = 0.0
+    for t in g["ts"]:
+        t = int(t)
+        tokens = torch.from_numpy(g[f"mid_tokens_{t}"].astype(np.int32))
+        ref = torch.from_numpy(g[f"mid_logits_{t}"])
+        worst = max(worst, _rel(e.denoise_logits(tokens, t).cpu(), ref))
+        if precision != "fast":
+            post = e.posterior(ref, tokens, t).cpu()
+            ref_post = torch.from_numpy(g[f"mid_post_{t}"])
+            assert (post - ref_post).abs().max().item() <= 2e-4, t
+            assert torch.equal(post.argmax(1), ref_post.argmax(1))
+    bad, n, margin, _ = _traj(e, _sub(g, "mid_"))
+    print(f"[trained-like/publaynet mid/{precision}] max rel logits error vs the reference {worst:.3e} (noise floor {floor:.3e}); "
+          f"greedy tokens differing {bad}/{n}" + (f" (largest reference margin among them {margin:.3e})" if bad else ""))
+    if precision == "fast":
+        assert worst <= FAST_ENVELOPE["mid"]
+        assert bad == 0 or margin < 2e-2, (bad, margin)
+    else:
+        assert worst <= max(2e-5, 3 * floor)
+        assert bad == 0
+
+
 @pytest.mark.parametrize("point", POINTS)
 def test_trained_like_logits_fast_mode_and_auto_selection(cuda, golden_dir, point):
     """The fast mode's measured error at every point, against the reference; `precision="auto"` keeps the fp16 engine
