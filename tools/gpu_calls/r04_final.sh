@@ -6,6 +6,7 @@ O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 900 python bench.py --steps 20 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json; tail -2 $O/bench.err
+if [ "${LIGHT:-0}" = "1" ]; then exit 0; fi   # LIGHT=1: the suite and the bench line only (no profiler passes)
 Q="--no-extras --no-cpu-baseline --no-traffic --modes none"
 bash tools/rocprof_stats.sh $O/rocprof_stats_config2.txt --steps 3 --warmup 1 $Q > /dev/null 2>&1
 bash tools/rocprof_stats.sh $O/rocprof_stats_exact.txt --precision exact --steps 2 --warmup 1 $Q > /dev/null 2>&1
