@@ -18,7 +18,11 @@ def mm(a, w, scaled, wscale=True):
     ah, al = split(a, scaled); wh, wl = split(w, scaled)
     out = ah @ wh.T + (al @ wh.T + ah @ wl.T)
     return out * (2.0 ** -k)
-def fwd(W, tokens, t, scaled, wscale=True):
+def bmm3(a, b):
+    # a @ b in split arithmetic (both operands unscaled hi + lo, three products, fp32 accumulation)
+    ah, al = split(a, False); bh, bl = split(b, False)
+    return ah @ bh + (al @ bh + ah @ bl)
+def fwd(W, tokens, t, scaled, wscale=True, attn=None):
     D,H,dh = spec.d_model, spec.n_head, spec.d_head
     B,S = tokens.shape
     g = lambda k: W[k]
@@ -35,8 +39,13 @@ def fwd(W, tokens, t, scaled, wscale=True):
         qkv = mm(x, g(b+"self_attn.in_proj_weight"), scaled, wscale) + g(b+"self_attn.in_proj_bias")
         q,k,v = qkv[..., :D], qkv[..., D:2*D], qkv[..., 2*D:]
         q = q.view(B,S,H,dh).transpose(1,2); k = k.view(B,S,H,dh).transpose(1,2); v = v.view(B,S,H,dh).transpose(1,2)
-        att = torch.softmax((q @ k.transpose(-1,-2))/math.sqrt(dh), dim=-1)
-        a = (att @ v).transpose(1,2).reshape(B,S,D)
+        if attn is None:
+            att = torch.softmax((q @ k.transpose(-1,-2))/math.sqrt(dh), dim=-1)
+            a = (att @ v).transpose(1,2).reshape(B,S,D)
+        else:  # attn16x3_k: raw scores from the split operands, scale inside the exponent, P x attn (2^10 or 1) before its split
+            sc = bmm3(q, k.transpose(-1,-2))
+            p = torch.exp((sc - sc.max(-1, keepdim=True).values) * (1.0/math.sqrt(dh))) * attn
+            a = (bmm3(p, v) / p.sum(-1, keepdim=True)).transpose(1,2).reshape(B,S,D)
         x = x + mm(a, g(b+"self_attn.out_proj.weight"), scaled, wscale) + g(b+"self_attn.out_proj.bias")
         hh = R._ln(x)*g(b+"norm2.weight")+g(b+"norm2.bias")
         hh = torch.relu(mm(hh, g(b+"linear1.weight"), scaled, wscale) + g(b+"linear1.bias"))
@@ -56,4 +65,7 @@ for point in ("init", "mid", "wide"):
         ref = R.denoiser_logits(W64, spec, tokens, t, dtype=torch.float64); mx = ref.abs().max().item()
         f32 = R.denoiser_logits(W, spec, tokens, t)
         e = lambda o: (o.double()-ref).abs().max().item()/mx
+        if len(sys.argv) > 1 and sys.argv[1] == "attention":
+            print(f"{point} t={t}: f32 {e(f32):.2e} | r04 split GEMMs + fp32 attention {e(fwd(W,tokens,t,False,True)):.2e} | + split attention, P x 2^10 (attn16x3_k) {e(fwd(W,tokens,t,False,True,1024.0)):.2e} | + split attention, P unscaled {e(fwd(W,tokens,t,False,True,1.0)):.2e}", flush=True)
+            continue
         print(f"{point} t={t}: f32 {e(f32):.2e} | split, lo x 2^11, two accumulators (r03) {e(fwd(W,tokens,t,True)):.2e} | lo unscaled + weight pre-scale, one accumulator (r04) {e(fwd(W,tokens,t,False,True)):.2e} | lo unscaled, NO pre-scale {e(fwd(W,tokens,t,False,False)):.2e}")
