@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of an experiment: the prefetch variants of kernels_stack.hip / ldm_pipes.h it timed were NOT kept in the source — results and the
+# description of what was built: profiles/r04_call26_27_loop_kernel_weight_stream_window_and_prefetch.txt)
 # r04: L2 prefetch of the FFN weight stream in the loop kernel (one extra 4-byte-per-lane LDS-DMA per wave and chunk, 3 chunks
 # ahead, every workgroup its 1/16 slice) vs the same build without it (LDM_FFN_PREFETCH=0), one box; parity of the new build
 O=gpurun_out/r04_call27; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (record of an experiment: the prefetch variants of kernels_stack.hip / ldm_pipes.h it timed were NOT kept in the source — results and the
+# description of what was built: profiles/r04_call26_27_loop_kernel_weight_stream_window_and_prefetch.txt)
 # r04: full-coverage L2 prefetch of the FFN weight stream (two 128-byte-stride LDS-DMAs per wave and chunk = every line of the
 # wave's 16 KiB, 3 or 8 chunks ahead) vs the build without it, one box; parity of the new build
 O=gpurun_out/r04_call28; mkdir -p $O
