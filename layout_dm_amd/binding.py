@@ -185,6 +185,16 @@ class Engine:
             self._check(self.lib.ldm_load_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
                         f"ldm_load_weight({k})")
         self._check(self.lib.ldm_finalize_weights(self._h), "ldm_finalize_weights")
+        self._round = None
+
+    @property
+    def batch_round(self) -> int:
+        """Layouts per "round" of a sampling call (ldm_describe `round`): the one-launch loop runs one workgroup per layout
+        on the device's compute units (256 on the MI355X), the per-step path `chunk` layouts on each of its lanes — a call
+        costs whole rounds, so B = round + 1 costs what B = 2 * round costs (bench.py `batch_shapes`)."""
+        if getattr(self, "_round", None) is None:
+            self._round = max(1, int(self.describe().get("round", "256")))
+        return self._round
 
     # ------------------------------------------------------------------ helpers
     def _tok(self, t: torch.Tensor) -> torch.Tensor:
@@ -364,10 +374,15 @@ class Engine:
     def describe(self) -> Dict[str, str]:
         """What this handle runs (ldm_describe): numerics mode, kernel family, loop structure, chunk / lanes, near-tie
         thresholds and the development knobs the LIBRARY honoured (LDM_DEV=1 only) — not what os.environ says."""
-        buf = C.create_string_buffer(1024)
-        n = self.lib.ldm_describe(self._h, buf, 1024)
-        if n < 0:
-            raise RuntimeError("ldm_describe failed")
+        cap = 1024
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = self.lib.ldm_describe(self._h, buf, cap)
+            if n < 0:
+                raise RuntimeError("ldm_describe failed")
+            if n < cap:
+                break
+            cap = n + 1   # (returns the length needed: the honoured-knob list is unbounded)
         out = {}
         for kv in buf.value.decode().split(";"):
             k, _, v = kv.partition("=")

@@ -67,6 +67,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   auto* h = new ldm_handle();
   h->cfg = *cfg;
   h->device = device;
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) h->n_cu = ncu;
+  }
   h->S = cfg->max_elem * cfg->n_attr;
   h->C = cfg->n_category + 4 * cfg->n_bin + 2;
   h->D = cfg->d_model;
@@ -217,6 +221,7 @@ extern "C" void ldm_destroy(ldm_handle* h) {
   for (auto& kv : h->raw)
     if (kv.second.d) (void)hipFree(kv.second.d);
   for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->derived) (void)hipFree(p);
   if (h->loop_a) (void)hipEventDestroy(h->loop_a);
   if (h->loop_b) (void)hipEventDestroy(h->loop_b);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
@@ -365,24 +370,33 @@ extern "C" int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, i
   return 0;
 }
 // ------------------------------------------------------------------------------------------ introspection
-// "key=value;..." description of what this handle runs: numerics mode, kernel family, chunk / lanes, near-tie thresholds
-// and the development knobs the library has honoured in this process (ldm_knobs.h).  Returns the length needed.
+// "key=value;..." description of what this handle runs: numerics mode, kernel family, chunk / lanes, near-tie thresholds,
+// the batch-shape rule of the one-launch loop (one workgroup per layout on the chip's compute units: a call costs whole
+// rounds of `round` layouts, so B = round + 1 costs what B = 2 * round costs) and the development knobs the library has
+// honoured in this process (ldm_knobs.h; always the LAST key: its value may itself contain ';').  Returns the length
+// needed (excluding the terminator), whatever `cap` is: call again with a larger buffer when the result is >= cap.
 extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   if (!h) return -1;
   static const char* prec[3] = {"exact_f32", "fast_f16", "split_f16"};
   const bool loop = loop_fusable(h, nullptr);
-  char tmp[768];
-  const int n = snprintf(tmp, sizeof(tmp),
-                         "abi=%d;precision=%s;kernels=%s;loop=%s;chunk=%d;lanes=%d;lane_offset_us=%d;tie_rel=%g;tie_abs=%g;knobs=%s",
-                         LDM_ABI_VERSION, prec[h->cfg.precision],
-                         h->cfg.precision != LDM_PREC_FAST_F16 ? "tiled_gemm+attn" : h->fused_attn == 6 ? "stack" : "generic16",
-                         loop ? "one_launch" : "per_step_graph", h->chunk, h->n_lanes, h->lane_offset_us, (double)h->tie_rel,
-                         (double)h->tie_abs, knobs_honoured().c_str());
+  char num[96];
+  std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->cfg.precision];
+  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? "tiled_gemm+attn" : h->fused_attn == 6 ? "stack" : "generic16");
+  s += std::string(";loop=") + (loop ? "one_launch" : "per_step_graph");
+  s += ";chunk=" + std::to_string(h->chunk) + ";lanes=" + std::to_string(h->n_lanes) + ";lane_offset_us=" + std::to_string(h->lane_offset_us);
+  snprintf(num, sizeof(num), ";tie_rel=%g;tie_abs=%g", (double)h->tie_rel, (double)h->tie_abs);
+  s += num;
+  // batch quantum: the loop kernel runs one workgroup per layout, one workgroup per compute unit; the per-step path runs
+  // `chunk` layouts per pass on `lanes` concurrent pipelines
+  s += ";round=" + std::to_string(loop ? h->n_cu : h->chunk * std::max(h->n_lanes, 1));
+  s += std::string(";batch_rule=") + (loop ? "whole_rounds_of_one_workgroup_per_layout" : "whole_chunks");
+  s += ";knobs=" + knobs_honoured();
   if (buf && cap > 0) {
-    strncpy(buf, tmp, (size_t)cap - 1);
-    buf[cap - 1] = 0;
+    const size_t n = std::min((size_t)cap - 1, s.size());
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
   }
-  return n;
+  return (int)s.size();
 }
 
 extern "C" int ldm_last_loop_ms(ldm_handle* h, float* ms) {

@@ -140,7 +140,11 @@ struct ldm_handle {
   const float *emb = nullptr, *head_g = nullptr, *head_b = nullptr, *head_w = nullptr;
   __half *head_w16 = nullptr, *head_w16lo = nullptr;
   float head_s = 1.f;
-  std::vector<void*> owned;  // everything hipMalloc'ed by the handle
+  std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
+  std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
+                               // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)
+  bool to_derived = false;     // dalloc's destination while ldm_finalize_weights runs
+  int n_cu = 256;              // compute units of the device: the batch quantum of the one-launch loop (one workgroup per layout)
   // workspace of ONE chunk.  These are the pointers the launch sequences use; with several lanes (below) they are
   // switched to the lane's own buffers by activate() before its launches are recorded / issued.
   float *P = nullptr, *Q = nullptr, *qkv32 = nullptr, *att32 = nullptr, *h32 = nullptr, *hid32 = nullptr,
@@ -244,7 +248,7 @@ struct ldm_handle {
       e = hipMemset(p, 0, bytes);
       if (e != hipSuccess) return fail(-3, "hipMemset failed: %s", hipGetErrorString(e));
     }
-    owned.push_back(p);
+    (to_derived ? derived : owned).push_back(p);
     *out = reinterpret_cast<Tp*>(p);
     return 0;
   }

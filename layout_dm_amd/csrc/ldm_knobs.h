@@ -29,7 +29,6 @@ inline const std::map<std::string, const char*>& knob_table() {
       {"LDM_GEMM32_WIDE", "160-wide fp32 GEMM tiles for N = 464"},
       {"LDM_GEMM32_SLOTS", "resident fp32 GEMM workgroups per CU"},
       {"LDM_GEMM32_BM64", "64-row fp32 GEMM tiles for one-round shapes"},
-      {"LDM_EXACT_LN", "0 = separate LayerNorm launches in the exact mode (pre-r04 structure)"},
       {"LDM_REL_FUSED", "0 = three launches per cond=relation step of the per-step path (pre-r04 structure)"},
       {"LDM_X3_CFG", "tile configuration of the split GEMM (8: 256x256 default, 0: 128x128, 1: 4 stages, 2: 256x128, 3: 128x256, 5: 128x128x64, 6 / 7: operands through registers, 9: dependent MFMA order, 10 / 11: non-temporal activation fills in the two-reader GEMMs / in every GEMM)"},
       {"LDM_X3_GRP", "column-group width of the split GEMM's tile order (0 = row-major)"},

@@ -53,7 +53,13 @@ static int check_relation(ldm_handle* h, const ldm_relation* rel, const ldm_cond
   if (h->cfg.max_elem > 32 || h->cfg.n_bin > 32) return h->fail(-4, "relation kernel: max_elem and n_bin must be <= 32");
   for (int x = 0; x < 4; ++x)
     if (rel->canvas_bins[x] < 0 || rel->canvas_bins[x] >= h->cfg.n_bin) return h->fail(-1, "canvas bin out of range");
-  for (int l = 0; l < h->n_lanes; ++l) {
+  // The (chunk, C, S) log-probability buffer exists only for the three-launch form of an adjusted step (posterior ->
+  // relation_update -> draw): the one-launch loop and relation_step_k keep the rows in LDS.  Allocated here, never inside
+  // step_all (which may run under stream capture), and only when that form can be reached.
+  PostArgs probe{};
+  fill_post(h, probe, nullptr, nullptr, 0, 1);
+  const bool three_launch = !loop_fusable(h, rel) && !(relation_step_supported(probe) && knob_int("LDM_REL_FUSED", 1) != 0);
+  for (int l = 0; three_launch && l < h->n_lanes; ++l) {
     if (h->ws[l].rel_logp) continue;
     float* buf = nullptr;
     int rc = h->dalloc(&buf, (size_t)h->chunk * h->C * h->S, false);
@@ -128,6 +134,7 @@ static int step_all(ldm_handle* h, const int32_t* tin, int32_t* tout, int t_mode
       launch_relation_step(q, a, st);
       continue;
     }
+    if (!h->rel_logp) return h->fail(-5, "cond=relation: the three-launch step has no log-probability buffer (check_relation)");
     {
       PostArgs q = p;
       q.pad_disable = 0;  // applied after the adjustment, below

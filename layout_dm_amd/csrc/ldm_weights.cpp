@@ -277,6 +277,23 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   if ((rc = need(h, tr + "head.1.weight", {C, D}, &h->head_w))) return rc;
   if (!h->pos && (rc = h->dalloc(&h->pos, (size_t)h->S * D))) return rc;
   if (!h->adaln && (rc = h->dalloc(&h->adaln, (size_t)T * L * 2 * D))) return rc;
+  // everything below is derived from the checkpoint: drop what an earlier finalize built (nothing may still be running on it),
+  // then collect the new allocations in h->derived
+  HIP_OK(h, hipDeviceSynchronize());
+  for (auto& g : h->graphs) g.destroy();
+  h->graphs.clear();
+  for (void* p : h->derived) (void)hipFree(p);
+  h->derived.clear();
+  h->fast.clear();
+  h->fast_head = nullptr;
+  h->head_img_ks = nullptr;
+  h->head_w16 = h->head_w16lo = nullptr;
+  h->tbl_att_static = h->tbl_att_dyn = h->tbl_ffn = h->tbl_head = nullptr;
+  struct Sink {
+    ldm_handle* h;
+    explicit Sink(ldm_handle* h_) : h(h_) { h->to_derived = true; }
+    ~Sink() { h->to_derived = false; }
+  } sink(h);
   launch_pos_table(elem, attr, h->pos, h->cfg.max_elem, h->cfg.n_attr, D, 0);
   const bool f16 = h->cfg.precision != LDM_PREC_EXACT_F32;
   h->layers.assign(L, LayerW{});

@@ -28,6 +28,17 @@ def _cfg_get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+def batch_cuts(B: int, max_batch: int, round_: int) -> List[int]:
+    """Sizes of the calls a batch of B layouts is cut into when it exceeds max_batch.  The reference caps a call at 512
+    (test.py splits 1000 into 512 + 488); here a call costs whole ROUNDS of `round_` layouts (Engine.batch_round: one
+    workgroup per layout per compute unit), so the cuts are the largest multiple of the round that fits max_batch — 1000
+    layouts under max_batch = 600 are 512 + 488 (4 rounds), not 600 + 400 (5)."""
+    if B <= max_batch:
+        return [B] if B > 0 else []
+    step = (max_batch // round_) * round_ or max_batch
+    return [step] * (B // step) + ([B % step] if B % step else [])
+
+
 def timestep_schedule(num_timesteps: int, num_timesteps_eval: int, time_difference: float = 0.0):
     """(t_model list, t_post list) exactly as base.py:310-315 + 218-240 derive them:
     diffusion_list = [int(i*T/T_eval)], skip_step = delta_t - 1, noise_t = clamp(t - int(T*td)),
@@ -73,10 +84,12 @@ class HipMaskAndReplaceDiffusion:
         self.verifier = verifier
         self.auto = precision == "auto"
         self.auto_tolerance = 1e-3
+        self.verifier_tolerance = 2.5e-4   # split vs a small fp32-MFMA probe engine (both carry their own fp32 noise floor)
+        self.verifier_check: Dict[str, float] = {}
         self.selected_precision = None if self.auto else precision
-        mk = lambda prec: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
+        self._mk = mk = lambda prec, mb=max_batch: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
                                  d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
-                                 precision=prec, max_batch=max_batch, chunk=chunk, device=device, q_type=q_type,
+                                 precision=prec, max_batch=mb, chunk=chunk, device=device, q_type=q_type,
                                  lanes=lanes)
         if precision in ("fast_verified", "auto"):
             from .verified import VerifiedGreedy
@@ -108,15 +121,66 @@ class HipMaskAndReplaceDiffusion:
     def eval(self):
         return self
 
+    def _check_verifier(self, state_dict) -> None:
+        """auto / fast_verified treat the verifier engine as ground truth: check THAT once per checkpoint.  The
+        split engine rounds every operand to an fp16 hi part (overflow above 65 504) and an unscaled fp16 lo part, so it is
+        compared with a small fp32-MFMA engine of the same weights on two probe states; if its logits are non-finite or
+        differ by more than `verifier_tolerance` the fp32-MFMA engine becomes the verifier, and if that one is non-finite
+        too the checkpoint is refused here, at load time — not at the first sampling call."""
+        from .verified import measure_fast_error, probe_states
+
+        v = self.verified
+        if self.verifier != "split":
+            states = probe_states(v.exact, n_layouts=4, ts=[v.exact.T // 2])
+            lg = v.exact.denoise_logits(*states[0])
+            if not bool(torch.isfinite(lg).all()):
+                raise FloatingPointError("reference-precision engine: non-finite logits on this checkpoint")
+            self.verifier_check = {"verifier": self.verifier, "finite": True}
+            return
+        n = 4
+        small = self._mk("exact", n)
+        try:
+            small.load_state_dict(state_dict)
+            states = probe_states(small, n_layouts=n, ts=[small.T - 1, small.T // 2, 1])
+            c = measure_fast_error(v.exact, small, states)
+            lg_ok = bool(torch.isfinite(small.denoise_logits(*states[0])).all())
+        finally:
+            small.close()
+        self.verifier_check = {"verifier": "split", "err_rel_vs_fp32_mfma": c["err_rel"], "finite": c["finite"],
+                               "tolerance": self.verifier_tolerance}
+        if c["finite"] and c["err_rel"] <= self.verifier_tolerance:
+            return
+        if not lg_ok:
+            raise FloatingPointError("reference-precision engines: non-finite logits on this checkpoint (fp32 MFMA too)")
+        import warnings
+
+        warnings.warn(f"split verifier outside {self.verifier_tolerance:g} of the fp32-MFMA engine on this checkpoint "
+                      f"({c['err_rel']:.3g}, finite={c['finite']}): verifying with the fp32-MFMA engine instead",
+                      RuntimeWarning)
+        old = v.exact
+        v.exact = self._mk("exact")
+        v.exact.load_state_dict(state_dict)
+        old.close()
+        self.verifier = "exact"
+        self.verifier_check["verifier"] = "exact (fallback)"
+
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         if self.verified is not None:
             self.engine = self.verified.fast                    # (auto may have switched to the exact engine before)
         self.engine.load_state_dict(state_dict)
         if self.verified is not None:
             self.verified.exact.load_state_dict(state_dict)
-            cal = self.verified.calibrate()                     # tie_abs <- 6 x safety x measured |logits error|
+            self._check_verifier(state_dict)
+            try:
+                cal = self.verified.calibrate()                 # tie_abs <- 6 x safety x measured |logits error|
+            except FloatingPointError:
+                if not self.auto:
+                    raise
+                # the fp16 engine overflows on this checkpoint (the verifier was checked finite above): auto's answer
+                cal = dict(self.verified.calibration, err_rel=float("inf"), finite=False)
+                self.verified.calibration = cal
             if self.auto:
-                ok = cal["err_rel"] <= self.auto_tolerance
+                ok = cal["err_rel"] <= self.auto_tolerance       # (NaN / inf compare False)
                 self.selected_precision = "fast_verified" if ok else self.verifier
                 if not ok:
                     self.engine = self.verified.exact
@@ -171,8 +235,8 @@ class HipMaskAndReplaceDiffusion:
         else:
             tokens = torch.full((B, eng.S), eng.mask_id, dtype=torch.int32, device=eng.device)
         outs, inters = [], []
-        for off in range(0, B, eng.max_batch):  # the reference caps a call at 512 (Converter); we chunk
-            n = min(eng.max_batch, B - off)
+        off = 0
+        for n in batch_cuts(B, eng.max_batch, eng.batch_round):  # the reference caps a call at 512 (Converter); we cut
             sub = None
             if cond:
                 sub = {k: (v[off:off + n] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.size(0) == B else v)
@@ -187,6 +251,7 @@ class HipMaskAndReplaceDiffusion:
                                             intermediates=get_intermediate_results, use_graph=self.use_graph)
             outs.append(tk)
             inters.append(inter)
+            off += n
         out = torch.cat(outs) if len(outs) > 1 else outs[0]
         if get_intermediate_results:
             inter = torch.cat(inters, dim=1) if len(inters) > 1 else inters[0]

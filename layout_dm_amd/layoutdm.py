@@ -144,8 +144,11 @@ class _ModuleShim:
 class LayoutDM:
     def __init__(self, backbone_cfg, tokenizer, transformer_type: str = "flattened", pos_emb: str = "elem_attr",
                  num_timesteps: int = 100, auxiliary_loss_weight: float = 1e-1, q_type: str = "single",
-                 seq_type: str = "poset", precision: str = "fast", max_batch: int = 512, device: Optional[int] = None,
+                 seq_type: str = "poset", precision: str = "auto", max_batch: int = 512, device: Optional[int] = None,
                  **kwargs) -> None:
+        # precision (not a reference argument): "auto" (default, r05) = the fp16 engine is measured against the
+        # reference-precision engine on the loaded checkpoint and kept — with verified greedy decoding — only inside the
+        # north star's 1e-3 logits tolerance; "fast" / "fast_verified" / "split" / "exact" pick an engine unconditionally
         if q_type not in ("constrained", "vanilla"):  # Q_TYPES, layoutdm.py:20-23
             raise NotImplementedError(f"q_type={q_type}: constrained (LayoutDM default, experiment/layoutdm.yaml:18) "
                                       "or vanilla")

@@ -20,7 +20,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
-from .diffusion import HipMaskAndReplaceDiffusion, _cfg_get, timestep_schedule
+from .diffusion import HipMaskAndReplaceDiffusion, _cfg_get, batch_cuts, timestep_schedule
 
 
 def graph_to_csr(graph, n_graph: int):
@@ -124,8 +124,8 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
         # fused path: every stage of every step inside ldm_sample_loop (one hipGraph per max_batch window)
         plan = hip_relation_plan(eng, cond, sampling_cfg, tokenizer, B)
         outs, inters = [], []
-        for off in range(0, B, eng.max_batch):
-            n = min(eng.max_batch, B - off)
+        off = 0
+        for n in batch_cuts(B, eng.max_batch, eng.batch_round):   # (whole rounds of the chip per call: diffusion.batch_cuts)
             sub = {"seq": hip_cond["seq"][off:off + n],
                    "mask": hip_cond["mask"][off:off + n] if hip_cond["mask"] is not None else None, "type": "relation"}
             tk, inter = eng.sample_loop(tokens[off:off + n].contiguous(), t_model, t_post, sampling_cfg, cond=sub,
@@ -134,6 +134,7 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
                                         relation=_relation_window(plan, off))
             outs.append(tk)
             inters.append(inter)
+            off += n
         torch.cuda.current_stream(eng.device).synchronize()  # `plan` keep-alives may go out of scope
         if get_intermediate_results:
             inter = torch.cat(inters, dim=1) if len(inters) > 1 else inters[0]

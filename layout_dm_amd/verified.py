@@ -62,30 +62,65 @@ def probe_states(eng: Engine, n_layouts: int = 8, ts: Optional[Sequence[int]] = 
     return out
 
 
+def trajectory_states(eng: Engine, n_layouts: int = 8, n_states: int = 6, seed: int = 0):
+    """[(tokens (n,S) int32 cpu, t)] taken from a REAL reverse trajectory of this checkpoint: one `random` run of the
+    engine's own sampling loop (the kernel path that decodes — the one-launch loop in the fast mode) from all-[MASK],
+    the states BEFORE `n_states` steps spread over the schedule, the last two steps included (greedy decoding decides
+    its tokens there: DESIGN.md section 3.5).  ADVICE r4: probe states drawn uniformly from the sub-vocabularies are
+    not what a trajectory visits once the model has started to commit tokens."""
+    T = eng.T
+    t_model = list(range(T - 1, -1, -1))
+    tok = torch.full((n_layouts, eng.S), eng.mask_id, dtype=torch.int32, device=eng.device)
+    _, inter = eng.sample_loop(tok, t_model, t_model, {"name": "random", "temperature": 1.0}, seed=seed,
+                               intermediates=True)
+    picks = {int(round(i * (T - 1) / max(n_states - 1, 1))) for i in range(n_states)} | {T - 2, T - 1}
+    # (the state before step 0 is all-[MASK]: probe_states covers it)
+    return [(inter[i - 1].cpu().clone(), t_model[i]) for i in sorted(picks) if 0 < i < T]
+
+
 def measure_fast_error(fast: Engine, exact: Engine, states=None) -> Dict[str, float]:
     """Largest logits error of the fast engine against the exact engine of the same weights on `states` (default:
-    probe_states): absolute, relative to the largest |logit| of the probe, and relative per row."""
-    states = states if states is not None else probe_states(fast)
+    probe_states + states of a real trajectory of the fast engine's own sampling loop): absolute, relative to the
+    largest |logit| of the probe, and relative per row.  Non-finite logits of either engine are reported (`finite`)
+    and make every error infinite: a NaN must never compare as "inside the tolerance"."""
+    states = states if states is not None else probe_states(fast) + trajectory_states(fast)
     e_abs = e_rel = e_row = absmax = 0.0
+    finite = True
     for tok, t in states:
         lf, le = fast.denoise_logits(tok, t), exact.denoise_logits(tok, t)
+        if not (bool(torch.isfinite(lf).all()) and bool(torch.isfinite(le).all())):
+            finite = False
+            continue
         d = (lf - le).abs()
         m = le.abs().max().item()
         e_abs = max(e_abs, d.max().item())
         e_rel = max(e_rel, d.max().item() / max(m, 1e-30))
         e_row = max(e_row, (d.amax(-1) / le.abs().amax(-1).clamp_min(1e-30)).max().item())
         absmax = max(absmax, m)
-    return {"err_abs": e_abs, "err_rel": e_rel, "err_rel_row": e_row, "absmax": absmax, "n_states": len(states)}
+    if not finite:
+        e_abs = e_rel = e_row = float("inf")
+    return {"err_abs": e_abs, "err_rel": e_rel, "err_rel_row": e_row, "absmax": absmax, "n_states": len(states),
+            "finite": finite}
 
 
 class VerifiedGreedy:
     """A fast-mode engine and an exact-mode engine of the same model; deterministic decoding only."""
 
+    # audit: fraction of the UNMARKED (step, layout) pairs re-decided by the reference-precision engine anyway.  The
+    # calibrated threshold is an observation on probe states, not a bound, so a small sample is checked by default
+    # (ADVICE r4): 0.5 % of the pairs = 256 layout-steps of a 512 x 100 call, one extra reference-precision step per
+    # audited timestep.  A mismatch there is a SOUNDNESS failure of the report for this checkpoint: it is counted in
+    # last_stats / audit_mismatch_total, warned about, and raised with strict_audit=True.
+    DEFAULT_AUDIT = 0.005
+
     def __init__(self, fast: Engine, exact: Engine, tie_rel: float = DEFAULT_TIE_REL, tie_abs: float = 0.0,
-                 safety: float = 2.0, audit: float = 0.0):
+                 safety: float = 2.0, audit: Optional[float] = None, strict_audit: bool = False):
         assert fast.S == exact.S and fast.C == exact.C and fast.device == exact.device
         self.fast, self.exact = fast, exact
+        audit = self.DEFAULT_AUDIT if audit is None else audit
         self.tie_rel, self.tie_abs, self.safety, self.audit = float(tie_rel), float(tie_abs), float(safety), float(audit)
+        self.strict_audit = bool(strict_audit)
+        self.audit_mismatch_total = 0
         self.calibration: Dict[str, float] = {}
         self.last_stats: Dict[str, float] = {}
         self._audit_gen = torch.Generator().manual_seed(0)
@@ -95,6 +130,9 @@ class VerifiedGreedy:
         """tie_abs <- 6 x safety x (largest absolute fast-vs-exact logits error on the probe states).  Call after the
         weights are loaded (HipMaskAndReplaceDiffusion.load_state_dict does)."""
         c = measure_fast_error(self.fast, self.exact, states)
+        if not c["finite"]:
+            raise FloatingPointError("fast_verified / auto: non-finite logits on the probe states of this checkpoint "
+                                     "(fp16 overflow of an operand, or a broken checkpoint): no threshold can be calibrated")
         self.tie_abs = LEAD_LIPSCHITZ * self.safety * c["err_abs"]
         c["tie_abs"], c["tie_rel"], c["safety"] = self.tie_abs, self.tie_rel, self.safety
         self.calibration = c
@@ -121,10 +159,19 @@ class VerifiedGreedy:
                 out[k] = v
         return out
 
+    AUDIT_STEPS = 4  # audited pairs are concentrated on this many random steps per pass: every audited step costs one
+                     # reference-precision launch sequence whatever the number of layouts in it
+
     def _audit_mask(self, flags: torch.Tensor) -> Optional[torch.Tensor]:
+        """(m, b) bool: ~audit * m * b UNMARKED pairs, on AUDIT_STEPS random steps of the pass."""
         if self.audit <= 0.0:
             return None
-        pick = torch.rand(flags.shape, generator=self._audit_gen) < self.audit
+        m, b = flags.shape
+        k = min(m, max(self.AUDIT_STEPS, int(-(-self.audit * m // 1))))   # (audit = 1: every step, every layout)
+        per_step = min(b, max(1, int(round(self.audit * m * b / k))))
+        pick = torch.zeros((m, b), dtype=torch.bool)
+        for s in torch.randperm(m, generator=self._audit_gen)[:k].tolist():
+            pick[s, torch.randperm(b, generator=self._audit_gen)[:per_step]] = True
         return pick.to(flags.device) & ~flags
 
     def sample_step(self, tokens: torch.Tensor, t_model: int, t_post: Optional[int] = None, cond: Optional[dict] = None,
@@ -203,6 +250,17 @@ class VerifiedGreedy:
                         work.append((idx[jd], i0 + s + 1, fixed.clone()))
                         st["relaunched"] += int(jd.numel()) * (m - s - 1)
         tokens.copy_(final)
+        if st["audit_mismatch"]:
+            self.audit_mismatch_total += st["audit_mismatch"]
+            msg = (f"fast_verified: {st['audit_mismatch']} of {st['audited']} audited UNMARKED (step, layout) pairs differ from "
+                   f"the reference-precision engine: the calibrated near-tie threshold (tie_abs {self.tie_abs:.3g}) is not "
+                   "sound on this checkpoint (the differing pairs were corrected; unaudited pairs are not covered) — use "
+                   "precision='split' / 'exact'")
+            if self.strict_audit:
+                raise RuntimeError(msg)
+            import warnings
+
+            warnings.warn(msg, RuntimeWarning)
         tot = float(max(B * n, 1))
         self.last_stats = {"layouts": B, "steps": n, "marked_layout_steps": st["marked"],
                            "exact_layout_steps": st["checked"], "mismatch_layout_steps": st["mismatch"],

@@ -27,10 +27,23 @@ import types
 
 REFERENCE_ROOT = os.environ.get("LAYOUTDM_REFERENCE", "/root/reference")
 _TRAINER_PATH = os.path.join(REFERENCE_ROOT, "src", "trainer")
+# oracle/_ref/: the same package byte-compiled by oracle/build_ref.py (git-ignored build output that travels to the GPU
+# box with the snapshot; no source text) — only the timing of the real reference (bench.py cpu_baseline) uses it
+_SNAPSHOT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
 
 
 def reference_available() -> bool:
+    """The reference TREE is present (build container): fixtures can be regenerated, sources inspected."""
     return os.path.isdir(os.path.join(_TRAINER_PATH, "trainer"))
+
+
+def snapshot_available() -> bool:
+    return os.path.exists(os.path.join(_SNAPSHOT_PATH, "trainer", "__init__.pyc"))
+
+
+def reference_importable() -> bool:
+    """The reference's `trainer` package can be imported: from the tree, or from the byte-compiled oracle/_ref/."""
+    return reference_available() or snapshot_available()
 
 
 # --------------------------------------------------------------------------- stubs
@@ -179,11 +192,12 @@ def install_stubs():
     global _INSTALLED
     if _INSTALLED:
         return
-    if not reference_available():
-        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    if not reference_importable():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT} (and no oracle/_ref/: python -m oracle.build_ref)")
     sys.dont_write_bytecode = True  # /root/reference must stay pristine
-    if _TRAINER_PATH not in sys.path:
-        sys.path.insert(0, _TRAINER_PATH)
+    path = _TRAINER_PATH if reference_available() else _SNAPSHOT_PATH
+    if path not in sys.path:
+        sys.path.insert(0, path)
 
     def need(name):
         try:

@@ -96,7 +96,7 @@ def test_verified_loop_reproduces_the_exact_trajectory(case):
         marks = {(t, k) for t in steps for k in range(B)}
         errors = {(12, 6)}
     fast, exact = FakeEngine(T, errors, marks), FakeEngine(T)
-    vg = VerifiedGreedy(fast, exact, tie_rel=6e-3, tie_abs=0.01)
+    vg = VerifiedGreedy(fast, exact, tie_rel=6e-3, tie_abs=0.01, audit=0.0)   # (the splice logic alone; audits below)
     start = (torch.arange(B * S).view(B, S) % C).int()
     cond = {"key": torch.arange(B), "type": "c"}             # the layout identity rides along like a cond tensor
     out, inter = vg.sample_loop(start.clone(), steps, steps, cond=cond, intermediates=True)
@@ -146,9 +146,28 @@ def test_verified_step_and_audit():
                 out[0, 0] = (out[0, 0] + 1) % C     # wrong, and NOT marked
             return out, flags
     vg2 = VerifiedGreedy(Unsound(T), FakeEngine(T), audit=1.0)
-    out, _ = vg2.sample_loop(start.clone(), steps, steps, cond=cond)
-    assert vg2.last_stats["audit_mismatch_layout_steps"] >= 1
+    with pytest.warns(RuntimeWarning, match="not\\s+sound on this checkpoint"):
+        out, _ = vg2.sample_loop(start.clone(), steps, steps, cond=cond)
+    assert vg2.last_stats["audit_mismatch_layout_steps"] >= 1 and vg2.audit_mismatch_total >= 1
     assert torch.equal(out, reference_run(B, steps)[-1])    # (with audit = 1 every pair is checked, so it is also repaired)
+    with pytest.raises(RuntimeError, match="audited UNMARKED"):
+        VerifiedGreedy(Unsound(T), FakeEngine(T), audit=1.0, strict_audit=True).sample_loop(start.clone(), steps, steps, cond=cond)
+
+
+def test_default_audit_is_on_and_clustered():
+    """r05: a small audit runs by default, concentrated on a few steps — each audited step is one
+    reference-precision launch sequence, whatever the number of layouts in it."""
+    B, T = 64, 40
+    fast, exact = FakeEngine(T), FakeEngine(T)
+    vg = VerifiedGreedy(fast, exact)
+    assert vg.audit == VerifiedGreedy.DEFAULT_AUDIT > 0
+    steps = list(range(T - 1, -1, -1))
+    start = (torch.arange(B * S).view(B, S) % C).int()
+    out, _ = vg.sample_loop(start.clone(), steps, steps, cond={"key": torch.arange(B), "type": "c"})
+    assert torch.equal(out, reference_run(B, steps)[-1])
+    st = vg.last_stats
+    assert 0 < st["audited_layout_steps"] <= max(VerifiedGreedy.AUDIT_STEPS, round(2 * vg.audit * B * T))
+    assert len(exact.calls) <= VerifiedGreedy.AUDIT_STEPS and st["audit_mismatch_layout_steps"] == 0
 
 
 def test_relation_is_refused():
