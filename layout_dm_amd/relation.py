@@ -135,7 +135,8 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
             outs.append(tk)
             inters.append(inter)
             off += n
-        torch.cuda.current_stream(eng.device).synchronize()  # `plan` keep-alives may go out of scope
+        if eng.device.type == "cuda":
+            torch.cuda.current_stream(eng.device).synchronize()  # `plan` keep-alives may go out of scope
         if get_intermediate_results:
             inter = torch.cat(inters, dim=1) if len(inters) > 1 else inters[0]
             return [x.long().cpu() for x in inter]

@@ -83,7 +83,9 @@ def measure_fast_error(fast: Engine, exact: Engine, states=None) -> Dict[str, fl
     probe_states + states of a real trajectory of the fast engine's own sampling loop): absolute, relative to the
     largest |logit| of the probe, and relative per row.  Non-finite logits of either engine are reported (`finite`)
     and make every error infinite: a NaN must never compare as "inside the tolerance"."""
-    states = states if states is not None else probe_states(fast) + trajectory_states(fast)
+    if states is None:
+        n = max(1, min(8, fast.max_batch, exact.max_batch))
+        states = probe_states(fast, n_layouts=n) + trajectory_states(fast, n_layouts=n)
     e_abs = e_rel = e_row = absmax = 0.0
     finite = True
     for tok, t in states:

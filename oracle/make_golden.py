@@ -341,6 +341,75 @@ def _relation_cond(spec, B, seed, edge_ratio=0.5):
     return graph, seq, seq != spec.mask_id
 
 
+GETCOND_TYPES = ("c", "cwh", "partial", "refinement", "relation")
+
+
+def getcond_sampling_cfg(ctype, name="random"):
+    """sampling_cfg as test.py:107-118 + aggregate_sampling_settings (base_model.py:124-150) leave it for `ctype`, with the
+    reference's TestConfig defaults (hydra_configs.py:34-47)."""
+    kw = {}
+    if ctype == "refinement":
+        kw = dict(refine_mode="uniform", refine_offset_ratio=0.1, refine_lambda=3.0)
+    if ctype == "relation":
+        kw = dict(relation_lambda=3e6, relation_mode="average", relation_tau=1.0, relation_num_update=3)
+    return rh.sampling_cfg(name, **kw)
+
+
+def getcond_cases(spec, B=2):
+    """the cond dicts are PRODUCED BY THE REFERENCE'S OWN get_cond (helpers/task.py:27-151) from a
+    collated batch (ref_harness.synth_layout_batch: for cond=relation through its own AddCanvasElement +
+    AddRelationConstraints transforms), for every cond type of the `test` entry point; each is then sampled by the
+    reference — the greedy sample() of test.py:195-200 and a stochastic trajectory with the greedy answer and top-2 margin
+    at every visited state.  The fixture stores the dicts field by field; the GPU test hands them, unchanged, to
+    layout_dm_amd.layoutdm.LayoutDM.sample."""
+    import copy
+    import random as pyrandom
+
+    m, tok = rh.build_reference_model(spec.name, seed=0)
+    load_synth(m, spec)
+    from trainer.helpers.task import get_cond
+
+    out = {"types": np.array(GETCOND_TYPES)}
+    for i, ctype in enumerate(GETCOND_TYPES):
+        rel = ctype == "relation"
+        batch = rh.synth_layout_batch(spec.n_category, B, seed=40 + i, relation=rel, transform_seed=0,
+                                      n_lo=8 if rel else 3, n_hi=14 if rel else 12)
+        pyrandom.seed(50 + i)           # set_seed (helpers/util.py:10-13): partial draws from `random` and torch
+        torch.manual_seed(50 + i)
+        cond = get_cond(batch=batch, tokenizer=tok, cond_type=ctype, model_type="LayoutDM")
+        p = ctype + "_"
+        out[p + "x"], out[p + "y"], out[p + "batch"] = batch.x.numpy(), batch.y.numpy(), batch.batch.numpy()
+        out[p + "cond_seq"] = cond["seq"].numpy().astype(np.int16)
+        out[p + "cond_mask"] = cond["mask"].numpy()
+        out[p + "cond_keys"] = np.array(sorted(cond.keys()))
+        if "num_element" in cond:
+            out[p + "num_element"] = cond["num_element"].numpy()
+        if "seq_orig" in cond:
+            out[p + "seq_orig"] = cond["seq_orig"].numpy().astype(np.int16)
+        if ctype == "relation":
+            gb = cond["batch_w_canvas"]
+            assert gb is batch
+            out[p + "edge_index"], out[p + "edge_attr"] = gb.edge_index.numpy(), gb.edge_attr.numpy()
+            bt = tok.bbox_tokenizer   # what logit_adjustment.py:30-41 reads from the tokenizer
+            out[p + "centres"] = np.stack([np.asarray(bt.clustering_models[f"{k}-{spec.n_bin}"].cluster_centers_,
+                                                      np.float64).reshape(-1) for k in ("x", "y", "w", "h")])
+            canvas_ids = bt.encode(torch.tensor([[[0.5, 0.5, 1.0, 1.0]]])).long().view(-1)
+            out[p + "canvas_bins"] = (canvas_ids - torch.arange(4) * spec.n_bin).numpy().astype(np.int32)
+        if ctype == "refinement":
+            from trainer.helpers.task import _index_to_smoothed_log_onehot
+
+            table = _index_to_smoothed_log_onehot(torch.arange(spec.n_class)[None], tok, mode="uniform",
+                                                  offset_ratio=0.1)[0].T.contiguous() * 3.0
+            out[p + "weak_table"] = table.numpy()   # [token, class], lambda applied (helpers/task.py:154-224)
+        torch.manual_seed(60 + i)
+        greedy = m.sample(batch_size=B, cond=copy.deepcopy(cond), sampling_cfg=getcond_sampling_cfg(ctype, "deterministic"))
+        out[p + "greedy_tokens"] = greedy.numpy().astype(np.int16)
+        tr = trajectory(m, spec, B, getcond_sampling_cfg(ctype, "random"), cond, seed=70 + i)
+        for k, v in tr.items():
+            out[p + "traj_" + k] = v
+    return out
+
+
 def trained_like_cases(spec, B=2, points=None):
     """VERDICT r3 next #1a: the reference itself on weight distributions other than its init (oracle/synth.py
     TRAINED_LIKE): teacher-forced denoiser logits / posterior at three timesteps, the reference's own float32 noise floor
@@ -490,6 +559,9 @@ def main(out_dir=None, only=None):
         np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
         np.savez_compressed(os.path.join(OUT, "publaynet_trained_like.npz"), **trained_like_cases(SP.SPECS["publaynet"], points=["mid"]))
         return
+    if only == "getcond":
+        np.savez_compressed(os.path.join(OUT, "rico25_getcond.npz"), **getcond_cases(SP.SPECS["rico25"]))
+        return
     if only == "config5":
         np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
         return
@@ -502,6 +574,7 @@ def main(out_dir=None, only=None):
     np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
     np.savez_compressed(os.path.join(OUT, "publaynet_trained_like.npz"), **trained_like_cases(SP.SPECS["publaynet"], points=["mid"]))
     np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())
+    np.savez_compressed(os.path.join(OUT, "rico25_getcond.npz"), **getcond_cases(SP.SPECS["rico25"]))
     for ds in ("rico25", "publaynet"):
         spec = SP.SPECS[ds]
         m, tok = rh.build_reference_model(ds, seed=0)

@@ -185,6 +185,69 @@ class GraphBatch:
         return self
 
 
+class Data:
+    """One layout as the reference's datasets hand it to a transform (torch_geometric.data.Data): x (n,4) boxes, y (n,)
+    labels, attr dict (datasets/rico.py: name, width, height, filtered, has_canvas_element, NoiseAdded)."""
+
+    def __init__(self, x, y, attr=None):
+        self.x, self.y = x, y
+        self.attr = attr if attr is not None else {"has_canvas_element": False, "filtered": False, "NoiseAdded": False}
+        self.edge_index, self.edge_attr = None, None
+
+
+class DataBatch(GraphBatch):
+    """What torch_geometric.loader.DataLoader's collate makes of a list of Data, reduced to the fields the reference's
+    sampling path reads (helpers/task.py:27-151 get_cond, data/util.py:270-286 sparse_to_dense, clg/const.py): nodes and
+    edges concatenated graph by graph, edge_index shifted by the node offsets, `batch` = node -> graph, dict attributes
+    collated key by key (bools -> a bool tensor, as PyG's collate does for numbers)."""
+
+    def __init__(self, datas):
+        import torch
+
+        off, eis, eas = 0, [], []
+        for d in datas:
+            if d.edge_index is not None:
+                eis.append(d.edge_index.view(2, -1) + off)
+                eas.append(d.edge_attr)
+            off += d.x.size(0)
+        ei = torch.cat(eis, dim=1) if eis else torch.zeros((2, 0), dtype=torch.long)
+        ea = torch.cat(eas) if eas else torch.zeros(0, dtype=torch.long)
+        super().__init__(torch.cat([d.y for d in datas]), ei, ea,
+                         torch.cat([torch.full((d.x.size(0),), i, dtype=torch.long) for i, d in enumerate(datas)]))
+        self.x = torch.cat([d.x for d in datas])
+        self.attr = {}
+        for k in datas[0].attr:
+            vals = [d.attr[k].item() if hasattr(d.attr[k], "item") else d.attr[k] for d in datas]
+            self.attr[k] = torch.tensor(vals) if all(isinstance(v, (bool, int, float)) for v in vals) else vals
+        self.num_graphs = len(datas)
+
+
+def synth_layout_batch(n_category: int, B: int, seed: int, relation: bool = False, edge_ratio: float = 0.1,
+                       n_lo: int = 3, n_hi: int = 12, transform_seed: int = 0):
+    """B random layouts collated like one batch of the reference's test DataLoader (test.py:169-180); with relation=True
+    every layout goes through the reference's OWN test-time transforms first — AddCanvasElement + AddRelationConstraints
+    (seed, edge_ratio as test.py:152-158; data/util.py:111-177)."""
+    import torch
+
+    install_stubs()
+    g = torch.Generator().manual_seed(seed)
+    tf = []
+    if relation:
+        from trainer.data.util import AddCanvasElement, AddRelationConstraints
+
+        tf = [AddCanvasElement(), AddRelationConstraints(seed=transform_seed, edge_ratio=edge_ratio)]
+    datas = []
+    for _ in range(B):
+        n = int(torch.randint(n_lo, n_hi + 1, (1,), generator=g))
+        box = torch.rand(n, 4, generator=g) * torch.tensor([0.8, 0.8, 0.5, 0.5]) + torch.tensor([0.1, 0.1, 0.05, 0.05])
+        lab = torch.randint(0, n_category, (n,), generator=g)
+        d = Data(box, lab, {"has_canvas_element": torch.tensor([False]), "filtered": False, "NoiseAdded": False})
+        for t in tf:
+            d = t(d)
+        datas.append(d)
+    return DataBatch(datas)
+
+
 _INSTALLED = False
 
 
@@ -230,6 +293,128 @@ def install_stubs():
     if "pytorch_fid.fid_score" not in sys.modules and need("pytorch_fid.fid_score"):
         _stub("pytorch_fid.fid_score")
     _INSTALLED = True
+
+
+# --------------------------------------------------------------------------- the `test` entry point's own imports
+class SynthLayoutDataset:
+    """Stands in for the reference's processed-dataset classes (datasets/base.py:19-34 load <dir>/<name>/processed/<split>.pt,
+    absent offline): `n` random layouts; __getitem__ applies the transform like torch_geometric's Dataset does."""
+    n, seed = 6, 0
+
+    def __init__(self, dir=None, split="test", max_seq_length=25, transform=None, n_category=25):
+        import torch
+
+        g = torch.Generator().manual_seed(self.seed)
+        self.transform, self.items = transform, []
+        for _ in range(self.n):
+            k = int(torch.randint(3, 10, (1,), generator=g))
+            box = torch.rand(k, 4, generator=g) * torch.tensor([0.8, 0.8, 0.5, 0.5]) + torch.tensor([0.1, 0.1, 0.05, 0.05])
+            self.items.append((box, torch.randint(0, n_category, (k,), generator=g)))
+        self.colors = [(0, 0, 0)] * n_category
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        import torch
+
+        box, lab = self.items[i]
+        d = Data(box.clone(), lab.clone(), {"has_canvas_element": torch.tensor([False]), "filtered": False, "NoiseAdded": False})
+        return self.transform(d) if self.transform is not None else d
+
+
+class _Loader:
+    """torch_geometric.loader.DataLoader(dataset, batch_size, shuffle=False) as test.py:176-180 uses it."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, **_k):
+        assert not shuffle
+        self.dataset, self.batch_size = dataset, batch_size
+
+    def __len__(self):
+        return -(-len(self.dataset) // self.batch_size)
+
+    def __iter__(self):
+        for i in range(0, len(self.dataset), self.batch_size):
+            yield DataBatch([self.dataset[j] for j in range(i, min(i + self.batch_size, len(self.dataset)))])
+
+
+def install_entry_stubs():
+    """What `import trainer.test` and its main() need beyond install_stubs(): hydra.main (key=value overrides of the
+    structured TestConfig), the ConfigStore, OmegaConf.load / set_struct, instantiate with _partial_, the PyG DataLoader,
+    torchvision's Compose.  Only where the real packages are absent (this image)."""
+    import functools
+
+    install_stubs()
+    store = {}
+
+    class ConfigStore:
+        @staticmethod
+        def instance():
+            return ConfigStore
+
+        @staticmethod
+        def store(name, node, **_k):
+            store[name] = node
+
+    def hydra_main(version_base=None, config_name=None, config_path=None):
+        def deco(fn):
+            @functools.wraps(fn)
+            def run():
+                node = store[config_name]
+                fields = {f.name: f for f in dataclasses.fields(node)}
+                kw = {}
+                for arg in sys.argv[1:]:
+                    k, v = arg.split("=", 1)
+                    k = k.lstrip("+")
+                    typ = fields[k].type
+                    if typ in (bool, "bool"):
+                        v = v.lower() in ("true", "1")
+                    elif typ in (int, "int"):
+                        v = int(v)
+                    elif typ in (float, "float"):
+                        v = float(v)
+                    kw[k] = v
+                return fn(to_cfg(node(**kw)))
+            return run
+        return deco
+
+    def instantiate(cfg, *args, **kwargs):
+        if isinstance(cfg, dict) and cfg.get("_partial_"):
+            c = dict(cfg)
+            c.pop("_partial_")
+            target = c.pop("_target_")
+            mod, name = target.rsplit(".", 1)
+            return functools.partial(getattr(importlib.import_module(mod), name), **c)
+        return _instantiate(cfg, *args, **kwargs)
+
+    def load(file_obj):
+        import yaml
+
+        return to_cfg(yaml.safe_load(file_obj))
+
+    hy = sys.modules["hydra"]
+    if getattr(hy, "__file__", None) is None:       # (our stub, not the real package)
+        hy.main = hydra_main
+        sys.modules["hydra.utils"].instantiate = instantiate
+        sys.modules["hydra.core.config_store"].ConfigStore = ConfigStore
+    oc = sys.modules["omegaconf"]
+    if getattr(oc, "__file__", None) is None:
+        _OmegaConf.load = staticmethod(load)
+        _OmegaConf.set_struct = staticmethod(lambda cfg, flag: None)
+    tg = sys.modules["torch_geometric.loader"]
+    if getattr(tg, "__file__", None) is None:
+        tg.DataLoader = _Loader
+    tv = sys.modules["torchvision.transforms"]
+    if getattr(tv, "__file__", None) is None:
+        class Compose:
+            def __init__(self, ts):
+                self.ts = ts
+
+            def __call__(self, d):
+                for t in self.ts:
+                    d = t(d)
+                return d
+        tv.Compose = Compose
 
 
 # --------------------------------------------------------------------------- configs
