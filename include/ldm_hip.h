@@ -221,6 +221,15 @@ int ldm_fid_features(ldm_fid* h, const float* d_bbox, const int64_t* d_label, co
 int ldm_prdc(const float* d_real, int n_real, const float* d_fake, int n_fake, int dim, int nearest_k, float* h_out4,
              void* stream);
 
+/* ---- alignment / overlap of generated layouts (r05; the remaining per-layout metrics of eval.py) ---------------------
+ * compute_alignment + compute_overlap (trainer/helpers/metric.py:98-203, called on every generated batch at
+ * eval.py:153-155,203-205) on decoded layouts resident in HBM — what ldm_decode_layouts wrote: d_bbox (B,S,4) float32
+ * (xc, yc, w, h), d_mask (B,S) uint8 (1 = valid element), 1 <= S <= 256.  d_out6 (B,6) float32, per layout:
+ * alignment-ACLayoutGAN, alignment-LayoutGAN++, alignment-NDN, overlap-ACLayoutGAN, overlap-LayoutGAN++,
+ * overlap-LayoutGAN (the reference's dictionary keys, in its order).  fp32 like the reference; sums in index order
+ * (parity to fp32 rounding).  Uses the current device; no handle.  Returns 0, -1 (bad argument) or -2 (launch failed). */
+int ldm_layout_metrics(const float* d_bbox, const uint8_t* d_mask, int B, int S, float* d_out6, void* stream);
+
 /* ---- introspection ------------------------------------------------------------------- */
 /* average device time (ms) of the most recent ldm_sample_loop, measured with HIP events on the
  * stream it ran on; blocks until that loop has finished. */

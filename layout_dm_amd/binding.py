@@ -30,7 +30,7 @@ EXPORTS = (
     "ldm_abi_version", "ldm_get_layout", "ldm_describe",
     # FID feature extractor (bound in layout_dm_amd/fid.py)
     "ldm_fid_create", "ldm_fid_destroy", "ldm_fid_last_error", "ldm_fid_load_weight", "ldm_fid_finalize",
-    "ldm_fid_features", "ldm_prdc",
+    "ldm_fid_features", "ldm_prdc", "ldm_layout_metrics",
 )
 
 
@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.ldm_profile_reset.argtypes = [vp]
     lib.ldm_get_layout.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ldm_describe.argtypes = [vp, C.c_char_p, i32]
+    lib.ldm_layout_metrics.argtypes = [vp, vp, i32, i32, vp, vp]
     for name in EXPORTS:
         if name not in ("ldm_destroy", "ldm_last_error") and not name.startswith("ldm_fid_"):
             getattr(lib, name).restype = C.c_int

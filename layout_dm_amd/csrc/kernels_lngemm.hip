@@ -1,0 +1,347 @@
+// Row-resident (Ada)LayerNorm + fp16 x 3 GEMM for the split (reference-precision) numerics mode: ONE launch where the
+// per-step path had two (a LayerNorm row kernel writing hi / lo operand rows to HBM, then gemm16x3_k reading them back
+// tile by tile).
+//
+//   out[M, N] = epi( LN(x)[M, 464] * W[N, 464]^T )        x rows in, LN output never leaves the registers
+//
+// Used for the three LayerNorm-fed GEMMs of a denoiser pass (transformer_utils.py:165-246, nn_lib.py:186-237):
+//   AdaLN  + in_proj (QKV)      fp32 out (the fp16 x 3 attention splits its own operands), also writes AdaLN(x): the block's
+//                               residual base (Block.forward: residual on the NORMED x)
+//   norm2  + linear1 + ReLU     hi / lo fp16 out (the A operand of gemm16x3_k for linear2)
+//   head LN + vocabulary head   fp32 logits
+//
+// Why: gemm16x3_k is bound by the per-CU operand fill path (37-40 GB/s per CU out of the L2), and a
+// 256 x 256 tile pulls FOUR images per stage (A hi, A lo, W hi, W lo).  Here a workgroup owns 128 rows for the whole GEMM —
+// the structure of the fast mode's stack kernel (kernels_stack.hip): their normalised hi / lo MFMA fragments sit in
+// registers (29 k16-steps x 2 x 4 registers per wave: hi in arch VGPRs, lo parked in AGPRs), only the WEIGHTS stream —
+// hi | lo tile images of 32 output columns, 64 KiB per stage, linear LDS-DMA through a 2-stage ring — i.e. half the fill
+// bytes per flop, no A operand traffic at all, no LayerNorm launch and no hi / lo activation round trip through HBM.
+// Per k16-step: two ds_read_b128 (W hi, W lo fragment) and three MFMAs on ONE accumulator (W_hi x_hi + W_hi x_lo + W_lo x_hi,
+// lo unscaled: ldm_kernels.h kSplitLoScale); the read queue is continuous across tiles (FfnStream's protocol: one
+// s_waitcnt vmcnt(0) + s_barrier per tile at step KS - PF); tiles alternate between two accumulators and the epilogue of
+// tile t — scale, bias, ReLU, transpose through LDS so that every row segment leaves as whole 64 / 128-byte pieces — is
+// issued inside the MFMA shadow of tile t + 1.
+// LayerNorm arithmetic: two-pass (mean, then sum of squared deviations) in fp32 on the row's registers, eps 1e-5, like
+// ln_rows (kernels_norm.hip).  Weight K axis in MFMA k-slot order (ldm_pack::kslot): a lane's accumulator-layout registers
+// of column groups 2ks, 2ks + 1 ARE its B fragment of k16-step ks.
+// gfx950 only; geometry: D == 464 (29 k16-steps), N % 4 == 0, N <= 2048.
+#include "ldm_dma.h"
+#include "ldm_kernels.h"
+#include "ldm_pipes.h"
+
+namespace ldm {
+
+namespace {
+
+constexpr int LG_KS = 29, LG_PF = 6, LG_SYNC = LG_KS - LG_PF;
+constexpr int LG_STAGE = 65536;                    // W hi tile (32 KiB) | W lo tile (32 KiB)
+constexpr int LG_LO = 32768;
+constexpr int LG_TP_LD = 36;                       // floats per row of a wave's 32 x 32 transpose buffer (16-B aligned rows)
+constexpr int LG_TP_BYTES = 32 * LG_TP_LD * 4;     // 4 608 B per wave
+constexpr int LG_PAR_OFF = 2 * LG_STAGE;           // multiplier [512] | shift [512]
+constexpr int LG_BIAS_OFF = LG_PAR_OFF + 2 * 512 * 4;   // bias [2048]
+constexpr int LG_TP_OFF = LG_BIAS_OFF + 2048 * 4;
+constexpr int LG_LDS = LG_TP_OFF + 4 * LG_TP_BYTES;     // 161 792 B
+static_assert(LG_LDS <= 160 * 1024, "LDS budget");
+
+template <int OFF>
+__device__ __forceinline__ void lg_dsr(f16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+struct LgState {
+  f16x8 qh[LG_PF], ql[LG_PF];   // W hi / lo fragment queue
+  unsigned aW[8];               // LDS byte addresses of the fragment columns in the CURRENT stage
+  const f16x8* xhi;             // [29] activation fragments, hi (arch VGPRs)
+  const f16x8* xlo;             // [29] ... lo (AGPRs)
+  f32x16 accA, accB;            // even / odd tiles
+  const char* img;              // weight image + wave * 16 KiB
+  unsigned lds_w;               // lds0 + wave * 16 KiB
+  unsigned voff;                // lane * 16
+  int stage_delta;              // +- 64 KiB: what moves aW from the current tile's stage to the next tile's
+  int n_tiles;
+};
+
+// item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT
+template <int IT>
+__device__ __forceinline__ void lg_read(LgState& s) {
+  lg_dsr<256 * (IT >> 3)>(s.qh[IT % LG_PF], s.aW[IT & 7]);
+  lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);
+}
+
+// piece J (of 16 1-KiB pieces per wave) of tile td -> stage td & 1.  M0 is written in front of every piece: the pieces of
+// one tile straddle a tile boundary with compiler-generated epilogue code in between.
+template <int J>
+__device__ __forceinline__ void lg_dma_piece(const LgState& s, int td) {
+  if (td < s.n_tiles) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.lds_w + (unsigned)(td & 1) * LG_STAGE + J * 1024) : "memory");
+    dma_lin<0>(s.voff, s.img + (size_t)td * LG_STAGE + J * 1024);
+  }
+}
+
+struct LgEpi {
+  const float* sbias;           // LDS bias table
+  float* tp;                    // this wave's transpose buffer (LDS)
+  float* C32;
+  __half *C16, *C16lo;
+  int ldc32, ldc16, N, M, row0; // row0: first row of this wave
+  float out_scale;
+  int relu;
+  int lane;
+};
+
+// epilogue of one finished 32-column tile, in three slices spread over the next tile's MFMA shadow
+// slice 0: scale / bias / ReLU, accumulator layout -> LDS (row-major 32 x 32)
+__device__ __forceinline__ void lg_epi_write(const LgEpi& e, const f32x16& acc, int tile) {
+  const int r = e.lane & 31, hi = e.lane >> 5;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const float4 b = *reinterpret_cast<const float4*>(e.sbias + tile * 32 + rq * 8 + hi * 4);
+    float4 v;
+    v.x = acc[rq * 4 + 0] * e.out_scale + b.x;
+    v.y = acc[rq * 4 + 1] * e.out_scale + b.y;
+    v.z = acc[rq * 4 + 2] * e.out_scale + b.z;
+    v.w = acc[rq * 4 + 3] * e.out_scale + b.w;
+    if (e.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(e.tp + r * LG_TP_LD + rq * 8 + hi * 4) = v;
+  }
+}
+// slice 1: LDS -> registers, 8 lanes per row (a row's 32 columns = 128 contiguous bytes), 8 rows per pass
+__device__ __forceinline__ void lg_epi_read(const LgEpi& e, float4 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    v[p] = *reinterpret_cast<const float4*>(e.tp + (p * 8 + (e.lane >> 3)) * LG_TP_LD + (e.lane & 7) * 4);
+}
+// slice 2: registers -> global (fp32 rows, or hi / lo fp16 rows)
+__device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4], int tile) {
+  const int col = tile * 32 + (e.lane & 7) * 4;
+  if (col >= e.N) return;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = e.row0 + p * 8 + (e.lane >> 3);
+    if (row >= e.M) continue;
+    if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)row * e.ldc32 + col) = v[p];
+    if (e.C16) {
+      const __half2 h0 = __floats2half2_rn(v[p].x, v[p].y), h1 = __floats2half2_rn(v[p].z, v[p].w);
+      uint2 pk;
+      pk.x = *reinterpret_cast<const unsigned*>(&h0);
+      pk.y = *reinterpret_cast<const unsigned*>(&h1);
+      *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
+      if (e.C16lo) {
+        const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+        const __half2 l0 = __floats2half2_rn((v[p].x - f0.x) * kSplitLoScale, (v[p].y - f0.y) * kSplitLoScale);
+        const __half2 l1 = __floats2half2_rn((v[p].z - f1.x) * kSplitLoScale, (v[p].w - f1.y) * kSplitLoScale);
+        pk.x = *reinterpret_cast<const unsigned*>(&l0);
+        pk.y = *reinterpret_cast<const unsigned*>(&l1);
+        *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
+      }
+    }
+  }
+}
+
+// One tile = 29 steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose
+// epilogue runs in this tile's shadow when prev >= 0.  The counted waits are never larger than the number of LDS operations
+// really issued behind the awaited fragment pair (extra operations of the epilogue slices only make them stricter).
+template <int PAR, int IT>
+__device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bool prev, float4 (&ev)[4]) {
+  if constexpr (IT < LG_KS) {
+    // LDS operations of a wave complete in order: all but the 2 (PF - 1) youngest = the fragment pairs of items IT + 1 ..
+    // IT + PF - 1.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
+    constexpr int tail = 2 * ((LG_KS - 1 - IT) < (LG_PF - 1) ? (LG_KS - 1 - IT) : (LG_PF - 1));
+    if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<tail>();
+    else wait_lgkm<2 * (LG_PF - 1)>();
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16& acc = PAR ? s.accB : s.accA;
+    const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
+    if constexpr (IT == 0) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
+    } else {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
+    }
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT == LG_SYNC) {
+      // the next tile's stage is complete (own DMA pieces landed, then everybody's); this tile's reads are all issued
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ... so the stage this tile was read from's PREDECESSOR is long free: from here on the DMA of tile + 2 may go into
+      // the stage of THIS tile (its first piece is issued below, > PF steps after this tile's last read was issued)
+    }
+    if constexpr (IT + LG_PF < LG_KS) {
+      lg_read<IT + LG_PF>(s);
+    } else {
+      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was toggled at step SYNC - 1
+      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_KS>(s);
+    }
+    if constexpr (IT == LG_SYNC - 1) {
+      // item KS - 1 (the last fragment pair of this tile) has just been issued: aW now points into the next tile's stage
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
+      s.stage_delta = -s.stage_delta;
+    }
+    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier (every wave has issued all its reads of
+    // it): pieces 0 .. 4 at steps SYNC + 1 .. KS - 1 of this tile, pieces 5 .. 15 at steps 0 .. 10 of the next one.
+    if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);
+    if constexpr (IT <= 10) {
+      if (tile >= 1) lg_dma_piece<IT + (LG_KS - 1 - LG_SYNC)>(s, tile + 1);
+    }
+    // previous tile's epilogue in this tile's MFMA shadow
+    if (prev) {
+      if constexpr (IT == 3) {
+        asm volatile("s_nop 7" ::: "memory");
+        lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
+      }
+      if constexpr (IT == 9) lg_epi_read(e, ev);
+      if constexpr (IT == 15) {
+        wait_lgkm<0>();
+        lg_epi_store(e, ev, tile - 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lg_step<PAR, IT + 1>(s, e, tile, prev, ev);
+  }
+}
+
+}  // namespace
+
+template <bool ADA>
+__global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, hi = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
+  const unsigned voff = (unsigned)lane * 16;
+  float* spar = reinterpret_cast<float*>(smem + LG_PAR_OFF);
+  float* sbias = reinterpret_cast<float*>(smem + LG_BIAS_OFF);
+
+  // ---- weights: tiles 0 / 1 -> stages 0 / 1 (this wave's 16 KiB of each)
+  const char* img = a.img + wave * 16384;
+  for (int t = 0; t < 2 && t < a.n_tiles; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+
+  // ---- parameter tables -> LDS: multiplier | shift (zero beyond D: padded columns come out as exact zeros), bias
+  for (int i = tid; i < 512; i += 256) {
+    const bool in = i < a.D;
+    spar[i] = in ? (ADA ? 1.0f + a.p0[i] : a.p0[i]) : 0.f;
+    spar[512 + i] = in ? a.p1[i] : 0.f;
+  }
+  for (int i = tid; i < a.n_tiles * 32; i += 256) sbias[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+
+  // ---- the rows, raw, in accumulator layout: lane (row, hi) owns columns 8 g + 4 hi .. + 3 of every 8-column group g
+  constexpr int NG = 58;
+  const int row = blockIdx.x * 128 + wave * 32 + r;
+  const int rrow = row < a.M ? row : a.M - 1;
+  float4 v[NG];
+  if (a.tokens) {  // x = emb[token] + pos[s]   (nn_lib.py:204,220)
+    const float* e = a.emb + (size_t)a.tokens[rrow] * a.D + hi * 4;
+    const float* p = a.pos + (size_t)(rrow % a.S) * a.D + hi * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 x = *reinterpret_cast<const float4*>(e + g * 8), y = *reinterpret_cast<const float4*>(p + g * 8);
+      v[g] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+  } else {
+    const float* x = a.x + (size_t)rrow * a.ldx + hi * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) v[g] = *reinterpret_cast<const float4*>(x + g * 8);
+  }
+  // two-pass statistics over the row (this lane's half + lane ^ 32)
+  float s1 = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) s1 += (v[g].x + v[g].y) + (v[g].z + v[g].w);
+  s1 += __shfl_xor(s1, 32, 64);
+  const float inv_d = 1.0f / (float)a.D;
+  const float mean = s1 * inv_d;
+  float s2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float dx = v[g].x - mean, dy = v[g].y - mean, dz = v[g].z - mean, dw = v[g].w - mean;
+    s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+  }
+  s2 += __shfl_xor(s2, 32, 64);
+  const float rstd = 1.0f / sqrtf(s2 * inv_d + 1e-5f);
+  __syncthreads();  // parameter tables visible
+  // normalise, write the residual base (ADA), split into hi / lo fragments: groups 2 ks, 2 ks + 1 -> fragment ks.  The hi
+  // fragment takes the place of the raw values it was made from (v[] dies pair by pair), the lo fragment goes to AGPRs.
+  f16x8 xhi[LG_KS], xlo[LG_KS];
+  float* yrow = (ADA && a.y32) ? a.y32 + (size_t)rrow * a.D + hi * 4 : nullptr;
+#pragma unroll
+  for (int ks = 0; ks < LG_KS; ++ks) {
+    f16x8 fh, fl;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = 2 * ks + u;
+      const float4 gm = *reinterpret_cast<const float4*>(spar + g * 8 + hi * 4);
+      const float4 sh = *reinterpret_cast<const float4*>(spar + 512 + g * 8 + hi * 4);
+      float4 y;
+      y.x = (v[g].x - mean) * rstd * gm.x + sh.x;
+      y.y = (v[g].y - mean) * rstd * gm.y + sh.y;
+      y.z = (v[g].z - mean) * rstd * gm.z + sh.z;
+      y.w = (v[g].w - mean) * rstd * gm.w + sh.w;
+      if (yrow && row < a.M) *reinterpret_cast<float4*>(yrow + g * 8) = y;
+      const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const _Float16 h = (_Float16)yy[c];
+        fh[u * 4 + c] = h;
+        fl[u * 4 + c] = (_Float16)((yy[c] - (float)h) * kSplitLoScale);
+      }
+    }
+    xhi[ks] = fh;
+    xlo[ks] = to_agpr4(fl);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- tile loop
+  LgState s;
+  s.xhi = xhi;
+  s.xlo = xlo;
+  s.img = img;
+  s.lds_w = lds0 + wave * 16384;
+  s.voff = voff;
+  s.n_tiles = a.n_tiles;
+  s.stage_delta = LG_STAGE;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+  LgEpi e;
+  e.sbias = sbias;
+  e.tp = reinterpret_cast<float*>(smem + LG_TP_OFF + wave * LG_TP_BYTES);
+  e.C32 = a.C32; e.C16 = a.C16; e.C16lo = a.C16lo; e.ldc32 = a.ldc32; e.ldc16 = a.ldc16;
+  e.N = a.N; e.M = a.M; e.row0 = blockIdx.x * 128 + wave * 32;
+  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane;
+  // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
+#pragma unroll
+  for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]));
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
+  float4 ev[4];
+  for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
+    lg_step<0, 0>(s, e, t, t > 0, ev);
+    lg_step<1, 0>(s, e, t + 1, true, ev);
+  }
+  // the last tile's epilogue (exposed)
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
+  lg_epi_write(e, s.accB, a.n_tiles - 1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  lg_epi_read(e, ev);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  lg_epi_store(e, ev, a.n_tiles - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
+  if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
+  auto kern = a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>;
+  allow_big_lds((const void*)kern);
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
+  return 0;
+}
+
+}  // namespace ldm

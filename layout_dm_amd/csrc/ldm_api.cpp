@@ -179,6 +179,18 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
   }
   h->save_ws(lane);
   }
+  if (cfg->precision == LDM_PREC_SPLIT_F16) {
+    // the LayerNorm-fed GEMMs as row-resident launches (kernels_lngemm.hip): d_model 464 (29 k16-steps, K padded to 512),
+    // every N within 2048 columns; LDM_DEV=1 LDM_X3_LNGEMM=0: LayerNorm launches + gemm16x3_k (the r04 structure)
+    auto even = [](int t) { return (t + 1) & ~1; };
+    h->x3_qkv_tiles = even((3 * h->D + 31) / 32);
+    h->x3_ffn1_tiles = even((h->F + 31) / 32);
+    h->x3_head_tiles = even(h->Cp / 32);
+    h->lngemm = h->D == 464 && h->Dp == 512 && (3 * h->D) % 4 == 0 && h->F % 4 == 0 && h->x3_qkv_tiles * 32 <= 2048 &&
+                h->x3_ffn1_tiles * 32 <= 2048 && h->x3_head_tiles * 32 <= 2048 && h->x3_qkv_tiles * 32 <= round_up(3 * h->D, 256) &&
+                h->x3_ffn1_tiles * 32 <= round_up(h->F, 256) && h->x3_head_tiles * 32 <= round_up(h->C, 256) &&
+                knob_int("LDM_X3_LNGEMM", 1) != 0;
+  }
   h->cur_lane = h->n_lanes - 1;
   h->activate(0);
   A(&h->tok_a, (size_t)cfg->max_batch * h->S);
@@ -381,7 +393,8 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   const bool loop = loop_fusable(h, nullptr);
   char num[96];
   std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->cfg.precision];
-  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? "tiled_gemm+attn" : h->fused_attn == 6 ? "stack" : "generic16");
+  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? (h->lngemm ? "row_resident_ln_gemm+tiled_gemm+attn" : "tiled_gemm+attn")
+                                   : h->fused_attn == 6 ? "stack" : "generic16");
   s += std::string(";loop=") + (loop ? "one_launch" : "per_step_graph");
   s += ";chunk=" + std::to_string(h->chunk) + ";lanes=" + std::to_string(h->n_lanes) + ";lane_offset_us=" + std::to_string(h->lane_offset_us);
   snprintf(num, sizeof(num), ";tie_rel=%g;tie_abs=%g", (double)h->tie_rel, (double)h->tie_abs);

@@ -117,34 +117,49 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
   for (int i = 0; i < h->L; ++i) {
     const LayerW& w = h->layers[i];
     const float* ss = h->adaln + ((size_t)t * h->L + i) * 2 * D;
-    {  // AdaLN (layer 0: fused with the embedding gather); P <- normed x (the residual base)
-      LnArgs a{};
-      a.x = h->P;
+    if (split && h->lngemm) {  // AdaLN + QKV projection in ONE row-resident launch (kernels_lngemm.hip); P <- normed x
+      LnGemmArgs a{};
+      a.x = h->P; a.ldx = D;
       a.tokens = (i == 0) ? d_tokens : nullptr;
-      a.emb = h->emb;
-      a.pos = h->pos;
-      a.p0 = ss;
-      a.p1 = ss + D;
+      a.emb = h->emb; a.pos = h->pos; a.S = h->S;
+      a.p0 = ss; a.p1 = ss + D; a.ada = 1;
       a.y32 = h->P;
-      a.y16 = f16 ? h->a16 : nullptr;
-      a.y16lo = split ? h->a16lo : nullptr;
-      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 1;
-      ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * (4 + 4 + (f16 ? 2 : 0)));
-      launch_layernorm(a, st);
-    }
-    {  // QKV projection
-      GemmArgs g{};
-      g.A = f16 ? (const void*)h->a16 : (const void*)h->P;
-      g.Alo = h->a16lo;
-      g.W = f16 ? (const void*)w.w_in16 : (const void*)w.w_in;
-      g.Wlo = w.w_in16lo; g.out_scale = w.s_in;
-      g.bias = w.b_in;
-      g.C32 = (prec == LDM_PREC_FAST_F16) ? nullptr : h->qkv32;
-      g.C16 = (prec == LDM_PREC_FAST_F16) ? h->qkv16 : nullptr;
-      g.M = M; g.N = 3 * D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D;
-      g.ldc32 = 3 * D; g.ldc16 = 3 * D; g.precision = prec;
-      ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * D * esz + (double)M * 3 * D * (prec == 1 ? 2 : 4));
-      launch_gemm_mode(g, 0, st);
+      a.img = (const char*)w.x3_qkv; a.n_tiles = h->x3_qkv_tiles;
+      a.bias = w.b_in; a.out_scale = w.s_in;
+      a.C32 = h->qkv32; a.ldc32 = 3 * D;
+      a.M = M; a.N = 3 * D; a.D = D;
+      ldm_handle::Scope sc(h, st, "gemm_qkv_ln", gemm_flops(M, 3 * D, D), (double)M * D * 8 + (double)M * 3 * D * 4);
+      if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
+    } else {
+      {  // AdaLN (layer 0: fused with the embedding gather); P <- normed x (the residual base)
+        LnArgs a{};
+        a.x = h->P;
+        a.tokens = (i == 0) ? d_tokens : nullptr;
+        a.emb = h->emb;
+        a.pos = h->pos;
+        a.p0 = ss;
+        a.p1 = ss + D;
+        a.y32 = h->P;
+        a.y16 = f16 ? h->a16 : nullptr;
+        a.y16lo = split ? h->a16lo : nullptr;
+        a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 1;
+        ldm_handle::Scope sc(h, st, i == 0 ? "embed_adaln" : "adaln", 0, (double)M * D * (4 + 4 + (f16 ? 2 : 0)));
+        launch_layernorm(a, st);
+      }
+      {  // QKV projection
+        GemmArgs g{};
+        g.A = f16 ? (const void*)h->a16 : (const void*)h->P;
+        g.Alo = h->a16lo;
+        g.W = f16 ? (const void*)w.w_in16 : (const void*)w.w_in;
+        g.Wlo = w.w_in16lo; g.out_scale = w.s_in;
+        g.bias = w.b_in;
+        g.C32 = (prec == LDM_PREC_FAST_F16) ? nullptr : h->qkv32;
+        g.C16 = (prec == LDM_PREC_FAST_F16) ? h->qkv16 : nullptr;
+        g.M = M; g.N = 3 * D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D;
+        g.ldc32 = 3 * D; g.ldc16 = 3 * D; g.precision = prec;
+        ldm_handle::Scope sc(h, st, "gemm_qkv", gemm_flops(M, 3 * D, D), (double)M * D * esz + (double)M * 3 * D * (prec == 1 ? 2 : 4));
+        launch_gemm_mode(g, 0, st);
+      }
     }
     {  // attention
       AttnArgs a{};
@@ -171,28 +186,40 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * D * (esz + 8));
       launch_gemm_mode(g, 1, st);
     }
-    {  // LayerNorm 2
-      LnArgs a{};
-      a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2;
-      a.y32 = f16 ? nullptr : h->h32;
-      a.y16 = f16 ? h->h16 : nullptr;
-      a.y16lo = split ? h->h16lo : nullptr;
-      a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
-      ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * (4 + esz));
-      launch_layernorm(a, st);
-    }
-    {  // FFN1 + ReLU
-      GemmArgs g{};
-      g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
-      g.Alo = h->h16lo;
-      g.W = f16 ? (const void*)w.w1_16 : (const void*)w.w1;
-      g.Wlo = w.w1_16lo; g.out_scale = w.s1;
-      g.bias = w.b1; g.relu = 1;
-      g.C32 = f16 ? nullptr : h->hid32; g.ldc32 = F;
-      g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
-      g.M = M; g.N = F; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
-      ldm_handle::Scope sc(h, st, "gemm_ffn1", gemm_flops(M, F, D), (double)M * D * esz + (double)M * F * esz);
-      launch_gemm_mode(g, 2, st);
+    if (split && h->lngemm) {  // LayerNorm 2 + FFN1 + ReLU in ONE row-resident launch: hi / lo hidden activations out
+      LnGemmArgs a{};
+      a.x = h->Q; a.ldx = D;
+      a.p0 = w.g2; a.p1 = w.be2; a.ada = 0;
+      a.img = (const char*)w.x3_ffn1; a.n_tiles = h->x3_ffn1_tiles;
+      a.bias = w.b1; a.out_scale = w.s1; a.relu = 1;
+      a.C16 = h->hid16; a.C16lo = h->hid16lo; a.ldc16 = Fp;
+      a.M = M; a.N = F; a.D = D; a.S = h->S;
+      ldm_handle::Scope sc(h, st, "gemm_ffn1_ln", gemm_flops(M, F, D), (double)M * D * 4 + (double)M * F * 4);
+      if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
+    } else {
+      {  // LayerNorm 2
+        LnArgs a{};
+        a.x = h->Q; a.p0 = w.g2; a.p1 = w.be2;
+        a.y32 = f16 ? nullptr : h->h32;
+        a.y16 = f16 ? h->h16 : nullptr;
+        a.y16lo = split ? h->h16lo : nullptr;
+        a.M = M; a.D = D; a.S = h->S; a.ld16 = Dp; a.ada = 0;
+        ldm_handle::Scope sc(h, st, "layernorm2", 0, (double)M * D * (4 + esz));
+        launch_layernorm(a, st);
+      }
+      {  // FFN1 + ReLU
+        GemmArgs g{};
+        g.A = f16 ? (const void*)h->h16 : (const void*)h->h32;
+        g.Alo = h->h16lo;
+        g.W = f16 ? (const void*)w.w1_16 : (const void*)w.w1;
+        g.Wlo = w.w1_16lo; g.out_scale = w.s1;
+        g.bias = w.b1; g.relu = 1;
+        g.C32 = f16 ? nullptr : h->hid32; g.ldc32 = F;
+        g.C16 = f16 ? h->hid16 : nullptr; g.C16lo = split ? h->hid16lo : nullptr; g.ldc16 = Fp;
+        g.M = M; g.N = F; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
+        ldm_handle::Scope sc(h, st, "gemm_ffn1", gemm_flops(M, F, D), (double)M * D * esz + (double)M * F * esz);
+        launch_gemm_mode(g, 2, st);
+      }
     }
     {  // FFN2 + residual:  P = Q + hid·W2^T + b2
       GemmArgs g{};
@@ -207,6 +234,18 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       ldm_handle::Scope sc(h, st, "gemm_ffn2", gemm_flops(M, D, F), (double)M * F * esz + (double)M * D * 8);
       launch_gemm_mode(g, 3, st);
     }
+  }
+  if (split && h->lngemm) {  // head: LayerNorm + vocabulary projection (no bias) in ONE row-resident launch
+    LnGemmArgs a{};
+    a.x = h->P; a.ldx = D;
+    a.p0 = h->head_g; a.p1 = h->head_b; a.ada = 0;
+    a.img = (const char*)h->x3_head; a.n_tiles = h->x3_head_tiles;
+    a.out_scale = h->head_s;
+    a.C32 = h->logits; a.ldc32 = h->Cp;
+    a.M = M; a.N = h->Cp; a.D = D; a.S = h->S;   // (columns C .. Cp of the image are zero rows: exact zeros in the padding)
+    ldm_handle::Scope sc(h, st, "gemm_head_ln", gemm_flops(M, C, D), (double)M * D * 4 + (double)M * C * 4);
+    if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
+    return 0;
   }
   {  // head: LayerNorm + vocab projection (no bias)
     LnArgs a{};

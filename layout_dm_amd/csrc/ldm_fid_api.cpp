@@ -222,3 +222,13 @@ extern "C" int ldm_prdc(const float* d_real, int n_real, const float* d_fake, in
   h_out4[3] = (float)((double)h[3] / (double)n_real);                           // coverage
   return done(0);
 }
+
+// ------------------------------------------------------------------------------------------ alignment / overlap
+// compute_alignment + compute_overlap (trainer/helpers/metric.py:98-203) on decoded layouts resident in HBM: six scores per layout
+extern "C" int ldm_layout_metrics(const float* d_bbox, const uint8_t* d_mask, int B, int S, float* d_out6, void* stream) {
+  if (B < 0 || (B > 0 && (!d_bbox || !d_mask || !d_out6))) return -1;
+  if (B == 0) return 0;
+  (void)hipGetLastError();
+  if (launch_layout_metrics(d_bbox, d_mask, B, S, d_out6, (hipStream_t)stream)) return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

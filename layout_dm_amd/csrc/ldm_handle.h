@@ -73,6 +73,7 @@ struct LayerW {
   const float *w_in, *b_in, *w_out, *b_out, *w1, *b1, *w2, *b2, *g2, *be2;  // fp32 views
   __half *w_in16, *w_in16lo, *w_out16, *w_out16lo, *w1_16, *w1_16lo, *w2_16, *w2_16lo;
   float s_in = 1.f, s_out = 1.f, s1 = 1.f, s2 = 1.f;  // split mode: 2^-k of each tensor's power-of-two pre-scale (GemmArgs.out_scale)
+  void *x3_qkv = nullptr, *x3_ffn1 = nullptr;         // split mode: hi | lo tile images of in_proj / linear1 (kernels_lngemm.hip)
 };
 
 struct ProfEntry {
@@ -140,6 +141,11 @@ struct ldm_handle {
   const float *emb = nullptr, *head_g = nullptr, *head_b = nullptr, *head_w = nullptr;
   __half *head_w16 = nullptr, *head_w16lo = nullptr;
   float head_s = 1.f;
+  // split mode on the reference's backbone: the three LayerNorm-fed GEMMs (AdaLN + in_proj, norm2 + linear1, head LN + head)
+  // run as ONE row-resident launch each (kernels_lngemm.hip) instead of a LayerNorm launch + gemm16x3_k
+  bool lngemm = false;
+  void* x3_head = nullptr;
+  int x3_qkv_tiles = 0, x3_ffn1_tiles = 0, x3_head_tiles = 0;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

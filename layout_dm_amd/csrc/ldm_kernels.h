@@ -81,6 +81,23 @@ struct GemmArgs {
 };
 void launch_gemm(const GemmArgs& g, hipStream_t st);
 
+// Row-resident (Ada)LayerNorm + fp16 x 3 GEMM (kernels_lngemm.hip): out = epi(LN(x) W^T) with the normalised hi / lo
+// fragments of 128 rows resident in a workgroup's registers and the weights streamed as hi | lo tile images
+// (ldm_pack::pack_x3_tile_image).  D == 464, n_tiles even, N % 4 == 0, N <= 32 n_tiles <= 2048.  -1: geometry not supported.
+struct LnGemmArgs {
+  const float* x;           // [M, ldx] rows (ignored when tokens != nullptr)
+  const int32_t* tokens;    // [M] or nullptr: x = emb[token] + pos[row % S]
+  const float *emb, *pos;
+  const float *p0, *p1;     // ada: AdaLN scale / shift; else gamma / beta   [D]
+  float* y32;               // ada: the normalised rows (the block's residual base) [M, D] or nullptr (may alias x)
+  const char* img;          // n_tiles x 64 KiB: W hi tile | W lo tile (K axis in k-slot order, tile swizzle applied)
+  const float* bias;        // [N] or nullptr
+  float* C32;               // [M, ldc32] or nullptr
+  __half *C16, *C16lo;      // [M, ldc16] hi / lo, or nullptr
+  int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
+  float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
+};
+int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);
@@ -142,6 +159,9 @@ constexpr int kStackPostMaxLive = 48;
 constexpr int kStackLoopMaxSteps = 128;  // timesteps travel in the kernel arguments
 void launch_stack_loop(const FusedLayerSet& ls, int F, int N, int B, int S, int H, int dh, const StackHead& head,
                        const StackLoop& lp, hipStream_t st);
+// alignment / overlap scores of decoded layouts (kernels_metrics.hip): bbox [B][S][4] f32, mask [B][S] u8 -> out [B][6];
+// -1 if S is outside [1, 256]
+int launch_layout_metrics(const float* bbox, const uint8_t* mask, int B, int S, float* out, hipStream_t st);
 // ids -> {bbox, label, mask} (kernels_decode.hip); centres: [4][n_bin] f64 cluster centres or nullptr (linear bins)
 void launch_decode_layouts(const int32_t* tokens, int B, int E, int A, int n_category, int n_bin,
                            const double* centres, int box_f64, void* bbox, int64_t* label, uint8_t* mask,

@@ -139,4 +139,19 @@ inline std::vector<uint16_t> pack_head_image(const uint16_t* w, int n_tiles) {
   return img;
 }
 
+// hi | lo tile images of the row-resident fp16 x 3 GEMM (kernels_lngemm.hip): per 32-row tile ONE 64-KiB stage = the hi tile
+// (1-KiB rows, tile swizzle: pack_head_image's format) followed by the lo tile.  hi / lo: [>= 32 n_tiles rows][512] fp16 with
+// the K axis already in k-slot order, zero rows beyond the GEMM's N.
+inline std::vector<uint16_t> pack_x3_tile_image(const uint16_t* hi, const uint16_t* lo, int n_tiles) {
+  std::vector<uint16_t> img((size_t)n_tiles * 32768, 0);
+  const uint16_t* rows[32];
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int i = 0; i < 32; ++i) rows[i] = hi + (size_t)(t * 32 + i) * 512;
+    put_tile_1k(img.data() + (size_t)t * 32768, rows);
+    for (int i = 0; i < 32; ++i) rows[i] = lo + (size_t)(t * 32 + i) * 512;
+    put_tile_1k(img.data() + (size_t)t * 32768 + 16384, rows);
+  }
+  return img;
+}
+
 }  // namespace ldm_pack

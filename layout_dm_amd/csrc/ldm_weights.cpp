@@ -86,6 +86,28 @@ static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half*
   return 0;
 }
 
+// hi | lo tile image of a split-mode weight for the row-resident x3 GEMM (kernels_lngemm.hip): the [>= 32 n_tiles][Kp = 512] hi / lo
+// copies make_w16 built (natural K order) -> K axis in k-slot order -> ldm_pack::pack_x3_tile_image
+static int make_x3_image(ldm_handle* h, const __half* hi, const __half* lo, int n_tiles, void** out) {
+  const size_t n = (size_t)n_tiles * 32 * 512;
+  std::vector<uint16_t> a(n), b(n), ak(n, 0), bk(n, 0);
+  HIP_OK(h, hipDeviceSynchronize());  // (the cast kernels of make_w16)
+  HIP_OK(h, hipMemcpy(a.data(), hi, n * 2, hipMemcpyDeviceToHost));
+  HIP_OK(h, hipMemcpy(b.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  for (int r = 0; r < n_tiles * 32; ++r)
+    for (int k = 0; k < 512; ++k) {
+      ak[(size_t)r * 512 + ldm_pack::kslot(k)] = a[(size_t)r * 512 + k];
+      bk[(size_t)r * 512 + ldm_pack::kslot(k)] = b[(size_t)r * 512 + k];
+    }
+  const std::vector<uint16_t> img = ldm_pack::pack_x3_tile_image(ak.data(), bk.data(), n_tiles);
+  __half* d = nullptr;
+  int rc = h->dalloc(&d, img.size(), false);
+  if (rc) return rc;
+  HIP_OK(h, hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
 // ---- fast-mode weight images (built on the host once; tiny compared with one sampling call)
 static uint16_t f2h_bits(float x) {
   const __half hh = __float2half(x);
@@ -288,6 +310,7 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   h->fast_head = nullptr;
   h->head_img_ks = nullptr;
   h->head_w16 = h->head_w16lo = nullptr;
+  h->x3_head = nullptr;
   h->tbl_att_static = h->tbl_att_dyn = h->tbl_ffn = h->tbl_head = nullptr;
   struct Sink {
     ldm_handle* h;
@@ -320,13 +343,18 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
       if ((rc = make_w16(h, w.w_out, D, D, h->Dp, &w.w_out16, &w.w_out16lo, &w.s_out))) return rc;
       if ((rc = make_w16(h, w.w1, F, D, h->Dp, &w.w1_16, &w.w1_16lo, &w.s1))) return rc;
       if ((rc = make_w16(h, w.w2, D, F, h->Fp, &w.w2_16, &w.w2_16lo, &w.s2))) return rc;
+      if (h->lngemm) {
+        if ((rc = make_x3_image(h, w.w_in16, w.w_in16lo, h->x3_qkv_tiles, &w.x3_qkv))) return rc;
+        if ((rc = make_x3_image(h, w.w1_16, w.w1_16lo, h->x3_ffn1_tiles, &w.x3_ffn1))) return rc;
+      }
     }
   }
   if (h->cfg.precision == LDM_PREC_FAST_F16) {
     if ((rc = build_fast_weights(h))) return rc;
     if ((rc = build_loop_tables(h))) return rc;
-  } else if (f16 && (rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo, &h->head_s))) {
-    return rc;
+  } else if (f16) {
+    if ((rc = make_w16(h, h->head_w, C, D, h->Dp, &h->head_w16, &h->head_w16lo, &h->head_s))) return rc;
+    if (h->lngemm && (rc = make_x3_image(h, h->head_w16, h->head_w16lo, h->x3_head_tiles, &h->x3_head))) return rc;
   }
   // schedule buffers are taken from the checkpoint, not recomputed
   static const char* names[kNumSched] = {"log_at",         "log_bt",         "log_ct",       "log_cumprod_at",

@@ -84,7 +84,8 @@ class HipMaskAndReplaceDiffusion:
         self.verifier = verifier
         self.auto = precision == "auto"
         self.auto_tolerance = 1e-3
-        self.verifier_tolerance = 2.5e-4   # split vs a small fp32-MFMA probe engine (both carry their own fp32 noise floor)
+        self.verifier_tolerance = 5e-4     # split vs a small fp32-MFMA probe engine: half the north star's tolerance (two valid fp32-level
+                                           # engines differ by 4.2e-4 on the "wide" point, where the reference's own f32 noise floor is 1.2e-4)
         self.verifier_check: Dict[str, float] = {}
         self.selected_precision = None if self.auto else precision
         self._mk = mk = lambda prec, mb=max_batch: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,

@@ -407,6 +407,9 @@ def getcond_cases(spec, B=2):
         tr = trajectory(m, spec, B, getcond_sampling_cfg(ctype, "random"), cond, seed=70 + i)
         for k, v in tr.items():
             out[p + "traj_" + k] = v
+        if ctype == "relation":
+            out[p + "traj_order_dependent"] = relation_order_dependent_tokens(m, tok, spec, tr, cond,
+                                                                              getcond_sampling_cfg(ctype, "random"))
     return out
 
 
@@ -450,6 +453,47 @@ def trained_like_cases(spec, B=2, points=None):
         for k, v in tr.items():
             out[f"{point}_{k}"] = v
     return out
+
+
+def relation_order_dependent_tokens(m, tok, spec, tr, cond, cfg):
+    """Annotation of a cond=relation trajectory fixture: the greedy tokens whose value in the reference's
+    float32 run is decided by ROUNDING inside its logit adjustment.  On every state the reference's float32 posterior (strong
+    mask applied, base.py:243-251) goes through logit_adjustment.update twice — in float32 as it runs, and with the same
+    numbers cast to float64 — then [PAD] disable + argmax (base.py:272-291).  Rows: [state, layout, position, float32 token,
+    float64 token] wherever the two differ.  An implementation with another summation order can agree with either."""
+    import copy
+
+    from einops import rearrange, repeat
+    from trainer.models.categorical_diffusion.logit_adjustment import update
+    from trainer.models.categorical_diffusion.util import LOG_EPS, index_to_log_onehot
+
+    seq, mask = cond["seq"], cond["mask"]
+    B, S = seq.shape
+    C = spec.n_class
+    det = rh.sampling_cfg("deterministic")
+    for k in cfg:
+        if k.startswith("relation") or k == "num_timesteps":
+            det[k] = cfg[k]
+    pad_mask = (repeat(torch.arange(S), "s -> b s", b=B) % spec.n_attr != 0) & (seq != spec.pad_id)
+    pad_mask = repeat(pad_mask, "b s -> b c s", c=C) & (rearrange(torch.arange(C), "c -> 1 c 1") == spec.pad_id)
+    rows = []
+    for i, t in enumerate(tr["steps"]):
+        t = int(t)
+        before = torch.from_numpy(tr["states_before"][i].astype(np.int64))
+        with torch.no_grad():
+            lz = index_to_log_onehot(before, C)
+            tt = torch.full((B,), t, dtype=torch.long)
+            post = m.q_posterior(log_x_start=m.predict_start(lz, tt), log_x_t=lz, t=tt)
+            post = torch.where(rearrange(mask, "b s -> b 1 s"), index_to_log_onehot(seq, C), post)
+        toks = []
+        for lp in (post.clone(), post.double()):
+            lp = update(t=t, cond=copy.copy(cond), model_log_prob=lp, tokenizer=tok, sampling_cfg=det).clone()
+            lp[pad_mask] = LOG_EPS
+            toks.append(lp.argmax(1))
+        assert np.array_equal(toks[0].numpy(), tr["greedy_next"][i])      # the float32 path here IS the fixture's
+        for b, s_ in (toks[0] != toks[1]).nonzero().tolist():
+            rows.append([i, b, s_, int(toks[0][b, s_]), int(toks[1][b, s_])])
+    return np.array(rows, np.int32).reshape(-1, 5)
 
 
 def config5_cases(B=2):
@@ -497,6 +541,7 @@ def config5_cases(B=2):
     tr = trajectory(m, spec, B, cfg, cond, seed=31)
     for k, v in tr.items():
         out["rel_" + k] = v
+    out["rel_order_dependent"] = relation_order_dependent_tokens(m, tok, spec, tr, cond, cfg)
     bt = tok.bbox_tokenizer
     out["rel_cond_seq"] = seq.numpy().astype(np.int16)
     out["rel_cond_mask"] = mask.numpy()
@@ -506,6 +551,45 @@ def config5_cases(B=2):
                                               np.float64).reshape(-1) for k in ("x", "y", "w", "h")])
     canvas_ids = bt.encode(torch.tensor([[[0.5, 0.5, 1.0, 1.0]]])).long().view(-1)
     out["rel_canvas_bins"] = (canvas_ids - torch.arange(4) * spec.n_bin).numpy().astype(np.int32)
+    return out
+
+
+def metrics_layouts(B=24, S=25, seed=5):
+    """Layouts for the alignment / overlap fixture: random ones as decode_layouts_k writes them (grid-quantised boxes, padded
+    slots zeroed), plus the edge cases the reference's code branches on: an empty layout, a single element, identical boxes
+    (distance 0), zero-area boxes, touching boxes (l_max == r_min), a full layout, and one whose padded slots carry stale
+    boxes (the alignment reads them: metric.py:113 masks rows only)."""
+    rng = np.random.default_rng(seed)
+    bbox = np.zeros((B, S, 4), np.float32)
+    mask = np.zeros((B, S), bool)
+    for b in range(B):
+        n = int(rng.integers(2, S + 1))
+        k = rng.integers(0, 32, size=(n, 4))
+        bbox[b, :n, 0], bbox[b, :n, 1] = k[:, 0] / 32.0, k[:, 1] / 32.0
+        bbox[b, :n, 2], bbox[b, :n, 3] = (k[:, 2] + 1) / 32.0, (k[:, 3] + 1) / 32.0
+        mask[b, :n] = True
+    mask[0] = False; bbox[0] = 0                                   # empty layout
+    mask[1] = False; mask[1, 0] = True; bbox[1, 1:] = 0            # a single element
+    bbox[2, 1] = bbox[2, 0]; mask[2, :2] = True                    # two identical boxes
+    bbox[3, :3, 2:] = 0; mask[3, :3] = True                        # zero-area boxes
+    bbox[4, 0] = [0.25, 0.5, 0.5, 0.5]; bbox[4, 1] = [0.75, 0.5, 0.5, 0.5]; mask[4] = False; mask[4, :2] = True; bbox[4, 2:] = 0  # touching
+    n = S; k = rng.integers(0, 32, size=(n, 4)); mask[5] = True    # a full layout
+    bbox[5] = np.stack([k[:, 0] / 32.0, k[:, 1] / 32.0, (k[:, 2] + 1) / 32.0, (k[:, 3] + 1) / 32.0], 1)
+    bbox[6] = rng.random((S, 4)).astype(np.float32) * 0.5 + 0.1; mask[6] = False; mask[6, :5] = True  # stale boxes in padded slots
+    bbox[7] = rng.random((S, 4)).astype(np.float32); mask[7] = rng.random(S) < 0.5                    # un-quantised, holes
+    return bbox, mask
+
+
+def metrics_cases():
+    """compute_alignment / compute_overlap of the REAL reference (helpers/metric.py:98-203) on metrics_layouts()."""
+    rh.install_stubs()
+    from trainer.helpers.metric import compute_alignment, compute_overlap
+
+    bbox, mask = metrics_layouts()
+    out = {"bbox": bbox, "mask": mask}
+    for fn in (compute_alignment, compute_overlap):
+        for k, v in fn(torch.from_numpy(bbox.copy()), torch.from_numpy(mask.copy())).items():
+            out[k] = v.numpy().astype(np.float32)
     return out
 
 
@@ -552,6 +636,9 @@ def main(out_dir=None, only=None):
         load_synth(m, SP.SPECS["rico25"])
         np.savez_compressed(os.path.join(OUT, "rico25_cond_variants.npz"), **cond_variant_cases(m, SP.SPECS["rico25"]))
         return
+    if only == "metrics":
+        np.savez_compressed(os.path.join(OUT, "layout_metrics.npz"), **metrics_cases())
+        return
     if only == "fid":
         np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
         return
@@ -571,6 +658,7 @@ def main(out_dir=None, only=None):
             np.savez_compressed(os.path.join(OUT, f"{ds}_decode.npz"), **decode_cases(tok, SP.SPECS[ds]))
         return
     np.savez_compressed(os.path.join(OUT, "fid_v3.npz"), **fid_cases())
+    np.savez_compressed(os.path.join(OUT, "layout_metrics.npz"), **metrics_cases())
     np.savez_compressed(os.path.join(OUT, "rico25_trained_like.npz"), **trained_like_cases(SP.SPECS["rico25"]))
     np.savez_compressed(os.path.join(OUT, "publaynet_trained_like.npz"), **trained_like_cases(SP.SPECS["publaynet"], points=["mid"]))
     np.savez_compressed(os.path.join(OUT, "rico25_config5_T200.npz"), **config5_cases())

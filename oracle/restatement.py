@@ -500,3 +500,58 @@ def relation_update(spec: ModelSpec, logp: torch.Tensor, cond_seq, graph: dict, 
         with torch.no_grad():
             x -= lr * x.grad
     return x.detach()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# alignment / overlap of generated layouts (eval.py:153-155,203-205) — restated element by element
+def layout_metrics(bbox, mask):
+    """compute_alignment + compute_overlap (trainer/helpers/metric.py:98-203) as plain loops over the elements of each
+    layout, float32 like the reference.  bbox (B,S,4) (xc, yc, w, h), mask (B,S) bool -> dict of (B,) float32 arrays with the
+    reference's six keys.  Quirks kept: in the alignment only the ROW of an invalid element is masked (metric.py:113), so the
+    stored boxes of padded slots take part in a valid element's minimum; a minimum of exactly 1.0 counts as 0
+    (metric.py:115,138); the overlap zeroes invalid boxes first (metric.py:164) and uses nan_to_num(ai / a1)."""
+    import numpy as np
+
+    bbox = np.asarray(bbox, np.float32)
+    mask = np.asarray(mask, bool)
+    B, S = mask.shape
+    f = np.float32
+    out = {k: np.zeros(B, np.float32) for k in ("alignment-ACLayoutGAN", "alignment-LayoutGAN++", "alignment-NDN",
+                                               "overlap-ACLayoutGAN", "overlap-LayoutGAN++", "overlap-LayoutGAN")}
+    for b in range(B):
+        xc, yc, w, h = (bbox[b, :, k] for k in range(4))
+        hw, hh = w / f(2), h / f(2)
+        co = np.stack([xc - hw, xc, xc + hw, yc - hh, yc, yc + hh])          # (6,S): xl xc xr yt yc yb (util.py:16-22)
+        sa = sy = so = su = f(0)
+        for i in range(S):
+            if not mask[b, i]:
+                continue
+            m = my = f(1)
+            l1, r1, t1, b1 = co[0, i], co[2, i], co[3, i], co[5, i]
+            a1 = (r1 - l1) * (b1 - t1)
+            ar = au = f(0)
+            for j in range(S):
+                if j == i:
+                    continue
+                m = min(m, np.abs(co[:, i] - co[:, j]).min())
+                if mask[b, j]:
+                    my = min(my, np.abs(co[:3, j] - co[:3, i]).min())
+                    l_max, r_min = max(l1, co[0, j]), min(r1, co[2, j])
+                    t_max, b_min = max(t1, co[3, j]), min(b1, co[5, j])
+                    ai = (r_min - l_max) * (b_min - t_max) if (l_max < r_min and t_max < b_min) else f(0)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        ar = f(ar + np.nan_to_num(f(ai) / a1))
+                    if j > i:
+                        au = f(au + ai)
+            m = f(0) if m == 1.0 else m
+            sa = f(sa - np.log(f(1) - f(m)))
+            sy = f(sy + (f(0) if my == 1.0 else my))
+            so, su = f(so + ar), f(su + au)
+        nv = f(mask[b].sum())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            na, no = sa / nv, so / nv
+        out["alignment-ACLayoutGAN"][b], out["alignment-LayoutGAN++"][b] = sa, (0.0 if np.isnan(na) else na)
+        out["alignment-NDN"][b] = sy
+        out["overlap-ACLayoutGAN"][b], out["overlap-LayoutGAN++"][b] = so, (0.0 if np.isnan(no) else no)
+        out["overlap-LayoutGAN"][b] = su
+    return out

@@ -206,6 +206,29 @@ int main() {
         }
     }
   }
+  {
+    // row-resident x3 GEMM (kernels_lngemm.hip): stage t = hi tile | lo tile of output columns 32 t .. 32 t + 31, each read
+    // with the tile formula (lg_read: hi at +0, lo at +32 KiB of the stage), K axis in k-slot order
+    const int N = 1392, n_tiles = 44;
+    std::vector<uint16_t> hi((size_t)n_tiles * 32 * Dq, 0), lo((size_t)n_tiles * 32 * Dq, 0);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < D; ++k) {
+      hi[(size_t)n * Dq + ldm_pack::kslot(k)] = id16(n + 100, k);
+      lo[(size_t)n * Dq + ldm_pack::kslot(k)] = id16(n + 30000, k);
+    }
+    const std::vector<uint16_t> img = ldm_pack::pack_x3_tile_image(hi.data(), lo.data(), n_tiles);
+    CHECK(img.size() == (size_t)n_tiles * 32768, "x3 tile image size");
+    for (int t = 0; t < n_tiles; ++t)
+      for (int part = 0; part < 2; ++part)
+        for (int r = 0; r < 32; ++r) for (int hh = 0; hh < 2; ++hh) for (int ks = 0; ks < 29; ++ks) {
+          const uint16_t* p = tile_read(img.data() + (size_t)t * 32768 + part * 16384, r, hh, ks);
+          for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * (e >> 2) + 4 * hh + (e & 3);
+            const int n = t * 32 + r;
+            const uint16_t want = (n < N && k < D) ? id16(n + (part ? 30000 : 100), k) : 0;
+            CHECK(p[e] == want, "x3 tile t=%d part=%d r=%d hi=%d ks=%d e=%d", t, part, r, hh, ks, e);
+          }
+        }
+  }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
   return 0;

@@ -189,11 +189,17 @@ def test_reference_getcond_trajectory_teacher_forced(models, golden_dir, ctype):
         plan = hip_relation_plan(eng, cond, cfg, m.tokenizer, B)
     bad = n = 0
     worst = 0.0
+    # (cond=relation: tokens the fixture annotates as decided by rounding inside the reference's own update may take either
+    #  of its float32 / float64 answers — none on this fixture; tests/test_r04_parity.py has the annotated case)
+    od = {(int(r[0]), int(r[1]), int(r[2])): (int(r[3]), int(r[4])) for r in sub.get("traj_order_dependent", [])}
     for i, t in enumerate(sub["traj_steps"]):
         before = torch.from_numpy(sub["traj_states_before"][i].astype(np.int32))
         nxt = eng.sample_step(before, int(t), cfg, cond=hip_cond, relation=plan).cpu().long()
         ref = torch.from_numpy(sub["traj_greedy_next"][i].astype(np.int64))
         d = nxt != ref
+        for b_, s_ in d.nonzero().tolist():
+            if (i, b_, s_) in od and int(nxt[b_, s_]) in od[(i, b_, s_)]:
+                d[b_, s_] = False
         if d.any():
             bad += int(d.sum())
             worst = max(worst, float(torch.from_numpy(sub["traj_greedy_margin"][i])[d].max()))

@@ -328,8 +328,10 @@ def _relation_plan(e, sub, B):
 def test_config5_T200_relation_teacher_forced(cuda, golden_dir, precision):
     """cond=relation on all 200 states of the reference's own T = 200 run: posterior -> strong mask -> logit adjustment
     (t >= 10; lr 3e6, 3 updates: the reference's defaults) -> [PAD] disable -> argmax.  The SGD steps are O(1e4) in
-    log-probability, so a greedy token can legitimately differ where the reference's margin is tiny RELATIVE TO THE
-    UPDATE; counted and bounded."""
+    log-probability and its hinges switch on the last bits of an expected box, so the reference's own float32 token can be
+    an artefact of its summation order: the fixture annotates those (exact: every other token bit-exact; fast: counted and
+    bounded).  (The final `bad_plain > bad` line only shows the adjustment is on the path; its STRENGTH is pinned by
+    test_relation_update_vs_reference_and_oracle against the reference's autograd update.)"""
     spec, g, sd = _config5(golden_dir)
     sub = _sub(g, "rel_")
     e = _engine(spec, "t200", sd, precision)
@@ -339,7 +341,28 @@ def test_config5_T200_relation_teacher_forced(cuda, golden_dir, precision):
     bad, n, worst, _ = _traj(e, sub, cond=cond, relation=plan)
     print(f"[config 5 shape / relation T=200 / {precision}] greedy tokens differing from the reference: {bad}/{n}"
           + (f" (largest reference margin among them {worst:.3e})" if bad else ""))
-    assert bad <= (2e-4 if precision == "exact" else 1e-3) * n, (bad, n, worst)
+    if precision == "exact":
+        # r05: bit-exact, except on the tokens the fixture ANNOTATES as decided by rounding inside the
+        # reference's own update — `rel_order_dependent`: the reference's float32 update and the same update in float64 on
+        # identical inputs pick different tokens there (oracle/make_golden.py relation_order_dependent_tokens; 1 of 50 000:
+        # state 3, float32 -> 152 with a margin of 0.18 nat, float64 -> 145; profiles/r05_relation_order_dependence.txt).
+        # On those the engine must return one of the two answers; everywhere else the reference's token.
+        od = {(int(r[0]), int(r[1]), int(r[2])): (int(r[3]), int(r[4])) for r in sub["order_dependent"]}
+        before = torch.from_numpy(sub["states_before"].astype(np.int32))
+        ref_next = torch.from_numpy(sub["greedy_next"].astype(np.int32))
+        unexplained, at_annotated = [], []
+        for i, t in enumerate(sub["steps"]):
+            out = e.sample_step(before[i], int(t), GREEDY, cond=cond, step=i, relation=plan).cpu()
+            for b_, s_ in (out != ref_next[i]).nonzero().tolist():
+                if (i, b_, s_) in od and int(out[b_, s_]) in od[(i, b_, s_)]:
+                    at_annotated.append((i, b_, s_, int(out[b_, s_])))
+                else:
+                    unexplained.append((i, b_, s_, int(out[b_, s_]), int(ref_next[i, b_, s_])))
+        print(f"[config 5 shape / relation T=200 / exact] differing tokens at annotated order-dependent positions: {at_annotated} "
+              f"(annotation: {sorted(od.items())}); unexplained: {unexplained}")
+        assert not unexplained and len(at_annotated) == bad <= len(od)     # nothing differs outside the annotation
+    else:
+        assert bad <= 1e-3 * n, (bad, n, worst)
     # and the adjustment is on the path: without it tokens differ
     bad_plain, _, _, _ = _traj(e, sub, cond=dict(cond, type="c"))
     assert bad_plain > bad
