@@ -33,7 +33,10 @@ namespace ldm {
 
 namespace {
 
-constexpr int LG_KS = 29, LG_PF = 6, LG_SYNC = LG_KS - LG_PF;
+// A tile is NIT = 30 queue items: the 29 k16-steps and ONE pseudo item (a fragment pair that is read and never used) so that
+// NIT % PF == 0 — item i of every tile then lives in queue slot i % PF and the queue runs on across tiles (FfnStream's trick).
+constexpr int LG_KS = 29, LG_NIT = 30, LG_PF = 6, LG_SYNC = LG_NIT - LG_PF;
+static_assert(LG_NIT % LG_PF == 0, "queue slots must line up across tiles");
 constexpr int LG_STAGE = 65536;                    // W hi tile (32 KiB) | W lo tile (32 KiB)
 constexpr int LG_LO = 32768;
 constexpr int LG_TP_LD = 36;                       // floats per row of a wave's 32 x 32 transpose buffer (16-B aligned rows)
@@ -62,11 +65,12 @@ struct LgState {
   int n_tiles;
 };
 
-// item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT
+// item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (item KS: the pseudo item re-reads step 0)
 template <int IT>
 __device__ __forceinline__ void lg_read(LgState& s) {
-  lg_dsr<256 * (IT >> 3)>(s.qh[IT % LG_PF], s.aW[IT & 7]);
-  lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);
+  constexpr int K = IT < LG_KS ? IT : 0;
+  lg_dsr<256 * (K >> 3)>(s.qh[IT % LG_PF], s.aW[K & 7]);
+  lg_dsr<256 * (K >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[K & 7]);
 }
 
 // piece J (of 16 1-KiB pieces per wave) of tile td -> stage td & 1.  M0 is written in front of every piece: the pieces of
@@ -146,48 +150,51 @@ __device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4
 // really issued behind the awaited fragment pair (extra operations of the epilogue slices only make them stricter).
 template <int PAR, int IT>
 __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bool prev, float4 (&ev)[4]) {
-  if constexpr (IT < LG_KS) {
+  if constexpr (IT < LG_NIT) {
     // LDS operations of a wave complete in order: all but the 2 (PF - 1) youngest = the fragment pairs of items IT + 1 ..
     // IT + PF - 1.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
-    constexpr int tail = 2 * ((LG_KS - 1 - IT) < (LG_PF - 1) ? (LG_KS - 1 - IT) : (LG_PF - 1));
+    constexpr int tail = 2 * ((LG_NIT - 1 - IT) < (LG_PF - 1) ? (LG_NIT - 1 - IT) : (LG_PF - 1));
     if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<tail>();
     else wait_lgkm<2 * (LG_PF - 1)>();
     __builtin_amdgcn_sched_barrier(0);
-    f32x16& acc = PAR ? s.accB : s.accA;
-    const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
-    if constexpr (IT == 0) {
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
+    if constexpr (IT < LG_KS) {
+      f32x16& acc = PAR ? s.accB : s.accA;
+      const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
+      if constexpr (IT == 0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
+      }
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
     } else {
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
+      asm volatile("" ::"v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]));  // the pseudo item: its slot is free again
     }
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT == LG_SYNC) {
-      // the next tile's stage is complete (own DMA pieces landed, then everybody's); this tile's reads are all issued
+      // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
+      // this tile (the last one, the pseudo item, at step SYNC - 1): this tile's stage may be overwritten from here on
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // ... so the stage this tile was read from's PREDECESSOR is long free: from here on the DMA of tile + 2 may go into
-      // the stage of THIS tile (its first piece is issued below, > PF steps after this tile's last read was issued)
     }
-    if constexpr (IT + LG_PF < LG_KS) {
+    if constexpr (IT + LG_PF < LG_NIT) {
       lg_read<IT + LG_PF>(s);
     } else {
-      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was toggled at step SYNC - 1
-      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_KS>(s);
+      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was moved at step SYNC - 1
+      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
     }
     if constexpr (IT == LG_SYNC - 1) {
-      // item KS - 1 (the last fragment pair of this tile) has just been issued: aW now points into the next tile's stage
+      // item NIT - 1 (the last read of this tile) has just been issued: aW now points into the next tile's stage
 #pragma unroll
       for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
       s.stage_delta = -s.stage_delta;
     }
-    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier (every wave has issued all its reads of
-    // it): pieces 0 .. 4 at steps SYNC + 1 .. KS - 1 of this tile, pieces 5 .. 15 at steps 0 .. 10 of the next one.
+    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier: pieces 0 .. 4 at steps SYNC + 1 .. NIT - 1 of
+    // this tile, pieces 5 .. 15 at steps 0 .. 10 of the next one.
     if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);
     if constexpr (IT <= 10) {
-      if (tile >= 1) lg_dma_piece<IT + (LG_KS - 1 - LG_SYNC)>(s, tile + 1);
+      if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);
     }
     // previous tile's epilogue in this tile's MFMA shadow
     if (prev) {
@@ -196,7 +203,9 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
         lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
       }
       if constexpr (IT == 9) lg_epi_read(e, ev);
-      if constexpr (IT == 15) {
+      // the stores go out right BEHIND this tile's barrier: the next s_waitcnt vmcnt(0) — which cannot tell stores from DMA
+      // pieces — is a whole tile away, instead of 8 steps (r05 call 2: 2.6-2.9 us per tile against 1.3 of MFMA and 1.7 of fill)
+      if constexpr (IT == LG_SYNC + 1) {
         wait_lgkm<0>();
         lg_epi_store(e, ev, tile - 1);
       }

@@ -1,0 +1,94 @@
+"""CPU: a replay of the issue schedule of the row-resident LayerNorm + x3 GEMM (csrc/kernels_lngemm.hip lg_step) — the
+protocol that r05's first GPU run got wrong (29 items per tile on a 6-deep queue: item 0 of the next tile landed in the slot
+of an unconsumed fragment).  The constants are parsed from the kernel source; the replay walks the steps of several tiles in
+program order and checks, for one wavefront:
+  * queue slots: the slot a step consumes holds exactly (tile, item) — nothing was overwritten before it was used;
+  * counted waits: `s_waitcnt lgkmcnt(N)` in front of a step leaves at most N LDS operations outstanding, and the LDS
+    operations of a wave complete in order, so the awaited fragment pair has landed iff at least ... at most N operations
+    were issued BEHIND it (the epilogue's extra LDS operations only make the wait stricter);
+  * the 2-stage ring: a fragment of tile t is read only after the barrier that certifies its stage (tiles 0 / 1: the prologue),
+    and the DMA of tile t + 2 into the stage of tile t is issued only behind tile t's barrier, by which every read of tile t
+    has been issued; all 16 pieces of a tile are issued before the barrier that certifies it."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _consts():
+    src = open(os.path.join(ROOT, "layout_dm_amd", "csrc", "kernels_lngemm.hip")).read()
+    m = re.search(r"constexpr int LG_KS = (\d+), LG_NIT = (\d+), LG_PF = (\d+), LG_SYNC = LG_NIT - LG_PF;", src)
+    assert m, "schedule constants not found: update this replay together with the kernel"
+    ks, nit, pf = (int(x) for x in m.groups())
+    # the structural facts the replay mirrors must still be in the source
+    for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);",
+                   "if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);", "if constexpr (IT <= 10)",
+                   "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<2 * (LG_PF - 1)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) lg_epi_read"):
+        assert needle in src, needle
+    return ks, nit, pf
+
+
+def test_schedule_replay():
+    KS, NIT, PF = _consts()
+    SYNC = NIT - PF
+    assert NIT % PF == 0 and KS < NIT
+    n_tiles = 6
+    lds_ops = []            # program-order list of LDS operations: ("frag", tile, item) twice per item, or ("epi",)
+    slot = {}               # queue slot -> (tile, item) it will hold once landed
+    stage_tile = {0: 0, 1: 1}            # stage -> tile whose image the prologue / the DMA put there
+    certified = {0, 1}                    # tiles whose stage is known complete (prologue barrier / a tile barrier)
+    barrier_done = set()                  # tiles whose step-SYNC barrier has been passed
+    dma_pieces = {}                       # tile -> pieces issued
+    cur_stage_of_aw = 0
+
+    def issue_read(tile, item):
+        nonlocal lds_ops
+        assert tile in certified, f"tile {tile} read before its stage was certified"
+        assert stage_tile[cur_stage_of_aw] == tile, f"aW points at stage {cur_stage_of_aw} = tile {stage_tile[cur_stage_of_aw]}, wanted {tile}"
+        slot[item % PF] = (tile, item)
+        lds_ops += [("frag", tile, item), ("frag", tile, item)]
+
+    for i in range(PF):                   # kernel prologue: lg_read<0..5>
+        issue_read(0, i)
+    for t in range(n_tiles):
+        last = t + 1 >= n_tiles
+        for it in range(NIT):
+            # ---- the counted wait in front of the step
+            n = 2 * min(NIT - 1 - it, PF - 1) if (it >= SYNC and last) else 2 * (PF - 1)
+            idx = max(i for i, op in enumerate(lds_ops) if op == ("frag", t, it))      # the younger of the pair
+            younger = len(lds_ops) - 1 - idx
+            assert n <= younger, f"tile {t} step {it}: lgkmcnt({n}) but only {younger} operations were issued behind the pair"
+            # ---- consumption
+            assert slot[it % PF] == (t, it), f"tile {t} step {it}: slot holds {slot[it % PF]}"
+            # ---- barrier
+            if it == SYNC:
+                if t + 1 < n_tiles:
+                    assert dma_pieces.get(t + 1, 16) == 16, f"tile {t + 1}: only {dma_pieces.get(t + 1)} pieces issued before its barrier"
+                    certified.add(t + 1)
+                barrier_done.add(t)
+            # ---- reads
+            if it + PF < NIT:
+                issue_read(t, it + PF)
+            elif not last:
+                issue_read(t + 1, it + PF - NIT)
+            if it == SYNC - 1:
+                cur_stage_of_aw ^= 1
+            # ---- DMA of tile t + 2 (behind this tile's barrier) / the rest of tile t + 1
+            piece = None
+            if it > SYNC:
+                piece, td = it - SYNC - 1, t + 2
+            if it <= 10 and t >= 1:
+                piece, td = it + (NIT - 1 - SYNC), t + 1
+            if piece is not None and td < n_tiles:
+                assert td - 2 in barrier_done, f"DMA of tile {td} into the stage of tile {td - 2} before that tile's barrier"
+                assert dma_pieces.get(td, 0) == piece, f"tile {td}: piece {piece} out of order"
+                dma_pieces[td] = piece + 1
+                stage_tile[td & 1] = td
+            # ---- the previous tile's epilogue: LDS operations of its three slices
+            if t > 0:
+                if it == 3:
+                    lds_ops += [("epi",)] * 8        # 4 bias reads + 4 ds_write_b128
+                if it == 9:
+                    lds_ops += [("epi",)] * 4        # 4 ds_read_b128
+    for td in range(2, n_tiles):
+        assert dma_pieces[td] == 16
