@@ -63,7 +63,13 @@ struct LgState {
   unsigned voff;                // lane * 16
   int stage_delta;              // +- 64 KiB: what moves aW from the current tile's stage to the next tile's
   int n_tiles;
+  int rot;                      // this workgroup visits the weight tiles in the order (k + rot) % n_tiles, k = 0, 1, ...
 };
+// k-th tile of this workgroup's visiting order -> tile of the image / 32-column block of the output
+__device__ __forceinline__ int lg_tile(const LgState& s, int k) {
+  const int t = k + s.rot;
+  return t >= s.n_tiles ? t - s.n_tiles : t;
+}
 
 // item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (item KS: the pseudo item re-reads step 0)
 template <int IT>
@@ -79,7 +85,7 @@ template <int J>
 __device__ __forceinline__ void lg_dma_piece(const LgState& s, int td) {
   if (td < s.n_tiles) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.lds_w + (unsigned)(td & 1) * LG_STAGE + J * 1024) : "memory");
-    dma_lin<0>(s.voff, s.img + (size_t)td * LG_STAGE + J * 1024);
+    dma_lin<0>(s.voff, s.img + (size_t)lg_tile(s, td) * LG_STAGE + J * 1024);
   }
 }
 
@@ -200,14 +206,14 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
     if (prev) {
       if constexpr (IT == 3) {
         asm volatile("s_nop 7" ::: "memory");
-        lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
+        lg_epi_write(e, PAR ? s.accA : s.accB, lg_tile(s, tile - 1));
       }
       if constexpr (IT == 9) lg_epi_read(e, ev);
       // the stores go out right BEHIND this tile's barrier: the next s_waitcnt vmcnt(0) — which cannot tell stores from DMA
       // pieces — is a whole tile away, instead of 8 steps (r05 call 2: 2.6-2.9 us per tile against 1.3 of MFMA and 1.7 of fill)
       if constexpr (IT == LG_SYNC + 1) {
         wait_lgkm<0>();
-        lg_epi_store(e, ev, tile - 1);
+        lg_epi_store(e, ev, lg_tile(s, tile - 1));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -227,11 +233,17 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   float* spar = reinterpret_cast<float*>(smem + LG_PAR_OFF);
   float* sbias = reinterpret_cast<float*>(smem + LG_BIAS_OFF);
 
-  // ---- weights: tiles 0 / 1 -> stages 0 / 1 (this wave's 16 KiB of each)
+  // ---- weights: the first two tiles of this workgroup's visiting order -> stages 0 / 1 (this wave's 16 KiB of each).
+  // The order is ROTATED per workgroup — workgroup b of an XCD (blockIdx.x = 8 j + xcd) starts at tile j: r05 call 3 measured
+  // 2.7-3.0 us per tile with every workgroup of the chip streaming the SAME 64-KiB tile at the same moment (every request of an
+  // XCD's 32 CUs on the same few L2 channels) against 1.7 us for the per-CU fill path when the CUs stream different lines.
   const char* img = a.img + wave * 16384;
-  for (int t = 0; t < 2 && t < a.n_tiles; ++t)
+  const int rot = (blockIdx.x >> 3) % a.n_tiles;
+  for (int t = 0; t < 2; ++t) {
+    const int ti = (t + rot) % a.n_tiles;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)ti * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+  }
 
   // ---- parameter tables -> LDS: multiplier | shift (zero beyond D: padded columns come out as exact zeros), bias
   for (int i = tid; i < 512; i += 256) {
@@ -314,6 +326,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   s.lds_w = lds0 + wave * 16384;
   s.voff = voff;
   s.n_tiles = a.n_tiles;
+  s.rot = rot;
   s.stage_delta = LG_STAGE;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
@@ -337,11 +350,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   }
   // the last tile's epilogue (exposed)
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
-  lg_epi_write(e, s.accB, a.n_tiles - 1);
+  lg_epi_write(e, s.accB, lg_tile(s, a.n_tiles - 1));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_read(e, ev);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epi_store(e, ev, a.n_tiles - 1);
+  lg_epi_store(e, ev, lg_tile(s, a.n_tiles - 1));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
