@@ -63,13 +63,8 @@ struct LgState {
   unsigned voff;                // lane * 16
   int stage_delta;              // +- 64 KiB: what moves aW from the current tile's stage to the next tile's
   int n_tiles;
-  int rot;                      // this workgroup visits the weight tiles in the order (k + rot) % n_tiles, k = 0, 1, ...
+  int abl;                      // dev ablations (LDM_LNGEMM_ABL, WRONG NUMERICS): 1 no MFMAs, 2 no weight DMA, 4 no output stores
 };
-// k-th tile of this workgroup's visiting order -> tile of the image / 32-column block of the output
-__device__ __forceinline__ int lg_tile(const LgState& s, int k) {
-  const int t = k + s.rot;
-  return t >= s.n_tiles ? t - s.n_tiles : t;
-}
 
 // item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (item KS: the pseudo item re-reads step 0)
 template <int IT>
@@ -83,9 +78,9 @@ __device__ __forceinline__ void lg_read(LgState& s) {
 // one tile straddle a tile boundary with compiler-generated epilogue code in between.
 template <int J>
 __device__ __forceinline__ void lg_dma_piece(const LgState& s, int td) {
-  if (td < s.n_tiles) {
+  if (td < s.n_tiles && !(s.abl & 2)) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.lds_w + (unsigned)(td & 1) * LG_STAGE + J * 1024) : "memory");
-    dma_lin<0>(s.voff, s.img + (size_t)lg_tile(s, td) * LG_STAGE + J * 1024);
+    dma_lin<0>(s.voff, s.img + (size_t)td * LG_STAGE + J * 1024);
   }
 }
 
@@ -98,6 +93,7 @@ struct LgEpi {
   float out_scale;
   int relu;
   int lane;
+  int no_store;
 };
 
 // epilogue of one finished 32-column tile, in three slices spread over the next tile's MFMA shadow
@@ -127,7 +123,7 @@ __device__ __forceinline__ void lg_epi_read(const LgEpi& e, float4 (&v)[4]) {
 // slice 2: registers -> global (fp32 rows, or hi / lo fp16 rows)
 __device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4], int tile) {
   const int col = tile * 32 + (e.lane & 7) * 4;
-  if (col >= e.N) return;
+  if (col >= e.N || e.no_store) return;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int row = e.row0 + p * 8 + (e.lane >> 3);
@@ -163,7 +159,7 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
     if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<tail>();
     else wait_lgkm<2 * (LG_PF - 1)>();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IT < LG_KS) {
+    if (IT < LG_KS && !(s.abl & 1)) {
       f32x16& acc = PAR ? s.accB : s.accA;
       const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
       if constexpr (IT == 0) {
@@ -206,14 +202,14 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
     if (prev) {
       if constexpr (IT == 3) {
         asm volatile("s_nop 7" ::: "memory");
-        lg_epi_write(e, PAR ? s.accA : s.accB, lg_tile(s, tile - 1));
+        lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
       }
       if constexpr (IT == 9) lg_epi_read(e, ev);
       // the stores go out right BEHIND this tile's barrier: the next s_waitcnt vmcnt(0) — which cannot tell stores from DMA
       // pieces — is a whole tile away, instead of 8 steps (r05 call 2: 2.6-2.9 us per tile against 1.3 of MFMA and 1.7 of fill)
       if constexpr (IT == LG_SYNC + 1) {
         wait_lgkm<0>();
-        lg_epi_store(e, ev, lg_tile(s, tile - 1));
+        lg_epi_store(e, ev, tile - 1);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -233,17 +229,14 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   float* spar = reinterpret_cast<float*>(smem + LG_PAR_OFF);
   float* sbias = reinterpret_cast<float*>(smem + LG_BIAS_OFF);
 
-  // ---- weights: the first two tiles of this workgroup's visiting order -> stages 0 / 1 (this wave's 16 KiB of each).
-  // The order is ROTATED per workgroup — workgroup b of an XCD (blockIdx.x = 8 j + xcd) starts at tile j: r05 call 3 measured
-  // 2.7-3.0 us per tile with every workgroup of the chip streaming the SAME 64-KiB tile at the same moment (every request of an
-  // XCD's 32 CUs on the same few L2 channels) against 1.7 us for the per-CU fill path when the CUs stream different lines.
+  // ---- weights: tiles 0 / 1 -> stages 0 / 1 (this wave's 16 KiB of each).  Every workgroup visits the tiles in the SAME order.
+  // (r05 negative result, profiles/r05_call3_4_*: a per-workgroup rotation of the order — 32 CUs of an XCD on 32 different
+  //  tiles instead of all on the same one — is 4 % SLOWER, 950 vs 988 layouts/s: the lock-step stream is served by the L2 once
+  //  per XCD, the rotated one is not.)
   const char* img = a.img + wave * 16384;
-  const int rot = (blockIdx.x >> 3) % a.n_tiles;
-  for (int t = 0; t < 2; ++t) {
-    const int ti = (t + rot) % a.n_tiles;
+  for (int t = 0; t < 2 && t < a.n_tiles; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)ti * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
-  }
+    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
 
   // ---- parameter tables -> LDS: multiplier | shift (zero beyond D: padded columns come out as exact zeros), bias
   for (int i = tid; i < 512; i += 256) {
@@ -326,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   s.lds_w = lds0 + wave * 16384;
   s.voff = voff;
   s.n_tiles = a.n_tiles;
-  s.rot = rot;
+  s.abl = a.abl;
   s.stage_delta = LG_STAGE;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
@@ -335,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   e.tp = reinterpret_cast<float*>(smem + LG_TP_OFF + wave * LG_TP_BYTES);
   e.C32 = a.C32; e.C16 = a.C16; e.C16lo = a.C16lo; e.ldc32 = a.ldc32; e.ldc16 = a.ldc16;
   e.N = a.N; e.M = a.M; e.row0 = blockIdx.x * 128 + wave * 32;
-  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane;
+  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane; e.no_store = a.abl & 4;
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
   for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]));
@@ -350,11 +343,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   }
   // the last tile's epilogue (exposed)
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
-  lg_epi_write(e, s.accB, lg_tile(s, a.n_tiles - 1));
+  lg_epi_write(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_read(e, ev);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epi_store(e, ev, lg_tile(s, a.n_tiles - 1));
+  lg_epi_store(e, ev, a.n_tiles - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -362,7 +355,9 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
   auto kern = a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>;
   allow_big_lds((const void*)kern);
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
+  LnGemmArgs b = a;
+  b.abl = knob_int("LDM_LNGEMM_ABL", 0);
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, b);
   return 0;
 }
 
