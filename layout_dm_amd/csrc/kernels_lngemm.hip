@@ -33,10 +33,28 @@ namespace ldm {
 
 namespace {
 
-// A tile is NIT = 30 queue items: the 29 k16-steps and ONE pseudo item (a fragment pair that is read and never used) so that
+// A tile is NIT = 32 queue items: the 29 k16-steps and three pseudo items (nothing is read, nothing is issued) so that
 // NIT % PF == 0 — item i of every tile then lives in queue slot i % PF and the queue runs on across tiles (FfnStream's trick).
-constexpr int LG_KS = 29, LG_NIT = 30, LG_PF = 6, LG_SYNC = LG_NIT - LG_PF;
+// PF = 8 fragment pairs in flight (14 LDS reads behind the awaited pair: lgkmcnt is a 4-bit counter).  r05 call 5: with PF = 6 the
+// kernel spent as long WITHOUT its MFMAs, weight DMA and stores as they add together — the LDS pipe of a CU is ~90 % busy with
+// this stream (2 KiB of fragments per wave and step, the DMA's writes, the epilogue's transposes), its latency under that load
+// is several hundred cycles, and a pair issued 6 x 96 cycles ahead had not landed when its step came.
+constexpr int LG_KS = 29, LG_NIT = 32, LG_PF = 8, LG_SYNC = LG_NIT - LG_PF;
 static_assert(LG_NIT % LG_PF == 0, "queue slots must line up across tiles");
+constexpr bool lg_real(int i) { return (i % LG_NIT) < LG_KS; }
+// LDS reads issued behind the pair of item IT when step IT waits for it: the real items among IT + 1 .. IT + PF - 1
+constexpr int lg_younger(int IT) {
+  int n = 0;
+  for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;
+  return n;
+}
+// ... when no further tile follows (nothing is issued behind item NIT - 1)
+constexpr int lg_younger_last(int IT) {
+  int n = 0;
+  for (int j = 1; j < LG_PF && IT + j < LG_NIT; ++j) n += lg_real(IT + j) ? 2 : 0;
+  return n;
+}
+static_assert(lg_younger(0) <= 15, "lgkmcnt is a 4-bit counter");
 constexpr int LG_STAGE = 65536;                    // W hi tile (32 KiB) | W lo tile (32 KiB)
 constexpr int LG_LO = 32768;
 constexpr int LG_TP_LD = 36;                       // floats per row of a wave's 32 x 32 transpose buffer (16-B aligned rows)
@@ -66,12 +84,13 @@ struct LgState {
   int abl;                      // dev ablations (LDM_LNGEMM_ABL, WRONG NUMERICS): 1 no MFMAs, 2 no weight DMA, 4 no output stores
 };
 
-// item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (item KS: the pseudo item re-reads step 0)
+// item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (pseudo items: nothing)
 template <int IT>
 __device__ __forceinline__ void lg_read(LgState& s) {
-  constexpr int K = IT < LG_KS ? IT : 0;
-  lg_dsr<256 * (K >> 3)>(s.qh[IT % LG_PF], s.aW[K & 7]);
-  lg_dsr<256 * (K >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[K & 7]);
+  if constexpr (IT < LG_KS) {
+    lg_dsr<256 * (IT >> 3)>(s.qh[IT % LG_PF], s.aW[IT & 7]);
+    lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);
+  }
 }
 
 // piece J (of 16 1-KiB pieces per wave) of tile td -> stage td & 1.  M0 is written in front of every piece: the pieces of
@@ -153,24 +172,23 @@ __device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4
 template <int PAR, int IT>
 __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bool prev, float4 (&ev)[4]) {
   if constexpr (IT < LG_NIT) {
-    // LDS operations of a wave complete in order: all but the 2 (PF - 1) youngest = the fragment pairs of items IT + 1 ..
-    // IT + PF - 1.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
-    constexpr int tail = 2 * ((LG_NIT - 1 - IT) < (LG_PF - 1) ? (LG_NIT - 1 - IT) : (LG_PF - 1));
-    if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<tail>();
-    else wait_lgkm<2 * (LG_PF - 1)>();
-    __builtin_amdgcn_sched_barrier(0);
-    if (IT < LG_KS && !(s.abl & 1)) {
-      f32x16& acc = PAR ? s.accB : s.accA;
-      const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
-      if constexpr (IT == 0) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
-      } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
+    // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
+    // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
+    if constexpr (IT < LG_KS) {
+      if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
+      else wait_lgkm<lg_younger(IT)>();
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(s.abl & 1)) {
+        f32x16& acc = PAR ? s.accB : s.accA;
+        const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
+        if constexpr (IT == 0) {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(wh), "v"(s.xhi[0]));
+        } else {
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wh), "v"(s.xhi[IT]));
+        }
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wh), "a"(s.xlo[IT]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wl), "v"(s.xhi[IT]));
       }
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
-    } else {
-      asm volatile("" ::"v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]));  // the pseudo item: its slot is free again
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT == LG_SYNC) {
@@ -187,15 +205,15 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
       if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
     }
     if constexpr (IT == LG_SYNC - 1) {
-      // item NIT - 1 (the last read of this tile) has just been issued: aW now points into the next tile's stage
+      // item NIT - 1 (the last item of this tile) has just been issued: aW now points into the next tile's stage
 #pragma unroll
       for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
       s.stage_delta = -s.stage_delta;
     }
-    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier: pieces 0 .. 4 at steps SYNC + 1 .. NIT - 1 of
-    // this tile, pieces 5 .. 15 at steps 0 .. 10 of the next one.
+    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier: pieces 0 .. NIT - 2 - SYNC at steps
+    // SYNC + 1 .. NIT - 1 of this tile, the rest of the 16 at the first steps of the next one.
     if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);
-    if constexpr (IT <= 10) {
+    if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) {
       if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);
     }
     // previous tile's epilogue in this tile's MFMA shadow
@@ -335,14 +353,15 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
+  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s); lg_read<6>(s); lg_read<7>(s);
+  static_assert(LG_PF == 8, "prologue primes PF items");
   float4 ev[4];
   for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
     lg_step<0, 0>(s, e, t, t > 0, ev);
     lg_step<1, 0>(s, e, t + 1, true, ev);
   }
   // the last tile's epilogue (exposed)
-  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
+  asm volatile("s_nop 7\n\ts_nop 7" : "+a"(s.accB));
   lg_epi_write(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_read(e, ev);

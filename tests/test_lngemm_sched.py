@@ -22,8 +22,10 @@ def _consts():
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
     for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);",
-                   "if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);", "if constexpr (IT <= 10)",
-                   "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<2 * (LG_PF - 1)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) lg_epi_read"):
+                   "if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);",
+                   "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16)", "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()",
+                   "wait_lgkm<lg_younger_last(IT)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) lg_epi_read",
+                   "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
 
@@ -43,6 +45,9 @@ def test_schedule_replay():
 
     def issue_read(tile, item):
         nonlocal lds_ops
+        if item >= KS:          # pseudo item: nothing is read (the slot bookkeeping alone)
+            slot[item % PF] = (tile, item)
+            return
         assert tile in certified, f"tile {tile} read before its stage was certified"
         assert stage_tile[cur_stage_of_aw] == tile, f"aW points at stage {cur_stage_of_aw} = tile {stage_tile[cur_stage_of_aw]}, wanted {tile}"
         slot[item % PF] = (tile, item)
@@ -53,11 +58,17 @@ def test_schedule_replay():
     for t in range(n_tiles):
         last = t + 1 >= n_tiles
         for it in range(NIT):
-            # ---- the counted wait in front of the step
-            n = 2 * min(NIT - 1 - it, PF - 1) if (it >= SYNC and last) else 2 * (PF - 1)
-            idx = max(i for i, op in enumerate(lds_ops) if op == ("frag", t, it))      # the younger of the pair
-            younger = len(lds_ops) - 1 - idx
-            assert n <= younger, f"tile {t} step {it}: lgkmcnt({n}) but only {younger} operations were issued behind the pair"
+            # ---- the counted wait in front of the step (real items only)
+            real = lambda i: (i % NIT) < KS
+            if it < KS:
+                if it >= SYNC and last:
+                    n = sum(2 for j in range(1, PF) if it + j < NIT and real(it + j))
+                else:
+                    n = sum(2 for j in range(1, PF) if real(it + j))
+                assert n <= 15
+                idx = max(i for i, op in enumerate(lds_ops) if op == ("frag", t, it))      # the younger of the pair
+                younger = len(lds_ops) - 1 - idx
+                assert n <= younger, f"tile {t} step {it}: lgkmcnt({n}) but only {younger} operations were issued behind the pair"
             # ---- consumption
             assert slot[it % PF] == (t, it), f"tile {t} step {it}: slot holds {slot[it % PF]}"
             # ---- barrier
@@ -77,7 +88,7 @@ def test_schedule_replay():
             piece = None
             if it > SYNC:
                 piece, td = it - SYNC - 1, t + 2
-            if it <= 10 and t >= 1:
+            if it + (NIT - 1 - SYNC) < 16 and t >= 1:
                 piece, td = it + (NIT - 1 - SYNC), t + 1
             if piece is not None and td < n_tiles:
                 assert td - 2 in barrier_done, f"DMA of tile {td} into the stage of tile {td - 2} before that tile's barrier"
