@@ -33,13 +33,15 @@ namespace ldm {
 
 namespace {
 
-// A tile is NIT = 32 queue items: the 29 k16-steps and three pseudo items (nothing is read, nothing is issued) so that
-// NIT % PF == 0 — item i of every tile then lives in queue slot i % PF and the queue runs on across tiles (FfnStream's trick).
-// PF = 8 fragment pairs in flight (14 LDS reads behind the awaited pair: lgkmcnt is a 4-bit counter).  r05 call 5: with PF = 6 the
-// kernel spent as long WITHOUT its MFMAs, weight DMA and stores as they add together — the LDS pipe of a CU is ~90 % busy with
-// this stream (2 KiB of fragments per wave and step, the DMA's writes, the epilogue's transposes), its latency under that load
-// is several hundred cycles, and a pair issued 6 x 96 cycles ahead had not landed when its step came.
-constexpr int LG_KS = 29, LG_NIT = 32, LG_PF = 8, LG_SYNC = LG_NIT - LG_PF;
+// A tile is NIT = 30 queue items: the 29 k16-steps and ONE pseudo item (nothing is read, nothing is issued) so that
+// NIT % PF == 0 — item i of every tile then lives in queue slot i % PF and the queue runs on across tiles (FfnStream's trick;
+// r05's first GPU run had 29 items on the 6-deep queue: item 0 of the next tile landed in the slot of an unconsumed pair).
+// PF = 6 fragment pairs in flight.  Measured alternatives that did NOT ship (same-box A/B builds,
+// profiles/r05_call7_lngemm_queue_depth_and_agpr_accumulators_ab.txt): PF = 8 (32 items per tile) leaves 14 fragment reads
+// behind the awaited pair, the epilogue's LDS operations come on top and the 4-bit lgkmcnt counter no longer covers what is in
+// flight — NaN logits; the tile accumulators in AGPRs ("+a" MFMA destinations beside the AGPR-resident lo fragments) lose low-order
+// terms (logits error 5e-5 instead of 9e-7) and are not faster.
+constexpr int LG_KS = 29, LG_NIT = 30, LG_PF = 6, LG_SYNC = LG_NIT - LG_PF;
 static_assert(LG_NIT % LG_PF == 0, "queue slots must line up across tiles");
 constexpr bool lg_real(int i) { return (i % LG_NIT) < LG_KS; }
 // LDS reads issued behind the pair of item IT when step IT waits for it: the real items among IT + 1 .. IT + PF - 1
@@ -115,6 +117,12 @@ struct LgEpi {
   int no_store;
 };
 
+#ifndef LDM_LG_DIRECT
+#define LDM_LG_DIRECT 0   // A/B builds: 1 = the epilogue stores straight from the accumulator layout (no LDS transpose)
+#endif
+// LDM_LG_DIRECT: scale / bias / ReLU and 16-byte stores of the lane's four 4-column groups (a row's lane pair writes 32 contiguous
+// bytes per group) — no LDS traffic for the epilogue, four times the write requests
+__device__ __forceinline__ void lg_epi_direct(const struct LgEpi& e, const f32x16& acc, int tile);
 // epilogue of one finished 32-column tile, in three slices spread over the next tile's MFMA shadow
 // slice 0: scale / bias / ReLU, accumulator layout -> LDS (row-major 32 x 32)
 __device__ __forceinline__ void lg_epi_write(const LgEpi& e, const f32x16& acc, int tile) {
@@ -166,6 +174,42 @@ __device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4
   }
 }
 
+__device__ __forceinline__ void lg_epi_direct(const LgEpi& e, const f32x16& acc, int tile) {
+  const int r = e.lane & 31, hi = e.lane >> 5;
+  const int row = e.row0 + r;
+  if (row >= e.M || e.no_store) return;
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const int col = tile * 32 + rq * 8 + hi * 4;
+    if (col >= e.N) continue;
+    const float4 b = *reinterpret_cast<const float4*>(e.sbias + col);
+    float4 v;
+    v.x = acc[rq * 4 + 0] * e.out_scale + b.x;
+    v.y = acc[rq * 4 + 1] * e.out_scale + b.y;
+    v.z = acc[rq * 4 + 2] * e.out_scale + b.z;
+    v.w = acc[rq * 4 + 3] * e.out_scale + b.w;
+    if (e.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)row * e.ldc32 + col) = v;
+    if (e.C16) {
+      const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+      uint2 pk;
+      pk.x = *reinterpret_cast<const unsigned*>(&h0);
+      pk.y = *reinterpret_cast<const unsigned*>(&h1);
+      *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
+      if (e.C16lo) {
+        const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+        const __half2 l0 = __floats2half2_rn((v.x - f0.x) * kSplitLoScale, (v.y - f0.y) * kSplitLoScale);
+        const __half2 l1 = __floats2half2_rn((v.z - f1.x) * kSplitLoScale, (v.w - f1.y) * kSplitLoScale);
+        pk.x = *reinterpret_cast<const unsigned*>(&l0);
+        pk.y = *reinterpret_cast<const unsigned*>(&l1);
+        *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
+      }
+    }
+  }
+}
+
 // One tile = 29 steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose
 // epilogue runs in this tile's shadow when prev >= 0.  The counted waits are never larger than the number of LDS operations
 // really issued behind the awaited fragment pair (extra operations of the epilogue slices only make them stricter).
@@ -182,12 +226,12 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
         f32x16& acc = PAR ? s.accB : s.accA;
         const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
         if constexpr (IT == 0) {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&a"(acc) : "v"(wh), "v"(s.xhi[0]));
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
         } else {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wh), "v"(s.xhi[IT]));
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
         }
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wh), "a"(s.xlo[IT]));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(wl), "v"(s.xhi[IT]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -217,12 +261,27 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
       if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);
     }
     // previous tile's epilogue in this tile's MFMA shadow
+#if LDM_LG_DIRECT
     if (prev) {
+      if constexpr (IT == LG_SYNC + 1) {   // behind the barrier: the next s_waitcnt vmcnt(0) is a whole tile away
+        wait_lgkm<6>();
+        asm volatile("s_nop 7" ::: "memory");
+        lg_epi_direct(e, PAR ? s.accA : s.accB, tile - 1);
+      }
+    }
+#else
+    if (prev) {
+      // (lgkmcnt is a 4-bit counter: the slices first drain the fragment queue far enough that their own 8 / 4 LDS operations
+      //  keep the number in flight below 16)
       if constexpr (IT == 3) {
+        wait_lgkm<6>();
         asm volatile("s_nop 7" ::: "memory");
         lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
       }
-      if constexpr (IT == 9) lg_epi_read(e, ev);
+      if constexpr (IT == 9) {
+        wait_lgkm<8>();
+        lg_epi_read(e, ev);
+      }
       // the stores go out right BEHIND this tile's barrier: the next s_waitcnt vmcnt(0) — which cannot tell stores from DMA
       // pieces — is a whole tile away, instead of 8 steps (r05 call 2: 2.6-2.9 us per tile against 1.3 of MFMA and 1.7 of fill)
       if constexpr (IT == LG_SYNC + 1) {
@@ -230,6 +289,7 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
         lg_epi_store(e, ev, tile - 1);
       }
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     lg_step<PAR, IT + 1>(s, e, tile, prev, ev);
   }
@@ -353,20 +413,24 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s); lg_read<6>(s); lg_read<7>(s);
-  static_assert(LG_PF == 8, "prologue primes PF items");
+  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
+  static_assert(LG_PF == 6, "prologue primes PF items");
   float4 ev[4];
   for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
     lg_step<0, 0>(s, e, t, t > 0, ev);
     lg_step<1, 0>(s, e, t + 1, true, ev);
   }
   // the last tile's epilogue (exposed)
-  asm volatile("s_nop 7\n\ts_nop 7" : "+a"(s.accB));
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
+#if LDM_LG_DIRECT
+  lg_epi_direct(e, s.accB, a.n_tiles - 1);
+#else
   lg_epi_write(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_read(e, ev);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_store(e, ev, a.n_tiles - 1);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

@@ -24,7 +24,7 @@ def _consts():
     for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);",
                    "if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);",
                    "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16)", "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()",
-                   "wait_lgkm<lg_younger_last(IT)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) lg_epi_read",
+                   "wait_lgkm<lg_younger_last(IT)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) {\n        wait_lgkm<8>();\n        lg_epi_read", "wait_lgkm<6>();",
                    "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
@@ -98,8 +98,10 @@ def test_schedule_replay():
             # ---- the previous tile's epilogue: LDS operations of its three slices
             if t > 0:
                 if it == 3:
+                    assert 6 + 8 <= 15               # wait_lgkm<6> in front of the slice: at most 6 + its own 8 operations in flight
                     lds_ops += [("epi",)] * 8        # 4 bias reads + 4 ds_write_b128
                 if it == 9:
+                    assert 8 + 4 <= 15               # wait_lgkm<8> in front of the slice
                     lds_ops += [("epi",)] * 4        # 4 ds_read_b128
     for td in range(2, n_tiles):
         assert dma_pieces[td] == 16
