@@ -117,12 +117,8 @@ struct LgEpi {
   int no_store;
 };
 
-#ifndef LDM_LG_DIRECT
-#define LDM_LG_DIRECT 0   // A/B builds: 1 = the epilogue stores straight from the accumulator layout (no LDS transpose)
-#endif
-// LDM_LG_DIRECT: scale / bias / ReLU and 16-byte stores of the lane's four 4-column groups (a row's lane pair writes 32 contiguous
-// bytes per group) — no LDS traffic for the epilogue, four times the write requests
-__device__ __forceinline__ void lg_epi_direct(const struct LgEpi& e, const f32x16& acc, int tile);
+// (r05 negative result, profiles/r05_call9_*: an epilogue that stores straight from the accumulator layout — no LDS transpose, 16-byte /
+//  8-byte pieces, four times the write requests — is 7 % slower on linear1 and was not bit-reproducible; not kept.)
 // epilogue of one finished 32-column tile, in three slices spread over the next tile's MFMA shadow
 // slice 0: scale / bias / ReLU, accumulator layout -> LDS (row-major 32 x 32)
 __device__ __forceinline__ void lg_epi_write(const LgEpi& e, const f32x16& acc, int tile) {
@@ -174,42 +170,6 @@ __device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4
   }
 }
 
-__device__ __forceinline__ void lg_epi_direct(const LgEpi& e, const f32x16& acc, int tile) {
-  const int r = e.lane & 31, hi = e.lane >> 5;
-  const int row = e.row0 + r;
-  if (row >= e.M || e.no_store) return;
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const int col = tile * 32 + rq * 8 + hi * 4;
-    if (col >= e.N) continue;
-    const float4 b = *reinterpret_cast<const float4*>(e.sbias + col);
-    float4 v;
-    v.x = acc[rq * 4 + 0] * e.out_scale + b.x;
-    v.y = acc[rq * 4 + 1] * e.out_scale + b.y;
-    v.z = acc[rq * 4 + 2] * e.out_scale + b.z;
-    v.w = acc[rq * 4 + 3] * e.out_scale + b.w;
-    if (e.relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)row * e.ldc32 + col) = v;
-    if (e.C16) {
-      const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
-      uint2 pk;
-      pk.x = *reinterpret_cast<const unsigned*>(&h0);
-      pk.y = *reinterpret_cast<const unsigned*>(&h1);
-      *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
-      if (e.C16lo) {
-        const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
-        const __half2 l0 = __floats2half2_rn((v.x - f0.x) * kSplitLoScale, (v.y - f0.y) * kSplitLoScale);
-        const __half2 l1 = __floats2half2_rn((v.z - f1.x) * kSplitLoScale, (v.w - f1.y) * kSplitLoScale);
-        pk.x = *reinterpret_cast<const unsigned*>(&l0);
-        pk.y = *reinterpret_cast<const unsigned*>(&l1);
-        *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
-      }
-    }
-  }
-}
-
 // One tile = 29 steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose
 // epilogue runs in this tile's shadow when prev >= 0.  The counted waits are never larger than the number of LDS operations
 // really issued behind the awaited fragment pair (extra operations of the epilogue slices only make them stricter).
@@ -233,6 +193,15 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
       }
+    }
+    if constexpr (IT == LG_KS) {
+      // The tile's last MFMA was issued one step ago.  hipcc cannot see that the asm above is an MFMA: nothing keeps it from
+      // reading the accumulator right behind it (a register copy is enough) — and a VALU read inside the MFMA's 8 passes sees
+      // the accumulator WITHOUT the last product(s).  r05 calls 7 / 8: two builds whose only difference was where hipcc placed
+      // such reads lost exactly the low-order terms (logits error 5e-5 instead of 9e-7).  Every later use of the accumulator is
+      // tied behind these wait states.
+      f32x16& acc = PAR ? s.accB : s.accA;
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT == LG_SYNC) {
@@ -261,15 +230,6 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
       if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);
     }
     // previous tile's epilogue in this tile's MFMA shadow
-#if LDM_LG_DIRECT
-    if (prev) {
-      if constexpr (IT == LG_SYNC + 1) {   // behind the barrier: the next s_waitcnt vmcnt(0) is a whole tile away
-        wait_lgkm<6>();
-        asm volatile("s_nop 7" ::: "memory");
-        lg_epi_direct(e, PAR ? s.accA : s.accB, tile - 1);
-      }
-    }
-#else
     if (prev) {
       // (lgkmcnt is a 4-bit counter: the slices first drain the fragment queue far enough that their own 8 / 4 LDS operations
       //  keep the number in flight below 16)
@@ -289,7 +249,6 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
         lg_epi_store(e, ev, tile - 1);
       }
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     lg_step<PAR, IT + 1>(s, e, tile, prev, ev);
   }
@@ -422,15 +381,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   }
   // the last tile's epilogue (exposed)
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
-#if LDM_LG_DIRECT
-  lg_epi_direct(e, s.accB, a.n_tiles - 1);
-#else
   lg_epi_write(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_read(e, ev);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lg_epi_store(e, ev, a.n_tiles - 1);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

@@ -682,6 +682,29 @@ def test_full_batch_512_one_step_vs_oracle(cuda, precision):
         assert (margin[mism] < 0.05).all()
 
 
+@pytest.mark.parametrize("precision", ["split", "fast"])
+def test_logits_bitwise_repeatable(cuda, precision):
+    """The same denoiser pass, 25 times, on a full chunk (256 layouts) and on a ragged one (37): bit-identical logits every time.
+    The hand-pipelined kernels order their LDS reads, DMA pieces and MFMAs with counted waits the compiler cannot check — a
+    wait that is one operation short shows up as a timing-dependent low-order difference long before it shows up as a parity
+    failure (r05: a discarded build of kernels_lngemm.hip was 6e-5 off and not repeatable while the tolerance tests passed)."""
+    spec, _ = weights("rico25")
+    for B in (256, 37):
+        e = engine("rico25", precision, max_batch=256)
+        g = torch.Generator().manual_seed(11 + B)
+        tokens = torch.empty(B, spec.seq_len, dtype=torch.long)
+        for a in range(spec.n_attr):
+            ids = torch.as_tensor(spec.full_ids(a))
+            tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (B, spec.max_elem), generator=g)]
+        tokens[torch.rand(B, spec.seq_len, generator=g) < 0.5] = spec.mask_id
+        tok = tokens.int().to(cuda)
+        first = e.denoise_logits(tok, 47).clone()
+        assert bool(torch.isfinite(first).all())
+        for i in range(24):
+            again = e.denoise_logits(tok, 47)
+            assert torch.equal(again, first), f"{precision} B={B}: repetition {i + 1} differs by {(again - first).abs().max().item():.3e}"
+
+
 # ----------------------------------------------------------------------------- drop-in layer
 class _MockTokenizer:
     """Duck-types the properties of the reference's LayoutSequenceTokenizer that LayoutDM reads

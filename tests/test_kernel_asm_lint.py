@@ -184,3 +184,48 @@ def test_split_mode_kernels_resources(tmp_path):
     ins = _kernels(asm)[sym]
     assert not any(i.startswith(("flat_load", "scratch_")) for i in ins), sym
     assert sum("v_mfma" in i for i in ins) == 96, sym  # 2 x (4 x 4 | 8 x 2) fragment pairs x 3 products
+
+
+def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
+    """kernels_lngemm.hip (r05): no scratch; no VALU write of an inline-asm MFMA operand inside the verified wait states; and the
+    failure class r05 found on hardware — hipcc reading a tile accumulator right behind the asm MFMAs it cannot recognise (two
+    builds lost the low-order products that way: logits error 5e-5 instead of 9e-7) — every non-MFMA instruction that READS the
+    destination registers of an inline-asm MFMA must sit at least one whole MFMA (8 passes = 32 cycles) of wait states behind it."""
+    asm = _compile("kernels_lngemm.hip", tmp_path)
+    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k}
+    assert len(kernels) == 2
+    sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
+    for name, instr in kernels.items():
+        assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
+        mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
+        assert len(mf) == 2 * 29 * 3, (name, len(mf))           # two tile bodies (accumulator parity) x 29 k16-steps x 3 products
+        for i in mf:
+            ops = [o.strip() for o in instr[i][4:].split(None, 1)[1].split(",")]
+            dst = _regs(ops[0])
+            ws = 0
+            for j in range(i + 1, min(i + 200, len(instr))):
+                p = instr[j][4:] if instr[j].startswith("asm:") else instr[j]
+                op = p.split()[0]
+                if op == "s_nop":
+                    ws += int(p.split()[1]) + 1
+                    continue
+                if op.startswith("v_mfma"):
+                    o2 = [o.strip() for o in p.split(None, 1)[1].split(",")]
+                    if _regs(o2[0]) & dst:
+                        break              # the same accumulator continues (or is re-initialised): the matrix pipe orders that itself
+                    ws += 8
+                    continue
+                if op in ("s_barrier", "s_waitcnt", "s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccz", "s_cbranch_vccnz",
+                          "s_cbranch_execz", "s_cbranch_execnz", "s_branch"):
+                    ws += 1
+                    continue
+                args = p.split(None, 1)[1].split(",") if " " in p else []
+                reads = set()
+                for a_ in args[1:] if not op.startswith(("ds_write", "global_store", "ds_read")) else args:
+                    reads |= _regs(a_.strip().split(" ")[0])
+                if reads & dst:
+                    assert ws >= 32, f"{name}: '{p}' reads the destination of '{instr[i][4:]}' only {ws} wait states behind it"
+                    break
+                ws += 1
+                if ws >= 64:
+                    break
