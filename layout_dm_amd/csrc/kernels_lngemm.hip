@@ -83,7 +83,9 @@ struct LgState {
   unsigned voff;                // lane * 16
   int stage_delta;              // +- 64 KiB: what moves aW from the current tile's stage to the next tile's
   int n_tiles;
-  int abl;                      // dev ablations (LDM_LNGEMM_ABL, WRONG NUMERICS): 1 no MFMAs, 2 no weight DMA, 4 no output stores
+  // the tile whose DMA is in progress: global / LDS address of its NEXT 4-KiB group of this wave's 16 KiB (uniform)
+  const char* dma_g;
+  unsigned dma_l;
 };
 
 // item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (pseudo items: nothing)
@@ -95,122 +97,156 @@ __device__ __forceinline__ void lg_read(LgState& s) {
   }
 }
 
-// piece J (of 16 1-KiB pieces per wave) of tile td -> stage td & 1.  M0 is written in front of every piece: the pieces of
-// one tile straddle a tile boundary with compiler-generated epilogue code in between.
-template <int J>
-__device__ __forceinline__ void lg_dma_piece(const LgState& s, int td) {
-  if (td < s.n_tiles && !(s.abl & 2)) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.lds_w + (unsigned)(td & 1) * LG_STAGE + J * 1024) : "memory");
-    dma_lin<0>(s.voff, s.img + (size_t)td * LG_STAGE + J * 1024);
+// Start the DMA of tile td (clamped to the last tile: re-loading it into a free stage is harmless and keeps the stream free of
+// branches) into stage td & 1: piece J = 1 KiB of this wave's 16; the pieces of one tile straddle a tile boundary.
+__device__ __forceinline__ void lg_dma_begin(LgState& s, int td) {
+  const int t = td < s.n_tiles ? td : s.n_tiles - 1;
+  s.dma_g = s.img + (size_t)t * LG_STAGE;
+  s.dma_l = s.lds_w + (unsigned)(td & 1) * LG_STAGE;
+}
+// M0 in front of every 4-KiB group and of the first piece behind the tile boundary (compiler-generated code sits in between)
+template <int J, bool SET_M0>
+__device__ __forceinline__ void lg_dma_piece(LgState& s) {
+  if constexpr ((J & 3) == 0 && J > 0) {
+    s.dma_g += 4096;
+    s.dma_l += 4096;
   }
+  if constexpr ((J & 3) == 0 || SET_M0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.dma_l) : "memory");
+  dma_lin<(J & 3) * 1024>(s.voff, s.dma_g);
 }
 
+typedef float lg_f32x4 __attribute__((ext_vector_type(4)));   // (a 4-register asm operand: HIP's float4 is a struct)
 struct LgEpi {
-  const float* sbias;           // LDS bias table
-  float* tp;                    // this wave's transpose buffer (LDS)
+  unsigned a_bias;              // LDS byte address of the bias table + (lane & 7) * 16: the lane's 4 columns AFTER the transpose
+  unsigned a_tpw, a_tpr;        // this lane's write / read address in the wave's transpose buffer (LDS bytes)
   float* C32;
   __half *C16, *C16lo;
   int ldc32, ldc16, N, M, row0; // row0: first row of this wave
   float out_scale;
   int relu;
   int lane;
-  int no_store;
+  lg_f32x4 bb;                  // bias of the lane's 4 columns of the tile whose epilogue is in flight
+  lg_f32x4 ev[4];               // the tile transposed: 8 lanes per row
 };
 
-// (r05 negative result, profiles/r05_call9_*: an epilogue that stores straight from the accumulator layout — no LDS transpose, 16-byte /
-//  8-byte pieces, four times the write requests — is 7 % slower on linear1 and was not bit-reproducible; not kept.)
-// epilogue of one finished 32-column tile, in three slices spread over the next tile's MFMA shadow
-// slice 0: scale / bias / ReLU, accumulator layout -> LDS (row-major 32 x 32)
-__device__ __forceinline__ void lg_epi_write(const LgEpi& e, const f32x16& acc, int tile) {
-  const int r = e.lane & 31, hi = e.lane >> 5;
-#pragma unroll
-  for (int rq = 0; rq < 4; ++rq) {
-    const float4 b = *reinterpret_cast<const float4*>(e.sbias + tile * 32 + rq * 8 + hi * 4);
-    float4 v;
-    v.x = acc[rq * 4 + 0] * e.out_scale + b.x;
-    v.y = acc[rq * 4 + 1] * e.out_scale + b.y;
-    v.z = acc[rq * 4 + 2] * e.out_scale + b.z;
-    v.w = acc[rq * 4 + 3] * e.out_scale + b.w;
-    if (e.relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(e.tp + r * LG_TP_LD + rq * 8 + hi * 4) = v;
+// The epilogue of tile t - 1, spread in small slices over the MFMA shadows of tile t.  Every LDS operation is issued through
+// asm: hipcc's own s_waitcnt for a load it knows about would be lgkmcnt(0), i.e. a drain of the whole fragment queue.  What
+// guarantees that a slice's data has landed is the per-step counted wait: an operation issued at step s is older than the
+// fragment pairs of items s + PF .. and therefore complete once step s + PF has waited (in-order LDS completion).
+//   steps 8 .. 11   one 4-column group each: the raw accumulator values, ds_write_b128 (accumulator layout -> row-major 32 x 32)
+//   step 13         the bias of the lane's 4 columns in the transposed view (1 x ds_read_b128)      -> landed at step 19
+//   steps 14, 15    the tile back, 8 lanes per row (2 x ds_read_b128 each)                          -> landed at step 21
+//   steps SYNC + 1 .. SYNC + 4   one 8-row pass each: scale, bias, ReLU, (hi / lo split,) 128-byte row segments to global memory
+//                   (behind this tile's barrier: the next s_waitcnt vmcnt(0), which cannot tell stores from DMA pieces, is a
+//                   whole tile away)
+// At most 2 extra LDS operations per step: 10 (counted wait) + 2 (the step's own pair) + 2 = 14 in flight (lgkmcnt: 4 bits).
+template <int IT>
+__device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, const f32x16& acc, int tile) {
+  if constexpr (IT >= 8 && IT <= 11) {
+    constexpr int rq = IT - 8;
+    const lg_f32x4 v = {acc[rq * 4 + 0], acc[rq * 4 + 1], acc[rq * 4 + 2], acc[rq * 4 + 3]};
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(e.a_tpw), "v"(v), "n"(rq * 32) : "memory");
   }
-}
-// slice 1: LDS -> registers, 8 lanes per row (a row's 32 columns = 128 contiguous bytes), 8 rows per pass
-__device__ __forceinline__ void lg_epi_read(const LgEpi& e, float4 (&v)[4]) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-    v[p] = *reinterpret_cast<const float4*>(e.tp + (p * 8 + (e.lane >> 3)) * LG_TP_LD + (e.lane & 7) * 4);
-}
-// slice 2: registers -> global (fp32 rows, or hi / lo fp16 rows)
-__device__ __forceinline__ void lg_epi_store(const LgEpi& e, const float4 (&v)[4], int tile) {
-  const int col = tile * 32 + (e.lane & 7) * 4;
-  if (col >= e.N || e.no_store) return;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  if constexpr (IT == 13) {
+    const unsigned ab = e.a_bias + (unsigned)tile * 128;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(e.bb) : "v"(ab) : "memory");
+  }
+  if constexpr (IT == 14 || IT == 15) {
+    constexpr int p0 = (IT - 14) * 2;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.ev[p0]) : "v"(e.a_tpr), "n"(p0 * 8 * LG_TP_LD * 4) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.ev[p0 + 1]) : "v"(e.a_tpr), "n"((p0 + 1) * 8 * LG_TP_LD * 4) : "memory");
+  }
+  if constexpr (IT > LG_SYNC && IT <= LG_SYNC + 4) {
+    constexpr int p = IT - LG_SYNC - 1;
+    const int col = tile * 32 + (e.lane & 7) * 4;
     const int row = e.row0 + p * 8 + (e.lane >> 3);
-    if (row >= e.M) continue;
-    if (e.C32) *reinterpret_cast<float4*>(e.C32 + (size_t)row * e.ldc32 + col) = v[p];
-    if (e.C16) {
-      const __half2 h0 = __floats2half2_rn(v[p].x, v[p].y), h1 = __floats2half2_rn(v[p].z, v[p].w);
-      uint2 pk;
-      pk.x = *reinterpret_cast<const unsigned*>(&h0);
-      pk.y = *reinterpret_cast<const unsigned*>(&h1);
-      *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
-      if (e.C16lo) {
-        const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
-        const __half2 l0 = __floats2half2_rn((v[p].x - f0.x) * kSplitLoScale, (v[p].y - f0.y) * kSplitLoScale);
-        const __half2 l1 = __floats2half2_rn((v[p].z - f1.x) * kSplitLoScale, (v[p].w - f1.y) * kSplitLoScale);
-        pk.x = *reinterpret_cast<const unsigned*>(&l0);
-        pk.y = *reinterpret_cast<const unsigned*>(&l1);
-        *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
+    if (col < e.N && row < e.M) {
+      lg_f32x4 v = e.ev[p] * e.out_scale + e.bb;
+      if (e.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      if (e.C32) *reinterpret_cast<lg_f32x4*>(e.C32 + (size_t)row * e.ldc32 + col) = v;
+      if (e.C16) {
+        const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+        uint2 pk;
+        pk.x = *reinterpret_cast<const unsigned*>(&h0);
+        pk.y = *reinterpret_cast<const unsigned*>(&h1);
+        *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
+        if (e.C16lo) {
+          const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+          const __half2 l0 = __floats2half2_rn((v.x - f0.x) * kSplitLoScale, (v.y - f0.y) * kSplitLoScale);
+          const __half2 l1 = __floats2half2_rn((v.z - f1.x) * kSplitLoScale, (v.w - f1.y) * kSplitLoScale);
+          pk.x = *reinterpret_cast<const unsigned*>(&l0);
+          pk.y = *reinterpret_cast<const unsigned*>(&l1);
+          *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
+        }
       }
     }
   }
 }
+constexpr bool lg_slice_step(int IT) {
+  return (IT >= 8 && IT <= 11) || IT == 13 || IT == 14 || IT == 15 || (IT > LG_SYNC && IT <= LG_SYNC + 4);
+}
 
-// One tile = 29 steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose
-// epilogue runs in this tile's shadow when prev >= 0.  The counted waits are never larger than the number of LDS operations
-// really issued behind the awaited fragment pair (extra operations of the epilogue slices only make them stricter).
+// One tile = NIT steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose epilogue
+// runs in this tile's shadow when prev.  Inside a step the three MFMAs are INTERLEAVED with the step's other work — the DMA
+// piece behind the first, the epilogue slice behind the second, the fragment reads behind the third: a workgroup is one wave per
+// SIMD, so nothing else fills the issue slots while a wave works through its non-MFMA instructions, and with the MFMAs issued
+// back to back (r05's first form) the matrix pipe idled through ~20 instructions per step (SQ counters,
+// profiles/r05_call10_*: pipes busy 0.32 at 2.3 GHz, 2.4 SALU + 2.3 VALU per MFMA; the kernel ran as long WITHOUT its MFMAs,
+// DMA and stores as they add to it).  The counted waits are never larger than the number of LDS operations really issued
+// behind the awaited fragment pair (the slices' extra operations only make them stricter).
 template <int PAR, int IT>
-__device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bool prev, float4 (&ev)[4]) {
+__device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
   if constexpr (IT < LG_NIT) {
+    f32x16& acc = PAR ? s.accB : s.accA;
+    f16x8 wh, wl;
     // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
     // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
     if constexpr (IT < LG_KS) {
       if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
       else wait_lgkm<lg_younger(IT)>();
       __builtin_amdgcn_sched_barrier(0);
-      if (!(s.abl & 1)) {
-        f32x16& acc = PAR ? s.accB : s.accA;
-        const f16x8 wh = s.qh[IT % LG_PF], wl = s.ql[IT % LG_PF];
-        if constexpr (IT == 0) {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
-        } else {
-          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
-        }
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
+      wh = s.qh[IT % LG_PF];
+      wl = s.ql[IT % LG_PF];
+      if constexpr (IT == 0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
       }
     }
-    if constexpr (IT == LG_KS) {
-      // The tile's last MFMA was issued one step ago.  hipcc cannot see that the asm above is an MFMA: nothing keeps it from
-      // reading the accumulator right behind it (a register copy is enough) — and a VALU read inside the MFMA's 8 passes sees
-      // the accumulator WITHOUT the last product(s).  r05 calls 7 / 8: two builds whose only difference was where hipcc placed
-      // such reads lost exactly the low-order terms (logits error 5e-5 instead of 9e-7).  Every later use of the accumulator is
-      // tied behind these wait states.
-      f32x16& acc = PAR ? s.accB : s.accA;
-      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
-    }
+    // ---- behind the first MFMA: the weight DMA.  Tile + 2 goes into the stage of THIS tile, free behind this tile's barrier
+    // (every wave has issued all its reads of it): pieces 0 .. NIT - 2 - SYNC at steps SYNC + 1 .. NIT - 1 of this tile, the rest of
+    // the 16 at the first steps of the next one (tile 0: the pieces re-load tile 1, which the prologue started: same bytes).
+    if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);
+    if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);
+    if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT < LG_KS) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
+    }
+    // ---- behind the second: the per-tile barrier, a slice of the previous tile's epilogue
     if constexpr (IT == LG_SYNC) {
       // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
-      // this tile (the last one, the pseudo item, at step SYNC - 1): this tile's stage may be overwritten from here on
+      // this tile (the last real one at step KS - 1 - PF): this tile's stage may be overwritten from here on
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+    if constexpr (lg_slice_step(IT)) {
+      if (prev) lg_epilogue_slice<IT>(e, PAR ? s.accA : s.accB, tile - 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT < LG_KS) {
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
+    }
+    if constexpr (IT == LG_KS) {
+      // (a precaution: hipcc does not know that the asm above are MFMAs — every later use of the accumulator is tied behind a
+      //  whole MFMA of wait states; tests/test_kernel_asm_lint.py checks the generated code for reads that are closer)
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- behind the third: the fragment pair PF items ahead (into the slot this step has just consumed)
     if constexpr (IT + LG_PF < LG_NIT) {
       lg_read<IT + LG_PF>(s);
     } else {
@@ -223,34 +259,8 @@ __device__ __forceinline__ void lg_step(LgState& s, const LgEpi& e, int tile, bo
       for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
       s.stage_delta = -s.stage_delta;
     }
-    // DMA of tile + 2 into the stage of THIS tile, free behind this tile's barrier: pieces 0 .. NIT - 2 - SYNC at steps
-    // SYNC + 1 .. NIT - 1 of this tile, the rest of the 16 at the first steps of the next one.
-    if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);
-    if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) {
-      if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);
-    }
-    // previous tile's epilogue in this tile's MFMA shadow
-    if (prev) {
-      // (lgkmcnt is a 4-bit counter: the slices first drain the fragment queue far enough that their own 8 / 4 LDS operations
-      //  keep the number in flight below 16)
-      if constexpr (IT == 3) {
-        wait_lgkm<6>();
-        asm volatile("s_nop 7" ::: "memory");
-        lg_epi_write(e, PAR ? s.accA : s.accB, tile - 1);
-      }
-      if constexpr (IT == 9) {
-        wait_lgkm<8>();
-        lg_epi_read(e, ev);
-      }
-      // the stores go out right BEHIND this tile's barrier: the next s_waitcnt vmcnt(0) — which cannot tell stores from DMA
-      // pieces — is a whole tile away, instead of 8 steps (r05 call 2: 2.6-2.9 us per tile against 1.3 of MFMA and 1.7 of fill)
-      if constexpr (IT == LG_SYNC + 1) {
-        wait_lgkm<0>();
-        lg_epi_store(e, ev, tile - 1);
-      }
-    }
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<PAR, IT + 1>(s, e, tile, prev, ev);
+    lg_step<PAR, IT + 1>(s, e, tile, prev);
   }
 }
 
@@ -356,16 +366,23 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   s.lds_w = lds0 + wave * 16384;
   s.voff = voff;
   s.n_tiles = a.n_tiles;
-  s.abl = a.abl;
   s.stage_delta = LG_STAGE;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
+  s.dma_g = img;   // (tile 0, steps 0 .. : the pieces of "tile 1" once more — what the prologue's DMA already brings)
+  lg_dma_begin(s, 1);
+  s.dma_g += 4096;   // pieces 5 .. 7 belong to the second 4-KiB group (lg_dma_piece bumps at pieces 8 and 12)
+  s.dma_l += 4096;
   LgEpi e;
-  e.sbias = sbias;
-  e.tp = reinterpret_cast<float*>(smem + LG_TP_OFF + wave * LG_TP_BYTES);
+  e.a_bias = lds0 + LG_BIAS_OFF + (lane & 7) * 16;
+  {
+    const unsigned tp = lds0 + LG_TP_OFF + wave * LG_TP_BYTES;
+    e.a_tpw = tp + (r * LG_TP_LD + hi * 4) * 4;
+    e.a_tpr = tp + ((lane >> 3) * LG_TP_LD + (lane & 7) * 4) * 4;
+  }
   e.C32 = a.C32; e.C16 = a.C16; e.C16lo = a.C16lo; e.ldc32 = a.ldc32; e.ldc16 = a.ldc16;
   e.N = a.N; e.M = a.M; e.row0 = blockIdx.x * 128 + wave * 32;
-  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane; e.no_store = a.abl & 4;
+  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane;
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
   for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]));
@@ -374,18 +391,25 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   asm volatile("" ::: "memory");
   lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
   static_assert(LG_PF == 6, "prologue primes PF items");
-  float4 ev[4];
   for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
-    lg_step<0, 0>(s, e, t, t > 0, ev);
-    lg_step<1, 0>(s, e, t + 1, true, ev);
+    lg_step<0, 0>(s, e, t, t > 0);
+    lg_step<1, 0>(s, e, t + 1, true);
   }
-  // the last tile's epilogue (exposed)
+  // the last tile's epilogue (exposed): the same slices, each behind a full wait
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
-  lg_epi_write(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<8>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<9>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<10>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<11>(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epi_read(e, ev);
+  lg_epilogue_slice<13>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<14>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<15>(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epi_store(e, ev, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 1>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 2>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 3>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 4>(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -393,9 +417,7 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
   auto kern = a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>;
   allow_big_lds((const void*)kern);
-  LnGemmArgs b = a;
-  b.abl = knob_int("LDM_LNGEMM_ABL", 0);
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, b);
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
   return 0;
 }
 

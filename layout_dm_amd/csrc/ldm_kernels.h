@@ -95,7 +95,6 @@ struct LnGemmArgs {
   float* C32;               // [M, ldc32] or nullptr
   __half *C16, *C16lo;      // [M, ldc16] hi / lo, or nullptr
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
-  int abl;                  // (set by the launcher from LDM_LNGEMM_ABL: timing ablations)
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);

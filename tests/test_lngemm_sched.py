@@ -21,10 +21,11 @@ def _consts():
     assert m, "schedule constants not found: update this replay together with the kernel"
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
-    for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1>(s, tile + 2);",
-                   "if (tile >= 1) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC)>(s, tile + 1);",
-                   "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16)", "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()",
-                   "wait_lgkm<lg_younger_last(IT)>()", "if constexpr (IT == 3)", "if constexpr (IT == 9) {\n        wait_lgkm<8>();\n        lg_epi_read", "wait_lgkm<6>();",
+    for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);",
+                   "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);",
+                   "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);",
+                   "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()", "wait_lgkm<lg_younger_last(IT)>()",
+                   "return (IT >= 8 && IT <= 11) || IT == 13 || IT == 14 || IT == 15 || (IT > LG_SYNC && IT <= LG_SYNC + 4);",
                    "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
@@ -88,20 +89,22 @@ def test_schedule_replay():
             piece = None
             if it > SYNC:
                 piece, td = it - SYNC - 1, t + 2
-            if it + (NIT - 1 - SYNC) < 16 and t >= 1:
-                piece, td = it + (NIT - 1 - SYNC), t + 1
-            if piece is not None and td < n_tiles:
+            if it + (NIT - 1 - SYNC) < 16:
+                piece, td = it + (NIT - 1 - SYNC), t + 1      # (tile 0: the pieces re-load tile 1, which the prologue brought)
+            if piece is not None and td < n_tiles and td >= 2:
                 assert td - 2 in barrier_done, f"DMA of tile {td} into the stage of tile {td - 2} before that tile's barrier"
                 assert dma_pieces.get(td, 0) == piece, f"tile {td}: piece {piece} out of order"
                 dma_pieces[td] = piece + 1
                 stage_tile[td & 1] = td
+            if piece is not None and td >= n_tiles:
+                # clamped: the last tile once more into the stage of tile td - 2, which must be free (its barrier passed)
+                assert td - 2 in barrier_done
             # ---- the previous tile's epilogue: LDS operations of its three slices
+            # (issued between the step's MFMAs, i.e. BEFORE the step's fragment reads: modelled by inserting them in front of the pair
+            #  just appended — conservative for the waits either way)
             if t > 0:
-                if it == 3:
-                    assert 6 + 8 <= 15               # wait_lgkm<6> in front of the slice: at most 6 + its own 8 operations in flight
-                    lds_ops += [("epi",)] * 8        # 4 bias reads + 4 ds_write_b128
-                if it == 9:
-                    assert 8 + 4 <= 15               # wait_lgkm<8> in front of the slice
-                    lds_ops += [("epi",)] * 4        # 4 ds_read_b128
+                extra = 1 if 8 <= it <= 11 or it == 13 else 2 if it in (14, 15) else 0
+                assert 2 * (PF - 1) + 2 + extra <= 15, "lgkmcnt is a 4-bit counter"
+                lds_ops += [("epi",)] * extra
     for td in range(2, n_tiles):
         assert dma_pieces[td] == 16
