@@ -72,7 +72,10 @@ __device__ __forceinline__ void lg_dsr(f16x8& d, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
 
+__device__ unsigned long long g_lngemm_phase[8];   // TM instantiation: workgroups | total | prologue | sync waits | lgkm waits | tail
+
 struct LgState {
+  unsigned long long t_sync = 0, t_lgkm = 0;   // (TM) cycles inside the per-tile vmcnt + barrier, inside the counted LDS waits
   f16x8 qh[LG_PF], ql[LG_PF];   // W hi / lo fragment queue
   unsigned aW[8];               // LDS byte addresses of the fragment columns in the CURRENT stage
   const f16x8* xhi;             // [29] activation fragments, hi (arch VGPRs)
@@ -196,7 +199,7 @@ constexpr bool lg_slice_step(int IT) {
 // profiles/r05_call10_*: pipes busy 0.32 at 2.3 GHz, 2.4 SALU + 2.3 VALU per MFMA; the kernel ran as long WITHOUT its MFMAs,
 // DMA and stores as they add to it).  The counted waits are never larger than the number of LDS operations really issued
 // behind the awaited fragment pair (the slices' extra operations only make them stricter).
-template <int PAR, int IT>
+template <int PAR, int IT, bool TM = false>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
   if constexpr (IT < LG_NIT) {
     f32x16& acc = PAR ? s.accB : s.accA;
@@ -204,8 +207,11 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
     // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
     if constexpr (IT < LG_KS) {
+      unsigned long long tw = 0;
+      if constexpr (TM) tw = __builtin_amdgcn_s_memtime();
       if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
       else wait_lgkm<lg_younger(IT)>();
+      if constexpr (TM) s.t_lgkm += __builtin_amdgcn_s_memtime() - tw;
       __builtin_amdgcn_sched_barrier(0);
       wh = s.qh[IT % LG_PF];
       wl = s.ql[IT % LG_PF];
@@ -229,9 +235,12 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     if constexpr (IT == LG_SYNC) {
       // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
       // this tile (the last real one at step KS - 1 - PF): this tile's stage may be overwritten from here on
+      unsigned long long tw = 0;
+      if constexpr (TM) tw = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
     }
     if constexpr (lg_slice_step(IT)) {
       if (prev) lg_epilogue_slice<IT>(e, PAR ? s.accA : s.accB, tile - 1);
@@ -260,15 +269,17 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       s.stage_delta = -s.stage_delta;
     }
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<PAR, IT + 1>(s, e, tile, prev);
+    lg_step<PAR, IT + 1, TM>(s, e, tile, prev);
   }
 }
 
 }  // namespace
 
-template <bool ADA>
+template <bool ADA, bool TM = false>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
+  if constexpr (TM) t_k0 = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, hi = lane >> 5;
   const unsigned lds0 = (unsigned)(size_t)(lds_char_ptr)smem;
@@ -389,12 +400,14 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();
   lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
   static_assert(LG_PF == 6, "prologue primes PF items");
   for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
-    lg_step<0, 0>(s, e, t, t > 0);
-    lg_step<1, 0>(s, e, t + 1, true);
+    lg_step<0, 0, TM>(s, e, t, t > 0);
+    lg_step<1, 0, TM>(s, e, t + 1, true);
   }
+  if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (exposed): the same slices, each behind a full wait
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
   lg_epilogue_slice<8>(e, s.accB, a.n_tiles - 1);
@@ -411,11 +424,30 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   lg_epilogue_slice<LG_SYNC + 3>(e, s.accB, a.n_tiles - 1);
   lg_epilogue_slice<LG_SYNC + 4>(e, s.accB, a.n_tiles - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (TM) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      atomicAdd(&g_lngemm_phase[0], 1ull);
+      atomicAdd(&g_lngemm_phase[1], t_end - t_k0);
+      atomicAdd(&g_lngemm_phase[2], t_pro - t_k0);
+      atomicAdd(&g_lngemm_phase[3], s.t_sync);
+      atomicAdd(&g_lngemm_phase[4], s.t_lgkm);
+      atomicAdd(&g_lngemm_phase[5], t_end - t_loop);
+    }
+  }
+}
+
+void lngemm_phase_read(unsigned long long* out8) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lngemm_phase), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lngemm_phase), z, sizeof(z));
 }
 
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
-  auto kern = a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>;
+  static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
+  auto kern = tm ? (a.ada ? lngemm16x3_k<true, true> : lngemm16x3_k<false, true>) : (a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>);
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
   return 0;

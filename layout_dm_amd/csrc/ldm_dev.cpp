@@ -130,3 +130,4 @@ namespace ldm {
 void stack_phase_read(unsigned long long* out16);
 }  // namespace ldm
 extern "C" void ldm_dev_stack_phases(unsigned long long* out16) { ldm::stack_phase_read(out16); }
+extern "C" void ldm_dev_lngemm_phases(unsigned long long* out8) { ldm::lngemm_phase_read(out8); }

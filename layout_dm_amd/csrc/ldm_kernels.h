@@ -98,6 +98,7 @@ struct LnGemmArgs {
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
+void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);
 int gemm16_block_k(int cfg);

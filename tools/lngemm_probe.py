@@ -21,5 +21,15 @@ for _ in range(reps):
     e.denoise_logits(tok, 50)
 torch.cuda.synchronize()
 rows = e.profile(reset=True)
+if os.environ.get("LDM_LNGEMM_TM") == "1":
+    import ctypes as C
+    ph = (C.c_ulonglong * 8)()
+    e.lib.ldm_dev_lngemm_phases.argtypes = [C.POINTER(C.c_ulonglong)]
+    e.lib.ldm_dev_lngemm_phases.restype = None
+    e.lib.ldm_dev_lngemm_phases(ph)
+    n = max(ph[0], 1)
+    print(json.dumps({"lngemm_phase_cycles_per_workgroup_mean_over_all_launches": {
+        "workgroups": ph[0], "total": ph[1] // n, "prologue": ph[2] // n, "sync_waits(vmcnt+barrier)": ph[3] // n,
+        "lgkm_waits": ph[4] // n, "tail_epilogue": ph[5] // n}, "note": "s_memtime ticks (100 MHz constant clock x ?): compare ratios"}))
 print(json.dumps({"abl": os.environ.get("LDM_LNGEMM_ABL", "0"), "knobs": e.describe().get("knobs"),
                   "us_per_launch": {r["name"]: round(1e3 * r["ms"] / max(r["launches"], 1), 1) for r in rows}}))
