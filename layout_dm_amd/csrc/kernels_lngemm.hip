@@ -80,7 +80,7 @@ struct LgState {
   unsigned aW[8];               // LDS byte addresses of the fragment columns in the CURRENT stage
   const f16x8* xhi;             // [29] activation fragments, hi (arch VGPRs)
   const f16x8* xlo;             // [29] ... lo (AGPRs)
-  f32x16 accA, accB;            // even / odd tiles
+  f32x16 accA, accB;            // the tile's TWO accumulator chains: the 87 MFMAs of a tile alternate between them (summed in the epilogue)
   const char* img;              // weight image + wave * 16 KiB
   unsigned lds_w;               // lds0 + wave * 16 KiB
   unsigned voff;                // lane * 16
@@ -132,30 +132,41 @@ struct LgEpi {
   lg_f32x4 ev[4];               // the tile transposed: 8 lanes per row
 };
 
-// The epilogue of tile t - 1, spread in small slices over the MFMA shadows of tile t.  Every LDS operation is issued through
-// asm: hipcc's own s_waitcnt for a load it knows about would be lgkmcnt(0), i.e. a drain of the whole fragment queue.  What
-// guarantees that a slice's data has landed is the per-step counted wait: an operation issued at step s is older than the
-// fragment pairs of items s + PF .. and therefore complete once step s + PF has waited (in-order LDS completion).
-//   steps 8 .. 11   one 4-column group each: the raw accumulator values, ds_write_b128 (accumulator layout -> row-major 32 x 32)
-//   step 13         the bias of the lane's 4 columns in the transposed view (1 x ds_read_b128)      -> landed at step 19
-//   steps 14, 15    the tile back, 8 lanes per row (2 x ds_read_b128 each)                          -> landed at step 21
+// The epilogue of a tile.  Its first part is exposed, at the tile's pseudo step: the two accumulator chains are summed and go to
+// the wave's transpose buffer (accumulator layout -> row-major 32 x 32) — the next tile's first MFMAs re-initialise both chains.
+// The rest runs in small slices inside the MFMA shadows of the NEXT tile.  Every LDS operation is issued through asm: hipcc's
+// own s_waitcnt for a load it knows about would be lgkmcnt(0), i.e. a drain of the whole fragment queue.  What guarantees that a
+// slice's data has landed is the per-step counted wait: an operation issued at step s is older than the fragment pairs of items
+// s + PF .. and therefore complete once step s + PF has waited (in-order LDS completion).
+//   step KS (pseudo)   chain A + chain B, 4 x ds_write_b128                                          (exposed: ~200 cycles per tile)
+//   step 1             the bias of the lane's 4 columns in the transposed view (1 x ds_read_b128)      -> landed at step 7
+//   steps 2, 3         the tile back, 8 lanes per row (2 x ds_read_b128 each)                          -> landed at step 9
 //   steps SYNC + 1 .. SYNC + 4   one 8-row pass each: scale, bias, ReLU, (hi / lo split,) 128-byte row segments to global memory
-//                   (behind this tile's barrier: the next s_waitcnt vmcnt(0), which cannot tell stores from DMA pieces, is a
-//                   whole tile away)
+//                      (behind the barrier: the next s_waitcnt vmcnt(0), which cannot tell stores from DMA pieces, is a whole
+//                      tile away)
 // At most 2 extra LDS operations per step: 10 (counted wait) + 2 (the step's own pair) + 2 = 14 in flight (lgkmcnt: 4 bits).
-template <int IT>
-__device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, const f32x16& acc, int tile) {
-  if constexpr (IT >= 8 && IT <= 11) {
-    constexpr int rq = IT - 8;
-    const lg_f32x4 v = {acc[rq * 4 + 0], acc[rq * 4 + 1], acc[rq * 4 + 2], acc[rq * 4 + 3]};
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(e.a_tpw), "v"(v), "n"(rq * 32) : "memory");
+// chain A + chain B -> the wave's transpose buffer (the exposed part)
+__device__ __forceinline__ void lg_epilogue_sum_write(const LgEpi& e, f32x16& a, f32x16& b) {
+  wait_lgkm<8>();   // (4 ds_write_b128 follow: lgkmcnt is a 4-bit counter)
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));   // the chains' last MFMAs (8 passes each): results visible to the VALU
+#pragma unroll
+  for (int rq = 0; rq < 4; ++rq) {
+    const lg_f32x4 v = {a[rq * 4 + 0] + b[rq * 4 + 0], a[rq * 4 + 1] + b[rq * 4 + 1], a[rq * 4 + 2] + b[rq * 4 + 2],
+                        a[rq * 4 + 3] + b[rq * 4 + 3]};
+    if (rq == 0) asm volatile("ds_write_b128 %0, %1" ::"v"(e.a_tpw), "v"(v) : "memory");
+    if (rq == 1) asm volatile("ds_write_b128 %0, %1 offset:32" ::"v"(e.a_tpw), "v"(v) : "memory");
+    if (rq == 2) asm volatile("ds_write_b128 %0, %1 offset:64" ::"v"(e.a_tpw), "v"(v) : "memory");
+    if (rq == 3) asm volatile("ds_write_b128 %0, %1 offset:96" ::"v"(e.a_tpw), "v"(v) : "memory");
   }
-  if constexpr (IT == 13) {
+}
+template <int IT>
+__device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
+  if constexpr (IT == 1) {
     const unsigned ab = e.a_bias + (unsigned)tile * 128;
     asm volatile("ds_read_b128 %0, %1" : "=v"(e.bb) : "v"(ab) : "memory");
   }
-  if constexpr (IT == 14 || IT == 15) {
-    constexpr int p0 = (IT - 14) * 2;
+  if constexpr (IT == 2 || IT == 3) {
+    constexpr int p0 = (IT - 2) * 2;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.ev[p0]) : "v"(e.a_tpr), "n"(p0 * 8 * LG_TP_LD * 4) : "memory");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(e.ev[p0 + 1]) : "v"(e.a_tpr), "n"((p0 + 1) * 8 * LG_TP_LD * 4) : "memory");
   }
@@ -188,21 +199,22 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, const f32x16& acc, i
   }
 }
 constexpr bool lg_slice_step(int IT) {
-  return (IT >= 8 && IT <= 11) || IT == 13 || IT == 14 || IT == 15 || (IT > LG_SYNC && IT <= LG_SYNC + 4);
+  return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);
 }
 
-// One tile = NIT steps.  PAR: accumulator of this tile (0: accA, 1: accB); the OTHER accumulator holds tile - 1, whose epilogue
-// runs in this tile's shadow when prev.  Inside a step the three MFMAs are INTERLEAVED with the step's other work — the DMA
-// piece behind the first, the epilogue slice behind the second, the fragment reads behind the third: a workgroup is one wave per
-// SIMD, so nothing else fills the issue slots while a wave works through its non-MFMA instructions, and with the MFMAs issued
-// back to back (r05's first form) the matrix pipe idled through ~20 instructions per step (SQ counters,
-// profiles/r05_call10_*: pipes busy 0.32 at 2.3 GHz, 2.4 SALU + 2.3 VALU per MFMA; the kernel ran as long WITHOUT its MFMAs,
-// DMA and stores as they add to it).  The counted waits are never larger than the number of LDS operations really issued
-// behind the awaited fragment pair (the slices' extra operations only make them stricter).
-template <int PAR, int IT, bool TM = false>
+// One tile = NIT steps.  The 87 MFMAs of a tile ALTERNATE between two accumulator chains (every product ends up in the same sum):
+// r05 call 12's phase timers put 73 % of the kernel inside the MFMA stream itself, ~62 cycles per MFMA against 32 of matrix-pipe
+// time, with all three MFMAs of a step on ONE chain — a dependent MFMA does not issue until its predecessor's result is back in the
+// register file.  Inside a step the MFMAs are interleaved with the step's other work (the DMA piece behind the first, the barrier /
+// an epilogue slice behind the second, the fragment reads behind the third): a workgroup is one wave per SIMD, nothing else fills
+// the issue slots.  The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment
+// pair (the slices' extra operations only make them stricter).
+template <int IT, bool TM = false>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
   if constexpr (IT < LG_NIT) {
-    f32x16& acc = PAR ? s.accB : s.accA;
+    // MFMA m of step IT (global index 3 IT + m) goes to chain (3 IT + m) & 1; a chain's first MFMA of the tile starts from zero
+    f32x16& c0 = ((3 * IT) & 1) ? s.accB : s.accA;       // chain of the step's 1st and 3rd MFMA
+    f32x16& c1 = ((3 * IT) & 1) ? s.accA : s.accB;       // ... of its 2nd
     f16x8 wh, wl;
     // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
     // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
@@ -216,9 +228,9 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       wh = s.qh[IT % LG_PF];
       wl = s.ql[IT % LG_PF];
       if constexpr (IT == 0) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wh), "v"(s.xhi[0]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c0) : "v"(wh), "v"(s.xhi[0]));
       } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "v"(s.xhi[IT]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c0) : "v"(wh), "v"(s.xhi[IT]));
       }
     }
     // ---- behind the first MFMA: the weight DMA.  Tile + 2 goes into the stage of THIS tile, free behind this tile's barrier
@@ -229,7 +241,11 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT < LG_KS) {
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wh), "a"(s.xlo[IT]));
+      if constexpr (IT == 0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c1) : "v"(wh), "a"(s.xlo[0]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c1) : "v"(wh), "a"(s.xlo[IT]));
+      }
     }
     // ---- behind the second: the per-tile barrier, a slice of the previous tile's epilogue
     if constexpr (IT == LG_SYNC) {
@@ -243,17 +259,10 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
     }
     if constexpr (lg_slice_step(IT)) {
-      if (prev) lg_epilogue_slice<IT>(e, PAR ? s.accA : s.accB, tile - 1);
+      if (prev) lg_epilogue_slice<IT>(e, tile - 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IT < LG_KS) {
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wl), "v"(s.xhi[IT]));
-    }
-    if constexpr (IT == LG_KS) {
-      // (a precaution: hipcc does not know that the asm above are MFMAs — every later use of the accumulator is tied behind a
-      //  whole MFMA of wait states; tests/test_kernel_asm_lint.py checks the generated code for reads that are closer)
-      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
-    }
+    if constexpr (IT < LG_KS) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c0) : "v"(wl), "v"(s.xhi[IT]));
     __builtin_amdgcn_sched_barrier(0);
     // ---- behind the third: the fragment pair PF items ahead (into the slot this step has just consumed)
     if constexpr (IT + LG_PF < LG_NIT) {
@@ -268,8 +277,10 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
       s.stage_delta = -s.stage_delta;
     }
+    // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
+    if constexpr (IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<PAR, IT + 1, TM>(s, e, tile, prev);
+    lg_step<IT + 1, TM>(s, e, tile, prev);
   }
 }
 
@@ -403,26 +414,17 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();
   lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
   static_assert(LG_PF == 6, "prologue primes PF items");
-  for (int t = 0; t < a.n_tiles; t += 2) {  // (launcher: n_tiles even)
-    lg_step<0, 0, TM>(s, e, t, t > 0);
-    lg_step<1, 0, TM>(s, e, t + 1, true);
-  }
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, TM>(s, e, t, t > 0);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
-  // the last tile's epilogue (exposed): the same slices, each behind a full wait
-  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s.accB));
-  lg_epilogue_slice<8>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<9>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<10>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<11>(e, s.accB, a.n_tiles - 1);
+  // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
+  lg_epilogue_slice<1>(e, a.n_tiles - 1);
+  lg_epilogue_slice<2>(e, a.n_tiles - 1);
+  lg_epilogue_slice<3>(e, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epilogue_slice<13>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<14>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<15>(e, s.accB, a.n_tiles - 1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epilogue_slice<LG_SYNC + 1>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 2>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 3>(e, s.accB, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 4>(e, s.accB, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 1>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 2>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 3>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 4>(e, a.n_tiles - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (TM) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -445,7 +447,7 @@ void lngemm_phase_read(unsigned long long* out8) {
 }
 
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
-  if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
+  if (a.D != 464 || a.n_tiles < 2 || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
   static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
   auto kern = tm ? (a.ada ? lngemm16x3_k<true, true> : lngemm16x3_k<false, true>) : (a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>);
   allow_big_lds((const void*)kern);

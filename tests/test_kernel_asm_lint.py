@@ -199,7 +199,7 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-        assert len(mf) == 2 * 29 * 3, (name, len(mf))           # two tile bodies (accumulator parity) x 29 k16-steps x 3 products
+        assert len(mf) == 29 * 3, (name, len(mf))               # one tile body: 29 k16-steps x 3 products, alternating between two chains
         for i in mf:
             ops = [o.strip() for o in instr[i][4:].split(None, 1)[1].split(",")]
             dst = _regs(ops[0])

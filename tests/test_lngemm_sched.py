@@ -25,7 +25,8 @@ def _consts():
                    "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);",
                    "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);",
                    "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()", "wait_lgkm<lg_younger_last(IT)>()",
-                   "return (IT >= 8 && IT <= 11) || IT == 13 || IT == 14 || IT == 15 || (IT > LG_SYNC && IT <= LG_SYNC + 4);",
+                   "return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);",
+                   "if constexpr (IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);", "wait_lgkm<8>();   // (4 ds_write_b128 follow",
                    "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
@@ -103,8 +104,11 @@ def test_schedule_replay():
             # (issued between the step's MFMAs, i.e. BEFORE the step's fragment reads: modelled by inserting them in front of the pair
             #  just appended — conservative for the waits either way)
             if t > 0:
-                extra = 1 if 8 <= it <= 11 or it == 13 else 2 if it in (14, 15) else 0
+                extra = 1 if it == 1 else 2 if it in (2, 3) else 0
                 assert 2 * (PF - 1) + 2 + extra <= 15, "lgkmcnt is a 4-bit counter"
                 lds_ops += [("epi",)] * extra
+            if it == KS:                              # the pseudo step: drain to 8, then the 4 ds_write_b128 of the tile's sum
+                assert 8 + 4 <= 15
+                lds_ops += [("epi",)] * 4
     for td in range(2, n_tiles):
         assert dma_pieces[td] == 16
