@@ -202,20 +202,19 @@ constexpr bool lg_slice_step(int IT) {
   return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);
 }
 
-// One tile = NIT steps.  The 87 MFMAs of a tile ALTERNATE between two accumulator chains (every product ends up in the same sum):
-// r05 call 12's phase timers put 73 % of the kernel inside the MFMA stream itself, ~62 cycles per MFMA against 32 of matrix-pipe
-// time, with all three MFMAs of a step on ONE chain — a dependent MFMA does not issue until its predecessor's result is back in the
-// register file.  Inside a step the MFMAs are interleaved with the step's other work (the DMA piece behind the first, the barrier /
-// an epilogue slice behind the second, the fragment reads behind the third): a workgroup is one wave per SIMD, nothing else fills
-// the issue slots.  The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment
-// pair (the slices' extra operations only make them stricter).
+// One tile = NIT steps.  A step's three MFMAs are ONE asm statement — back to back on one accumulator chain, no issue slot
+// between them — and consecutive steps alternate between the tile's two chains (summed in the epilogue); everything else a step
+// has to do (the DMA piece, the barrier, an epilogue slice, the fragment pair PF items ahead) is issued behind the triple, in
+// its 96 cycles of matrix-pipe time, i.e. between MFMAs on DIFFERENT accumulators.  Why (r05 calls 5 - 13, and
+// MI355X_MICROARCH.md's issue-slot table): with one wave per SIMD an issue slot between two MFMAs on the SAME accumulator costs
+// ~43 cycles — hipcc puts an s_nop between two asm statements, so the first forms of this loop (three asm MFMAs per step, then
+// MFMAs interleaved with the step's other work, one chain or two alternating per MFMA) all ran at 62 - 92 cycles per MFMA whatever
+// else was changed: instruction count, queue depth, accumulator placement, DMA, stores.
+// The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment pair (the
+// slices' extra operations only make them stricter).
 template <int IT, bool TM = false>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
   if constexpr (IT < LG_NIT) {
-    // MFMA m of step IT (global index 3 IT + m) goes to chain (3 IT + m) & 1; a chain's first MFMA of the tile starts from zero
-    f32x16& c0 = ((3 * IT) & 1) ? s.accB : s.accA;       // chain of the step's 1st and 3rd MFMA
-    f32x16& c1 = ((3 * IT) & 1) ? s.accA : s.accB;       // ... of its 2nd
-    f16x8 wh, wl;
     // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
     // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
     if constexpr (IT < LG_KS) {
@@ -225,29 +224,45 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       else wait_lgkm<lg_younger(IT)>();
       if constexpr (TM) s.t_lgkm += __builtin_amdgcn_s_memtime() - tw;
       __builtin_amdgcn_sched_barrier(0);
-      wh = s.qh[IT % LG_PF];
-      wl = s.ql[IT % LG_PF];
-      if constexpr (IT == 0) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c0) : "v"(wh), "v"(s.xhi[0]));
+      f32x16& acc = (IT & 1) ? s.accB : s.accA;   // chain of this step
+      // W_hi x_hi + W_hi x_lo + W_lo x_hi  (lo unscaled: one accumulator takes all three)
+      if constexpr (IT < 2) {  // the chain's first step of the tile starts from zero
+        asm volatile(
+            "v_mfma_f32_32x32x16_f16 %0, %1, %3, 0\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0"
+            : "=&v"(acc)
+            : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
       } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c0) : "v"(wh), "v"(s.xhi[IT]));
+        asm volatile(
+            "v_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0"
+            : "+v"(acc)
+            : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- behind the first MFMA: the weight DMA.  Tile + 2 goes into the stage of THIS tile, free behind this tile's barrier
-    // (every wave has issued all its reads of it): pieces 0 .. NIT - 2 - SYNC at steps SYNC + 1 .. NIT - 1 of this tile, the rest of
-    // the 16 at the first steps of the next one (tile 0: the pieces re-load tile 1, which the prologue started: same bytes).
+    // ---- behind the triple: the fragment pair PF items ahead (into the slot this step has just consumed) ...
+    if constexpr (IT + LG_PF < LG_NIT) {
+      lg_read<IT + LG_PF>(s);
+    } else if constexpr (IT > LG_SYNC) {
+      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was moved at step SYNC - 1
+      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
+    }
+    if constexpr (IT == LG_SYNC - 1) {
+      // item NIT - 1 (the last item of this tile) has just been issued: aW now points into the next tile's stage
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
+      s.stage_delta = -s.stage_delta;
+    }
+    // ---- ... the weight DMA: tile + 2 goes into the stage of THIS tile, free behind this tile's barrier (every wave has issued
+    // all its reads of it): pieces 0 .. NIT - 2 - SYNC at steps SYNC + 1 .. NIT - 1 of this tile, the rest of the 16 at the first
+    // steps of the next one (tile 0: the pieces re-load tile 1, which the prologue started: same bytes) ...
     if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);
     if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);
     if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IT < LG_KS) {
-      if constexpr (IT == 0) {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c1) : "v"(wh), "a"(s.xlo[0]));
-      } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c1) : "v"(wh), "a"(s.xlo[IT]));
-      }
-    }
-    // ---- behind the second: the per-tile barrier, a slice of the previous tile's epilogue
+    // ---- ... the per-tile barrier ...
     if constexpr (IT == LG_SYNC) {
       // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
       // this tile (the last real one at step KS - 1 - PF): this tile's stage may be overwritten from here on
@@ -257,25 +272,12 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
-    }
-    if constexpr (lg_slice_step(IT)) {
-      if (prev) lg_epilogue_slice<IT>(e, tile - 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IT < LG_KS) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c0) : "v"(wl), "v"(s.xhi[IT]));
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- behind the third: the fragment pair PF items ahead (into the slot this step has just consumed)
-    if constexpr (IT + LG_PF < LG_NIT) {
-      lg_read<IT + LG_PF>(s);
-    } else {
-      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was moved at step SYNC - 1
+      // (the next tile's item 0 is read only now, behind the barrier)
       if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
     }
-    if constexpr (IT == LG_SYNC - 1) {
-      // item NIT - 1 (the last item of this tile) has just been issued: aW now points into the next tile's stage
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
-      s.stage_delta = -s.stage_delta;
+    // ---- ... and a slice of the previous tile's epilogue
+    if constexpr (lg_slice_step(IT)) {
+      if (prev) lg_epilogue_slice<IT>(e, tile - 1);
     }
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);

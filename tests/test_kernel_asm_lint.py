@@ -199,7 +199,7 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-        assert len(mf) == 29 * 3, (name, len(mf))               # one tile body: 29 k16-steps x 3 products, alternating between two chains
+        assert len(mf) >= 87 and len(mf) % 87 == 0, (name, len(mf))   # tile bodies of 29 k16-steps x 3 products (hipcc may specialise the first / last tile)
         for i in mf:
             ops = [o.strip() for o in instr[i][4:].split(None, 1)[1].split(",")]
             dst = _regs(ops[0])

@@ -21,7 +21,8 @@ def _consts():
     assert m, "schedule constants not found: update this replay together with the kernel"
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
-    for needle in ("if constexpr (IT == LG_SYNC - 1)", "if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);",
+    for needle in ("if constexpr (IT == LG_SYNC - 1)", "} else if constexpr (IT > LG_SYNC) {",
+                   "if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);\n    }\n    // ---- ... and a slice", "if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);",
                    "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);",
                    "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);",
                    "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()", "wait_lgkm<lg_younger_last(IT)>()",
