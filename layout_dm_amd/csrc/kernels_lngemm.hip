@@ -212,21 +212,28 @@ constexpr bool lg_slice_step(int IT) {
 // else was changed: instruction count, queue depth, accumulator placement, DMA, stores.
 // The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment pair (the
 // slices' extra operations only make them stricter).
-template <int IT, bool TM = false>
+template <int IT, bool TM = false, int ABL = 0>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
+  // ABL (dev builds only, LDM_LNGEMM_ABL): compile-time removal of 1 = the MFMAs, 2 = the fragment reads and their counted waits,
+  // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores) — timing variants of this loop, results meaningless
+  constexpr bool kMf = !(ABL & 1), kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
   if constexpr (IT < LG_NIT) {
     // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
     // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
     if constexpr (IT < LG_KS) {
       unsigned long long tw = 0;
       if constexpr (TM) tw = __builtin_amdgcn_s_memtime();
-      if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
-      else wait_lgkm<lg_younger(IT)>();
+      if constexpr (kRd) {
+        if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
+        else wait_lgkm<lg_younger(IT)>();
+      }
       if constexpr (TM) s.t_lgkm += __builtin_amdgcn_s_memtime() - tw;
       __builtin_amdgcn_sched_barrier(0);
       f32x16& acc = (IT & 1) ? s.accB : s.accA;   // chain of this step
       // W_hi x_hi + W_hi x_lo + W_lo x_hi  (lo unscaled: one accumulator takes all three)
-      if constexpr (IT < 2) {  // the chain's first step of the tile starts from zero
+      if constexpr (!kMf) {
+        asm volatile("" : "+v"(acc) : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
+      } else if constexpr (IT < 2) {  // the chain's first step of the tile starts from zero
         asm volatile(
             "v_mfma_f32_32x32x16_f16 %0, %1, %3, 0\n\t"
             "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0\n\t"
@@ -244,7 +251,8 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- behind the triple: the fragment pair PF items ahead (into the slot this step has just consumed) ...
-    if constexpr (IT + LG_PF < LG_NIT) {
+    if constexpr (!kRd) {
+    } else if constexpr (IT + LG_PF < LG_NIT) {
       lg_read<IT + LG_PF>(s);
     } else if constexpr (IT > LG_SYNC) {
       // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was moved at step SYNC - 1
@@ -259,9 +267,11 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     // ---- ... the weight DMA: tile + 2 goes into the stage of THIS tile, free behind this tile's barrier (every wave has issued
     // all its reads of it): pieces 0 .. NIT - 2 - SYNC at steps SYNC + 1 .. NIT - 1 of this tile, the rest of the 16 at the first
     // steps of the next one (tile 0: the pieces re-load tile 1, which the prologue started: same bytes) ...
-    if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);
-    if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);
-    if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
+    if constexpr (kDm) {
+      if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);
+      if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);
+      if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
+    }
     // ---- ... the per-tile barrier ...
     if constexpr (IT == LG_SYNC) {
       // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
@@ -273,22 +283,23 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       asm volatile("" ::: "memory");
       if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
       // (the next tile's item 0 is read only now, behind the barrier)
-      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
+      if constexpr (kRd)
+        if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
     }
     // ---- ... and a slice of the previous tile's epilogue
-    if constexpr (lg_slice_step(IT)) {
+    if constexpr (kEp && lg_slice_step(IT)) {
       if (prev) lg_epilogue_slice<IT>(e, tile - 1);
     }
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
-    if constexpr (IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
+    if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<IT + 1, TM>(s, e, tile, prev);
+    lg_step<IT + 1, TM, ABL>(s, e, tile, prev);
   }
 }
 
 }  // namespace
 
-template <bool ADA, bool TM = false>
+template <bool ADA, bool TM = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
@@ -414,9 +425,15 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();
-  lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
+  if constexpr (ABL != 0) {   // (timing variants: whatever they leave unwritten starts defined)
+    for (int k = 0; k < 16; ++k) s.accA[k] = s.accB[k] = 0.f;
+    for (int k = 0; k < LG_PF; ++k) s.qh[k] = s.ql[k] = xhi[k];
+  }
+  if constexpr (!(ABL & 2)) {
+    lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
+  }
   static_assert(LG_PF == 6, "prologue primes PF items");
-  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, TM>(s, e, t, t > 0);
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, TM, ABL>(s, e, t, t > 0);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
   lg_epilogue_slice<1>(e, a.n_tiles - 1);
@@ -452,6 +469,12 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.D != 464 || a.n_tiles < 2 || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
   static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
   auto kern = tm ? (a.ada ? lngemm16x3_k<true, true> : lngemm16x3_k<false, true>) : (a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>);
+#ifdef LDM_LNGEMM_ABL_BUILD   // dev build (tools/gpu_calls/r05_call16.sh): compile-time timing variants of the loop
+  static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
+#define LG_ABL(n) case n: kern = a.ada ? lngemm16x3_k<true, false, n> : lngemm16x3_k<false, false, n>; break;
+  switch (abl) { LG_ABL(1) LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(15) default: break; }
+#undef LG_ABL
+#endif
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
   return 0;

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, 1) void stack_stream_k(StackArgs a) {
 #if !defined(LDM_ABL_FFN_WINDOW)
         F.gnext = fimg + (size_t)(c == A.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
 #elif LDM_ABL_FFN_WINDOW == 1
-        // MEASUREMENT builds only (tools/build_ffn_window_variants.py, profiles/r04_call26_*; wrong numbers by design, never the
+        // MEASUREMENT builds only (tools/build_measurement_variants.py, profiles/r04_call26_*; wrong numbers by design, never the
         // shipped library): the FFN weight stream — 65 % of the 23.4 MB a workgroup-step pulls — re-reads stage 0 of the layer's
         // image: a 64-KiB window that the XCD's L2 serves (no fabric / Infinity-Cache traffic) ...
         F.gnext = fimg + wave * 16384;

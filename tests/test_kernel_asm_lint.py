@@ -193,7 +193,7 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     destination registers of an inline-asm MFMA must sit at least one whole MFMA (8 passes = 32 cycles) of wait states behind it."""
     asm = _compile("kernels_lngemm.hip", tmp_path)
     # the product instantiations (TM = false: the second template argument mangles as Lb0; the phase-timer builds are dev only)
-    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and k.endswith("ELb0EEEvNS_10LnGemmArgsE")}
+    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and k.endswith("ELb0ELi0EEEvNS_10LnGemmArgsE")}
     assert len(kernels) == 2, list(_kernels(asm))
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     for name, instr in kernels.items():

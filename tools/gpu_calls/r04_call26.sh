@@ -1,5 +1,5 @@
 #!/bin/bash
-# r04: what does the weight stream cost the loop kernel?  Measurement builds (tools/build_ffn_window_variants.py): the FFN weight
+# r04: what does the weight stream cost the loop kernel?  Measurement builds (tools/build_measurement_variants.py): the FFN weight
 # stream (65 % of the 23.4 MB per workgroup-step) re-reads a 64-KiB window (served by the XCD's L2: no fabric traffic) or a
 # 16-KiB window (served by the CU's L1: no L2 -> CU traffic either); same instruction stream, same LDS-DMA count
 O=gpurun_out/r04_call26; mkdir -p $O
