@@ -50,12 +50,6 @@ constexpr int lg_younger(int IT) {
   for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;
   return n;
 }
-// ... when no further tile follows (nothing is issued behind item NIT - 1)
-constexpr int lg_younger_last(int IT) {
-  int n = 0;
-  for (int j = 1; j < LG_PF && IT + j < LG_NIT; ++j) n += lg_real(IT + j) ? 2 : 0;
-  return n;
-}
 static_assert(lg_younger(0) <= 15, "lgkmcnt is a 4-bit counter");
 constexpr int LG_STAGE = 65536;                    // W hi tile (32 KiB) | W lo tile (32 KiB)
 constexpr int LG_LO = 32768;
@@ -107,17 +101,6 @@ __device__ __forceinline__ void lg_dma_begin(LgState& s, int td) {
   s.dma_g = s.img + (size_t)t * LG_STAGE;
   s.dma_l = s.lds_w + (unsigned)(td & 1) * LG_STAGE;
 }
-// M0 in front of every 4-KiB group and of the first piece behind the tile boundary (compiler-generated code sits in between)
-template <int J, bool SET_M0>
-__device__ __forceinline__ void lg_dma_piece(LgState& s) {
-  if constexpr ((J & 3) == 0 && J > 0) {
-    s.dma_g += 4096;
-    s.dma_l += 4096;
-  }
-  if constexpr ((J & 3) == 0 || SET_M0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.dma_l) : "memory");
-  dma_lin<(J & 3) * 1024>(s.voff, s.dma_g);
-}
-
 typedef float lg_f32x4 __attribute__((ext_vector_type(4)));   // (a 4-register asm operand: HIP's float4 is a struct)
 struct LgEpi {
   unsigned a_bias;              // LDS byte address of the bias table + (lane & 7) * 16: the lane's 4 columns AFTER the transpose
@@ -202,61 +185,96 @@ constexpr bool lg_slice_step(int IT) {
   return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);
 }
 
-// One tile = NIT steps.  A step's three MFMAs are ONE asm statement — back to back on one accumulator chain, no issue slot
-// between them — and consecutive steps alternate between the tile's two chains (summed in the epilogue); everything else a step
-// has to do (the DMA piece, the barrier, an epilogue slice, the fragment pair PF items ahead) is issued behind the triple, in
-// its 96 cycles of matrix-pipe time, i.e. between MFMAs on DIFFERENT accumulators.  Why (r05 calls 5 - 13, and
-// MI355X_MICROARCH.md's issue-slot table): with one wave per SIMD an issue slot between two MFMAs on the SAME accumulator costs
-// ~43 cycles — hipcc puts an s_nop between two asm statements, so the first forms of this loop (three asm MFMAs per step, then
-// MFMAs interleaved with the step's other work, one chain or two alternating per MFMA) all ran at 62 - 92 cycles per MFMA whatever
-// else was changed: instruction count, queue depth, accumulator placement, DMA, stores.
+// One tile = NIT steps.  A real step (a k16-step) is ONE asm statement: the counted wait, then its three MFMAs with the step's
+// LDS-DMA piece and its two fragment reads BETWEEN them — one filler per MFMA gap, issued while the matrix pipe works:
+//     s_waitcnt lgkmcnt(n)        ; fragment pair of this item landed
+//     [s_mov_b32 m0, <LDS group>] ; (steps that carry a DMA piece)
+//     v_mfma  c0 += Wh x_hi
+//     [global_load_lds_dwordx4]   ; the piece: 1 KiB of weight tile t + 1 / t + 2
+//     v_mfma  c1 += Wh x_lo
+//     ds_read_b128 Wh'            ; the pair PF items ahead, into the queue slot this step is consuming: Wh is dead from here
+//     v_mfma  c0 += Wl x_hi
+//     ds_read_b128 Wl'
+// c0 / c1 are the tile's two accumulator chains, swapped every step: consecutive MFMAs are ALWAYS on different accumulators
+// (A B A | B A B | ...), each chain gets 3 MFMAs per two steps, and the two are summed in the epilogue (lo unscaled: any chain may
+// take any of the three products).  Why this form (r05 calls 5 - 16, profiles/r05_call16_lngemm_compile_time_variants.txt, and
+// MI355X_MICROARCH.md's issue-slot table): one wave per SIMD issues in order; a filler placed BEHIND a run of MFMAs overlaps
+// only the last one (the earlier forms of this loop — three asm MFMAs per step with hipcc's s_nop between them, then one asm
+// triple per step with everything else behind it — ran at MFMA time PLUS fragment reads PLUS DMA pieces PLUS epilogue: 95 + 16 +
+// 28 + 54 us of linear1's 207), and an issue slot between two MFMAs on the SAME accumulator costs ~43 cycles, between MFMAs on
+// different accumulators ~6.
 // The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment pair (the
-// slices' extra operations only make them stricter).
+// slices' extra operations only make them stricter).  The reads run on into the NEXT tile's stage unconditionally: behind the
+// last tile they fetch bytes nobody uses (the stage exists; keeps the stream free of branches and the waits uniform).
+#define LG_MFMA(D, B, A, C) "v_mfma_f32_32x32x16_f16 " D ", " B ", " A ", " C "\n\t"
+#define LG_STEP_ASM(C0, C1, M0SET, PIECE, RD_HI, RD_LO)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LG_MFMA("%[c0]", "%[qh]", "%[xh]", C0) PIECE                                 \
+                   LG_MFMA("%[c1]", "%[qh]", "%[xl]", C1) RD_HI LG_MFMA("%[c0]", "%[ql]", "%[xh]", "%[c0]") RD_LO              \
+               : [c0] "+v"(c0), [c1] "+v"(c1), [qh] "+v"(qh), [ql] "+v"(ql)                                                     \
+               : [xh] "v"(s.xhi[IT]), [xl] "a"(s.xlo[IT]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l), \
+                 [w] "n"(W), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                               \
+               : "memory")
+#define LG_A_M0 "s_mov_b32 m0, %[dl]\n\t"
+#define LG_A_PIECE "global_load_lds_dwordx4 %[vo], %[dg] offset:%[doff]\n\t"
+#define LG_A_RDH "ds_read_b128 %[qh], %[aw] offset:%[ro]\n\t"
+#define LG_A_RDL "ds_read_b128 %[ql], %[aw] offset:%[rl]"
+
+// which DMA piece (of the 16 per tile and wave) step IT carries, or -1: pieces 0 .. NIT - 2 - SYNC of tile + 2 at steps SYNC + 1 ..
+// NIT - 1 (its stage — this tile's — is free behind this tile's barrier), the rest at the first steps of the next tile
+constexpr int lg_piece(int IT) {
+  if (IT > LG_SYNC) return IT - LG_SYNC - 1;
+  if (IT + (LG_NIT - 1 - LG_SYNC) < 16) return IT + (LG_NIT - 1 - LG_SYNC);
+  return -1;
+}
+static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(0) == lg_piece(LG_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
+
 template <int IT, bool TM = false, int ABL = 0>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
-  // ABL (dev builds only, LDM_LNGEMM_ABL): compile-time removal of 1 = the MFMAs, 2 = the fragment reads and their counted waits,
+  // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
   // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores) — timing variants of this loop, results meaningless
-  constexpr bool kMf = !(ABL & 1), kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
+  constexpr bool kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
   if constexpr (IT < LG_NIT) {
-    // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item
-    // IT's.  Behind the last tile's step SYNC nothing is issued any more: the count shrinks with the queue.
-    if constexpr (IT < LG_KS) {
-      unsigned long long tw = 0;
-      if constexpr (TM) tw = __builtin_amdgcn_s_memtime();
-      if constexpr (kRd) {
-        if (IT >= LG_SYNC && tile + 1 >= s.n_tiles) wait_lgkm<lg_younger_last(IT)>();
-        else wait_lgkm<lg_younger(IT)>();
-      }
-      if constexpr (TM) s.t_lgkm += __builtin_amdgcn_s_memtime() - tw;
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16& acc = (IT & 1) ? s.accB : s.accA;   // chain of this step
-      // W_hi x_hi + W_hi x_lo + W_lo x_hi  (lo unscaled: one accumulator takes all three)
-      if constexpr (!kMf) {
-        asm volatile("" : "+v"(acc) : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
-      } else if constexpr (IT < 2) {  // the chain's first step of the tile starts from zero
-        asm volatile(
-            "v_mfma_f32_32x32x16_f16 %0, %1, %3, 0\n\t"
-            "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0\n\t"
-            "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0"
-            : "=&v"(acc)
-            : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
-      } else {
-        asm volatile(
-            "v_mfma_f32_32x32x16_f16 %0, %1, %3, %0\n\t"
-            "v_mfma_f32_32x32x16_f16 %0, %1, %4, %0\n\t"
-            "v_mfma_f32_32x32x16_f16 %0, %2, %3, %0"
-            : "+v"(acc)
-            : "v"(s.qh[IT % LG_PF]), "v"(s.ql[IT % LG_PF]), "v"(s.xhi[IT]), "a"(s.xlo[IT]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    constexpr int J = lg_piece(IT);
+    constexpr bool hasD = kDm && J >= 0;
+    // the DMA stream's uniform address state: a new tile at piece 0, the next 4-KiB group of this wave's 16 KiB at pieces 4, 8, 12
+    if constexpr (hasD && J == 0) lg_dma_begin(s, tile + 2);
+    if constexpr (hasD && J > 0 && (J & 3) == 0) {
+      s.dma_g += 4096;
+      s.dma_l += 4096;
     }
-    // ---- behind the triple: the fragment pair PF items ahead (into the slot this step has just consumed) ...
-    if constexpr (!kRd) {
-    } else if constexpr (IT + LG_PF < LG_NIT) {
-      lg_read<IT + LG_PF>(s);
-    } else if constexpr (IT > LG_SYNC) {
-      // items of the NEXT tile, in the other stage (certified by the barrier at step SYNC); aW was moved at step SYNC - 1
-      if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
+    // the fragment pair PF items ahead (pseudo items: nothing); the one behind the barrier step is read behind the barrier
+    constexpr int RI = (IT + LG_PF) % LG_NIT;
+    constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;
+    constexpr int RO = 256 * (RI >> 3);
+    constexpr int DOFF = hasD ? (J & 3) * 1024 : 0;
+    if constexpr (IT < LG_KS) {
+      // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item IT's
+      constexpr int W = kRd ? lg_younger(IT) : 15;
+      f32x16& c0 = (IT & 1) ? s.accB : s.accA;   // two of the step's MFMAs
+      f32x16& c1 = (IT & 1) ? s.accA : s.accB;   // one
+      f16x8& qh = s.qh[IT % LG_PF];
+      f16x8& ql = s.ql[IT % LG_PF];
+      const unsigned aw = s.aW[RI & 7];
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IT == 0) {  // both chains start from zero
+        if constexpr (hasD && hasR) LG_STEP_ASM("0", "0", LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL);
+        else if constexpr (hasD) LG_STEP_ASM("0", "0", LG_A_M0, LG_A_PIECE, "", "");
+        else if constexpr (hasR) LG_STEP_ASM("0", "0", "", "", LG_A_RDH, LG_A_RDL);
+        else LG_STEP_ASM("0", "0", "", "", "", "");
+      } else {
+        if constexpr (hasD && hasR) LG_STEP_ASM("%[c0]", "%[c1]", LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL);
+        else if constexpr (hasD) LG_STEP_ASM("%[c0]", "%[c1]", LG_A_M0, LG_A_PIECE, "", "");
+        else if constexpr (hasR) LG_STEP_ASM("%[c0]", "%[c1]", "", "", LG_A_RDH, LG_A_RDL);
+        else LG_STEP_ASM("%[c0]", "%[c1]", "", "", "", "");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // the pseudo step: no MFMAs; its read and its DMA piece issue as plain statements
+      if constexpr (hasR) lg_read<RI>(s);
+      if constexpr (hasD) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.dma_l) : "memory");
+        dma_lin<DOFF>(s.voff, s.dma_g);
+      }
     }
     if constexpr (IT == LG_SYNC - 1) {
       // item NIT - 1 (the last item of this tile) has just been issued: aW now points into the next tile's stage
@@ -264,15 +282,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       for (int k = 0; k < 8; ++k) s.aW[k] += (unsigned)s.stage_delta;
       s.stage_delta = -s.stage_delta;
     }
-    // ---- ... the weight DMA: tile + 2 goes into the stage of THIS tile, free behind this tile's barrier (every wave has issued
-    // all its reads of it): pieces 0 .. NIT - 2 - SYNC at steps SYNC + 1 .. NIT - 1 of this tile, the rest of the 16 at the first
-    // steps of the next one (tile 0: the pieces re-load tile 1, which the prologue started: same bytes) ...
-    if constexpr (kDm) {
-      if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);
-      if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);
-      if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);
-    }
-    // ---- ... the per-tile barrier ...
+    // ---- the per-tile barrier ...
     if constexpr (IT == LG_SYNC) {
       // the next tile's stage is complete (own DMA pieces landed, then everybody's), and every wave has ISSUED all its reads of
       // this tile (the last real one at step KS - 1 - PF): this tile's stage may be overwritten from here on
@@ -283,8 +293,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       asm volatile("" ::: "memory");
       if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
       // (the next tile's item 0 is read only now, behind the barrier)
-      if constexpr (kRd)
-        if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);
+      if constexpr (kRd) lg_read<RI>(s);
     }
     // ---- ... and a slice of the previous tile's epilogue
     if constexpr (kEp && lg_slice_step(IT)) {
@@ -296,6 +305,8 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     lg_step<IT + 1, TM, ABL>(s, e, tile, prev);
   }
 }
+#undef LG_STEP_ASM
+#undef LG_MFMA
 
 }  // namespace
 
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
   s.dma_g = img;   // (tile 0, steps 0 .. : the pieces of "tile 1" once more — what the prologue's DMA already brings)
   lg_dma_begin(s, 1);
-  s.dma_g += 4096;   // pieces 5 .. 7 belong to the second 4-KiB group (lg_dma_piece bumps at pieces 8 and 12)
+  s.dma_g += 4096;   // pieces 5 .. 7 belong to the second 4-KiB group (lg_step bumps at pieces 8 and 12)
   s.dma_l += 4096;
   LgEpi e;
   e.a_bias = lds0 + LG_BIAS_OFF + (lane & 7) * 16;
@@ -472,7 +483,7 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
 #ifdef LDM_LNGEMM_ABL_BUILD   // dev build (tools/gpu_calls/r05_call16.sh): compile-time timing variants of the loop
   static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
 #define LG_ABL(n) case n: kern = a.ada ? lngemm16x3_k<true, false, n> : lngemm16x3_k<false, false, n>; break;
-  switch (abl) { LG_ABL(1) LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(15) default: break; }
+  switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) default: break; }
 #undef LG_ABL
 #endif
   allow_big_lds((const void*)kern);

@@ -21,13 +21,13 @@ def _consts():
     assert m, "schedule constants not found: update this replay together with the kernel"
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
-    for needle in ("if constexpr (IT == LG_SYNC - 1)", "} else if constexpr (IT > LG_SYNC) {",
-                   "if (tile + 1 < s.n_tiles) lg_read<IT + LG_PF - LG_NIT>(s);\n    }\n    // ---- ... and a slice", "if constexpr (IT == LG_SYNC + 1) lg_dma_begin(s, tile + 2);",
-                   "if constexpr (IT > LG_SYNC) lg_dma_piece<IT - LG_SYNC - 1, false>(s);",
-                   "if constexpr (IT + (LG_NIT - 1 - LG_SYNC) < 16) lg_dma_piece<IT + (LG_NIT - 1 - LG_SYNC), IT == 0>(s);",
-                   "lg_read<IT + LG_PF - LG_NIT>(s)", "wait_lgkm<lg_younger(IT)>()", "wait_lgkm<lg_younger_last(IT)>()",
+    for needle in ("if constexpr (IT == LG_SYNC - 1)", "constexpr int RI = (IT + LG_PF) % LG_NIT;",
+                   "constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;", "if constexpr (kRd) lg_read<RI>(s);",
+                   "if constexpr (hasD && J == 0) lg_dma_begin(s, tile + 2);", "if (IT > LG_SYNC) return IT - LG_SYNC - 1;",
+                   "if (IT + (LG_NIT - 1 - LG_SYNC) < 16) return IT + (LG_NIT - 1 - LG_SYNC);",
+                   "constexpr int W = kRd ? lg_younger(IT) : 15;", "const unsigned aw = s.aW[RI & 7];",
                    "return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);",
-                   "if constexpr (IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);", "wait_lgkm<8>();   // (4 ds_write_b128 follow",
+                   "if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);", "wait_lgkm<8>();   // (4 ds_write_b128 follow",
                    "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
@@ -64,10 +64,7 @@ def test_schedule_replay():
             # ---- the counted wait in front of the step (real items only)
             real = lambda i: (i % NIT) < KS
             if it < KS:
-                if it >= SYNC and last:
-                    n = sum(2 for j in range(1, PF) if it + j < NIT and real(it + j))
-                else:
-                    n = sum(2 for j in range(1, PF) if real(it + j))
+                n = sum(2 for j in range(1, PF) if real(it + j))     # uniform: the reads run on behind the last tile
                 assert n <= 15
                 idx = max(i for i, op in enumerate(lds_ops) if op == ("frag", t, it))      # the younger of the pair
                 younger = len(lds_ops) - 1 - idx
@@ -85,6 +82,9 @@ def test_schedule_replay():
                 issue_read(t, it + PF)
             elif not last:
                 issue_read(t + 1, it + PF - NIT)
+            elif it + PF - NIT < KS:
+                # behind the last tile the reads go on into the other stage (bytes nobody consumes): LDS operations all the same
+                lds_ops += [("frag", t + 1, it + PF - NIT)] * 2
             if it == SYNC - 1:
                 cur_stage_of_aw ^= 1
             # ---- DMA of tile t + 2 (behind this tile's barrier) / the rest of tile t + 1
