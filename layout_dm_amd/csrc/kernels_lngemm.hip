@@ -197,7 +197,7 @@ constexpr bool lg_slice_step(int IT) {
 //     ds_read_b128 Wl'
 // c0 / c1 are the tile's two accumulator chains, swapped every step: consecutive MFMAs are ALWAYS on different accumulators
 // (A B A | B A B | ...), each chain gets 3 MFMAs per two steps, and the two are summed in the epilogue (lo unscaled: any chain may
-// take any of the three products).  Why this form (r05 calls 5 - 16, profiles/r05_call16_lngemm_compile_time_variants.txt, and
+// take any of the three products).  Why this form (r05 calls 5 - 16, profiles/r05_call16_17_lngemm_compile_time_variants.txt, and
 // MI355X_MICROARCH.md's issue-slot table): one wave per SIMD issues in order; a filler placed BEHIND a run of MFMAs overlaps
 // only the last one (the earlier forms of this loop — three asm MFMAs per step with hipcc's s_nop between them, then one asm
 // triple per step with everything else behind it — ran at MFMA time PLUS fragment reads PLUS DMA pieces PLUS epilogue: 95 + 16 +
