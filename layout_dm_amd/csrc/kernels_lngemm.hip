@@ -102,32 +102,39 @@ __device__ __forceinline__ void lg_dma_begin(LgState& s, int td) {
   s.dma_l = s.lds_w + (unsigned)(td & 1) * LG_STAGE;
 }
 typedef float lg_f32x4 __attribute__((ext_vector_type(4)));   // (a 4-register asm operand: HIP's float4 is a struct)
+typedef unsigned lg_u32x2 __attribute__((ext_vector_type(2)));
 struct LgEpi {
   unsigned a_bias;              // LDS byte address of the bias table + (lane & 7) * 16: the lane's 4 columns AFTER the transpose
   unsigned a_tpw, a_tpr;        // this lane's write / read address in the wave's transpose buffer (LDS bytes)
-  float* C32;
-  __half *C16, *C16lo;
-  int ldc32, ldc16, N, M, row0; // row0: first row of this wave
+  const char *C0, *C1;          // output bases: fp32 C | fp16 hi, fp16 lo
+  const char *b0, *b1;          // ... of the tile whose epilogue is in flight (uniform: + tile * 32 columns)
+  unsigned voff[4];             // this lane's byte offset in 8-row pass p: (row0 + 8 p + lane / 8) * ld + (lane & 7) * 4 columns
+  unsigned long long rowmask[4];   // lanes whose row of pass p exists (row < M)
+  unsigned long long colmask;   // lanes whose 4 columns of the tile in flight exist (col < N; N % 4 == 0)
+  int N, c4;                    // c4 = (lane & 7) * 4
   float out_scale;
-  int relu;
-  int lane;
   lg_f32x4 bb;                  // bias of the lane's 4 columns of the tile whose epilogue is in flight
   lg_f32x4 ev[4];               // the tile transposed: 8 lanes per row
 };
 
 // The epilogue of a tile.  Its first part is exposed, at the tile's pseudo step: the two accumulator chains are summed and go to
 // the wave's transpose buffer (accumulator layout -> row-major 32 x 32) — the next tile's first MFMAs re-initialise both chains.
-// The rest runs in small slices inside the MFMA shadows of the NEXT tile.  Every LDS operation is issued through asm: hipcc's
+// The rest runs in small slices beside the MFMAs of the NEXT tile.  Every LDS operation is issued through asm: hipcc's
 // own s_waitcnt for a load it knows about would be lgkmcnt(0), i.e. a drain of the whole fragment queue.  What guarantees that a
 // slice's data has landed is the per-step counted wait: an operation issued at step s is older than the fragment pairs of items
 // s + PF .. and therefore complete once step s + PF has waited (in-order LDS completion).
 //   step KS (pseudo)   chain A + chain B, 4 x ds_write_b128                                          (exposed: ~200 cycles per tile)
 //   step 1             the bias of the lane's 4 columns in the transposed view (1 x ds_read_b128)      -> landed at step 7
 //   steps 2, 3         the tile back, 8 lanes per row (2 x ds_read_b128 each)                          -> landed at step 9
-//   steps SYNC + 1 .. SYNC + 4   one 8-row pass each: scale, bias, ReLU, (hi / lo split,) 128-byte row segments to global memory
+//   steps SYNC + 1 .. SYNC + 4   one 8-row pass each: scale + bias, (ReLU, hi / lo split,) 128- / 64-byte row segments to global memory
 //                      (behind the barrier: the next s_waitcnt vmcnt(0), which cannot tell stores from DMA pieces, is a whole
 //                      tile away)
 // At most 2 extra LDS operations per step: 10 (counted wait) + 2 (the step's own pair) + 2 = 14 in flight (lgkmcnt: 4 bits).
+// A store pass is ONE branch-free asm statement (r05 call 17: every non-MFMA instruction of this loop costs ~6 cycles of issue,
+// hidden or not; hipcc's version of a pass was 62 - 75 instructions with eight branches): rows beyond M and columns beyond N are
+// masked through EXEC (SGPR lane masks, restored inside the statement), the address is an SGPR base + a per-lane 32-bit offset that
+// does not change from tile to tile.  OUT = 0: fp32; OUT = 1: ReLU, then hi = fp16(v) and lo = fp16(v - hi) (kSplitLoScale == 1).
+static_assert(kSplitLoScale == 1.0f, "the lo half is stored unscaled");
 // chain A + chain B -> the wave's transpose buffer (the exposed part)
 __device__ __forceinline__ void lg_epilogue_sum_write(const LgEpi& e, f32x16& a, f32x16& b) {
   wait_lgkm<8>();   // (4 ds_write_b128 follow: lgkmcnt is a 4-bit counter)
@@ -142,11 +149,14 @@ __device__ __forceinline__ void lg_epilogue_sum_write(const LgEpi& e, f32x16& a,
     if (rq == 3) asm volatile("ds_write_b128 %0, %1 offset:96" ::"v"(e.a_tpw), "v"(v) : "memory");
   }
 }
-template <int IT>
+template <int IT, int OUT>
 __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
   if constexpr (IT == 1) {
     const unsigned ab = e.a_bias + (unsigned)tile * 128;
     asm volatile("ds_read_b128 %0, %1" : "=v"(e.bb) : "v"(ab) : "memory");
+    e.colmask = __ballot(tile * 32 + e.c4 < e.N);
+    e.b0 = e.C0 + (size_t)tile * (OUT == 0 ? 128 : 64);
+    e.b1 = e.C1 + (size_t)tile * 64;
   }
   if constexpr (IT == 2 || IT == 3) {
     constexpr int p0 = (IT - 2) * 2;
@@ -155,29 +165,42 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
   }
   if constexpr (IT > LG_SYNC && IT <= LG_SYNC + 4) {
     constexpr int p = IT - LG_SYNC - 1;
-    const int col = tile * 32 + (e.lane & 7) * 4;
-    const int row = e.row0 + p * 8 + (e.lane >> 3);
-    if (col < e.N && row < e.M) {
-      lg_f32x4 v = e.ev[p] * e.out_scale + e.bb;
-      if (e.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      if (e.C32) *reinterpret_cast<lg_f32x4*>(e.C32 + (size_t)row * e.ldc32 + col) = v;
-      if (e.C16) {
-        const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
-        uint2 pk;
-        pk.x = *reinterpret_cast<const unsigned*>(&h0);
-        pk.y = *reinterpret_cast<const unsigned*>(&h1);
-        *reinterpret_cast<uint2*>(e.C16 + (size_t)row * e.ldc16 + col) = pk;
-        if (e.C16lo) {
-          const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
-          const __half2 l0 = __floats2half2_rn((v.x - f0.x) * kSplitLoScale, (v.y - f0.y) * kSplitLoScale);
-          const __half2 l1 = __floats2half2_rn((v.z - f1.x) * kSplitLoScale, (v.w - f1.y) * kSplitLoScale);
-          pk.x = *reinterpret_cast<const unsigned*>(&l0);
-          pk.y = *reinterpret_cast<const unsigned*>(&l1);
-          *reinterpret_cast<uint2*>(e.C16lo + (size_t)row * e.ldc16 + col) = pk;
-        }
-      }
+    const lg_f32x4 ev = e.ev[p];
+    float t0, t1, t2, t3;
+    if constexpr (OUT == 0) {
+      asm volatile(
+          "v_fma_f32 %[t0], %[e0], %[sc], %[b0]\n\tv_fma_f32 %[t1], %[e1], %[sc], %[b1]\n\t"
+          "v_fma_f32 %[t2], %[e2], %[sc], %[b2]\n\tv_fma_f32 %[t3], %[e3], %[sc], %[b3]"
+          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+          : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
+            [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
+      const lg_f32x4 T = {t0, t1, t2, t3};
+      asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b]\n\ts_mov_b64 exec, -1"
+                   ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [T] "v"(T), [b] "s"(e.b0)
+                   : "memory");
+    } else {
+      unsigned h01, h23, l01, l23;
+      asm volatile(
+          "v_fma_f32 %[t0], %[e0], %[sc], %[b0]\n\tv_fma_f32 %[t1], %[e1], %[sc], %[b1]\n\t"
+          "v_fma_f32 %[t2], %[e2], %[sc], %[b2]\n\tv_fma_f32 %[t3], %[e3], %[sc], %[b3]\n\t"
+          "v_max_f32 %[t0], 0, %[t0]\n\tv_max_f32 %[t1], 0, %[t1]\n\tv_max_f32 %[t2], 0, %[t2]\n\tv_max_f32 %[t3], 0, %[t3]\n\t"
+          "v_cvt_pk_f16_f32 %[h01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[h23], %[t2], %[t3]\n\t"
+          // lo = v - float(hi): exact in fp32 (one fma_mix per value: -hi(f16 half of the pair) * 1.0 + v)
+          "v_fma_mix_f32 %[t0], -%[h01], 1.0, %[t0] op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mix_f32 %[t1], -%[h01], 1.0, %[t1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mix_f32 %[t2], -%[h23], 1.0, %[t2] op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mix_f32 %[t3], -%[h23], 1.0, %[t3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+          "v_cvt_pk_f16_f32 %[l01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[l23], %[t2], %[t3]"
+          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [h01] "=&v"(h01), [h23] "=&v"(h23), [l01] "=&v"(l01),
+            [l23] "=&v"(l23)
+          : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
+            [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
+      const lg_u32x2 H = {h01, h23}, L = {l01, l23};
+      asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh]\n\tglobal_store_dwordx2 %[vo], %[L], %[bl]\n\t"
+                   "s_mov_b64 exec, -1"
+                   ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [H] "v"(H), [L] "v"(L), [bh] "s"(e.b0),
+                   [bl] "s"(e.b1)
+                   : "memory");
     }
   }
 }
@@ -228,7 +251,7 @@ constexpr int lg_piece(int IT) {
 }
 static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(0) == lg_piece(LG_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
 
-template <int IT, bool TM = false, int ABL = 0>
+template <int IT, int OUT, bool TM = false, int ABL = 0>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
   // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
   // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores) — timing variants of this loop, results meaningless
@@ -297,12 +320,12 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
     }
     // ---- ... and a slice of the previous tile's epilogue
     if constexpr (kEp && lg_slice_step(IT)) {
-      if (prev) lg_epilogue_slice<IT>(e, tile - 1);
+      if (prev) lg_epilogue_slice<IT, OUT>(e, tile - 1);
     }
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<IT + 1, TM, ABL>(s, e, tile, prev);
+    lg_step<IT + 1, OUT, TM, ABL>(s, e, tile, prev);
   }
 }
 #undef LG_STEP_ASM
@@ -310,7 +333,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
 
 }  // namespace
 
-template <bool ADA, bool TM = false, int ABL = 0>
+template <bool ADA, int OUT, bool TM = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
@@ -426,9 +449,18 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     e.a_tpw = tp + (r * LG_TP_LD + hi * 4) * 4;
     e.a_tpr = tp + ((lane >> 3) * LG_TP_LD + (lane & 7) * 4) * 4;
   }
-  e.C32 = a.C32; e.C16 = a.C16; e.C16lo = a.C16lo; e.ldc32 = a.ldc32; e.ldc16 = a.ldc16;
-  e.N = a.N; e.M = a.M; e.row0 = blockIdx.x * 128 + wave * 32;
-  e.out_scale = a.out_scale; e.relu = a.relu; e.lane = lane;
+  e.C0 = OUT == 0 ? reinterpret_cast<const char*>(a.C32) : reinterpret_cast<const char*>(a.C16);
+  e.C1 = reinterpret_cast<const char*>(a.C16lo);
+  e.b0 = e.C0; e.b1 = e.C1; e.colmask = 0;
+  e.N = a.N; e.c4 = (lane & 7) * 4;
+  e.out_scale = a.out_scale;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int orow = blockIdx.x * 128 + wave * 32 + p * 8 + (lane >> 3);
+    e.rowmask[p] = __ballot(orow < a.M);
+    // (launch_lngemm16x3 checks that M * ld * element size fits 32 bits)
+    e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
+  }
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
   for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]));
@@ -444,17 +476,17 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
   }
   static_assert(LG_PF == 6, "prologue primes PF items");
-  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, TM, ABL>(s, e, t, t > 0);
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL>(s, e, t, t > 0);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
-  lg_epilogue_slice<1>(e, a.n_tiles - 1);
-  lg_epilogue_slice<2>(e, a.n_tiles - 1);
-  lg_epilogue_slice<3>(e, a.n_tiles - 1);
+  lg_epilogue_slice<1, OUT>(e, a.n_tiles - 1);
+  lg_epilogue_slice<2, OUT>(e, a.n_tiles - 1);
+  lg_epilogue_slice<3, OUT>(e, a.n_tiles - 1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lg_epilogue_slice<LG_SYNC + 1>(e, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 2>(e, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 3>(e, a.n_tiles - 1);
-  lg_epilogue_slice<LG_SYNC + 4>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 1, OUT>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 2, OUT>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 3, OUT>(e, a.n_tiles - 1);
+  lg_epilogue_slice<LG_SYNC + 4, OUT>(e, a.n_tiles - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (TM) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -478,11 +510,16 @@ void lngemm_phase_read(unsigned long long* out8) {
 
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.D != 464 || a.n_tiles < 2 || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
+  // two output forms: fp32 (no ReLU) | ReLU + hi / lo fp16; the epilogue addresses with 32-bit byte offsets
+  const bool half_out = a.C16 != nullptr;
+  if (half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu)) return -1;
+  if ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)) return -1;
   static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
-  auto kern = tm ? (a.ada ? lngemm16x3_k<true, true> : lngemm16x3_k<false, true>) : (a.ada ? lngemm16x3_k<true> : lngemm16x3_k<false>);
-#ifdef LDM_LNGEMM_ABL_BUILD   // dev build (tools/gpu_calls/r05_call16.sh): compile-time timing variants of the loop
+  auto kern = half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
+  if (tm) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
+#ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
-#define LG_ABL(n) case n: kern = a.ada ? lngemm16x3_k<true, false, n> : lngemm16x3_k<false, false, n>; break;
+#define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
   switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) default: break; }
 #undef LG_ABL
 #endif
