@@ -94,6 +94,15 @@ __device__ __forceinline__ void lg_read(LgState& s) {
   }
 }
 
+// the kernel prologue primes the queue: items 0 .. PF - 1 of tile 0
+template <int I>
+__device__ __forceinline__ void lg_prime(LgState& s) {
+  if constexpr (I < LG_PF) {
+    lg_read<I>(s);
+    lg_prime<I + 1>(s);
+  }
+}
+
 // Start the DMA of tile td (clamped to the last tile: re-loading it into a free stage is harmless and keeps the stream free of
 // branches) into stage td & 1: piece J = 1 KiB of this wave's 16; the pieces of one tile straddle a tile boundary.
 __device__ __forceinline__ void lg_dma_begin(LgState& s, int td) {
@@ -154,7 +163,8 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
   if constexpr (IT == 1) {
     const unsigned ab = e.a_bias + (unsigned)tile * 128;
     asm volatile("ds_read_b128 %0, %1" : "=v"(e.bb) : "v"(ab) : "memory");
-    e.colmask = __ballot(tile * 32 + e.c4 < e.N);
+    // (tile == -1, the slices of the first tile's steps: an unsigned compare masks every lane — the passes run and store nothing)
+    e.colmask = __ballot((unsigned)(tile * 32 + e.c4) < (unsigned)e.N);
     e.b0 = e.C0 + (size_t)tile * (OUT == 0 ? 128 : 64);
     e.b1 = e.C1 + (size_t)tile * 64;
   }
@@ -252,7 +262,7 @@ constexpr int lg_piece(int IT) {
 static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(0) == lg_piece(LG_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
 
 template <int IT, int OUT, bool TM = false, int ABL = 0>
-__device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool prev) {
+__device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
   // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
   // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores) — timing variants of this loop, results meaningless
   constexpr bool kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
@@ -319,13 +329,11 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile, bool pre
       if constexpr (kRd) lg_read<RI>(s);
     }
     // ---- ... and a slice of the previous tile's epilogue
-    if constexpr (kEp && lg_slice_step(IT)) {
-      if (prev) lg_epilogue_slice<IT, OUT>(e, tile - 1);
-    }
+    if constexpr (kEp && lg_slice_step(IT)) lg_epilogue_slice<IT, OUT>(e, tile - 1);
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<IT + 1, OUT, TM, ABL>(s, e, tile, prev);
+    lg_step<IT + 1, OUT, TM, ABL>(s, e, tile);
   }
 }
 #undef LG_STEP_ASM
@@ -440,8 +448,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   for (int k = 0; k < 8; ++k) s.aW[k] = lds0 + r * RKB + ((((k << 1) | hi) ^ (r & 15)) << 4);
   s.dma_g = img;   // (tile 0, steps 0 .. : the pieces of "tile 1" once more — what the prologue's DMA already brings)
   lg_dma_begin(s, 1);
-  s.dma_g += 4096;   // pieces 5 .. 7 belong to the second 4-KiB group (lg_step bumps at pieces 8 and 12)
-  s.dma_l += 4096;
+  {  // the 4-KiB group of the first piece issued at step 0 (lg_step itself moves on at pieces 4, 8, 12)
+    constexpr int J0 = lg_piece(0), pre = (J0 >> 2) - ((J0 & 3) == 0 ? 1 : 0);
+    s.dma_g += pre * 4096;
+    s.dma_l += pre * 4096;
+  }
   LgEpi e;
   e.a_bias = lds0 + LG_BIAS_OFF + (lane & 7) * 16;
   {
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   }
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
-  for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]));
+  for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]), "+a"(xlo[k]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -472,11 +483,8 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     for (int k = 0; k < 16; ++k) s.accA[k] = s.accB[k] = 0.f;
     for (int k = 0; k < LG_PF; ++k) s.qh[k] = s.ql[k] = xhi[k];
   }
-  if constexpr (!(ABL & 2)) {
-    lg_read<0>(s); lg_read<1>(s); lg_read<2>(s); lg_read<3>(s); lg_read<4>(s); lg_read<5>(s);
-  }
-  static_assert(LG_PF == 6, "prologue primes PF items");
-  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL>(s, e, t, t > 0);
+  if constexpr (!(ABL & 2)) lg_prime<0>(s);
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL>(s, e, t);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
   lg_epilogue_slice<1, OUT>(e, a.n_tiles - 1);
