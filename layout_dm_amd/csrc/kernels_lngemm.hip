@@ -158,15 +158,16 @@ __device__ __forceinline__ void lg_epilogue_sum_write(const LgEpi& e, f32x16& a,
     if (rq == 3) asm volatile("ds_write_b128 %0, %1 offset:96" ::"v"(e.a_tpw), "v"(v) : "memory");
   }
 }
-template <int IT, int OUT>
+template <int IT, int OUT, int ABL = 0>
 __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
   if constexpr (IT == 1) {
     const unsigned ab = e.a_bias + (unsigned)tile * 128;
     asm volatile("ds_read_b128 %0, %1" : "=v"(e.bb) : "v"(ab) : "memory");
     // (tile == -1, the slices of the first tile's steps: an unsigned compare masks every lane — the passes run and store nothing)
     e.colmask = __ballot((unsigned)(tile * 32 + e.c4) < (unsigned)e.N);
-    e.b0 = e.C0 + (size_t)tile * (OUT == 0 ? 128 : 64);
-    e.b1 = e.C1 + (size_t)tile * 64;
+    // (measurement variant 32: every tile stores to the columns of tile 0 — the same bytes per store, an L2-resident target)
+    e.b0 = e.C0 + ((ABL & 32) ? 0 : (size_t)tile * (OUT == 0 ? 128 : 64));
+    e.b1 = e.C1 + ((ABL & 32) ? 0 : (size_t)tile * 64);
   }
   if constexpr (IT == 2 || IT == 3) {
     constexpr int p0 = (IT - 2) * 2;
@@ -185,7 +186,8 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
           : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
             [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
       const lg_f32x4 T = {t0, t1, t2, t3};
-      asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b]\n\ts_mov_b64 exec, -1"
+      if constexpr (ABL & 16) asm volatile("" ::"v"(T));   // (measurement variant 16: the pass without its store)
+      else asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b]\n\ts_mov_b64 exec, -1"
                    ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [T] "v"(T), [b] "s"(e.b0)
                    : "memory");
     } else {
@@ -206,7 +208,8 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
           : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
             [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
       const lg_u32x2 H = {h01, h23}, L = {l01, l23};
-      asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh]\n\tglobal_store_dwordx2 %[vo], %[L], %[bl]\n\t"
+      if constexpr (ABL & 16) asm volatile("" ::"v"(H), "v"(L));
+      else asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh]\n\tglobal_store_dwordx2 %[vo], %[L], %[bl]\n\t"
                    "s_mov_b64 exec, -1"
                    ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [H] "v"(H), [L] "v"(L), [bh] "s"(e.b0),
                    [bl] "s"(e.b1)
@@ -264,7 +267,8 @@ static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(
 template <int IT, int OUT, bool TM = false, int ABL = 0>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
   // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
-  // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores) — timing variants of this loop, results meaningless
+  // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores), 16 = the epilogue's global stores only, 32 = every tile's stores
+  // aimed at the columns of tile 0 — timing variants of this loop, results meaningless
   constexpr bool kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
   if constexpr (IT < LG_NIT) {
     constexpr int J = lg_piece(IT);
@@ -329,7 +333,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
       if constexpr (kRd) lg_read<RI>(s);
     }
     // ---- ... and a slice of the previous tile's epilogue
-    if constexpr (kEp && lg_slice_step(IT)) lg_epilogue_slice<IT, OUT>(e, tile - 1);
+    if constexpr (kEp && lg_slice_step(IT)) lg_epilogue_slice<IT, OUT, ABL>(e, tile - 1);
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
@@ -528,7 +532,7 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
-  switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) default: break; }
+  switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) default: break; }
 #undef LG_ABL
 #endif
   allow_big_lds((const void*)kern);

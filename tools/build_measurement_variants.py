@@ -3,7 +3,7 @@
   libldm_hip_abl_ffnwin1.so  -DLDM_ABL_FFN_WINDOW=1   FFN stream re-reads a 64-KiB window (L2-served; WRONG numbers)
   libldm_hip_abl_ffnwin2.so  -DLDM_ABL_FFN_WINDOW=2   ... a 16-KiB window (L1-served; WRONG numbers)
   libldm_hip_abl_lngemm.so   -DLDM_LNGEMM_ABL_BUILD   kernels_lngemm.hip with its compile-time timing variants (LDM_LNGEMM_ABL=mask:
-                                                      1 no MFMAs, 2 no fragment reads, 4 no weight DMA, 8 no epilogue; WRONG numbers)"""
+                                                      2 no fragment reads, 4 no weight DMA, 8 no epilogue, 16 no epilogue stores, 32 stores to tile 0 columns; WRONG numbers)"""
 import os
 import subprocess
 import sys
