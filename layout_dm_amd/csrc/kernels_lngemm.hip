@@ -480,6 +480,13 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
 #pragma unroll
   for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]), "+a"(xlo[k]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // Phase offset between workgroups.  All workgroups walk the tiles in lock step, so their store passes (4 of a tile's 30 steps)
+  // hit the memory system together: ~4 MB per burst from the 250 workgroups, far above what the write path takes at once — the
+  // stores then hold the waves (r05 call 19: linear1 187 us, 155 without the stores, 160 with the same stores aimed at an
+  // L2-resident target).  Eight phases, one eighth of a tile period apart, within every XCD (blockIdx % 8 is the XCD): the
+  // demand becomes steady.  Costs the last phase's offset once per launch.
+  if (wave == 0)
+    for (int i = ((blockIdx.x >> 3) & 7) * a.phase_sleep; i > 0; --i) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();
@@ -536,7 +543,10 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
 #undef LG_ABL
 #endif
   allow_big_lds((const void*)kern);
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
+  static const int phase = (int)knob_int("LDM_LNGEMM_PHASE", 12);   // 64-cycle units per phase step (dev knob; 0 = lock step)
+  LnGemmArgs b = a;
+  b.phase_sleep = phase < 0 ? 0 : phase;
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, b);
   return 0;
 }
 
