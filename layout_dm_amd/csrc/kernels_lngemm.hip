@@ -187,6 +187,10 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
             [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
       const lg_f32x4 T = {t0, t1, t2, t3};
       if constexpr (ABL & 16) asm volatile("" ::"v"(T));   // (measurement variant 16: the pass without its store)
+      else if constexpr (ABL & 64)   // (measurement variant 64: non-temporal stores)
+        asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b] nt\n\ts_mov_b64 exec, -1"
+                     ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [T] "v"(T), [b] "s"(e.b0)
+                     : "memory");
       else asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b]\n\ts_mov_b64 exec, -1"
                    ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [T] "v"(T), [b] "s"(e.b0)
                    : "memory");
@@ -209,6 +213,12 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
             [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
       const lg_u32x2 H = {h01, h23}, L = {l01, l23};
       if constexpr (ABL & 16) asm volatile("" ::"v"(H), "v"(L));
+      else if constexpr (ABL & 64)
+        asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh] nt\n\tglobal_store_dwordx2 %[vo], %[L], %[bl] nt\n\t"
+                     "s_mov_b64 exec, -1"
+                     ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [H] "v"(H), [L] "v"(L), [bh] "s"(e.b0),
+                     [bl] "s"(e.b1)
+                     : "memory");
       else asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh]\n\tglobal_store_dwordx2 %[vo], %[L], %[bl]\n\t"
                    "s_mov_b64 exec, -1"
                    ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [H] "v"(H), [L] "v"(L), [bh] "s"(e.b0),
@@ -480,13 +490,9 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
 #pragma unroll
   for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]), "+a"(xlo[k]));
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  // Phase offset between workgroups.  All workgroups walk the tiles in lock step, so their store passes (4 of a tile's 30 steps)
-  // hit the memory system together: ~4 MB per burst from the 250 workgroups, far above what the write path takes at once — the
-  // stores then hold the waves (r05 call 19: linear1 187 us, 155 without the stores, 160 with the same stores aimed at an
-  // L2-resident target).  Eight phases, one eighth of a tile period apart, within every XCD (blockIdx % 8 is the XCD): the
-  // demand becomes steady.  Costs the last phase's offset once per launch.
-  if (wave == 0)
-    for (int i = ((blockIdx.x >> 3) & 7) * a.phase_sleep; i > 0; --i) __builtin_amdgcn_s_sleep(1);
+  // (r05 calls 19 - 21, profiles/r05_call18_21_lngemm_store_cost.txt: of linear1's 187 us, 33 are its global stores — 6 with the same
+  //  stores aimed at an L2-resident target, i.e. the cost is the 237 MB of hi / lo hidden rows on their way to HBM, not store issue;
+  //  a phase offset between the lock-step workgroups changes nothing, non-temporal stores are 25 % slower.)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if constexpr (TM) t_pro = __builtin_amdgcn_s_memtime();
@@ -539,14 +545,11 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
-  switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) default: break; }
+  switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) LG_ABL(64) default: break; }
 #undef LG_ABL
 #endif
   allow_big_lds((const void*)kern);
-  static const int phase = (int)knob_int("LDM_LNGEMM_PHASE", 12);   // 64-cycle units per phase step (dev knob; 0 = lock step)
-  LnGemmArgs b = a;
-  b.phase_sleep = phase < 0 ? 0 : phase;
-  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, b);
+  hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
   return 0;
 }
 

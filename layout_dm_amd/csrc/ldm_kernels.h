@@ -96,7 +96,6 @@ struct LnGemmArgs {
   __half *C16, *C16lo;      // [M, ldc16] hi / lo, or nullptr
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
-  int phase_sleep;          // workgroup phase offset in 64-cycle units per phase step (launch_lngemm16x3 fills it in)
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
 void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)

@@ -34,7 +34,6 @@ inline const std::map<std::string, const char*>& knob_table() {
       {"LDM_X3_GRP", "column-group width of the split GEMM's tile order (0 = row-major)"},
       {"LDM_X3_LNGEMM", "0 = LayerNorm launches + gemm16x3_k for the LayerNorm-fed GEMMs of the split mode instead of the row-resident LayerNorm + x3 GEMM (the r04 structure)"},
       {"LDM_LNGEMM_TM", "row-resident LayerNorm + x3 GEMM: phase-timer instantiation (tools/lngemm_probe.py)"},
-      {"LDM_LNGEMM_PHASE", "row-resident LayerNorm + x3 GEMM: phase offset between workgroups in 64-cycle units per phase step (default 12, 0 = lock step)"},
       {"LDM_LNGEMM_ABL", "row-resident LayerNorm + x3 GEMM: compile-time timing variants, measurement build only (tools/build_measurement_variants.py lngemm; WRONG NUMERICS)"},
       {"LDM_SPLIT_GEMM", "old = the register-staged split GEMM of r03 instead of the LDS-DMA fp16 x 3 kernel"},
       {"LDM_REL_LOOP", "0 = cond=relation on the per-step path instead of inside the one-launch loop (fast mode)"},
