@@ -16,11 +16,11 @@
 // registers (29 k16-steps x 2 x 4 registers per wave: hi in arch VGPRs, lo parked in AGPRs), only the WEIGHTS stream —
 // hi | lo tile images of 32 output columns, 64 KiB per stage, linear LDS-DMA through a 2-stage ring — i.e. half the fill
 // bytes per flop, no A operand traffic at all, no LayerNorm launch and no hi / lo activation round trip through HBM.
-// Per k16-step: two ds_read_b128 (W hi, W lo fragment) and three MFMAs on ONE accumulator (W_hi x_hi + W_hi x_lo + W_lo x_hi,
+// Per k16-step: two ds_read_b128 (W hi, W lo fragment) and three MFMAs (W_hi x_hi + W_hi x_lo + W_lo x_hi into ONE sum,
 // lo unscaled: ldm_kernels.h kSplitLoScale); the read queue is continuous across tiles (FfnStream's protocol: one
-// s_waitcnt vmcnt(0) + s_barrier per tile at step KS - PF); tiles alternate between two accumulators and the epilogue of
-// tile t — scale, bias, ReLU, transpose through LDS so that every row segment leaves as whole 64 / 128-byte pieces — is
-// issued inside the MFMA shadow of tile t + 1.
+// s_waitcnt vmcnt(0) + s_barrier per tile at step NIT - PF); a tile runs on two accumulator chains and its epilogue — sum,
+// transpose through LDS so that every row segment leaves as whole 64 / 128-byte pieces, scale, bias, ReLU, hi / lo split — is
+// issued in small branch-free slices beside the MFMAs of tile t + 1.
 // LayerNorm arithmetic: two-pass (mean, then sum of squared deviations) in fp32 on the row's registers, eps 1e-5, like
 // ln_rows (kernels_norm.hip).  Weight K axis in MFMA k-slot order (ldm_pack::kslot): a lane's accumulator-layout registers
 // of column groups 2ks, 2ks + 1 ARE its B fragment of k16-step ks.
@@ -232,7 +232,7 @@ constexpr bool lg_slice_step(int IT) {
 }
 
 // One tile = NIT steps.  A real step (a k16-step) is ONE asm statement: the counted wait, then its three MFMAs with the step's
-// LDS-DMA piece and its two fragment reads BETWEEN them — one filler per MFMA gap, issued while the matrix pipe works:
+// LDS-DMA piece and its two fragment reads BETWEEN them:
 //     s_waitcnt lgkmcnt(n)        ; fragment pair of this item landed
 //     [s_mov_b32 m0, <LDS group>] ; (steps that carry a DMA piece)
 //     v_mfma  c0 += Wh x_hi
@@ -243,12 +243,16 @@ constexpr bool lg_slice_step(int IT) {
 //     ds_read_b128 Wl'
 // c0 / c1 are the tile's two accumulator chains, swapped every step: consecutive MFMAs are ALWAYS on different accumulators
 // (A B A | B A B | ...), each chain gets 3 MFMAs per two steps, and the two are summed in the epilogue (lo unscaled: any chain may
-// take any of the three products).  Why this form (r05 calls 5 - 16, profiles/r05_call16_17_lngemm_compile_time_variants.txt, and
-// MI355X_MICROARCH.md's issue-slot table): one wave per SIMD issues in order; a filler placed BEHIND a run of MFMAs overlaps
-// only the last one (the earlier forms of this loop — three asm MFMAs per step with hipcc's s_nop between them, then one asm
-// triple per step with everything else behind it — ran at MFMA time PLUS fragment reads PLUS DMA pieces PLUS epilogue: 95 + 16 +
-// 28 + 54 us of linear1's 207), and an issue slot between two MFMAs on the SAME accumulator costs ~43 cycles, between MFMAs on
-// different accumulators ~6.
+// take any of the three products).
+// What r05 measured on the way here (profiles/r05_call16_17_lngemm_compile_time_variants.txt, r05_call18_21_lngemm_store_cost.txt;
+// linear1, 58 tiles x 87 MFMAs per wave, 128 rows per workgroup, us per launch): prologue + empty loop 36; the MFMAs alone +90
+// (the matrix-pipe floor at the ~1.8 - 1.9 GHz a dense MFMA stream clocks at: chain arrangement — one chain, two alternating per
+// MFMA or per step — does not move it); fragment reads +11, DMA pieces +10, epilogue +44.  With one wave per SIMD the parts ADD:
+// a filler between two MFMAs costs about what it costs behind them (~6 cycles of issue per non-MFMA instruction,
+// MI355X_MICROARCH.md's issue-slot table), so what pays is instruction COUNT — this form has ~260 non-MFMA instructions per tile
+// and wave where the first had ~450 (hipcc's epilogue passes: 62 - 75 instructions and eight branches each) — and, for the
+// epilogue, bytes: 33 of linear1's last 44 us are its 237 MB of hi / lo hidden rows on their way to HBM (6 us with the same stores
+// aimed at an L2-resident target).  207 -> 187 us per launch over these steps; in_proj 166 -> 156.
 // The counted waits are never larger than the number of LDS operations really issued behind the awaited fragment pair (the
 // slices' extra operations only make them stricter).  The reads run on into the NEXT tile's stage unconditionally: behind the
 // last tile they fetch bytes nobody uses (the stage exists; keeps the stream free of branches and the waits uniform).
