@@ -21,6 +21,7 @@ The ONE JSON line carries the headline numerics mode (--precision, default `fast
   "configs"   the other BASELINE configurations and the "next" rows of SURVEY section 8f at a few steps each: 3 (PubLayNet
               cond=c top-p, 1024), 4 (the per-GPU shard of the scaling run, 1024), refinement, relation (512 each);
   "fid_features"  layouts/s of the FID feature extractor (section 8f row 3);
+  "layout_metrics"  layouts/s of the alignment / overlap metrics kernel (section 8f row 1);
   "tokens_sha256" of the first 512 layouts of a fixed-seed Rico25 unconditional run: independent of N by construction
               (Philox keyed by global layout index), so a scaling run can prove it.
 
@@ -752,6 +753,7 @@ def main():
     if world == 1 and not a.no_extras and not a.total and not a.batch:
         out["configs"] = extras(a, SP, config, rank, world, local_rank, dist)
         out["fid_features"] = fid_timing(SP, local_rank)
+        out["layout_metrics"] = layout_metrics_timing(local_rank)
         if "4" in out["configs"]:   # the per-GPU workload of every N > 1 run, under the same key there
             out["scaling_point"] = {"workload": "BASELINE config 4 shard: rico25 uncond T=100 1024 layouts/GPU sampling=random",
                                     "layouts_per_s_per_gpu": out["configs"]["4"]["value"]}
@@ -999,6 +1001,33 @@ def fid_timing(SP, local_rank):
     assert f.shape == (B, 256) and bool(torch.isfinite(f).all())
     return {"value": round(B / (ms * 1e-3), 1), "unit": "layouts/s", "ms_per_batch": round(ms, 4), "batch": B,
             "what": "fid_features_k: FIDNetV3 encoder (26 x 256, 4 layers) per layout, fp32, inputs resident in HBM"}
+
+
+def layout_metrics_timing(local_rank):
+    """compute_alignment + compute_overlap (trainer/helpers/metric.py:98-203) of 512 x 25 random elements, inputs resident."""
+    import numpy as np
+    import torch
+
+    from layout_dm_amd.metrics import layout_metrics
+
+    B, N = 512, 25
+    rng = np.random.default_rng(0)
+    n = rng.integers(1, N + 1, size=B)
+    dev = torch.device("cuda", local_rank)
+    bbox = torch.from_numpy(rng.random((B, N, 4)).astype(np.float32)).to(dev)
+    mask = torch.from_numpy(np.arange(N)[None] < n[:, None]).to(dev).to(torch.uint8)
+    for _ in range(3):
+        o = layout_metrics(bbox, mask)
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o = layout_metrics(bbox, mask)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    assert o.shape == (B, 6) and bool(torch.isfinite(o).all())
+    return {"value": round(B / (ms * 1e-3), 1), "unit": "layouts/s", "ms_per_batch": round(ms, 4), "batch": B,
+            "what": "layout_metrics_k: alignment (3 scores) + overlap (3 scores) per layout, fp32, one wavefront per layout, "
+                    "inputs resident in HBM (call + stream sync included)"}
 
 
 def traffic_detail(vals, note, kernel, spec):

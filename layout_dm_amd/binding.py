@@ -71,6 +71,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise RuntimeError(
             f"{p} not found: the MI355X HIP extension is not built (run `python -m layout_dm_amd.build` "
             "or __graft_entry__.build()). There is no CPU fallback.")
+    if path is None and not os.environ.get("LDM_HIP_LIB"):
+        # build provenance: the prebuilt library must come from THIS tree's sources (a snapshot pushed to a GPU box carries both)
+        from . import build as _build
+
+        want, have = _build.source_digest(), _build.built_digest(p)
+        if have != want:
+            try:
+                _build.build(verbose=False)
+            except Exception as e:  # no hipcc on this machine
+                raise RuntimeError(f"{p} was built from other sources (library {have}, tree {want}) and could not be rebuilt: {e}") from e
     lib = C.CDLL(p)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     lib.ldm_abi_version.restype = C.c_int

@@ -387,6 +387,14 @@ extern "C" int ldm_get_tie_flags(ldm_handle* h, uint8_t* d_flags, int n_steps, i
 // rounds of `round` layouts, so B = round + 1 costs what B = 2 * round costs) and the development knobs the library has
 // honoured in this process (ldm_knobs.h; always the LAST key: its value may itself contain ';').  Returns the length
 // needed (excluding the terminator), whatever `cap` is: call again with a larger buffer when the result is >= cap.
+#ifndef LDM_SRC_DIGEST
+#define LDM_SRC_DIGEST "unknown"
+#endif
+// sha256 over the sources this library was built from (layout_dm_amd/build.py source_digest(), passed at compile time): the
+// marker is what build.py / the tests scan a built .so for — a pushed tree whose prebuilt library lags its sources is rebuilt
+// (or refused), not silently used
+extern "C" const char ldm_build_source_digest[] = "LDM_SRC_DIGEST=" LDM_SRC_DIGEST;
+
 extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   if (!h) return -1;
   static const char* prec[3] = {"exact_f32", "fast_f16", "split_f16"};
@@ -403,6 +411,7 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   // `chunk` layouts per pass on `lanes` concurrent pipelines
   s += ";round=" + std::to_string(loop ? h->n_cu : h->chunk * std::max(h->n_lanes, 1));
   s += std::string(";batch_rule=") + (loop ? "whole_rounds_of_one_workgroup_per_layout" : "whole_chunks");
+  s += std::string(";src_digest=") + (ldm_build_source_digest + sizeof("LDM_SRC_DIGEST=") - 1);
   s += ";knobs=" + knobs_honoured();
   if (buf && cap > 0) {
     const size_t n = std::min((size_t)cap - 1, s.size());

@@ -133,7 +133,9 @@ def load_fidnet_v3(dataset, weight_dir: str, device=None) -> FIDNetV3:
 def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
     """pytorch_fid 0.2.1 fid_score.calculate_frechet_distance (the dependency pinned by the reference's pyproject,
     imported at helpers/metric.py:11): ||mu1 - mu2||^2 + Tr(S1) + Tr(S2) - 2 Tr(sqrt(S1 S2)), with the same
-    singular-product offset and imaginary-component handling."""
+    singular-product offset and imaginary-component handling.
+    (A third-party algorithm, Apache-2.0, restated here because the score IS this formula with these two numerical guards —
+    results must equal the reference's to the last digit; the statements follow the published function closely for that reason.)"""
     from scipy import linalg
 
     mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)

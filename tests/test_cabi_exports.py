@@ -34,6 +34,25 @@ def test_header_symbols_exported(lib_path):
     assert lib.ldm_abi_version() == binding.ABI_VERSION
 
 
+def test_built_library_carries_the_digest_of_this_tree(lib_path, tmp_path):
+    """Build provenance: the library embeds the sha256 of the sources it was built from; a prebuilt .so
+    that lags the tree is detected by content (not by mtime) and rebuilt, and `ldm_describe` reports the digest."""
+    from layout_dm_amd import build
+
+    want = build.source_digest()
+    assert len(want) == 64 and build.built_digest(lib_path) == want and not build.needs_build()
+    lib = ctypes.CDLL(lib_path)
+    marker = (ctypes.c_char * 80).in_dll(lib, "ldm_build_source_digest")
+    assert marker.value == b"LDM_SRC_DIGEST=" + want.encode()
+    # a library built from other sources is recognised whatever its mtime is
+    stale = tmp_path / "libldm_hip_stale.so"
+    data = open(lib_path, "rb").read().replace(want.encode(), b"0" * 64)
+    stale.write_bytes(data)
+    os.utime(stale, None)
+    assert build.built_digest(str(stale)) == "0" * 64 != want
+    assert build.built_digest(str(tmp_path / "missing.so")) is None
+
+
 def test_binding_struct_layout_matches_header(tmp_path):
     """sizeof / offsetof of every struct of include/ldm_hip.h as gcc lays them out == the ctypes mirrors in
     layout_dm_amd/binding.py (the header is compiled, not transcribed)."""

@@ -13,10 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _stub():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    sec = text[text.index("## 3."):text.index("## 4.")]
+    sec = text[text.index("## 3."):text.index("### 3a.")]
     blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
     assert len(blocks) == 1, "section 3 must hold exactly one python block"
     return ast.parse(blocks[0])
+
+
+def _eval_stub():
+    """Section 3a (the evaluation side): its python blocks, the FFI call last."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("### 3a."):text.index("## 4.")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 2
+    return [ast.parse(b) for b in blocks]
 
 
 def _header():
@@ -79,3 +88,25 @@ def test_stub_call_arity_matches_prototypes():
             assert len(n.args) == protos[name], f"{name}: the stub passes {len(n.args)} arguments, the header declares {protos[name]}"
             seen.add(name)
     assert {"ldm_create", "ldm_load_weight", "ldm_finalize_weights", "ldm_sample_loop", "ldm_decode_layouts"} <= seen
+
+
+def test_eval_side_stub_matches_header_and_package():
+    """Section 3a: the names it imports exist with the reference's signatures, and its FFI call has the header's arity."""
+    imports, ffi = _eval_stub()
+    protos = _prototypes(_header())
+    calls = [n for n in ast.walk(ffi) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)
+             and isinstance(n.func.value, ast.Name) and n.func.value.id == "lib"]
+    assert [c.func.attr for c in calls] == ["ldm_layout_metrics"]
+    assert len(calls[0].args) == protos["ldm_layout_metrics"]
+    import importlib
+    import inspect
+
+    for node in imports.body:
+        assert isinstance(node, ast.ImportFrom)
+        mod = importlib.import_module(node.module)
+        for a in node.names:
+            assert hasattr(mod, a.name), f"{node.module}.{a.name}"
+    from layout_dm_amd import metrics
+
+    for fn in (metrics.compute_alignment, metrics.compute_overlap):
+        assert list(inspect.signature(fn).parameters) == ["bbox", "mask"]     # helpers/metric.py:98,152

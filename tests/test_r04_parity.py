@@ -544,6 +544,9 @@ def test_dev_knobs_are_refused_outside_dev_mode(cuda, monkeypatch):
     assert d["precision"] == "fast_f16" and d["loop"] == "one_launch" and d["kernels"] == "stack", d
     # (d["knobs"] lists what the library honoured so far in this PROCESS — other tests of this session run in dev mode)
     assert d["abi"] == "5" and "knobs" in d
+    from layout_dm_amd import build
+
+    assert d["src_digest"] == build.source_digest()   # the library that runs was built from this tree
     e.close()
 
 
