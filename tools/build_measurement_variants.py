@@ -4,6 +4,7 @@
   libldm_hip_abl_ffnwin2.so  -DLDM_ABL_FFN_WINDOW=2   ... a 16-KiB window (L1-served; WRONG numbers)
   libldm_hip_abl_lngemm.so   -DLDM_LNGEMM_ABL_BUILD   kernels_lngemm.hip with its compile-time timing variants (LDM_LNGEMM_ABL=mask:
                                                       2 no fragment reads, 4 no weight DMA, 8 no epilogue, 16 no epilogue stores, 32 stores to tile 0 columns; WRONG numbers)"""
+# libldm_hip_abl_noslp.so: kernels_stack.hip under -fno-slp-vectorize (no SLP-packed v_pk_*_f32 beside the MFMAs; same numerics)
 import os
 import subprocess
 import sys
@@ -12,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layout_dm_amd import build as B
 
 VARIANTS = {"ffnwin1": ("kernels_stack.hip", ["-DLDM_ABL_FFN_WINDOW=1"]), "ffnwin2": ("kernels_stack.hip", ["-DLDM_ABL_FFN_WINDOW=2"]),
-            "lngemm": ("kernels_lngemm.hip", ["-DLDM_LNGEMM_ABL_BUILD"])}
+            "lngemm": ("kernels_lngemm.hip", ["-DLDM_LNGEMM_ABL_BUILD"]),
+            "noslp": ("kernels_stack.hip", ["-fno-slp-vectorize"])}
 
 B.build()
 cc = B.hipcc()
