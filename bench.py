@@ -783,11 +783,13 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(spec, sd, a.timesteps, a.sampling, cond_global, a.cpu_budget)
         out["config"]["cpu_baseline_kind"] = out["cpu_baseline"]["kind"]
+        out["cpu_baseline_kind"] = out["cpu_baseline"]["kind"]
     ws = out.get("weight_sensitivity", {})
     for point in ("mid", "wide"):   # scalars a reader that drops nested objects still sees
         if point in ws:
-            out["config"][f"auto_selected_{point}"] = ws[point]["auto_selected"]
-            out["config"][f"auto_layouts_per_s_{point}"] = ws[point]["value"]
+            for key, val in ((f"auto_selected_{point}", ws[point]["auto_selected"]), (f"auto_layouts_per_s_{point}", ws[point]["value"])):
+                out[key] = val              # top level ...
+                out["config"][key] = val    # ... and inside `config`
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
