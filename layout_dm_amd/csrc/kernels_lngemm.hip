@@ -58,7 +58,8 @@ constexpr int LG_TP_BYTES = 32 * LG_TP_LD * 4;     // 4 608 B per wave
 constexpr int LG_PAR_OFF = 2 * LG_STAGE;           // multiplier [512] | shift [512]
 constexpr int LG_BIAS_OFF = LG_PAR_OFF + 2 * 512 * 4;   // bias [2048]
 constexpr int LG_TP_OFF = LG_BIAS_OFF + 2048 * 4;
-constexpr int LG_LDS = LG_TP_OFF + 4 * LG_TP_BYTES;     // 161 792 B
+constexpr int LG_PBIAS_OFF = LG_TP_OFF + 4 * LG_TP_BYTES;   // bias of the GEMM prologue [512]
+constexpr int LG_LDS = LG_PBIAS_OFF + 512 * 4;              // 163 840 B = all of a CU's LDS
 static_assert(LG_LDS <= 160 * 1024, "LDS budget");
 
 template <int OFF>
@@ -357,9 +358,118 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
 #undef LG_STEP_ASM
 #undef LG_MFMA
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GEMM prologue (PRE = true): acc[t] (15 tiles of 32 output columns, AGPRs) += A[rows, K] · Wpre[:, K]^T in fp16 x 3, the rows'
+// x = residual + bias + scale * acc then takes the place of the rows the plain kernel reads.  Same machinery as the tile loop —
+// 2-stage ring of 64-KiB weight stages by linear LDS-DMA, one s_waitcnt vmcnt(0) + s_barrier per stage, a 6-deep fragment
+// queue that runs on across stages, one asm statement per item — with the roles turned: a stage is a K-SLAB (32 k = two
+// k16-steps of ALL 480 output columns, ldm_pack::pack_x3_slab_image), an item is (k16-step s, tile t) = 2 x 15 per stage, its three
+// MFMAs go to the persistent accumulator of tile t, and the A operand — the wave's 32 rows, 8 halves per lane and k16-step — comes
+// straight from global memory into registers, one stage ahead (plain loads: landed by the stage's vmcnt(0)).
+// Per workgroup: K / 32 stages x 64 KiB through the per-CU fill path (linear2: 58 stages = 3.7 MB ~ 95 us at 38 GB/s per CU, the
+// same bytes gemm16x3_k's 256 x 256 tile pulls for BOTH operands) and no launch, no fp32 round trip of the sum, no epilogue.
+constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;   // items per stage
+static_assert(LP_NIT == LG_NIT, "the prologue shares the tile loop's DMA schedule (lg_piece) and queue depth");
+constexpr int LP_SYNC = LP_NIT - LG_PF;
+
+struct LpState {
+  f16x8 qh[LG_PF], ql[LG_PF];   // W hi / lo fragment queue
+  unsigned aS[2];               // this lane's LDS address of k16-step s in the CURRENT stage (tile t: + t * 2 KiB)
+  f16x8 fh[2][2], fl[2][2];     // A fragments [stage parity][k16-step]: the current stage's, and the next stage's (in flight until
+                                // the current stage's barrier) — two register sets, no copies behind MFMAs that still read them
+  const __half *pa, *pal;       // this lane's row of A hi / lo + 8 * (lane / 32) halves
+  const char* img;              // slab image + wave * 16 KiB
+  unsigned lds_w, voff;
+  int stage_delta, n_stages;
+  const char* dma_g;
+  unsigned dma_l;
+};
+
+template <int IT>
+__device__ __forceinline__ void lp_read(LpState& s) {   // item IT of the stage aS points at
+  constexpr int sx = IT / LP_NT, t = IT % LP_NT;
+  lg_dsr<t * 2048>(s.qh[IT % LG_PF], s.aS[sx]);
+  lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LG_PF], s.aS[sx]);
+}
+template <int I>
+__device__ __forceinline__ void lp_prime(LpState& s) {
+  if constexpr (I < LG_PF) {
+    lp_read<I>(s);
+    lp_prime<I + 1>(s);
+  }
+}
+__device__ __forceinline__ void lp_dma_begin(LpState& s, int sd) {   // stage sd (clamped) -> ring slot sd & 1
+  const int t = sd < s.n_stages ? sd : s.n_stages - 1;
+  s.dma_g = s.img + (size_t)t * LG_STAGE;
+  s.dma_l = s.lds_w + (unsigned)(sd & 1) * LG_STAGE;
+}
+// A fragments of stage sd (clamped) into register set P: k16-steps 2 sd, 2 sd + 1 -> 16 halves apart
+template <int P>
+__device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
+  const int t = sd < s.n_stages ? sd : s.n_stages - 1;
+  s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32);
+  s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32 + 16);
+  s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * 32);
+  s.fl[P][1] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * 32 + 16);
+}
+
+#define LP_MFMA(B, A) "v_mfma_f32_32x32x16_f16 %[c], " B ", " A ", %[c]\n\t"
+#define LP_STEP_ASM(M0SET, PIECE, RD_HI, RD_LO)                                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LP_MFMA("%[qh]", "%[xh]") LP_MFMA("%[qh]", "%[xl]") LP_MFMA("%[ql]", "%[xh]")    \
+                   PIECE RD_HI RD_LO                                                                                               \
+               : [c] "+a"(acc), [qh] "+v"(qh), [ql] "+v"(ql)                                                                       \
+               : [xh] "v"(s.fh[PAR][sx]), [xl] "v"(s.fl[PAR][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
+                 [w] "n"(2 * (LG_PF - 1)), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                    \
+               : "memory")
+
+template <int IT, int PAR>   // PAR: parity of the stage = the A register set it multiplies
+__device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
+  if constexpr (IT < LP_NIT) {
+    constexpr int sx = IT / LP_NT, t = IT % LP_NT;
+    constexpr int J = lg_piece(IT);
+    constexpr bool hasD = J >= 0;
+    if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);
+    if constexpr (hasD && J > 0 && (J & 3) == 0) {
+      s.dma_g += 4096;
+      s.dma_l += 4096;
+    }
+    // the next stage's A fragments: requested early in the stage, landed by its barrier
+    if constexpr (IT == 1) lp_load_a<PAR ^ 1>(s, stage + 1);
+    constexpr int RI = (IT + LG_PF) % LP_NIT;
+    constexpr bool hasR = IT != LP_SYNC;
+    constexpr int RO = (RI % LP_NT) * 2048;
+    constexpr int DOFF = hasD ? (J & 3) * 1024 : 0;
+    f32x16& acc = accs[t];
+    f16x8& qh = s.qh[IT % LG_PF];
+    f16x8& ql = s.ql[IT % LG_PF];
+    const unsigned aw = s.aS[RI / LP_NT];
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (hasD && hasR) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL);
+    else if constexpr (hasD) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, "", "");
+    else if constexpr (hasR) LP_STEP_ASM("", "", LG_A_RDH, LG_A_RDL);
+    else LP_STEP_ASM("", "", "", "");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IT == LP_SYNC - 1) {   // the stage's last item has been requested: aS moves to the next stage's slot
+      s.aS[0] += (unsigned)s.stage_delta;
+      s.aS[1] += (unsigned)s.stage_delta;
+      s.stage_delta = -s.stage_delta;
+    }
+    if constexpr (IT == LP_SYNC) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's slab (own pieces) and its A fragments
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" : "+v"(s.fh[PAR ^ 1][0]), "+v"(s.fh[PAR ^ 1][1]), "+v"(s.fl[PAR ^ 1][0]), "+v"(s.fl[PAR ^ 1][1])::"memory");   // (hipcc's own wait for them lands here)
+      lp_read<RI>(s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lp_step<IT + 1, PAR>(s, accs, stage);
+  }
+}
+#undef LP_STEP_ASM
+#undef LP_MFMA
+
 }  // namespace
 
-template <bool ADA, int OUT, bool TM = false, int ABL = 0>
+template <bool ADA, int OUT, bool TM = false, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
@@ -371,6 +481,63 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   float* spar = reinterpret_cast<float*>(smem + LG_PAR_OFF);
   float* sbias = reinterpret_cast<float*>(smem + LG_BIAS_OFF);
 
+  // ---- parameter tables -> LDS: multiplier | shift (zero beyond D: padded columns come out as exact zeros), bias
+  for (int i = tid; i < 512; i += 256) {
+    const bool in = i < a.D;
+    spar[i] = in ? (ADA ? 1.0f + a.p0[i] : a.p0[i]) : 0.f;
+    spar[512 + i] = in ? a.p1[i] : 0.f;
+  }
+  for (int i = tid; i < a.n_tiles * 32; i += 256) sbias[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
+  constexpr int NG = 58;
+  const int row = blockIdx.x * 128 + wave * 32 + r;
+  const int rrow = row < a.M ? row : a.M - 1;
+
+  // ---- GEMM prologue: the rows are computed here instead of read (out_proj / linear2 in front of the LayerNorm that takes their sum)
+  f32x16 pacc[PRE ? LP_NT : 1];
+  if constexpr (PRE) {
+    float* spb = reinterpret_cast<float*>(smem + LG_PBIAS_OFF);
+    for (int i = tid; i < 512; i += 256) spb[i] = (a.pre_bias && i < a.D) ? a.pre_bias[i] : 0.f;
+    LpState ps;
+    ps.img = a.pre_img + wave * 16384;
+    ps.lds_w = lds0 + wave * 16384;
+    ps.voff = voff;
+    ps.n_stages = a.pre_stages;
+    ps.stage_delta = LG_STAGE;
+    ps.pa = a.preA + (size_t)rrow * a.pre_lda + hi * 8;
+    ps.pal = a.preAlo + (size_t)rrow * a.pre_lda + hi * 8;
+    for (int t = 0; t < 2; ++t)   // slabs 0 / 1 -> ring slots 0 / 1
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+    lp_load_a<0>(ps, 0);
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) ps.aS[sx] = lds0 + r * 64 + ((((sx << 1) | hi) ^ ((r >> 2) & 3)) << 4);
+#pragma unroll
+    for (int t = 0; t < LP_NT; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pacc[t][k] = 0.f;
+    lp_dma_begin(ps, 1);
+    {  // (stage 0, steps 0 ..: the pieces of slab 1 once more, as in the tile loop)
+      constexpr int J0 = lg_piece(0), pre = (J0 >> 2) - ((J0 & 3) == 0 ? 1 : 0);
+      ps.dma_g += pre * 4096;
+      ps.dma_l += pre * 4096;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1])::"memory");
+    lp_prime<0>(ps);
+    for (int st = 0; st < a.pre_stages; st += 2) {   // (launch_lngemm16x3: an even number of stages)
+      lp_step<0, 0>(ps, pacc, st);
+      lp_step<0, 1>(ps, pacc, st + 1);
+    }
+    // the queue's trailing reads and the clamped re-load of the last slab are out, the last MFMAs have written their tiles, and every
+    // wave is through with the ring: from here it belongs to the tile loop
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < LP_NT; ++t) asm volatile("" : "+a"(pacc[t]));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
   // ---- weights: tiles 0 / 1 -> stages 0 / 1 (this wave's 16 KiB of each).  Every workgroup visits the tiles in the SAME order.
   // (r05 negative result, profiles/r05_call3_4_*: a per-workgroup rotation of the order — 32 CUs of an XCD on 32 different
   //  tiles instead of all on the same one — is 4 % SLOWER, 950 vs 988 layouts/s: the lock-step stream is served by the L2 once
@@ -380,20 +547,24 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
 
-  // ---- parameter tables -> LDS: multiplier | shift (zero beyond D: padded columns come out as exact zeros), bias
-  for (int i = tid; i < 512; i += 256) {
-    const bool in = i < a.D;
-    spar[i] = in ? (ADA ? 1.0f + a.p0[i] : a.p0[i]) : 0.f;
-    spar[512 + i] = in ? a.p1[i] : 0.f;
-  }
-  for (int i = tid; i < a.n_tiles * 32; i += 256) sbias[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
-
   // ---- the rows, raw, in accumulator layout: lane (row, hi) owns columns 8 g + 4 hi .. + 3 of every 8-column group g
-  constexpr int NG = 58;
-  const int row = blockIdx.x * 128 + wave * 32 + r;
-  const int rrow = row < a.M ? row : a.M - 1;
   float4 v[NG];
-  if (a.tokens) {  // x = emb[token] + pos[s]   (nn_lib.py:204,220)
+  if constexpr (PRE) {   // x = residual + bias + scale * (A . Wpre^T): tile t of the prologue holds groups 4 t .. 4 t + 3
+    const float* spb = reinterpret_cast<const float*>(smem + LG_PBIAS_OFF);
+    const float* rs = a.pre_res + (size_t)rrow * a.D + hi * 4;
+    float* po = (a.pre_out && row < a.M) ? a.pre_out + (size_t)row * a.D + hi * 4 : nullptr;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 pb = *reinterpret_cast<const float4*>(spb + g * 8 + hi * 4);
+      const float4 rr = *reinterpret_cast<const float4*>(rs + g * 8);
+      const f32x16& c = pacc[g >> 2];
+      v[g].x = (c[(g & 3) * 4 + 0] * a.pre_scale + pb.x) + rr.x;
+      v[g].y = (c[(g & 3) * 4 + 1] * a.pre_scale + pb.y) + rr.y;
+      v[g].z = (c[(g & 3) * 4 + 2] * a.pre_scale + pb.z) + rr.z;
+      v[g].w = (c[(g & 3) * 4 + 3] * a.pre_scale + pb.w) + rr.w;
+      if (po) *reinterpret_cast<float4*>(po + g * 8) = v[g];
+    }
+  } else if (a.tokens) {  // x = emb[token] + pos[s]   (nn_lib.py:204,220)
     const float* e = a.emb + (size_t)a.tokens[rrow] * a.D + hi * 4;
     const float* p = a.pos + (size_t)(rrow % a.S) * a.D + hi * 4;
 #pragma unroll
@@ -544,10 +715,17 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu)) return -1;
   if ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)) return -1;
   static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
+  const bool pre = a.pre_img != nullptr;
+  // GEMM prologue: an even number (>= 2) of 32-wide K slabs, all d_model columns inside its 15 tiles, fp32 residual rows
+  if (pre && (a.pre_stages < 2 || (a.pre_stages & 1) || a.D > 32 * LP_NT || !a.preA || !a.preAlo || !a.pre_res || a.tokens ||
+              a.pre_lda < 32 * a.pre_stages || (a.pre_lda & 7)))
+    return -1;
   auto kern = half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
-  if (tm) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
+  if (pre) kern = half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;
+  if (tm && !pre) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
-  static const int abl = (int)knob_int("LDM_LNGEMM_ABL", 0);
+  static const int abl_knob = (int)knob_int("LDM_LNGEMM_ABL", 0);
+  const int abl = pre ? 0 : abl_knob;
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
   switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) LG_ABL(64) default: break; }
 #undef LG_ABL

@@ -189,7 +189,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->lngemm = h->D == 464 && h->Dp == 512 && (3 * h->D) % 4 == 0 && h->F % 4 == 0 && h->x3_qkv_tiles * 32 <= 2048 &&
                 h->x3_ffn1_tiles * 32 <= 2048 && h->x3_head_tiles * 32 <= 2048 && h->x3_qkv_tiles * 32 <= round_up(3 * h->D, 256) &&
                 h->x3_ffn1_tiles * 32 <= round_up(h->F, 256) && h->x3_head_tiles * 32 <= round_up(h->C, 256) &&
-                knob_int("LDM_X3_LNGEMM", 1) != 0;
+                knob_int("LDM_X3_LNGEMM", 2) != 0;
+    // level 2 (default): the two N = d_model GEMMs (out_proj, linear2) run as the GEMM prologue of the row-resident kernel that
+    // normalises their sum; LDM_X3_LNGEMM=1: they stay gemm16x3_k launches (the first r05 structure)
+    h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && knob_int("LDM_X3_LNGEMM", 2) >= 2;
   }
   h->cur_lane = h->n_lanes - 1;
   h->activate(0);
@@ -401,7 +404,7 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   const bool loop = loop_fusable(h, nullptr);
   char num[96];
   std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->cfg.precision];
-  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? (h->lngemm ? "row_resident_ln_gemm+tiled_gemm+attn" : "tiled_gemm+attn")
+  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? (h->lngemm_pre ? "row_resident_gemm_ln_gemm+attn" : h->lngemm ? "row_resident_ln_gemm+tiled_gemm+attn" : "tiled_gemm+attn")
                                    : h->fused_attn == 6 ? "stack" : "generic16");
   s += std::string(";loop=") + (loop ? "one_launch" : "per_step_graph");
   s += ";chunk=" + std::to_string(h->chunk) + ";lanes=" + std::to_string(h->n_lanes) + ";lane_offset_us=" + std::to_string(h->lane_offset_us);

@@ -74,6 +74,7 @@ struct LayerW {
   __half *w_in16, *w_in16lo, *w_out16, *w_out16lo, *w1_16, *w1_16lo, *w2_16, *w2_16lo;
   float s_in = 1.f, s_out = 1.f, s1 = 1.f, s2 = 1.f;  // split mode: 2^-k of each tensor's power-of-two pre-scale (GemmArgs.out_scale)
   void *x3_qkv = nullptr, *x3_ffn1 = nullptr;         // split mode: hi | lo tile images of in_proj / linear1 (kernels_lngemm.hip)
+  void *x3_out_slab = nullptr, *x3_ffn2_slab = nullptr;   // ... K-slab images of out_proj / linear2 (its GEMM prologue, lngemm level 2)
 };
 
 struct ProfEntry {
@@ -144,6 +145,7 @@ struct ldm_handle {
   // split mode on the reference's backbone: the three LayerNorm-fed GEMMs (AdaLN + in_proj, norm2 + linear1, head LN + head)
   // run as ONE row-resident launch each (kernels_lngemm.hip) instead of a LayerNorm launch + gemm16x3_k
   bool lngemm = false;
+  bool lngemm_pre = false;   // level 2: out_proj / linear2 as the GEMM prologue of the row-resident kernel that consumes their sum
   void* x3_head = nullptr;
   int x3_qkv_tiles = 0, x3_ffn1_tiles = 0, x3_head_tiles = 0;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime

@@ -96,6 +96,15 @@ struct LnGemmArgs {
   __half *C16, *C16lo;      // [M, ldc16] hi / lo, or nullptr
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
+  // GEMM prologue (pre_img != nullptr): x = pre_res + pre_bias + pre_scale * (preA · Wpre^T) is computed by the kernel itself instead
+  // of being read — out_proj in front of norm2 + linear1, linear2 in front of the next AdaLN + in_proj / of the head
+  const __half *preA, *preAlo;   // [M, pre_lda] hi / lo rows (attention output / hidden activations), K = 32 * pre_stages columns read
+  const char* pre_img;           // pre_stages x 64 KiB K-slab image (ldm_pack::pack_x3_slab_image) of Wpre [D, K]
+  const float* pre_bias;         // [D]
+  const float* pre_res;          // [M, D] fp32 residual rows
+  float* pre_out;                // [M, D] or nullptr: x written back (the residual base of a later GEMM)
+  int pre_lda, pre_stages;
+  float pre_scale;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
 void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)

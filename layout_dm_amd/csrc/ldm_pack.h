@@ -154,4 +154,22 @@ inline std::vector<uint16_t> pack_x3_tile_image(const uint16_t* hi, const uint16
   return img;
 }
 
+// K-slab image of a split-mode weight for the GEMM PROLOGUE of the row-resident kernel (kernels_lngemm.hip, PRE = true: out_proj /
+// linear2 run in front of the LayerNorm that consumes their sum).  hi / lo: [N rows][ld] fp16, natural K order, K % 32 == 0.
+// One 64-KiB stage per 32 k (two k16-steps): hi slab at byte 0, lo slab at byte 32 768; a slab is 480 rows (output columns,
+// zero beyond N) x 64 B, 16-byte chunk L (k = 32 stage + 8 L ..) of row n at physical chunk L ^ ((n >> 2) & 3) — the W2-slab
+// format of the fused FFN (pack_ffn_image), conflict-free for ds_read_b128 by (column, k half) lanes.
+inline std::vector<uint16_t> pack_x3_slab_image(const uint16_t* hi, const uint16_t* lo, int N, int ld, int K) {
+  const int n_stage = K / 32;
+  std::vector<uint16_t> img((size_t)n_stage * 32768, 0);
+  for (int st = 0; st < n_stage; ++st)
+    for (int part = 0; part < 2; ++part) {
+      const uint16_t* src = part ? lo : hi;
+      uint16_t* dst = img.data() + (size_t)st * 32768 + part * 16384;
+      for (int n = 0; n < N && n < 480; ++n)
+        for (int L = 0; L < 4; ++L) memcpy(dst + n * 32 + ((L ^ ((n >> 2) & 3)) << 3), src + (size_t)n * ld + st * 32 + L * 8, 16);
+    }
+  return img;
+}
+
 }  // namespace ldm_pack

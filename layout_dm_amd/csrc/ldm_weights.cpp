@@ -108,6 +108,22 @@ static int make_x3_image(ldm_handle* h, const __half* hi, const __half* lo, int 
   return 0;
 }
 
+// K-slab image (ldm_pack::pack_x3_slab_image) of a split-mode weight [N][ld] hi / lo for the GEMM prologue of kernels_lngemm.hip
+static int make_x3_slab(ldm_handle* h, const __half* hi, const __half* lo, int N, int ld, int K, void** out) {
+  const size_t n = (size_t)N * ld;
+  std::vector<uint16_t> a(n), b(n);
+  HIP_OK(h, hipDeviceSynchronize());  // (the cast kernels of make_w16)
+  HIP_OK(h, hipMemcpy(a.data(), hi, n * 2, hipMemcpyDeviceToHost));
+  HIP_OK(h, hipMemcpy(b.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  const std::vector<uint16_t> img = ldm_pack::pack_x3_slab_image(a.data(), b.data(), N, ld, K);
+  __half* d = nullptr;
+  int rc = h->dalloc(&d, img.size(), false);
+  if (rc) return rc;
+  HIP_OK(h, hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
 // ---- fast-mode weight images (built on the host once; tiny compared with one sampling call)
 static uint16_t f2h_bits(float x) {
   const __half hh = __float2half(x);
@@ -346,6 +362,10 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
       if (h->lngemm) {
         if ((rc = make_x3_image(h, w.w_in16, w.w_in16lo, h->x3_qkv_tiles, &w.x3_qkv))) return rc;
         if ((rc = make_x3_image(h, w.w1_16, w.w1_16lo, h->x3_ffn1_tiles, &w.x3_ffn1))) return rc;
+      }
+      if (h->lngemm_pre) {
+        if ((rc = make_x3_slab(h, w.w_out16, w.w_out16lo, D, h->Dp, h->Dp, &w.x3_out_slab))) return rc;
+        if ((rc = make_x3_slab(h, w.w2_16, w.w2_16lo, D, h->Fp, h->Fp, &w.x3_ffn2_slab))) return rc;
       }
     }
   }

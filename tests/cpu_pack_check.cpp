@@ -229,6 +229,29 @@ int main() {
           }
         }
   }
+  {  // K-slab image of the row-resident kernel's GEMM prologue (kernels_lngemm.hip lp_read: lane (column j, k half hh) of tile t reads
+     // 16 bytes at stage + t * 2 KiB + j * 64 + (((2 s + hh) ^ ((j >> 2) & 3)) << 4) for k16-step s of the stage; lo slab: + 32 KiB)
+    const int N = 464, ld = 1856, K = 1856;
+    std::vector<uint16_t> hi((size_t)N * ld), lo((size_t)N * ld);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < ld; ++k) {
+        hi[(size_t)n * ld + k] = id16(n + 7, k);
+        lo[(size_t)n * ld + k] = id16(n + 20000, k);
+      }
+    const std::vector<uint16_t> img = ldm_pack::pack_x3_slab_image(hi.data(), lo.data(), N, ld, K);
+    CHECK(img.size() == (size_t)(K / 32) * 32768, "x3 slab image size");
+    for (int st = 0; st < K / 32; ++st)
+      for (int part = 0; part < 2; ++part)
+        for (int t = 0; t < 15; ++t) for (int j = 0; j < 32; ++j) for (int hh = 0; hh < 2; ++hh) for (int sx = 0; sx < 2; ++sx) {
+          const size_t byte = (size_t)st * 65536 + part * 32768 + t * 2048 + j * 64 + ((((sx << 1) | hh) ^ ((j >> 2) & 3)) << 4);
+          const uint16_t* p = img.data() + byte / 2;
+          for (int e = 0; e < 8; ++e) {
+            const int n = t * 32 + j, k = st * 32 + sx * 16 + hh * 8 + e;   // natural MFMA k order: lane half hh holds k = 8 hh .. 8 hh + 7
+            const uint16_t want = n < N ? id16(n + (part ? 20000 : 7), k) : 0;
+            CHECK(p[e] == want, "x3 slab st=%d part=%d t=%d j=%d hh=%d s=%d e=%d", st, part, t, j, hh, sx, e);
+          }
+        }
+  }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
   return 0;

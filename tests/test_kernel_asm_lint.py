@@ -192,14 +192,16 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     builds lost the low-order products that way: logits error 5e-5 instead of 9e-7) — every non-MFMA instruction that READS the
     destination registers of an inline-asm MFMA must sit at least one whole MFMA (8 passes = 32 cycles) of wait states behind it."""
     asm = _compile("kernels_lngemm.hip", tmp_path)
-    # the product instantiations (TM = false, ABL = 0: the last two template arguments mangle as Lb0ELi0; the phase-timer and measurement builds are dev only)
-    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and k.endswith("ELb0ELi0EEEvNS_10LnGemmArgsE")}
-    assert len(kernels) == 3, list(_kernels(asm))
+    # the product instantiations (TM = false, ABL = 0: template arguments 3 and 4 mangle as Lb0ELi0; the phase-timer and measurement builds are dev only)
+    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and re.search(r"ELb0ELi0ELb[01]EEEvNS_10LnGemmArgsE$", k)}
+    assert len(kernels) == 6, list(_kernels(asm))   # (ADA, OUT) in {(1, 0), (0, 1), (0, 0)} x {plain, with the GEMM prologue}
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-        assert len(mf) >= 87 and len(mf) % 87 == 0, (name, len(mf))   # tile bodies of 29 k16-steps x 3 products (hipcc may specialise the first / last tile)
+        pre = name.endswith("ELb1EEEvNS_10LnGemmArgsE")
+        # tile body: 29 k16-steps x 3 products; the GEMM prologue adds two stage bodies (one per A register set) of 30 items x 3
+        assert len(mf) == 87 + (180 if pre else 0), (name, len(mf))
         for i in mf:
             ops = [o.strip() for o in instr[i][4:].split(None, 1)[1].split(",")]
             dst = _regs(ops[0])
