@@ -414,9 +414,9 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
 }
 
 #define LP_MFMA(B, A) "v_mfma_f32_32x32x16_f16 %[c], " B ", " A ", %[c]\n\t"
-#define LP_STEP_ASM(M0SET, PIECE, RD_HI, RD_LO)                                                                                   \
+#define LP_STEP_ASM(M0SET, PIECE, RD_HI, RD_LO, TAIL)                                                                             \
   asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LP_MFMA("%[qh]", "%[xh]") LP_MFMA("%[qh]", "%[xl]") LP_MFMA("%[ql]", "%[xh]")    \
-                   PIECE RD_HI RD_LO                                                                                               \
+                   PIECE RD_HI RD_LO TAIL                                                                                          \
                : [c] "+a"(acc), [qh] "+v"(qh), [ql] "+v"(ql)                                                                       \
                : [xh] "v"(s.fh[PAR][sx]), [xl] "v"(s.fl[PAR][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
                  [w] "n"(2 * (LG_PF - 1)), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                    \
@@ -444,10 +444,14 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
     f16x8& ql = s.ql[IT % LG_PF];
     const unsigned aw = s.aS[RI / LP_NT];
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (hasD && hasR) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL);
-    else if constexpr (hasD) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, "", "");
-    else if constexpr (hasR) LP_STEP_ASM("", "", LG_A_RDH, LG_A_RDL);
-    else LP_STEP_ASM("", "", "", "");
+    // the stage's last item: 32 wait states behind its MFMAs, inside the statement (whatever hipcc places behind the stage loop —
+    // its v_accvgpr_reads of the tiles — then finds every MFMA of the phase finished)
+    static_assert(lg_piece(LP_NIT - 1) >= 0 && LP_NIT - 1 != LP_SYNC, "the last item carries a DMA piece and its reads");
+    if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL "\n\t", "s_nop 15\n\ts_nop 15");
+    else if constexpr (hasD && hasR) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL, "");
+    else if constexpr (hasD) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, "", "", "");
+    else if constexpr (hasR) LP_STEP_ASM("", "", LG_A_RDH, LG_A_RDL, "");
+    else LP_STEP_ASM("", "", "", "", "");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IT == LP_SYNC - 1) {   // the stage's last item has been requested: aS moves to the next stage's slot
       s.aS[0] += (unsigned)s.stage_delta;
@@ -531,9 +535,10 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     }
     // the queue's trailing reads and the clamped re-load of the last slab are out, the last MFMAs have written their tiles, and every
     // wave is through with the ring: from here it belongs to the tile loop
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < LP_NT; ++t) asm volatile("" : "+a"(pacc[t]));
+    // (the accumulators were written by asm MFMAs hipcc cannot see: the wait states its v_accvgpr_reads need sit INSIDE the last
+    //  item's statement of every stage — see LP_STEP_ASM's TAIL; r05's first run of this phase read the last tiles early, logits
+    //  error 3e-2, and neither a statement owning all 240 AGPRs nor builtin MFMAs behind the loop kept hipcc's copies behind them)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }

@@ -192,7 +192,10 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
                 knob_int("LDM_X3_LNGEMM", 2) != 0;
     // level 2 (default): the two N = d_model GEMMs (out_proj, linear2) run as the GEMM prologue of the row-resident kernel that
     // normalises their sum; LDM_X3_LNGEMM=1: they stay gemm16x3_k launches (the first r05 structure)
-    h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && knob_int("LDM_X3_LNGEMM", 2) >= 2;
+    const int lv = (int)knob_int("LDM_X3_LNGEMM", 2);
+    h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && lv >= 2;
+    h->pre_out = h->lngemm_pre && lv != 4;
+    h->pre_ffn2 = h->lngemm_pre && lv != 3;
   }
   h->cur_lane = h->n_lanes - 1;
   h->activate(0);

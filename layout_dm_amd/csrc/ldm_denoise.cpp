@@ -135,7 +135,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.bias = w.b_in; a.out_scale = w.s_in;
       a.C32 = h->qkv32; a.ldc32 = 3 * D;
       a.M = M; a.N = 3 * D; a.D = D;
-      const bool pre = h->lngemm_pre && i > 0;   // x = Q + hid · W2^T + b2 of the PREVIOUS layer, computed in this launch (never stored)
+      const bool pre = h->pre_ffn2 && i > 0;   // x = Q + hid · W2^T + b2 of the PREVIOUS layer, computed in this launch (never stored)
       if (pre) ffn2_prologue(h, h->layers[i - 1], a);
       ldm_handle::Scope sc(h, st, pre ? "gemm_ffn2_qkv_ln" : "gemm_qkv_ln", gemm_flops(M, 3 * D, D) + (pre ? gemm_flops(M, D, F) : 0.0),
                            (double)M * D * 8 + (double)M * 3 * D * 4 + (pre ? (double)M * F * 4 : 0.0));
@@ -183,7 +183,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
                            (double)M * 3 * D * (a.in_f16 ? 2 : 4) + (double)M * D * esz);
       launch_attention(a, st);
     }
-    if (!(split && h->lngemm_pre)) {  // out-proj + residual onto the normed x:  Q = P + att·Wo^T + bo
+    if (!(split && h->pre_out)) {  // out-proj + residual onto the normed x:  Q = P + att·Wo^T + bo
       GemmArgs g{};
       g.A = f16 ? (const void*)h->att16 : (const void*)h->att32;
       g.Alo = h->att16lo;
@@ -204,13 +204,13 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.bias = w.b1; a.out_scale = w.s1; a.relu = 1;
       a.C16 = h->hid16; a.C16lo = h->hid16lo; a.ldc16 = Fp;
       a.M = M; a.N = F; a.D = D; a.S = h->S;
-      if (h->lngemm_pre) {   // Q = P + att · Wo^T + bo computed in this launch, written once (linear2's residual base)
+      if (h->pre_out) {   // Q = P + att · Wo^T + bo computed in this launch, written once (linear2's residual base)
         a.preA = h->att16; a.preAlo = h->att16lo; a.pre_lda = Dp; a.pre_stages = Dp / 32;
         a.pre_img = (const char*)w.x3_out_slab; a.pre_bias = w.b_out; a.pre_scale = w.s_out;
         a.pre_res = h->P; a.pre_out = h->Q;
       }
-      ldm_handle::Scope sc(h, st, h->lngemm_pre ? "gemm_out_ffn1_ln" : "gemm_ffn1_ln", gemm_flops(M, F, D) + (h->lngemm_pre ? gemm_flops(M, D, D) : 0.0),
-                           (double)M * D * 4 + (double)M * F * 4 + (h->lngemm_pre ? (double)M * D * 12 : 0.0));
+      ldm_handle::Scope sc(h, st, h->pre_out ? "gemm_out_ffn1_ln" : "gemm_ffn1_ln", gemm_flops(M, F, D) + (h->pre_out ? gemm_flops(M, D, D) : 0.0),
+                           (double)M * D * 4 + (double)M * F * 4 + (h->pre_out ? (double)M * D * 12 : 0.0));
       if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
     } else {
       {  // LayerNorm 2
@@ -237,7 +237,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
         launch_gemm_mode(g, 2, st);
       }
     }
-    if (!(split && h->lngemm_pre)) {  // FFN2 + residual:  P = Q + hid·W2^T + b2
+    if (!(split && h->pre_ffn2)) {  // FFN2 + residual:  P = Q + hid·W2^T + b2   (level 2: the prologue of the next AdaLN + in_proj launch / of the head)
       GemmArgs g{};
       g.A = f16 ? (const void*)h->hid16 : (const void*)h->hid32;
       g.Alo = h->hid16lo;
@@ -259,9 +259,9 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     a.out_scale = h->head_s;
     a.C32 = h->logits; a.ldc32 = h->Cp;
     a.M = M; a.N = h->Cp; a.D = D; a.S = h->S;   // (columns C .. Cp of the image are zero rows: exact zeros in the padding)
-    if (h->lngemm_pre) ffn2_prologue(h, h->layers[h->L - 1], a);
-    ldm_handle::Scope sc(h, st, h->lngemm_pre ? "gemm_ffn2_head_ln" : "gemm_head_ln", gemm_flops(M, C, D) + (h->lngemm_pre ? gemm_flops(M, D, F) : 0.0),
-                         (double)M * D * 4 + (double)M * C * 4 + (h->lngemm_pre ? (double)M * F * 4 : 0.0));
+    if (h->pre_ffn2) ffn2_prologue(h, h->layers[h->L - 1], a);
+    ldm_handle::Scope sc(h, st, h->pre_ffn2 ? "gemm_ffn2_head_ln" : "gemm_head_ln", gemm_flops(M, C, D) + (h->pre_ffn2 ? gemm_flops(M, D, F) : 0.0),
+                         (double)M * D * 4 + (double)M * C * 4 + (h->pre_ffn2 ? (double)M * F * 4 : 0.0));
     if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
     return 0;
   }

@@ -146,6 +146,7 @@ struct ldm_handle {
   // run as ONE row-resident launch each (kernels_lngemm.hip) instead of a LayerNorm launch + gemm16x3_k
   bool lngemm = false;
   bool lngemm_pre = false;   // level 2: out_proj / linear2 as the GEMM prologue of the row-resident kernel that consumes their sum
+  bool pre_out = false, pre_ffn2 = false;   // ... which of the two (dev: LDM_X3_LNGEMM=3 / 4 = only out_proj / only linear2)
   void* x3_head = nullptr;
   int x3_qkv_tiles = 0, x3_ffn1_tiles = 0, x3_head_tiles = 0;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
