@@ -189,10 +189,12 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->lngemm = h->D == 464 && h->Dp == 512 && (3 * h->D) % 4 == 0 && h->F % 4 == 0 && h->x3_qkv_tiles * 32 <= 2048 &&
                 h->x3_ffn1_tiles * 32 <= 2048 && h->x3_head_tiles * 32 <= 2048 && h->x3_qkv_tiles * 32 <= round_up(3 * h->D, 256) &&
                 h->x3_ffn1_tiles * 32 <= round_up(h->F, 256) && h->x3_head_tiles * 32 <= round_up(h->C, 256) &&
-                knob_int("LDM_X3_LNGEMM", 2) != 0;
-    // level 2 (default): the two N = d_model GEMMs (out_proj, linear2) run as the GEMM prologue of the row-resident kernel that
-    // normalises their sum; LDM_X3_LNGEMM=1: they stay gemm16x3_k launches (the first r05 structure)
-    const int lv = (int)knob_int("LDM_X3_LNGEMM", 2);
+                knob_int("LDM_X3_LNGEMM", 1) != 0;
+    // LDM_DEV=1 LDM_X3_LNGEMM=2 (3 / 4: only out_proj / only linear2): the two N = d_model GEMMs as the GEMM PROLOGUE of the row-resident
+    // kernel that normalises their sum (kernels_lngemm.hip PRE) instead of gemm16x3_k launches.  Correct (parity tests) and 5 % faster per
+    // launch, but no faster whole-job (profiles/r05_call24_26_*): the fused launches fill every CU alone, so the two chunk pipelines no
+    // longer overlap.  Kept as a measured alternative; its K-slab weight images are only built when it is selected.
+    const int lv = (int)knob_int("LDM_X3_LNGEMM", 1);
     h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && lv >= 2;
     h->pre_out = h->lngemm_pre && lv != 4;
     h->pre_ffn2 = h->lngemm_pre && lv != 3;

@@ -705,6 +705,48 @@ def test_logits_bitwise_repeatable(cuda, precision):
             assert torch.equal(again, first), f"{precision} B={B}: repetition {i + 1} differs by {(again - first).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("level", ["0", "2", "3", "4"])
+def test_split_mode_alternative_structures_agree(cuda, monkeypatch, level):
+    """The split mode's other launch structures behind LDM_X3_LNGEMM (dev knob) against the default one and the oracle: 0 = the r04
+    structure (LayerNorm launches + tiled GEMMs), 2 = out_proj / linear2 as GEMM prologues of the row-resident kernels (3 / 4: only one
+    of the two).  Same numerics class (fp16 x 3, fp32 accumulation): logits within the split mode's tolerance of the oracle and within
+    2e-6 of the default structure; greedy step identical.  Full chunk and ragged batch (the last workgroup's rows are partly masked)."""
+    from oracle import restatement as R
+
+    spec, W = weights("rico25")
+    for B in (256, 37):
+        g = torch.Generator().manual_seed(3 + B)
+        tokens = torch.empty(B, spec.seq_len, dtype=torch.long)
+        for a in range(spec.n_attr):
+            ids = torch.as_tensor(spec.full_ids(a))
+            tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (B, spec.max_elem), generator=g)]
+        tokens[torch.rand(B, spec.seq_len, generator=g) < 0.5] = spec.mask_id
+        tok = tokens.int().to(cuda)
+        monkeypatch.delenv("LDM_X3_LNGEMM", raising=False)
+        monkeypatch.delenv("LDM_DEV", raising=False)
+        e0 = engine("rico25", "split", max_batch=256)
+        base = e0.denoise_logits(tok, 33).cpu()
+        nxt0 = e0.sample_step(tok, 33, {"name": "deterministic"}).cpu()
+        monkeypatch.setenv("LDM_DEV", "1")
+        monkeypatch.setenv("LDM_X3_LNGEMM", level)
+        from layout_dm_amd.binding import Engine
+
+        e1 = Engine(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem, d_model=spec.d_model, n_head=spec.n_head,
+                    d_ff=spec.d_ff, n_layer=spec.n_layer, n_step=spec.n_step, precision="split", max_batch=256)   # (not cached: built under the knob)
+        e1.load_state_dict(synth.synth_state_dict(spec, seed=WEIGHT_SEED, perturb=True))
+        assert f"LDM_X3_LNGEMM={level}" in e1.describe()["knobs"]
+        got = e1.denoise_logits(tok, 33).cpu()
+        nxt1 = e1.sample_step(tok, 33, {"name": "deterministic"}).cpu()
+        e1.close()
+        ref = R.denoiser_logits(W, spec, tokens[:8], 33)
+        scale = ref.abs().max().item()
+        err_ref = (got[:8] - ref).abs().max().item() / scale
+        err_base = (got - base).abs().max().item() / scale
+        print(f"[split structure {level}, B={B}] vs oracle {err_ref:.2e}, vs the default structure {err_base:.2e}")
+        assert err_ref <= 5e-5 and err_base <= 2e-6
+        assert torch.equal(nxt1, nxt0)
+
+
 # ----------------------------------------------------------------------------- drop-in layer
 class _MockTokenizer:
     """Duck-types the properties of the reference's LayoutSequenceTokenizer that LayoutDM reads
