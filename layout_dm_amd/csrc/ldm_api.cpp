@@ -189,15 +189,16 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->lngemm = h->D == 464 && h->Dp == 512 && (3 * h->D) % 4 == 0 && h->F % 4 == 0 && h->x3_qkv_tiles * 32 <= 2048 &&
                 h->x3_ffn1_tiles * 32 <= 2048 && h->x3_head_tiles * 32 <= 2048 && h->x3_qkv_tiles * 32 <= round_up(3 * h->D, 256) &&
                 h->x3_ffn1_tiles * 32 <= round_up(h->F, 256) && h->x3_head_tiles * 32 <= round_up(h->C, 256) &&
-                knob_int("LDM_X3_LNGEMM", 1) != 0;
-    // LDM_DEV=1 LDM_X3_LNGEMM=2 (3 / 4: only out_proj / only linear2): the two N = d_model GEMMs as the GEMM PROLOGUE of the row-resident
-    // kernel that normalises their sum (kernels_lngemm.hip PRE) instead of gemm16x3_k launches.  Correct (parity tests) and 5 % faster per
-    // launch, but no faster whole-job (profiles/r05_call24_26_*): the fused launches fill every CU alone, so the two chunk pipelines no
-    // longer overlap.  Kept as a measured alternative; its K-slab weight images are only built when it is selected.
-    const int lv = (int)knob_int("LDM_X3_LNGEMM", 1);
+                knob_int("LDM_X3_LNGEMM", 4) != 0;
+    // The two N = d_model GEMMs can run as the GEMM PROLOGUE of the row-resident kernel that normalises their sum (kernels_lngemm.hip PRE)
+    // instead of as gemm16x3_k launches.  Default (level 4): linear2 only — the fused launch is 28 us per layer cheaper than the two it
+    // replaces, +4 % whole-job same-box.  Fusing out_proj as well (LDM_DEV=1 LDM_X3_LNGEMM=2; 3 = out_proj only) saves nothing per launch
+    // and costs the overlap between the two chunk pipelines (a fused launch fills every CU alone): -5 % (profiles/r05_call24_27_*).
+    // LDM_X3_LNGEMM=1: no prologue (the first r05 structure).  The K-slab weight images are only built for what is selected.
+    const int lv = (int)knob_int("LDM_X3_LNGEMM", 4);
     h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && lv >= 2;
-    h->pre_out = h->lngemm_pre && lv != 4;
-    h->pre_ffn2 = h->lngemm_pre && lv != 3;
+    h->pre_out = h->lngemm_pre && (lv == 2 || lv == 3);
+    h->pre_ffn2 = h->lngemm_pre && (lv == 2 || lv == 4);
   }
   h->cur_lane = h->n_lanes - 1;
   h->activate(0);
@@ -409,8 +410,14 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   const bool loop = loop_fusable(h, nullptr);
   char num[96];
   std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->cfg.precision];
-  s += std::string(";kernels=") + (h->cfg.precision != LDM_PREC_FAST_F16 ? (h->lngemm_pre ? "row_resident_gemm_ln_gemm+attn" : h->lngemm ? "row_resident_ln_gemm+tiled_gemm+attn" : "tiled_gemm+attn")
-                                   : h->fused_attn == 6 ? "stack" : "generic16");
+  std::string kern = h->fused_attn == 6 ? "stack" : "generic16";
+  if (h->cfg.precision != LDM_PREC_FAST_F16) {
+    kern = "tiled_gemm+attn";
+    if (h->lngemm)
+      kern = std::string("row_resident_ln_gemm") + (h->pre_ffn2 ? "+linear2_prologue" : "") + (h->pre_out ? "+out_proj_prologue" : "") +
+             (h->pre_ffn2 && h->pre_out ? "+attn" : "+tiled_gemm+attn");
+  }
+  s += ";kernels=" + kern;
   s += std::string(";loop=") + (loop ? "one_launch" : "per_step_graph");
   s += ";chunk=" + std::to_string(h->chunk) + ";lanes=" + std::to_string(h->n_lanes) + ";lane_offset_us=" + std::to_string(h->lane_offset_us);
   snprintf(num, sizeof(num), ";tie_rel=%g;tie_abs=%g", (double)h->tie_rel, (double)h->tie_abs);

@@ -363,10 +363,8 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
         if ((rc = make_x3_image(h, w.w_in16, w.w_in16lo, h->x3_qkv_tiles, &w.x3_qkv))) return rc;
         if ((rc = make_x3_image(h, w.w1_16, w.w1_16lo, h->x3_ffn1_tiles, &w.x3_ffn1))) return rc;
       }
-      if (h->lngemm_pre) {
-        if ((rc = make_x3_slab(h, w.w_out16, w.w_out16lo, D, h->Dp, h->Dp, &w.x3_out_slab))) return rc;
-        if ((rc = make_x3_slab(h, w.w2_16, w.w2_16lo, D, h->Fp, h->Fp, &w.x3_ffn2_slab))) return rc;
-      }
+      if (h->pre_out && (rc = make_x3_slab(h, w.w_out16, w.w_out16lo, D, h->Dp, h->Dp, &w.x3_out_slab))) return rc;
+      if (h->pre_ffn2 && (rc = make_x3_slab(h, w.w2_16, w.w2_16lo, D, h->Fp, h->Fp, &w.x3_ffn2_slab))) return rc;
     }
   }
   if (h->cfg.precision == LDM_PREC_FAST_F16) {
