@@ -35,8 +35,25 @@ def _consts():
 
 def test_schedule_replay():
     KS, NIT, PF = _consts()
+    _replay(KS, NIT, PF, epilogue=True)
+
+
+def test_schedule_replay_gemm_prologue():
+    """The GEMM prologue (lp_step) runs the same protocol with 30 REAL items per stage (2 k16-steps x 15 column tiles, no pseudo
+    item), no epilogue slices, the same DMA schedule (lg_piece) and queue depth."""
+    _, NIT, PF = _consts()
+    src = open(os.path.join(ROOT, "layout_dm_amd", "csrc", "kernels_lngemm.hip")).read()
+    for needle in ("constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;", "static_assert(LP_NIT == LG_NIT,", "constexpr int LP_SYNC = LP_NIT - LG_PF;",
+                   "constexpr int RI = (IT + LG_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LG_PF - 1))",
+                   "if constexpr (IT == LP_SYNC - 1) {", "if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);",
+                   "if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL \"\\n\\t\", \"s_nop 15\\n\\ts_nop 15\");"):
+        assert needle in src, needle
+    _replay(NIT, NIT, PF, epilogue=False)
+
+
+def _replay(KS, NIT, PF, epilogue):
     SYNC = NIT - PF
-    assert NIT % PF == 0 and KS < NIT
+    assert NIT % PF == 0 and KS <= NIT
     n_tiles = 6
     lds_ops = []            # program-order list of LDS operations: ("frag", tile, item) twice per item, or ("epi",)
     slot = {}               # queue slot -> (tile, item) it will hold once landed
@@ -104,11 +121,11 @@ def test_schedule_replay():
             # ---- the previous tile's epilogue: LDS operations of its three slices
             # (issued between the step's MFMAs, i.e. BEFORE the step's fragment reads: modelled by inserting them in front of the pair
             #  just appended — conservative for the waits either way)
-            if t > 0:
+            if t > 0 and epilogue:
                 extra = 1 if it == 1 else 2 if it in (2, 3) else 0
                 assert 2 * (PF - 1) + 2 + extra <= 15, "lgkmcnt is a 4-bit counter"
                 lds_ops += [("epi",)] * extra
-            if it == KS:                              # the pseudo step: drain to 8, then the 4 ds_write_b128 of the tile's sum
+            if it == KS and epilogue:                 # the pseudo step: drain to 8, then the 4 ds_write_b128 of the tile's sum
                 assert 8 + 4 <= 15
                 lds_ops += [("epi",)] * 4
     for td in range(2, n_tiles):
