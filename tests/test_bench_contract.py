@@ -56,5 +56,15 @@ def test_bench_line_contract(d):
         nd = d["modes"]["fast_verified"]["nondegenerate"]
         assert all(nd[k]["tokens_equal_exact_mode"] for k in nd if k.startswith("from_step_"))
         assert set(d["configs"]) >= {"5_refinement_T200", "5_relation_T200"}
-        assert d["config"]["cpu_baseline_kind"] == "port" and d["config"]["library"]["knobs"] == ""
+        assert d["config"]["cpu_baseline_kind"] == d["cpu_baseline"]["kind"] and d["config"]["library"]["knobs"] == ""
         assert d["world_size_seen"] == 1 and d["scaling_point"]["layouts_per_s_per_gpu"] == d["configs"]["4"]["value"]
+    if "batch_shapes" in d:       # r05 lines: what a user gets — the reference-precision figures as scalars, the reference as the CPU baseline
+        assert d["cpu_baseline"]["kind"] == "reference" and "oracle/_ref" in d["cpu_baseline"]["source"]
+        assert d["reference_precision_layouts_per_s"] == d["modes"]["split"]["value"] == d["config"]["reference_precision_layouts_per_s"]
+        assert d["fp32_mfma_layouts_per_s"] == d["modes"]["exact"]["value"]
+        for point in ("mid", "wide"):
+            assert d["config"][f"auto_selected_{point}"] in ("fast_verified", "split", "exact")
+            assert d["config"][f"auto_layouts_per_s_{point}"] == d["weight_sensitivity"][point]["value"]
+            assert d["weight_sensitivity"][point]["fast_engine_err_rel_measured_at_load"] > d["weight_sensitivity"][point]["tolerance"] \
+                or d["config"][f"auto_selected_{point}"] == "fast_verified"
+        assert set(d["batch_shapes"]) >= {"rule", "300", "488", "640"} and d["layout_metrics"]["value"] > 0
