@@ -9,6 +9,10 @@
 //                               residual base (Block.forward: residual on the NORMED x)
 //   norm2  + linear1 + ReLU     hi / lo fp16 out (the A operand of gemm16x3_k for linear2)
 //   head LN + vocabulary head   fp32 logits
+// and, r05 second half, optionally a GEMM in FRONT of the LayerNorm as well (PRE, "GEMM prologue", further down): the launch
+// computes its rows x = residual + bias + scale * (A . Wpre^T) instead of reading them.  Shipped for linear2 — in front of the
+// next layer's AdaLN + in_proj and of the head — so that a layer is three launches besides the attention:
+//   [linear2 of layer l - 1 +] AdaLN + in_proj   |   attention   |   out_proj (gemm16x3_k)   |   norm2 + linear1 + ReLU
 //
 // Why: gemm16x3_k is bound by the per-CU operand fill path (37-40 GB/s per CU out of the L2), and a
 // 256 x 256 tile pulls FOUR images per stage (A hi, A lo, W hi, W lo).  Here a workgroup owns 128 rows for the whole GEMM —
