@@ -11,7 +11,6 @@ tensors on the input's device.  No CPU fallback: without the extension or a GPU 
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Dict
 
 import torch
