@@ -385,6 +385,9 @@ struct LpState {
   const char* img;              // slab image + wave * 16 KiB
   unsigned lds_w, voff;
   int stage_delta, n_stages;
+#ifdef LDM_LNGEMM_ABL_BUILD
+  int a_hot;                    // (measurement build only)
+#endif
   const char* dma_g;
   unsigned dma_l;
 };
@@ -410,6 +413,9 @@ __device__ __forceinline__ void lp_dma_begin(LpState& s, int sd) {   // stage sd
 // A fragments of stage sd (clamped) into register set P: k16-steps 2 sd, 2 sd + 1 -> 16 halves apart
 template <int P>
 __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
+#ifdef LDM_LNGEMM_ABL_BUILD   // measurement build, LDM_LNGEMM_ABL=128: every stage re-reads the A fragments of stage 0 (L2-resident)
+  if (s.a_hot) sd = 0;
+#endif
   const int t = sd < s.n_stages ? sd : s.n_stages - 1;
   s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32);
   s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32 + 16);
@@ -510,6 +516,9 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     ps.lds_w = lds0 + wave * 16384;
     ps.voff = voff;
     ps.n_stages = a.pre_stages;
+#ifdef LDM_LNGEMM_ABL_BUILD
+    ps.a_hot = a.relu >> 8;   // (launch_lngemm16x3 passes the variant in the upper bits)
+#endif
     ps.stage_delta = LG_STAGE;
     ps.pa = a.preA + (size_t)rrow * a.pre_lda + hi * 8;
     ps.pal = a.preAlo + (size_t)rrow * a.pre_lda + hi * 8;
@@ -740,6 +749,14 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
 #undef LG_ABL
 #endif
   allow_big_lds((const void*)kern);
+#ifdef LDM_LNGEMM_ABL_BUILD
+  if (pre && abl_knob == 128) {
+    LnGemmArgs b = a;
+    b.relu |= 1 << 8;
+    hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, b);
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((a.M + 127) / 128), dim3(256), LG_LDS, st, a);
   return 0;
 }
