@@ -373,18 +373,28 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
 // Per workgroup: K / 32 stages x 64 KiB through the per-CU fill path (linear2: 58 stages = 3.7 MB ~ 95 us at 38 GB/s per CU, the
 // same bytes gemm16x3_k's 256 x 256 tile pulls for BOTH operands) and no launch, no fp32 round trip of the sum, no epilogue.
 constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;   // items per stage
-static_assert(LP_NIT == LG_NIT, "the prologue shares the tile loop's DMA schedule (lg_piece) and queue depth");
-constexpr int LP_SYNC = LP_NIT - LG_PF;
+// a 3-deep fragment queue (the tile loop: 6): 24 registers — what it saves holds the third A register set, which hides the HBM latency of
+// the A rows (22 - 27 us per launch, measurement variant 128); 3 items ahead are ~300 cycles of MFMA time, the LDS answers in ~130
+constexpr int LP_PF = 3, LP_SYNC = LP_NIT - LP_PF;
+static_assert(LP_NIT % LP_PF == 0, "queue slots must line up across stages");
+// which of the 16 DMA pieces per wave and stage step IT carries: pieces 0 .. behind the barrier, the rest at the first steps of the next stage
+constexpr int lp_piece(int IT) {
+  if (IT > LP_SYNC) return IT - LP_SYNC - 1;
+  if (IT + (LP_NIT - 1 - LP_SYNC) < 16) return IT + (LP_NIT - 1 - LP_SYNC);
+  return -1;
+}
+static_assert(lp_piece(LP_SYNC) == -1 && lp_piece(LP_SYNC + 1) == 0 && lp_piece(0) == lp_piece(LP_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
 
 struct LpState {
-  f16x8 qh[LG_PF], ql[LG_PF];   // W hi / lo fragment queue
+  f16x8 qh[LP_PF], ql[LP_PF];   // W hi / lo fragment queue
   unsigned aS[2];               // this lane's LDS address of k16-step s in the CURRENT stage (tile t: + t * 2 KiB)
-  f16x8 fh[2][2], fl[2][2];     // A fragments [stage parity][k16-step]: the current stage's, and the next stage's (in flight until
-                                // the current stage's barrier) — two register sets, no copies behind MFMAs that still read them
+  f16x8 fh[3][2], fl[3][2];     // A fragments [stage % 3][k16-step]: the current stage's, the next stage's (landed by the current
+                                // stage's barrier) and the one after's (requested in this stage, in flight across its barrier: the
+                                // rows come from HBM, a stage is ~1.5 us) — three register sets in rotation, no copies
   const __half *pa, *pal;       // this lane's row of A hi / lo + 8 * (lane / 32) halves
   const char* img;              // slab image + wave * 16 KiB
   unsigned lds_w, voff;
-  int stage_delta, n_stages;
+  int stage_delta, n_stages, n_astages;   // stages of the image (a multiple of 3) / of them with real A columns
 #ifdef LDM_LNGEMM_ABL_BUILD
   int a_hot;                    // (measurement build only)
 #endif
@@ -395,12 +405,12 @@ struct LpState {
 template <int IT>
 __device__ __forceinline__ void lp_read(LpState& s) {   // item IT of the stage aS points at
   constexpr int sx = IT / LP_NT, t = IT % LP_NT;
-  lg_dsr<t * 2048>(s.qh[IT % LG_PF], s.aS[sx]);
-  lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LG_PF], s.aS[sx]);
+  lg_dsr<t * 2048>(s.qh[IT % LP_PF], s.aS[sx]);
+  lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);
 }
 template <int I>
 __device__ __forceinline__ void lp_prime(LpState& s) {
-  if constexpr (I < LG_PF) {
+  if constexpr (I < LP_PF) {
     lp_read<I>(s);
     lp_prime<I + 1>(s);
   }
@@ -410,13 +420,15 @@ __device__ __forceinline__ void lp_dma_begin(LpState& s, int sd) {   // stage sd
   s.dma_g = s.img + (size_t)t * LG_STAGE;
   s.dma_l = s.lds_w + (unsigned)(sd & 1) * LG_STAGE;
 }
-// A fragments of stage sd (clamped) into register set P: k16-steps 2 sd, 2 sd + 1 -> 16 halves apart
+// A fragments of stage sd (clamped) into register set P: k16-steps 2 sd, 2 sd + 1 -> 16 halves apart.  EXACTLY LP_A_LOADS vector
+// memory instructions: the stage barrier's counted wait leaves that many outstanding.
+constexpr int LP_A_LOADS = 4;
 template <int P>
 __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build, LDM_LNGEMM_ABL=128: every stage re-reads the A fragments of stage 0 (L2-resident)
   if (s.a_hot) sd = 0;
 #endif
-  const int t = sd < s.n_stages ? sd : s.n_stages - 1;
+  const int t = sd < s.n_astages ? sd : s.n_astages - 1;   // (the zero slabs at the end of the image multiply the last real columns again)
   s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32);
   s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32 + 16);
   s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * 32);
@@ -428,35 +440,40 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
   asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LP_MFMA("%[qh]", "%[xh]") LP_MFMA("%[qh]", "%[xl]") LP_MFMA("%[ql]", "%[xh]")    \
                    PIECE RD_HI RD_LO TAIL                                                                                          \
                : [c] "+a"(acc), [qh] "+v"(qh), [ql] "+v"(ql)                                                                       \
-               : [xh] "v"(s.fh[PAR][sx]), [xl] "v"(s.fl[PAR][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
-                 [w] "n"(2 * (LG_PF - 1)), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                    \
+               : [xh] "v"(s.fh[SET][sx]), [xl] "v"(s.fl[SET][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
+                 [w] "n"(2 * (LP_PF - 1)), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                    \
                : "memory")
 
-template <int IT, int PAR>   // PAR: parity of the stage = the A register set it multiplies
+// the step at which the stage requests the A fragments of stage + 2: behind the last DMA piece of the slab the barrier certifies
+constexpr int LP_A_STEP = 15;
+static_assert(lp_piece(LP_A_STEP - 1) < 0 && lp_piece(LP_A_STEP) < 0 && LP_A_STEP < LP_SYNC, "A loads are the youngest vector memory operations at the barrier");
+
+template <int IT, int SET>   // SET = stage % 3: the A register set the stage multiplies
 __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
   if constexpr (IT < LP_NIT) {
     constexpr int sx = IT / LP_NT, t = IT % LP_NT;
-    constexpr int J = lg_piece(IT);
+    constexpr int J = lp_piece(IT);
     constexpr bool hasD = J >= 0;
     if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);
     if constexpr (hasD && J > 0 && (J & 3) == 0) {
       s.dma_g += 4096;
       s.dma_l += 4096;
     }
-    // the next stage's A fragments: requested early in the stage, landed by its barrier
-    if constexpr (IT == 1) lp_load_a<PAR ^ 1>(s, stage + 1);
-    constexpr int RI = (IT + LG_PF) % LP_NIT;
+    // the A fragments of stage + 2: requested behind this stage's last DMA piece, so that they are the LP_A_LOADS youngest vector
+    // memory operations at the barrier, which does not wait for them (loads return in order: everything older has landed)
+    if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3>(s, stage + 2);
+    constexpr int RI = (IT + LP_PF) % LP_NIT;
     constexpr bool hasR = IT != LP_SYNC;
     constexpr int RO = (RI % LP_NT) * 2048;
     constexpr int DOFF = hasD ? (J & 3) * 1024 : 0;
     f32x16& acc = accs[t];
-    f16x8& qh = s.qh[IT % LG_PF];
-    f16x8& ql = s.ql[IT % LG_PF];
+    f16x8& qh = s.qh[IT % LP_PF];
+    f16x8& ql = s.ql[IT % LP_PF];
     const unsigned aw = s.aS[RI / LP_NT];
     __builtin_amdgcn_sched_barrier(0);
     // the stage's last item: 32 wait states behind its MFMAs, inside the statement (whatever hipcc places behind the stage loop —
     // its v_accvgpr_reads of the tiles — then finds every MFMA of the phase finished)
-    static_assert(lg_piece(LP_NIT - 1) >= 0 && LP_NIT - 1 != LP_SYNC, "the last item carries a DMA piece and its reads");
+    static_assert(lp_piece(LP_NIT - 1) >= 0 && LP_NIT - 1 != LP_SYNC, "the last item carries a DMA piece and its reads");
     if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL "\n\t", "s_nop 15\n\ts_nop 15");
     else if constexpr (hasD && hasR) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL, "");
     else if constexpr (hasD) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, "", "", "");
@@ -469,13 +486,14 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
       s.stage_delta = -s.stage_delta;
     }
     if constexpr (IT == LP_SYNC) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's slab (own pieces) and its A fragments
+      // the next stage's slab (own pieces) and its A fragments (requested a stage ago); the fragments of stage + 2 stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP_A_LOADS) : "memory");
       __builtin_amdgcn_s_barrier();
-      asm volatile("" : "+v"(s.fh[PAR ^ 1][0]), "+v"(s.fh[PAR ^ 1][1]), "+v"(s.fl[PAR ^ 1][0]), "+v"(s.fl[PAR ^ 1][1])::"memory");   // (hipcc's own wait for them lands here)
+      asm volatile("" : "+v"(s.fh[(SET + 1) % 3][0]), "+v"(s.fh[(SET + 1) % 3][1]), "+v"(s.fl[(SET + 1) % 3][0]), "+v"(s.fl[(SET + 1) % 3][1])::"memory");   // (hipcc's own counted wait for them lands here)
       lp_read<RI>(s);
     }
     __builtin_amdgcn_sched_barrier(0);
-    lp_step<IT + 1, PAR>(s, accs, stage);
+    lp_step<IT + 1, SET>(s, accs, stage);
   }
 }
 #undef LP_STEP_ASM
@@ -516,6 +534,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     ps.lds_w = lds0 + wave * 16384;
     ps.voff = voff;
     ps.n_stages = a.pre_stages;
+    ps.n_astages = a.pre_astages;
 #ifdef LDM_LNGEMM_ABL_BUILD
     ps.a_hot = a.relu >> 8;   // (launch_lngemm16x3 passes the variant in the upper bits)
 #endif
@@ -526,6 +545,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
     lp_load_a<0>(ps, 0);
+    lp_load_a<1>(ps, 1);
 #pragma unroll
     for (int sx = 0; sx < 2; ++sx) ps.aS[sx] = lds0 + r * 64 + ((((sx << 1) | hi) ^ ((r >> 2) & 3)) << 4);
 #pragma unroll
@@ -534,17 +554,19 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
       for (int k = 0; k < 16; ++k) pacc[t][k] = 0.f;
     lp_dma_begin(ps, 1);
     {  // (stage 0, steps 0 ..: the pieces of slab 1 once more, as in the tile loop)
-      constexpr int J0 = lg_piece(0), pre = (J0 >> 2) - ((J0 & 3) == 0 ? 1 : 0);
+      constexpr int J0 = lp_piece(0), pre = (J0 >> 2) - ((J0 & 3) == 0 ? 1 : 0);
       ps.dma_g += pre * 4096;
       ps.dma_l += pre * 4096;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1])::"memory");
+    asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1]), "+v"(ps.fh[1][0]), "+v"(ps.fh[1][1]),
+                 "+v"(ps.fl[1][0]), "+v"(ps.fl[1][1])::"memory");
     lp_prime<0>(ps);
-    for (int st = 0; st < a.pre_stages; st += 2) {   // (launch_lngemm16x3: an even number of stages)
-      lp_step<0, 0>(ps, pacc, st);
+    for (int st = 0; st < a.pre_stages; st += 3) {   // three stage bodies, one per A register set (the ring slot follows aS);
+      lp_step<0, 0>(ps, pacc, st);                    // launch_lngemm16x3: a multiple of three stages (the image ends in zero slabs)
       lp_step<0, 1>(ps, pacc, st + 1);
+      lp_step<0, 2>(ps, pacc, st + 2);
     }
     // the queue's trailing reads and the clamped re-load of the last slab are out, the last MFMAs have written their tiles, and every
     // wave is through with the ring: from here it belongs to the tile loop
@@ -734,9 +756,9 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)) return -1;
   static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
   const bool pre = a.pre_img != nullptr;
-  // GEMM prologue: an even number (>= 2) of 32-wide K slabs, all d_model columns inside its 15 tiles, fp32 residual rows
-  if (pre && (a.pre_stages < 2 || (a.pre_stages & 1) || a.D > 32 * LP_NT || !a.preA || !a.preAlo || !a.pre_res || a.tokens ||
-              a.pre_lda < 32 * a.pre_stages || (a.pre_lda & 7)))
+  // GEMM prologue: a multiple of three 32-wide K slabs (zero slabs behind the pre_astages real ones), all d_model columns inside its 15 tiles, fp32 residual rows
+  if (pre && (a.pre_stages < 3 || a.pre_stages % 3 || a.pre_astages < 2 || a.pre_astages > a.pre_stages || a.D > 32 * LP_NT || !a.preA ||
+              !a.preAlo || !a.pre_res || a.tokens || a.pre_lda < 32 * a.pre_astages || (a.pre_lda & 7)))
     return -1;
   auto kern = half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
   if (pre) kern = half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;

@@ -1,6 +1,7 @@
 // Host side of libldm_hip.so: the launch sequence of ONE denoiser pass over a chunk of layouts, per numerics mode
 // (CategoricalTransformer.forward, nn_lib.py:191-237 + transformer_utils.py:165-246).
 #include "ldm_handle.h"
+#include "ldm_pack.h"
 
 using namespace ldm_host;
 
@@ -109,7 +110,7 @@ static void launch_gemm_mode(const GemmArgs& g, int tag, hipStream_t st) {
 
 // lngemm level 2: linear2 of layer `w` (+ bias + the residual Q) as the GEMM prologue of the launch that normalises its sum
 static void ffn2_prologue(ldm_handle* h, const LayerW& w, LnGemmArgs& a) {
-  a.preA = h->hid16; a.preAlo = h->hid16lo; a.pre_lda = h->Fp; a.pre_stages = h->Fp / 32;
+  a.preA = h->hid16; a.preAlo = h->hid16lo; a.pre_lda = h->Fp; a.pre_astages = h->Fp / 32; a.pre_stages = ldm_pack::x3_slab_stages(h->Fp);
   a.pre_img = (const char*)w.x3_ffn2_slab; a.pre_bias = w.b2; a.pre_scale = w.s2;
   a.pre_res = h->Q; a.pre_out = nullptr;
 }
@@ -205,7 +206,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.C16 = h->hid16; a.C16lo = h->hid16lo; a.ldc16 = Fp;
       a.M = M; a.N = F; a.D = D; a.S = h->S;
       if (h->pre_out) {   // Q = P + att · Wo^T + bo computed in this launch, written once (linear2's residual base)
-        a.preA = h->att16; a.preAlo = h->att16lo; a.pre_lda = Dp; a.pre_stages = Dp / 32;
+        a.preA = h->att16; a.preAlo = h->att16lo; a.pre_lda = Dp; a.pre_astages = Dp / 32; a.pre_stages = ldm_pack::x3_slab_stages(Dp);
         a.pre_img = (const char*)w.x3_out_slab; a.pre_bias = w.b_out; a.pre_scale = w.s_out;
         a.pre_res = h->P; a.pre_out = h->Q;
       }

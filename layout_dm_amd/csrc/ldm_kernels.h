@@ -103,7 +103,7 @@ struct LnGemmArgs {
   const float* pre_bias;         // [D]
   const float* pre_res;          // [M, D] fp32 residual rows
   float* pre_out;                // [M, D] or nullptr: x written back (the residual base of a later GEMM)
-  int pre_lda, pre_stages;
+  int pre_lda, pre_stages, pre_astages;   // stages of the image (a multiple of 3, zero slabs at the end) / stages with real K columns
   float pre_scale;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);

@@ -159,9 +159,10 @@ inline std::vector<uint16_t> pack_x3_tile_image(const uint16_t* hi, const uint16
 // One 64-KiB stage per 32 k (two k16-steps): hi slab at byte 0, lo slab at byte 32 768; a slab is 480 rows (output columns,
 // zero beyond N) x 64 B, 16-byte chunk L (k = 32 stage + 8 L ..) of row n at physical chunk L ^ ((n >> 2) & 3) — the W2-slab
 // format of the fused FFN (pack_ffn_image), conflict-free for ds_read_b128 by (column, k half) lanes.
+inline int x3_slab_stages(int K) { return (K / 32 + 2) / 3 * 3; }   // the kernel walks the slabs three at a time: zero slabs fill up
 inline std::vector<uint16_t> pack_x3_slab_image(const uint16_t* hi, const uint16_t* lo, int N, int ld, int K) {
   const int n_stage = K / 32;
-  std::vector<uint16_t> img((size_t)n_stage * 32768, 0);
+  std::vector<uint16_t> img((size_t)x3_slab_stages(K) * 32768, 0);
   for (int st = 0; st < n_stage; ++st)
     for (int part = 0; part < 2; ++part) {
       const uint16_t* src = part ? lo : hi;

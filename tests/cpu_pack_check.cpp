@@ -239,7 +239,8 @@ int main() {
         lo[(size_t)n * ld + k] = id16(n + 20000, k);
       }
     const std::vector<uint16_t> img = ldm_pack::pack_x3_slab_image(hi.data(), lo.data(), N, ld, K);
-    CHECK(img.size() == (size_t)(K / 32) * 32768, "x3 slab image size");
+    CHECK(img.size() == (size_t)ldm_pack::x3_slab_stages(K) * 32768 && ldm_pack::x3_slab_stages(K) == 60 && ldm_pack::x3_slab_stages(512) == 18, "x3 slab image size");
+    for (size_t i = (size_t)(K / 32) * 32768; i < img.size(); ++i) CHECK(img[i] == 0, "x3 slab padding stage not zero at %zu", i);
     for (int st = 0; st < K / 32; ++st)
       for (int part = 0; part < 2; ++part)
         for (int t = 0; t < 15; ++t) for (int j = 0; j < 32; ++j) for (int hh = 0; hh < 2; ++hh) for (int sx = 0; sx < 2; ++sx) {

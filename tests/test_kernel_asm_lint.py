@@ -200,13 +200,13 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
         pre = name.endswith("ELb1EEEvNS_10LnGemmArgsE")
-        # tile body: 29 k16-steps x 3 products; the GEMM prologue adds two stage bodies (one per A register set) of 30 items x 3
-        assert len(mf) == 87 + (180 if pre else 0), (name, len(mf))
+        # tile body: 29 k16-steps x 3 products; the GEMM prologue adds three stage bodies (one per A register set) of 30 items x 3
+        assert len(mf) == 87 + (270 if pre else 0), (name, len(mf))
         if pre:
             # the matrix pipe runs its queue in order: the last stage's final MFMAs are still in flight when the stage loop falls through, and
             # hipcc (which cannot see asm MFMAs) puts its v_accvgpr_reads of the accumulator tiles right there — the wait states must sit inside
-            # the asm statement of the stage's last item, in BOTH stage bodies (r05 call 24: logits error 3e-2 without them)
-            for last in (mf[89], mf[179]):
+            # the asm statement of the stage's last item, in ALL THREE stage bodies (r05 call 24: logits error 3e-2 without them)
+            for last in (mf[89], mf[179], mf[269]):
                 tail = instr[last + 1:last + 8]
                 assert tail.count("asm:s_nop 15") == 2, (name, tail)
                 assert not any(t.startswith("v_accvgpr_read") for t in tail), (name, tail)

@@ -40,15 +40,29 @@ def test_schedule_replay():
 
 def test_schedule_replay_gemm_prologue():
     """The GEMM prologue (lp_step) runs the same protocol with 30 REAL items per stage (2 k16-steps x 15 column tiles, no pseudo
-    item), no epilogue slices, the same DMA schedule (lg_piece) and queue depth."""
-    _, NIT, PF = _consts()
+    item), no epilogue slices, its own (shallower) queue and the DMA schedule that follows from it (lp_piece); its A fragments are
+    requested behind the stage's last DMA piece, so that the barrier's counted wait may leave exactly those loads outstanding."""
+    _, NIT, _ = _consts()
     src = open(os.path.join(ROOT, "layout_dm_amd", "csrc", "kernels_lngemm.hip")).read()
-    for needle in ("constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;", "static_assert(LP_NIT == LG_NIT,", "constexpr int LP_SYNC = LP_NIT - LG_PF;",
-                   "constexpr int RI = (IT + LG_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LG_PF - 1))",
+    m = re.search(r"constexpr int LP_PF = (\d+), LP_SYNC = LP_NIT - LP_PF;", src)
+    a = re.search(r"constexpr int LP_A_STEP = (\d+);", src)
+    n = re.search(r"constexpr int LP_A_LOADS = (\d+);", src)
+    assert m and a and n
+    PF, A_STEP, A_LOADS = int(m.group(1)), int(a.group(1)), int(n.group(1))
+    for needle in ("constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;", "static_assert(LP_NIT % LP_PF == 0,",
+                   "constexpr int RI = (IT + LP_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LP_PF - 1))",
                    "if constexpr (IT == LP_SYNC - 1) {", "if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);",
+                   "if (IT > LP_SYNC) return IT - LP_SYNC - 1;", "if (IT + (LP_NIT - 1 - LP_SYNC) < 16) return IT + (LP_NIT - 1 - LP_SYNC);",
+                   "if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3>(s, stage + 2);",
+                   "asm volatile(\"s_waitcnt vmcnt(%0)\" ::\"n\"(LP_A_LOADS) : \"memory\");",
                    "if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL \"\\n\\t\", \"s_nop 15\\n\\ts_nop 15\");"):
         assert needle in src, needle
+    SYNC = NIT - PF
     _replay(NIT, NIT, PF, epilogue=False)
+    # vector-memory order inside a stage: DMA pieces at steps SYNC + 1 .. and 0 .. (16 in all), then the A loads; nothing behind them
+    pieces = [it for it in range(NIT) if it > SYNC or it + (NIT - 1 - SYNC) < 16]
+    assert len(pieces) == 16 and A_LOADS == 4
+    assert max(p for p in pieces if p < SYNC) < A_STEP < SYNC, "the A loads must be the youngest vector memory operations at the barrier"
 
 
 def _replay(KS, NIT, PF, epilogue):
