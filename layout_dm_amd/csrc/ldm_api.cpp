@@ -193,7 +193,7 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     // The two N = d_model GEMMs can run as the GEMM PROLOGUE of the row-resident kernel that normalises their sum (kernels_lngemm.hip PRE)
     // instead of as gemm16x3_k launches.  Default (level 4): linear2 only — the fused launch is 28 us per layer cheaper than the two it
     // replaces, +4 % whole-job same-box.  Fusing out_proj as well (LDM_DEV=1 LDM_X3_LNGEMM=2; 3 = out_proj only) saves nothing per launch
-    // and costs the overlap between the two chunk pipelines (a fused launch fills every CU alone): -5 % (profiles/r05_call24_28_*).
+    // and costs the overlap between the two chunk pipelines (a fused launch fills every CU alone): -5 % (profiles/r05_call24_31_*).
     // LDM_X3_LNGEMM=1: no prologue (the first r05 structure).  The K-slab weight images are only built for what is selected.
     const int lv = (int)knob_int("LDM_X3_LNGEMM", 4);
     h->lngemm_pre = h->lngemm && h->Dp % 32 == 0 && h->Fp % 32 == 0 && h->D <= 480 && lv >= 2;
