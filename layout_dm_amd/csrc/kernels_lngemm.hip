@@ -14,7 +14,7 @@
 // next layer's AdaLN + in_proj and of the head — so that a layer is three launches besides the attention:
 //   [linear2 of layer l - 1 +] AdaLN + in_proj   |   attention   |   out_proj (gemm16x3_k)   |   norm2 + linear1 + ReLU
 //
-// Why: gemm16x3_k is bound by the per-CU operand fill path (37-40 GB/s per CU out of the L2), and a
+// Why: gemm16x3_k is bound by its operand fills (one 64-KiB stage in flight per ~1.7 us of fill latency), and a
 // 256 x 256 tile pulls FOUR images per stage (A hi, A lo, W hi, W lo).  Here a workgroup owns 128 rows for the whole GEMM —
 // the structure of the fast mode's stack kernel (kernels_stack.hip): their normalised hi / lo MFMA fragments sit in
 // registers (29 k16-steps x 2 x 4 registers per wave: hi in arch VGPRs, lo parked in AGPRs), only the WEIGHTS stream —
@@ -365,12 +365,13 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // GEMM prologue (PRE = true): acc[t] (15 tiles of 32 output columns, AGPRs) += A[rows, K] · Wpre[:, K]^T in fp16 x 3, the rows'
 // x = residual + bias + scale * acc then takes the place of the rows the plain kernel reads.  Same machinery as the tile loop —
-// 2-stage ring of 64-KiB weight stages by linear LDS-DMA, one s_waitcnt vmcnt(0) + s_barrier per stage, a 6-deep fragment
+// 2-stage ring of 64-KiB weight stages by linear LDS-DMA, one counted s_waitcnt vmcnt + s_barrier per stage, a fragment
 // queue that runs on across stages, one asm statement per item — with the roles turned: a stage is a K-SLAB (32 k = two
 // k16-steps of ALL 480 output columns, ldm_pack::pack_x3_slab_image), an item is (k16-step s, tile t) = 2 x 15 per stage, its three
 // MFMAs go to the persistent accumulator of tile t, and the A operand — the wave's 32 rows, 8 halves per lane and k16-step — comes
-// straight from global memory into registers, one stage ahead (plain loads: landed by the stage's vmcnt(0)).
-// Per workgroup: K / 32 stages x 64 KiB through the per-CU fill path (linear2: 58 stages = 3.7 MB ~ 95 us at 38 GB/s per CU, the
+// straight from global memory into registers, TWO stages ahead (plain loads into one of three register sets; the stage barrier's
+// counted vmcnt leaves the youngest four of them in flight).
+// Per workgroup: K / 32 stages x 64 KiB of weight slabs (linear2: 58 stages = 3.7 MB, the
 // same bytes gemm16x3_k's 256 x 256 tile pulls for BOTH operands) and no launch, no fp32 round trip of the sum, no epilogue.
 constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;   // items per stage
 // a 3-deep fragment queue (the tile loop: 6): 24 registers — what it saves holds the third A register set, which hides the HBM latency of
