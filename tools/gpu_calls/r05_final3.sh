@@ -2,7 +2,7 @@
 # Dev tool (GPU box): last check at HEAD — the GPU suite, the bench line exactly as the driver runs it (no flags), and the N > 1 code path
 # (RCCL init / all_gather / barrier / all_reduce) with one rank.
 set -u
-O=gpurun_out/r05_final3; mkdir -p $O
+O=gpurun_out/${1:-r05_final3}; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; tail -2 $O/bench.err
