@@ -206,6 +206,17 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
             # the matrix pipe runs its queue in order: the last stage's final MFMAs are still in flight when the stage loop falls through, and
             # hipcc (which cannot see asm MFMAs) puts its v_accvgpr_reads of the accumulator tiles right there — the wait states must sit inside
             # the asm statement of the stage's last item, in ALL THREE stage bodies (r05 call 24: logits error 3e-2 without them)
+            # the stage barrier's COUNTED wait (vmcnt(4)) is only right if the four youngest vector-memory operations in front of it are the
+            # A loads of stage + 2 — plain loads hipcc schedules — and everything older is a DMA piece: nothing else may sit between them
+            waits = [i for i, t in enumerate(instr) if t == "asm:s_waitcnt vmcnt(4)"]
+            assert len(waits) == 3, (name, len(waits))
+            for w in waits:
+                vm = [t for t in instr[max(0, w - 400):w] if t.split()[0].replace("asm:", "") in
+                      ("global_load_dwordx4", "global_load_lds_dwordx4", "global_load_dwordx2", "global_load_dword", "global_store_dwordx4",
+                       "global_store_dwordx2", "global_store_dword", "scratch_load_dword", "scratch_store_dword", "scratch_load_dwordx4",
+                       "scratch_store_dwordx4")]
+                assert [t.split()[0] for t in vm[-4:]] == ["global_load_dwordx4"] * 4, (name, vm[-6:])
+                assert vm[-5].startswith("asm:global_load_lds_dwordx4"), (name, vm[-6:])
             for last in (mf[89], mf[179], mf[269]):
                 tail = instr[last + 1:last + 8]
                 assert tail.count("asm:s_nop 15") == 2, (name, tail)
