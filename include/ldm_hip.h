@@ -248,6 +248,11 @@ int ldm_abi_version(void);
  * they are honoured only together with LDM_DEV=1, and ldm_create fails while one is set without it.
  * Writes at most cap - 1 characters + NUL; returns the length needed (ABI 5). */
 int ldm_describe(const ldm_handle* h, char* buf, int cap);
+
+/* Build provenance: "LDM_SRC_DIGEST=" followed by the sha256 (64 hex digits) of the sources this library was built from
+ * (layout_dm_amd/build.py source_digest(): csrc, this header, the source list and the flags).  build.py and binding.py compare
+ * it with the tree before loading a prebuilt library; ldm_describe reports it as src_digest. */
+extern const char ldm_build_source_digest[];
 /* layouts per chunk and number of concurrent lanes the handle was created with (after the 0 = auto defaults) */
 int ldm_get_layout(const ldm_handle* h, int* chunk, int* lanes);
 
