@@ -122,6 +122,7 @@ struct LgEpi {
   unsigned a_tpw, a_tpr;        // this lane's write / read address in the wave's transpose buffer (LDS bytes)
   const char *C0, *C1;          // output bases: fp32 C | fp16 hi, fp16 lo
   const char *b0, *b1;          // ... of the tile whose epilogue is in flight (uniform: + tile * 32 columns)
+  size_t tstride;               // bytes per tile in C0 / C1: 128 (fp32 rows) | 64 (fp16 rows) | 2 panels (OUT = 2: panel-major hi / lo)
   unsigned voff[4];             // this lane's byte offset in 8-row pass p: (row0 + 8 p + lane / 8) * ld + (lane & 7) * 4 columns
   unsigned long long rowmask[4];   // lanes whose row of pass p exists (row < M)
   unsigned long long colmask;   // lanes whose 4 columns of the tile in flight exist (col < N; N % 4 == 0)
@@ -171,8 +172,8 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
     // (tile == -1, the slices of the first tile's steps: an unsigned compare masks every lane — the passes run and store nothing)
     e.colmask = __ballot((unsigned)(tile * 32 + e.c4) < (unsigned)e.N);
     // (measurement variant 32: every tile stores to the columns of tile 0 — the same bytes per store, an L2-resident target)
-    e.b0 = e.C0 + ((ABL & 32) ? 0 : (size_t)tile * (OUT == 0 ? 128 : 64));
-    e.b1 = e.C1 + ((ABL & 32) ? 0 : (size_t)tile * 64);
+    e.b0 = e.C0 + ((ABL & 32) ? 0 : (size_t)tile * e.tstride);
+    e.b1 = e.C1 + ((ABL & 32) ? 0 : (size_t)tile * e.tstride);
   }
   if constexpr (IT == 2 || IT == 3) {
     constexpr int p0 = (IT - 2) * 2;
@@ -201,21 +202,25 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
                    : "memory");
     } else {
       unsigned h01, h23, l01, l23;
-      asm volatile(
-          "v_fma_f32 %[t0], %[e0], %[sc], %[b0]\n\tv_fma_f32 %[t1], %[e1], %[sc], %[b1]\n\t"
-          "v_fma_f32 %[t2], %[e2], %[sc], %[b2]\n\tv_fma_f32 %[t3], %[e3], %[sc], %[b3]\n\t"
-          "v_max_f32 %[t0], 0, %[t0]\n\tv_max_f32 %[t1], 0, %[t1]\n\tv_max_f32 %[t2], 0, %[t2]\n\tv_max_f32 %[t3], 0, %[t3]\n\t"
-          "v_cvt_pk_f16_f32 %[h01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[h23], %[t2], %[t3]\n\t"
-          // lo = v - float(hi): exact in fp32 (one fma_mix per value: -hi(f16 half of the pair) * 1.0 + v)
-          "v_fma_mix_f32 %[t0], -%[h01], 1.0, %[t0] op_sel_hi:[1,0,0]\n\t"
-          "v_fma_mix_f32 %[t1], -%[h01], 1.0, %[t1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-          "v_fma_mix_f32 %[t2], -%[h23], 1.0, %[t2] op_sel_hi:[1,0,0]\n\t"
-          "v_fma_mix_f32 %[t3], -%[h23], 1.0, %[t3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-          "v_cvt_pk_f16_f32 %[l01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[l23], %[t2], %[t3]"
-          : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [h01] "=&v"(h01), [h23] "=&v"(h23), [l01] "=&v"(l01),
-            [l23] "=&v"(l23)
-          : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
-            [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
+      // scale + bias, (ReLU,) hi = fp16(v), lo = fp16(v - float(hi)): exact in fp32 (one fma_mix per value: -hi(f16 half of the pair) * 1.0 + v)
+#define LG_SPLIT_PASS(RELU4)                                                                                                             \
+  asm volatile("v_fma_f32 %[t0], %[e0], %[sc], %[b0]\n\tv_fma_f32 %[t1], %[e1], %[sc], %[b1]\n\t"                                         \
+               "v_fma_f32 %[t2], %[e2], %[sc], %[b2]\n\tv_fma_f32 %[t3], %[e3], %[sc], %[b3]\n\t" RELU4                                   \
+               "v_cvt_pk_f16_f32 %[h01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[h23], %[t2], %[t3]\n\t"                                       \
+               "v_fma_mix_f32 %[t0], -%[h01], 1.0, %[t0] op_sel_hi:[1,0,0]\n\t"                                                          \
+               "v_fma_mix_f32 %[t1], -%[h01], 1.0, %[t1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                           \
+               "v_fma_mix_f32 %[t2], -%[h23], 1.0, %[t2] op_sel_hi:[1,0,0]\n\t"                                                          \
+               "v_fma_mix_f32 %[t3], -%[h23], 1.0, %[t3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                                           \
+               "v_cvt_pk_f16_f32 %[l01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[l23], %[t2], %[t3]"                                           \
+               : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [h01] "=&v"(h01), [h23] "=&v"(h23), [l01] "=&v"(l01),     \
+                 [l23] "=&v"(l23)                                                                                                         \
+               : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y), \
+                 [b2] "v"(e.bb.z), [b3] "v"(e.bb.w))
+      if constexpr (OUT == 1)
+        LG_SPLIT_PASS("v_max_f32 %[t0], 0, %[t0]\n\tv_max_f32 %[t1], 0, %[t1]\n\tv_max_f32 %[t2], 0, %[t2]\n\tv_max_f32 %[t3], 0, %[t3]\n\t");
+      else   // OUT == 2: q / k / v, no ReLU
+        LG_SPLIT_PASS("");
+#undef LG_SPLIT_PASS
       const lg_u32x2 H = {h01, h23}, L = {l01, l23};
       if constexpr (ABL & 16) asm volatile("" ::"v"(H), "v"(L));
       else if constexpr (ABL & 64)
@@ -693,6 +698,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   e.C0 = OUT == 0 ? reinterpret_cast<const char*>(a.C32) : reinterpret_cast<const char*>(a.C16);
   e.C1 = reinterpret_cast<const char*>(a.C16lo);
   e.b0 = e.C0; e.b1 = e.C1; e.colmask = 0;
+  e.tstride = OUT == 0 ? 128 : OUT == 1 ? 64 : 2 * a.panel_stride;
   e.N = a.N; e.c4 = (lane & 7) * 4;
   e.out_scale = a.out_scale;
 #pragma unroll
@@ -700,7 +706,10 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     const int orow = blockIdx.x * 128 + wave * 32 + p * 8 + (lane >> 3);
     e.rowmask[p] = __ballot(orow < a.M);
     // (launch_lngemm16x3 checks that M * ld * element size fits 32 bits)
-    e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
+    if constexpr (OUT == 2)   // panel-major: a tile is two panels of 16 columns; lanes 0-3 / 4-7 of a row's eight sit in the first / second
+      e.voff[p] = (unsigned)(e.c4 >> 4) * (unsigned)a.panel_stride + (unsigned)orow * 32u + (unsigned)(e.c4 & 15) * 2u;
+    else
+      e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
   }
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
@@ -750,23 +759,31 @@ void lngemm_phase_read(unsigned long long* out8) {
 }
 
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
-  if (a.D != 464 || a.n_tiles < 2 || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
-  // two output forms: fp32 (no ReLU) | ReLU + hi / lo fp16; the epilogue addresses with 32-bit byte offsets
+  // (everything LnGemmArgs documents or the kernel assumes is checked here, not only by ldm_create)
+  if (a.D != 464 || a.n_tiles < 2 || (a.n_tiles & 1) || a.n_tiles * 32 > 2048 || a.N > a.n_tiles * 32 || (a.N & 3) || a.M < 1) return -1;
+  if (a.tokens && a.S <= 0) return -1;
+  // three output forms: fp32 (no ReLU) | ReLU + hi / lo fp16 rows | hi / lo fp16 panels without ReLU (q / k / v for kernels_attnout.hip);
+  // the epilogue addresses with 32-bit byte offsets
   const bool half_out = a.C16 != nullptr;
-  if (half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu)) return -1;
-  if ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)) return -1;
-  static const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py)
+  const bool panel = half_out && a.panel_out;
+  if (panel ? (!a.C16lo || a.C32 || a.relu || !a.ada || (a.N & 15) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 32)
+            : half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu))
+    return -1;
+  if (panel ? (a.panel_stride + (unsigned long long)a.M * 32 >= (1ull << 32))
+            : ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)))
+    return -1;
+  const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py; read per launch: cheap, dev mode only)
   const bool pre = a.pre_img != nullptr;
   // GEMM prologue: a multiple of three 32-wide K slabs (zero slabs behind the pre_astages real ones), all d_model columns inside its 15 tiles, fp32 residual rows
   if (pre && (a.pre_stages < 3 || a.pre_stages % 3 || a.pre_astages < 2 || a.pre_astages > a.pre_stages || a.D > 32 * LP_NT || !a.preA ||
               !a.preAlo || !a.pre_res || a.tokens || a.pre_lda < 32 * a.pre_astages || (a.pre_lda & 7)))
     return -1;
-  auto kern = half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
-  if (pre) kern = half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;
-  if (tm && !pre) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
+  auto kern = panel ? lngemm16x3_k<true, 2> : half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
+  if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;
+  if (tm && !pre && !panel) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl_knob = (int)knob_int("LDM_LNGEMM_ABL", 0);
-  const int abl = pre ? 0 : abl_knob;
+  const int abl = (pre || panel) ? 0 : abl_knob;
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
   switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) LG_ABL(64) default: break; }
 #undef LG_ABL

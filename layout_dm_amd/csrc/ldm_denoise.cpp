@@ -132,10 +132,17 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.emb = h->emb; a.pos = h->pos; a.S = h->S;
       a.p0 = ss; a.p1 = ss + D; a.ada = 1;
       a.y32 = h->P;
-      a.img = (const char*)w.x3_qkv; a.n_tiles = h->x3_qkv_tiles;
-      a.bias = w.b_in; a.out_scale = w.s_in;
-      a.C32 = h->qkv32; a.ldc32 = 3 * D;
-      a.M = M; a.N = 3 * D; a.D = D;
+      a.out_scale = w.s_in;
+      a.M = M; a.D = D;
+      if (h->attnout) {   // q / k / v as head-padded hi / lo panels for the fused attention + out_proj launch (kernels_attnout.hip)
+        a.img = (const char*)w.x3_qkv_pad; a.n_tiles = 3 * h->H * 2;
+        a.bias = w.b_in_pad; a.N = 3 * h->H * 64;
+        a.C16 = h->qkvp_hi; a.C16lo = h->qkvp_lo; a.panel_out = 1; a.panel_stride = h->panel_rows * 32;
+      } else {
+        a.img = (const char*)w.x3_qkv; a.n_tiles = h->x3_qkv_tiles;
+        a.bias = w.b_in; a.N = 3 * D;
+        a.C32 = h->qkv32; a.ldc32 = 3 * D;
+      }
       const bool pre = h->pre_ffn2 && i > 0;   // x = Q + hid · W2^T + b2 of the PREVIOUS layer, computed in this launch (never stored)
       if (pre) ffn2_prologue(h, h->layers[i - 1], a);
       ldm_handle::Scope sc(h, st, pre ? "gemm_ffn2_qkv_ln" : "gemm_qkv_ln", gemm_flops(M, 3 * D, D) + (pre ? gemm_flops(M, D, F) : 0.0),
@@ -172,6 +179,16 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
         launch_gemm_mode(g, 0, st);
       }
     }
+    if (split && h->attnout) {  // attention + out-proj + residual in ONE layout-resident launch:  Q = P + softmax(q k^T) v · Wo^T + bo
+      AttnOutArgs a{};
+      a.qkv_hi = (const char*)h->qkvp_hi; a.qkv_lo = (const char*)h->qkvp_lo; a.panel_stride = h->panel_rows * 32;
+      a.w_img = (const char*)w.x3_out_kstep;
+      a.res = h->P; a.bias = w.b_out; a.out = h->Q;
+      a.S = h->S; a.D = D; a.scale = 1.0f / sqrtf((float)h->dh); a.out_scale = w.s_out;
+      ldm_handle::Scope sc(h, st, "attn_out_fused", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D),
+                           (double)M * 3 * h->H * 64 * 4 + (double)M * D * 8);
+      if (launch_attnout16x3(a, Bc, st)) return h->fail(-4, "fused attention + out_proj: geometry not supported");
+    } else {
     {  // attention
       AttnArgs a{};
       a.in_f16 = (prec == LDM_PREC_FAST_F16);
@@ -196,6 +213,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       g.M = M; g.N = D; g.K = f16 ? Dp : D; g.lda = f16 ? Dp : D; g.ldw = f16 ? Dp : D; g.precision = prec;
       ldm_handle::Scope sc(h, st, "gemm_attn_out", gemm_flops(M, D, D), (double)M * D * (esz + 8));
       launch_gemm_mode(g, 1, st);
+    }
     }
     if (split && h->lngemm) {  // LayerNorm 2 + FFN1 + ReLU in ONE row-resident launch: hi / lo hidden activations out
       LnGemmArgs a{};

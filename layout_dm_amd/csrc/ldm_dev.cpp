@@ -131,3 +131,130 @@ void stack_phase_read(unsigned long long* out16);
 }  // namespace ldm
 extern "C" void ldm_dev_stack_phases(unsigned long long* out16) { ldm::stack_phase_read(out16); }
 extern "C" void ldm_dev_lngemm_phases(unsigned long long* out8) { ldm::lngemm_phase_read(out8); }
+
+// Unit check of the split mode's fused attention + out_proj launch (kernels_attnout.hip) on synthetic operands against a float64
+// host computation of the same block: q / k / v (amplitude qk_amp / 1) -> hi / lo panels as in_proj's epilogue writes them, out_proj
+// weights with max |w| in [1, 2) (what ldm_weights.cpp make_w16's power-of-two pre-scale produces) -> k-step image, residual rows,
+// bias.  err_out[0] = max |out - ref| / max |ref - res| over the B layouts (every row, every column), err_out[1] = the same for a
+// computation from the fp16 hi parts only (what a dropped lo term would look like: the yardstick), err_out[2] = max |ref - res|.
+// tests/test_attnout_gpu.py.
+#include <cmath>
+
+#include "ldm_pack.h"
+// zero_lo (debugging aid): bit 0 / 1 / 2 / 3 = drop the lo halves of q / k / v / the weights from the INPUTS (kernel and reference alike)
+extern "C" int ldm_dev_attnout_check(int B, int S, float qk_amp, uint32_t seed, double* err_out, int zero_lo) {
+  const int H = 8, dh = 58, D = 464, NP = 96;
+  if (B < 1 || S < 1 || S > 128) return -1;
+  const size_t M = (size_t)B * S, rows = M + 64;
+  const size_t PS = rows * 32;
+  uint32_t s = seed * 2654435761u + 12345u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    return ((float)(s >> 8) / 8388608.0f) - 1.0f;
+  };
+  std::vector<float> q(M * H * dh), k(M * H * dh), v(M * H * dh), res(M * D), bias(D), wo((size_t)D * D);
+  for (auto& x : q) x = rnd() * qk_amp;
+  for (auto& x : k) x = rnd() * qk_amp;
+  for (auto& x : v) x = rnd();
+  for (auto& x : res) x = rnd() * 2.0f;
+  for (auto& x : bias) x = rnd() * 0.1f;
+  for (auto& x : wo) x = rnd() * 1.9f;
+  if (zero_lo & 16)   // (debug: W = 32 I, so that out - res - bias IS the attention output)
+    for (int n = 0; n < D; ++n)
+      for (int kk = 0; kk < D; ++kk) wo[(size_t)n * D + kk] = n == kk ? 32.0f : 0.0f;
+  const float out_scale = 1.0f / 32.0f;
+  auto split = [&](float x, uint16_t& hi, uint16_t& lo) {
+    const __half hh = __float2half(x);
+    const __half ll = __float2half(x - __half2float(hh));
+    memcpy(&hi, &hh, 2);
+    memcpy(&lo, &ll, 2);
+  };
+  std::vector<uint16_t> ph((size_t)NP * rows * 16, 0), pl((size_t)NP * rows * 16, 0);
+  const std::vector<float>* src[3] = {&q, &k, &v};
+  for (int which = 0; which < 3; ++which)
+    for (size_t r = 0; r < M; ++r)
+      for (int h = 0; h < H; ++h)
+        for (int d = 0; d < dh; ++d) {
+          const size_t pn = (size_t)(which * H + h) * 4 + d / 16;
+          split((*src[which])[(r * H + h) * dh + d], ph[(pn * rows + r) * 16 + d % 16], pl[(pn * rows + r) * 16 + d % 16]);
+          if (zero_lo & (1 << which)) pl[(pn * rows + r) * 16 + d % 16] = 0;
+        }
+  std::vector<uint16_t> wh((size_t)D * 512, 0), wl((size_t)D * 512, 0);
+  for (int n = 0; n < D; ++n)
+    for (int kk = 0; kk < D; ++kk) {
+      split(wo[(size_t)n * D + kk], wh[(size_t)n * 512 + kk], wl[(size_t)n * 512 + kk]);
+      if (zero_lo & 8) wl[(size_t)n * 512 + kk] = 0;
+    }
+  const std::vector<uint16_t> img = ldm_pack::pack_x3_kstep_image(wh.data(), wl.data(), D, 512, H, dh);
+  DevScope dv;
+  char *dph = nullptr, *dpl = nullptr, *dimg = nullptr;
+  float *dres = nullptr, *dbias = nullptr, *dout = nullptr;
+  if (!dv.alloc(&dph, ph.size() * 2, ph.data()) || !dv.alloc(&dpl, pl.size() * 2, pl.data()) || !dv.alloc(&dimg, img.size() * 2, img.data()) ||
+      !dv.alloc(&dres, res.size() * 4, res.data()) || !dv.alloc(&dbias, bias.size() * 4, bias.data()) || !dv.alloc(&dout, res.size() * 4))
+    return -3;
+  AttnOutArgs a{};
+  a.qkv_hi = dph; a.qkv_lo = dpl; a.panel_stride = PS; a.w_img = dimg; a.res = dres; a.bias = dbias; a.out = dout;
+  a.S = S; a.D = D; a.scale = 1.0f / sqrtf((float)dh); a.out_scale = out_scale;
+  if (launch_attnout16x3(a, B, 0)) return -4;
+  std::vector<float> out(res.size());
+  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess ||
+      hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return -2;
+  double e_full = 0, e_hi = 0, mag = 0;
+  for (int i = 3; i < 25; ++i) err_out[i] = 0;   // (debug: [3..5] location of the maximum, [6..9] per wave, [10..24] per column tile)
+  auto h2d = [&](uint16_t u) {
+    __half hh;
+    memcpy(&hh, &u, 2);
+    return (double)__half2float(hh);
+  };
+  std::vector<double> att((size_t)S * H * dh), att_hi((size_t)S * H * dh), p(S);
+  for (int b = 0; b < B; ++b) {
+    for (int variant = 0; variant < 2; ++variant) {   // 0: full values, 1: fp16 hi parts only
+      std::vector<double>& o = variant ? att_hi : att;
+      auto val = [&](int which, size_t r, int h, int d) {
+        const size_t pn = (size_t)(which * H + h) * 4 + d / 16, i = (pn * rows + r) * 16 + d % 16;
+        return variant ? h2d(ph[i]) : h2d(ph[i]) + h2d(pl[i]);
+      };
+      for (int h = 0; h < H; ++h)
+        for (int i = 0; i < S; ++i) {
+          double mx = -1e300;
+          for (int j = 0; j < S; ++j) {
+            double sc = 0;
+            for (int d = 0; d < dh; ++d) sc += val(0, (size_t)b * S + i, h, d) * val(1, (size_t)b * S + j, h, d);
+            p[j] = sc * (double)a.scale;
+            mx = std::max(mx, p[j]);
+          }
+          double sum = 0;
+          for (int j = 0; j < S; ++j) sum += (p[j] = std::exp(p[j] - mx));
+          for (int d = 0; d < dh; ++d) {
+            double acc = 0;
+            for (int j = 0; j < S; ++j) acc += p[j] * val(2, (size_t)b * S + j, h, d);
+            o[((size_t)i * H + h) * dh + d] = acc / sum;
+          }
+        }
+    }
+    for (int i = 0; i < S; ++i)
+      for (int n = 0; n < D; ++n) {
+        double acc = 0, acc_hi = 0;
+        for (int kk = 0; kk < D; ++kk) {
+          acc += att[(size_t)i * D + kk] * (h2d(wh[(size_t)n * 512 + kk]) + h2d(wl[(size_t)n * 512 + kk]));
+          acc_hi += att_hi[(size_t)i * D + kk] * h2d(wh[(size_t)n * 512 + kk]);
+        }
+        const size_t idx = ((size_t)b * S + i) * D + n;
+        const double ref = (double)res[idx] + (double)bias[n] + acc * out_scale;
+        const double ref_hi = (double)res[idx] + (double)bias[n] + acc_hi * out_scale;
+        mag = std::max(mag, std::fabs(ref - (double)res[idx]));
+        if (std::fabs((double)out[idx] - ref) > e_full) { err_out[3] = b; err_out[4] = i; err_out[5] = n; }
+        e_full = std::max(e_full, std::fabs((double)out[idx] - ref));
+        if ((zero_lo & 16) && std::fabs((double)out[idx] - ref) > 3e-6)
+          printf("  row %d col %d (head %d d %d): got %.9g ref %.9g diff %.3e\n", i, n, n / dh, n % dh, (double)out[idx] - res[idx] - bias[n], ref - res[idx] - bias[n], (double)out[idx] - ref);
+        err_out[6 + i / 32] = std::max(err_out[6 + i / 32], std::fabs((double)out[idx] - ref));          // per wave
+        err_out[10 + n / 32] = std::max(err_out[10 + n / 32], std::fabs((double)out[idx] - ref));        // per column tile
+        e_hi = std::max(e_hi, std::fabs(ref_hi - ref));
+      }
+  }
+  err_out[0] = e_full / mag;
+  err_out[1] = e_hi / mag;
+  err_out[2] = mag;
+  return 0;
+}

@@ -75,6 +75,10 @@ struct LayerW {
   float s_in = 1.f, s_out = 1.f, s1 = 1.f, s2 = 1.f;  // split mode: 2^-k of each tensor's power-of-two pre-scale (GemmArgs.out_scale)
   void *x3_qkv = nullptr, *x3_ffn1 = nullptr;         // split mode: hi | lo tile images of in_proj / linear1 (kernels_lngemm.hip)
   void *x3_out_slab = nullptr, *x3_ffn2_slab = nullptr;   // ... K-slab images of out_proj / linear2 (its GEMM prologue, lngemm level 2)
+  // r06, fused attention + out_proj (kernels_attnout.hip): in_proj with head-padded output columns (48 tiles, bias [1536]) and
+  // out_proj as a k-step image (ldm_pack::pack_x3_kstep_image)
+  void *x3_qkv_pad = nullptr, *x3_out_kstep = nullptr;
+  float* b_in_pad = nullptr;
 };
 
 struct ProfEntry {
@@ -149,6 +153,10 @@ struct ldm_handle {
   bool pre_out = false, pre_ffn2 = false;   // ... which of the two (dev: LDM_X3_LNGEMM=3 / 4 = only out_proj / only linear2)
   void* x3_head = nullptr;
   int x3_qkv_tiles = 0, x3_ffn1_tiles = 0, x3_head_tiles = 0;
+  // r06: attention and out_proj of the split mode as ONE layout-resident launch (kernels_attnout.hip); q / k / v travel from in_proj
+  // to it as head-padded hi / lo fp16 PANELS (qkvp_hi / qkvp_lo: [96][panel_rows][16]); LDM_DEV=1 LDM_X3_ATTNOUT=0: attn16x3_k + gemm16x3_k
+  bool attnout = false;
+  size_t panel_rows = 0;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)
@@ -159,7 +167,7 @@ struct ldm_handle {
   float *P = nullptr, *Q = nullptr, *qkv32 = nullptr, *att32 = nullptr, *h32 = nullptr, *hid32 = nullptr,
         *logits = nullptr;
   __half *a16 = nullptr, *a16lo = nullptr, *qkv16 = nullptr, *att16 = nullptr, *att16lo = nullptr, *h16 = nullptr,
-         *h16lo = nullptr, *hid16 = nullptr, *hid16lo = nullptr;
+         *h16lo = nullptr, *hid16 = nullptr, *hid16lo = nullptr, *qkvp_hi = nullptr, *qkvp_lo = nullptr;
   // Lanes: chunks c, c + n_lanes, ... form lane (c % n_lanes); every lane has its own workspace, stream and
   // captured graph, and the lanes run CONCURRENTLY, lane l starting l * lane_offset_us late.  Why: the fused
   // kernels alternate HBM-bound phases (row loads / stores, ~30 % of a block) with MFMA-bound phases, and with one
@@ -167,7 +175,7 @@ struct ldm_handle {
   // idles).  Two half-chip kernels out of phase halve each burst (profiles/r02_call2_phase_vs_blocks.txt).
   struct Workspace {
     float *P, *Q, *qkv32, *att32, *h32, *hid32, *logits, *rel_logp;
-    __half *a16, *a16lo, *qkv16, *att16, *att16lo, *h16, *h16lo, *hid16, *hid16lo;
+    __half *a16, *a16lo, *qkv16, *att16, *att16lo, *h16, *h16lo, *hid16, *hid16lo, *qkvp_hi, *qkvp_lo;
     float2 *stats_a, *stats_b;
   };
   std::vector<Workspace> ws;
@@ -177,7 +185,7 @@ struct ldm_handle {
   int n_lanes = 1, lane_offset_us = 0, cur_lane = -1;
   void save_ws(int l) {
     ws[l] = Workspace{P, Q, qkv32, att32, h32, hid32, logits, rel_logp, a16, a16lo, qkv16, att16, att16lo,
-                      h16, h16lo, hid16, hid16lo, stats_a, stats_b};
+                      h16, h16lo, hid16, hid16lo, qkvp_hi, qkvp_lo, stats_a, stats_b};
   }
   void activate(int l) {
     if (l == cur_lane) return;
@@ -185,7 +193,8 @@ struct ldm_handle {
     const Workspace& w = ws[l];
     P = w.P; Q = w.Q; qkv32 = w.qkv32; att32 = w.att32; h32 = w.h32; hid32 = w.hid32; logits = w.logits;
     rel_logp = w.rel_logp; a16 = w.a16; a16lo = w.a16lo; qkv16 = w.qkv16; att16 = w.att16; att16lo = w.att16lo;
-    h16 = w.h16; h16lo = w.h16lo; hid16 = w.hid16; hid16lo = w.hid16lo; stats_a = w.stats_a; stats_b = w.stats_b;
+    h16 = w.h16; h16lo = w.h16lo; hid16 = w.hid16; hid16lo = w.hid16lo; qkvp_hi = w.qkvp_hi; qkvp_lo = w.qkvp_lo;
+    stats_a = w.stats_a; stats_b = w.stats_b;
     cur_lane = l;
   }
   // fast-mode (fp16 LDS-DMA GEMM + MFMA attention) layout: K padded to 64, heads padded 58 -> 64

@@ -96,6 +96,10 @@ struct LnGemmArgs {
   __half *C16, *C16lo;      // [M, ldc16] hi / lo, or nullptr
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
+  // r06: hi / lo fp16 output WITHOUT ReLU in PANEL-major form (in_proj in front of kernels_attnout.hip): C16 / C16lo are arrays
+  // [N / 16 panels][panel_rows][16 halfs] — column c of row r at panel c / 16, byte r * 32 + (c % 16) * 2; ldc16 is ignored
+  int panel_out;
+  size_t panel_stride;      // bytes between panels (>= (M + slack) * 32, a multiple of 16)
   // GEMM prologue (pre_img != nullptr): x = pre_res + pre_bias + pre_scale * (preA · Wpre^T) is computed by the kernel itself instead
   // of being read — out_proj in front of norm2 + linear1, linear2 in front of the next AdaLN + in_proj / of the head
   const __half *preA, *preAlo;   // [M, pre_lda] hi / lo rows (attention output / hidden activations), K = 32 * pre_stages columns read
@@ -212,6 +216,25 @@ void launch_attention(const AttnArgs& a, hipStream_t st);
 bool attention16x3_supported(int S, int dh, int D, int ld, int ldo);
 void launch_attention16x3(const float* qkv, __half* out_hi, __half* out_lo, int B, int S, int H, int dh, int D, int ld,
                           int ldo, hipStream_t st);
+
+// split mode, r06 (kernels_attnout.hip): attention AND out_proj in one launch, one workgroup per layout:
+//   out[row, :] = res[row, :] + bias + out_scale * sum_h softmax(q_h k_h^T * scale) v_h · Wo_h^T
+// q / k / v arrive head-padded and PANEL-major from in_proj's epilogue (kernels_lngemm.hip, panel_out): hi and lo fp16 arrays
+// [3 * 8 * 4 panels][rows][16], panel (which * 8 + head) * 4 + d / 16, panel_stride bytes apart; the kernel reads up to 128 rows per
+// layout (rows S .. 127 belong to the next layout or to the buffer's slack: finite values, masked).
+struct AttnOutArgs {
+  const char *qkv_hi, *qkv_lo;   // panel arrays
+  size_t panel_stride;           // bytes, a multiple of 16
+  const char* w_img;             // ldm_pack::pack_x3_kstep_image of out_proj: 32 stages x 32 KiB
+  const float* res;              // [M, D] residual rows (AdaLN(x))
+  const float* bias;             // [D] out_proj bias
+  float* out;                    // [M, D]
+  int S, D;
+  float scale;                   // 1 / sqrt(head dim)
+  float out_scale;               // 2^-k of out_proj's power-of-two pre-scale
+};
+bool attnout16x3_supported(int S, int H, int dh, int D);
+int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st);   // -1: geometry not supported
 
 // ---- posterior + categorical draw (kernels_post.hip) ------------------------------------
 struct VocabTables {  // built on the host from the tokenizer geometry (layout_tokenizer.py:429-467)

@@ -173,4 +173,27 @@ inline std::vector<uint16_t> pack_x3_slab_image(const uint16_t* hi, const uint16
   return img;
 }
 
+// k-step image of out_proj for the fused attention + out_proj kernel of the split mode (kernels_attnout.hip).  hi / lo: [N rows][ld]
+// fp16, natural K order (k = head * dh + d).  One 32-KiB stage per (head, k16-step s of the head's 64 padded d): hi half at byte 0, lo
+// half at byte 16 384; a half is 480 rows (output columns, zero beyond N) x 32 B = two 16-byte chunks, chunk g of row n at physical
+// chunk g ^ ((n >> 3) & 1) (conflict-free ds_read_b128 by (column, k half) lanes).  Chunk g, element e holds d = 16 s + 8 (e >> 2) + 4 g +
+// (e & 3) — MFMA k-slot order (kslot above): the attention output's accumulator registers 8 s' .. 8 s' + 7 of d tile s / 2 (s' = s & 1)
+// ARE the B operand of the stage; zero for d >= dh.
+inline std::vector<uint16_t> pack_x3_kstep_image(const uint16_t* hi, const uint16_t* lo, int N, int ld, int H, int dh) {
+  std::vector<uint16_t> img((size_t)H * 4 * 16384, 0);
+  for (int hh = 0; hh < H; ++hh)
+    for (int s = 0; s < 4; ++s)
+      for (int part = 0; part < 2; ++part) {
+        const uint16_t* src = part ? lo : hi;
+        uint16_t* dst = img.data() + (size_t)(hh * 4 + s) * 16384 + part * 8192;
+        for (int n = 0; n < N && n < 480; ++n)
+          for (int g = 0; g < 2; ++g)
+            for (int e = 0; e < 8; ++e) {
+              const int d = 16 * s + 8 * (e >> 2) + 4 * g + (e & 3);
+              if (d < dh) dst[n * 16 + ((g ^ ((n >> 3) & 1)) << 3) + e] = src[(size_t)n * ld + hh * dh + d];
+            }
+      }
+  return img;
+}
+
 }  // namespace ldm_pack

@@ -2,6 +2,8 @@
 // fp16 / split copies, the LDS weight images and parameter tables of the layout-resident kernels (ldm_pack.h).
 #include "ldm_handle.h"
 
+#include <functional>
+
 using namespace ldm_host;
 
 // ------------------------------------------------------------------------------------------ weights
@@ -82,23 +84,37 @@ static int make_w16(ldm_handle* h, const float* w, int N, int K, int Kp, __half*
     HIP_OK(h, hipMemcpy2DAsync(*hi, (size_t)Kp * 2, thi, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
     if (split)
       HIP_OK(h, hipMemcpy2DAsync(*lo, (size_t)Kp * 2, tlo, (size_t)K * 2, (size_t)K * 2, N, hipMemcpyDeviceToDevice, 0));
+    // (the unpadded temporaries are not kept until the next finalize)
+    HIP_OK(h, hipStreamSynchronize(0));
+    for (__half* t : {thi, tlo}) {
+      if (!t) continue;
+      auto& v = h->to_derived ? h->derived : h->owned;
+      v.erase(std::remove(v.begin(), v.end(), (void*)t), v.end());
+      (void)hipFree(t);
+    }
   }
   return 0;
 }
 
 // hi | lo tile image of a split-mode weight for the row-resident x3 GEMM (kernels_lngemm.hip): the [>= 32 n_tiles][Kp = 512] hi / lo
 // copies make_w16 built (natural K order) -> K axis in k-slot order -> ldm_pack::pack_x3_tile_image
-static int make_x3_image(ldm_handle* h, const __half* hi, const __half* lo, int n_tiles, void** out) {
+// rowmap (optional): image row rowmap(r) <- weight row r for the n_src first rows, every other image row zero (the head-padded in_proj
+// in front of kernels_attnout.hip: ldm_pack::qkv_row)
+static int make_x3_image(ldm_handle* h, const __half* hi, const __half* lo, int n_tiles, void** out, int n_src = 0,
+                         const std::function<int(int)>& rowmap = nullptr) {
   const size_t n = (size_t)n_tiles * 32 * 512;
-  std::vector<uint16_t> a(n), b(n), ak(n, 0), bk(n, 0);
+  const int rows = rowmap ? n_src : n_tiles * 32;
+  std::vector<uint16_t> a((size_t)rows * 512), b((size_t)rows * 512), ak(n, 0), bk(n, 0);
   HIP_OK(h, hipDeviceSynchronize());  // (the cast kernels of make_w16)
-  HIP_OK(h, hipMemcpy(a.data(), hi, n * 2, hipMemcpyDeviceToHost));
-  HIP_OK(h, hipMemcpy(b.data(), lo, n * 2, hipMemcpyDeviceToHost));
-  for (int r = 0; r < n_tiles * 32; ++r)
+  HIP_OK(h, hipMemcpy(a.data(), hi, a.size() * 2, hipMemcpyDeviceToHost));
+  HIP_OK(h, hipMemcpy(b.data(), lo, b.size() * 2, hipMemcpyDeviceToHost));
+  for (int r = 0; r < rows; ++r) {
+    const size_t d = (size_t)(rowmap ? rowmap(r) : r) * 512;
     for (int k = 0; k < 512; ++k) {
-      ak[(size_t)r * 512 + ldm_pack::kslot(k)] = a[(size_t)r * 512 + k];
-      bk[(size_t)r * 512 + ldm_pack::kslot(k)] = b[(size_t)r * 512 + k];
+      ak[d + ldm_pack::kslot(k)] = a[(size_t)r * 512 + k];
+      bk[d + ldm_pack::kslot(k)] = b[(size_t)r * 512 + k];
     }
+  }
   const std::vector<uint16_t> img = ldm_pack::pack_x3_tile_image(ak.data(), bk.data(), n_tiles);
   __half* d = nullptr;
   int rc = h->dalloc(&d, img.size(), false);
@@ -116,6 +132,22 @@ static int make_x3_slab(ldm_handle* h, const __half* hi, const __half* lo, int N
   HIP_OK(h, hipMemcpy(a.data(), hi, n * 2, hipMemcpyDeviceToHost));
   HIP_OK(h, hipMemcpy(b.data(), lo, n * 2, hipMemcpyDeviceToHost));
   const std::vector<uint16_t> img = ldm_pack::pack_x3_slab_image(a.data(), b.data(), N, ld, K);
+  __half* d = nullptr;
+  int rc = h->dalloc(&d, img.size(), false);
+  if (rc) return rc;
+  HIP_OK(h, hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+  *out = d;
+  return 0;
+}
+
+// k-step image (ldm_pack::pack_x3_kstep_image) of out_proj's split copies [D][ld] for kernels_attnout.hip
+static int make_x3_kstep(ldm_handle* h, const __half* hi, const __half* lo, int N, int ld, void** out) {
+  const size_t n = (size_t)N * ld;
+  std::vector<uint16_t> a(n), b(n);
+  HIP_OK(h, hipDeviceSynchronize());  // (the cast kernels of make_w16)
+  HIP_OK(h, hipMemcpy(a.data(), hi, n * 2, hipMemcpyDeviceToHost));
+  HIP_OK(h, hipMemcpy(b.data(), lo, n * 2, hipMemcpyDeviceToHost));
+  const std::vector<uint16_t> img = ldm_pack::pack_x3_kstep_image(a.data(), b.data(), N, ld, h->H, h->dh);
   __half* d = nullptr;
   int rc = h->dalloc(&d, img.size(), false);
   if (rc) return rc;
@@ -318,6 +350,7 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
   // everything below is derived from the checkpoint: drop what an earlier finalize built (nothing may still be running on it),
   // then collect the new allocations in h->derived
   HIP_OK(h, hipDeviceSynchronize());
+  h->finalized = false;   // (a finalize that fails part-way must not leave an earlier success standing over freed images)
   for (auto& g : h->graphs) g.destroy();
   h->graphs.clear();
   for (void* p : h->derived) (void)hipFree(p);
@@ -362,6 +395,16 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
       if (h->lngemm) {
         if ((rc = make_x3_image(h, w.w_in16, w.w_in16lo, h->x3_qkv_tiles, &w.x3_qkv))) return rc;
         if ((rc = make_x3_image(h, w.w1_16, w.w1_16lo, h->x3_ffn1_tiles, &w.x3_ffn1))) return rc;
+      }
+      if (h->attnout) {   // in_proj with head-padded output columns (+ bias), out_proj as per-(head, k16-step) stages
+        const int H = h->H, dh = h->dh;
+        if ((rc = make_x3_image(h, w.w_in16, w.w_in16lo, 3 * H * 2, &w.x3_qkv_pad, 3 * D, [=](int n) { return ldm_pack::qkv_row(n, D, H, dh); }))) return rc;
+        std::vector<float> b(3 * D), bp((size_t)3 * H * 64, 0.f);
+        HIP_OK(h, hipMemcpy(b.data(), w.b_in, b.size() * 4, hipMemcpyDeviceToHost));
+        for (int n = 0; n < 3 * D; ++n) bp[ldm_pack::qkv_row(n, D, H, dh)] = b[n];
+        if ((rc = h->dalloc(&w.b_in_pad, bp.size(), false))) return rc;
+        HIP_OK(h, hipMemcpy(w.b_in_pad, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+        if ((rc = make_x3_kstep(h, w.w_out16, w.w_out16lo, D, h->Dp, &w.x3_out_kstep))) return rc;
       }
       if (h->pre_out && (rc = make_x3_slab(h, w.w_out16, w.w_out16lo, D, h->Dp, h->Dp, &w.x3_out_slab))) return rc;
       if (h->pre_ffn2 && (rc = make_x3_slab(h, w.w2_16, w.w2_16lo, D, h->Fp, h->Fp, &w.x3_ffn2_slab))) return rc;

@@ -253,6 +253,32 @@ int main() {
           }
         }
   }
+  {  // k-step image of out_proj for the fused attention + out_proj kernel (kernels_attnout.hip: lane (column m, k half g) of tile t reads 16
+     // bytes at stage + t * 1 KiB + m * 32 + ((g ^ ((m >> 3) & 1)) << 4), lo half + 16 KiB; stage = head * 4 + s; element e = the attention
+     // output d = f_slot(s & 1, g, e) of d tile s >> 1, i.e. accumulator register 8 (s & 1) + e of the lane's O^T tile)
+    const int N = 464, ld = 512;
+    std::vector<uint16_t> hi((size_t)N * ld), lo((size_t)N * ld);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < ld; ++k) {
+        hi[(size_t)n * ld + k] = id16(n + 11, k);
+        lo[(size_t)n * ld + k] = id16(n + 21000, k);
+      }
+    const std::vector<uint16_t> img = ldm_pack::pack_x3_kstep_image(hi.data(), lo.data(), N, ld, H, dh);
+    CHECK(img.size() == (size_t)H * 4 * 16384, "x3 k-step image size");
+    for (int hh = 0; hh < H; ++hh) for (int s = 0; s < 4; ++s) for (int part = 0; part < 2; ++part)
+      for (int t = 0; t < 15; ++t) for (int m = 0; m < 32; ++m) for (int g = 0; g < 2; ++g) {
+        const size_t byte = (size_t)(hh * 4 + s) * 32768 + part * 16384 + t * 1024 + m * 32 + ((g ^ ((m >> 3) & 1)) << 4);
+        const uint16_t* p = img.data() + byte / 2;
+        for (int e = 0; e < 8; ++e) {
+          const int n = t * 32 + m, d = 32 * (s >> 1) + f_slot(s & 1, g, e);
+          const uint16_t want = (n < N && d < dh) ? id16(n + (part ? 21000 : 11), hh * dh + d) : 0;
+          CHECK(p[e] == want, "x3 k-step head=%d s=%d part=%d t=%d m=%d g=%d e=%d", hh, s, part, t, m, g, e);
+        }
+      }
+    // the 1 KiB behind each 15-KiB half (rows 480 .. 511) is never read and stays zero
+    for (int st = 0; st < H * 4; ++st) for (int part = 0; part < 2; ++part)
+      for (int i = 480 * 16; i < 8192; ++i) CHECK(img[(size_t)st * 16384 + part * 8192 + i] == 0, "x3 k-step padding not zero");
+  }
   if (fails) { printf("FAILED: %d mismatches\n", fails); return 1; }
   printf("OK: FFN image (58 chunks) and attention image (63 tiles + pad) match the kernels' read formulas\n");
   return 0;
