@@ -17,13 +17,20 @@
 // every product as hi·hi + lo·hi + hi·lo on v_mfma_f32_32x32x16_f16 (lo unscaled, ldm_kernels.h kSplitLoScale; P scaled by 2^10
 // before its split as in attn16x3_k; Wo pre-scaled by a power of two per tensor, undone by out_scale).
 //
-// Operands.  in_proj writes q / k / v head-padded (58 -> 64) and PANEL-major: hi and lo arrays [96 panels][rows][16 halfs], panel
-// (which * 8 + head) * 4 + d / 16 — a layout's 125 rows of a panel are 4 000 contiguous bytes.
-//   K, V   whole-panel LDS-DMA (global_load_lds_dwordx4: no staging registers) into [panel][key][32 B] images; the DMA's per-lane
-//          SOURCE address applies the bank swizzle (16-byte chunk ^ key bit 3; odd panels: key ^ 4) so that the image is linear in
-//          LDS.  K fragments by ds_read_b128; V is needed TRANSPOSED (the contraction runs over keys): ds_read_b64_tr_b16 reads
-//          a [4 keys][16 d] block per 16-lane group and hands each lane its d column — no transposed copy of V anywhere.
-//   Q      straight from global memory into fragment registers (a wave's 32 rows x 32 B of a panel are 1 KiB contiguous).
+// Operands.  in_proj writes q / k / v head-padded (58 -> 64) and PANEL-major: hi and lo arrays [48 panels][rows][32 halfs], panel
+// (which * 8 + head) * 2 + d / 32 — a layout's 125 rows of a panel are 8 000 contiguous bytes, 16 rows are one 1-KiB DMA piece.
+//   K, V   whole-head LDS-DMA (global_load_lds_dwordx4: no staging registers); the DMA's per-lane SOURCE address permutes the 16-byte
+//          chunks inside each 1-KiB piece, the destination is linear:
+//            K image  [d / 32][key][64 B], chunk c of a key at c ^ ((key >> 2) & 3)  (the W2-slab format of the fused FFN: conflict-free
+//                     ds_read_b128 by (key, k half) lanes);
+//            V image  [d / 32][key / 4][(d / 16) & 1][key % 4][32 B]: V is needed TRANSPOSED (the contraction runs over keys) and
+//                     ds_read_b64_tr_b16 does that in the LDS pipe — a 16-lane group reads a [4 keys][16 d] block and every lane
+//                     receives its d column (cdna_hip_programming.md T10).  In this image the four blocks of one read — (d half 0 / 1)
+//                     x (key quad q, q + 1): exactly what the MFMA A operand's lanes 0-15 / 16-31 / 32-47 / 48-63 hold — are 512
+//                     CONTIGUOUS bytes, lane l at + 8 l: the guide's conflict-free form.  (r06 first form: [d / 16][key][32 B] with
+//                     an XOR swizzle, conflict-free under the plain 64-bank model of MI355X_MICROARCH.md, ran the P V phase at
+//                     7 400 cycles per head instead of ~1 700: the transpose read has its own conflict classes.)
+//   Q      straight from global memory into fragment registers.
 //   Wo     k-step image (ldm_pack::pack_x3_kstep_image): per (head, k16-step) one 32-KiB stage = hi | lo of 480 rows x 32 B, by
 //          linear LDS-DMA through a 3-slot ring; L2-resident (1 MiB per layer, every workgroup streams the same bytes).
 // Schedule per head: S^T | softmax | P V | 4 out_proj stages, six workgroup barriers, each behind a COUNTED s_waitcnt vmcnt: the
@@ -54,11 +61,19 @@ __device__ __forceinline__ void ao_dma8(unsigned voff, const char* g0, unsigned 
   dma_lin4(voff, g1, l1);
 }
 
-template <int N>
-__device__ __forceinline__ void ao_sync() {   // everything but the N youngest vector-memory operations of this wave landed; then everybody's
+__device__ unsigned long long g_attnout_phase[24];   // TM instantiation (tools/attnout_probe.py phases): see attnout_phase_read
+template <int N, bool TM = false>
+__device__ __forceinline__ void ao_sync(unsigned long long* tw = nullptr, unsigned long long* tb = nullptr) {   // everything but the N youngest vector-memory operations of this wave landed; then everybody's
+  unsigned long long t0 = 0, t1 = 0;
+  if constexpr (TM) t0 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+  if constexpr (TM) t1 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if constexpr (TM) {
+    *tw += t1 - t0;
+    *tb += __builtin_amdgcn_s_memtime() - t1;
+  }
 }
 
 template <int OFF>
@@ -136,7 +151,15 @@ __device__ __forceinline__ void ao_split8(const float (&x)[8], f16x8& hi, f16x8&
 
 }  // namespace
 
+template <bool TM>
 __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
+  // (TM: cycles in the counted vmcnt waits [0..5] and in the barriers behind them [6..11] per sync site Ba Bb Bc Bd1 Bd2 Bd3, the
+  //  head loop [12], the epilogue [13], the whole kernel [14], workgroups [15])
+  unsigned long long tw[6] = {0, 0, 0, 0, 0, 0}, tb[6] = {0, 0, 0, 0, 0, 0}, t_k0 = 0, t_l0 = 0, t_l1 = 0;
+  unsigned long long tp[5] = {0, 0, 0, 0, 0}, tq = 0;   // [16..20]: softmax | P V | O split | out_proj stages (without their syncs) | scores
+#define AO_T0() do { if constexpr (TM) tq = __builtin_amdgcn_s_memtime(); } while (0)
+#define AO_T1(i) do { if constexpr (TM) tp[i] += __builtin_amdgcn_s_memtime() - tq; } while (0)
+  if constexpr (TM) t_k0 = __builtin_amdgcn_s_memtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,27 +171,30 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   const int q = wave * 32 + m;                            // this lane's query row inside the layout
 
   // ---- addresses
-  // K / V whole-panel DMA: wave w moves panel w of the head (hi and lo: 4 + 4 pieces).  LDS slot (piece j, lane l) = row position
-  // 32 j + l / 2, physical chunk l & 1; it receives key = position ^ (4 on odd panels), logical chunk = physical ^ key bit 3.
-  const unsigned pos_l = (unsigned)lane >> 1;
-  const unsigned voff_kv = ((pos_l ^ ((wave & 1) ? 4u : 0u)) << 5) | ((((unsigned)lane & 1u) ^ ((pos_l >> 3) & 1u)) << 4);
-  const unsigned voff_lin = (unsigned)lane * 16;
-  // per head: panels (which * 8 + head) * 4 + wave, rows row0 ..
-  const char* gq_hi = a.qkv_hi + row0 * 32;               // + panel * PS
-  const char* gq_lo = a.qkv_lo + row0 * 32;
-  // fragment addresses (LDS bytes): K rows / Wo rows by (m, g); V blocks by 16-lane group
-  const unsigned a_row = ((unsigned)m << 5) | ((((unsigned)g) ^ (((unsigned)m >> 3) & 1u)) << 4);          // even panels, Wo stages
-  const unsigned a_row_odd = ((((unsigned)m) ^ 4u) << 5) | ((((unsigned)g) ^ (((unsigned)m >> 3) & 1u)) << 4);   // odd K panels
-  const unsigned G = (unsigned)lane >> 4, sl = (unsigned)lane & 15u;
-  const unsigned v_key0 = (4u * (G >> 1) + (sl >> 2)) ^ (4u * (G & 1u));
-  const unsigned a_v1 = lds0 + (G & 1u) * 4096u + (v_key0 << 5) + (((sl & 3u) >> 1) << 4) + ((sl & 1u) << 3);
-  const unsigned a_v2 = lds0 + (G & 1u) * 4096u + (v_key0 << 5) + ((((sl & 3u) >> 1) ^ 1u) << 4) + ((sl & 1u) << 3) + 256u;
-  // Q fragments: this lane's row of panel ks, chunk g
-  const unsigned voff_q = (unsigned)q * 32u + (unsigned)g * 16u;
+  // K / V whole-head DMA, 16 + 16 pieces of 1 KiB (16 keys x 64 B of one panel) per operand: wave w moves pieces 4 w .. 4 w + 3 of the
+  // hi and of the lo image = panel w >> 1, keys 64 (w & 1) + 16 j.  LDS slot l of a piece receives
+  //   K: key l >> 2, logical chunk (l & 3) ^ ((key >> 2) & 3)        V: key 4 (l >> 4) + ((l >> 1) & 3), chunk 2 ((l >> 3) & 1) + (l & 1)
+  const unsigned lu = (unsigned)lane;
+  const unsigned voff_k = ((lu >> 2) << 6) | (((lu & 3u) ^ ((lu >> 4) & 3u)) << 4);
+  const unsigned voff_v = ((4u * (lu >> 4) + ((lu >> 1) & 3u)) << 6) | ((2u * ((lu >> 3) & 1u) + (lu & 1u)) << 4);
+  const unsigned voff_lin = lu * 16;
+  // per head: panels (which * 8 + head) * 2 + (wave >> 1), rows row0 + 64 (wave & 1) ..
+  const char* gq_hi = a.qkv_hi + row0 * 64;               // + panel * PS
+  const char* gq_lo = a.qkv_lo + row0 * 64;
+  // fragment addresses (LDS bytes).  K rows by (m, g): + (ks >> 1) * 8 KiB + kt * 2 KiB, chunk (2 (ks & 1) + g) ^ ((m >> 2) & 3);
+  // Wo stage rows by (m, g): 32-byte rows, chunk g ^ ((m >> 3) & 1)
+  const unsigned a_k0 = ((unsigned)m << 6) | ((((unsigned)g) ^ (((unsigned)m >> 2) & 3u)) << 4);           // even k16-steps
+  const unsigned a_k1 = ((unsigned)m << 6) | (((2u + (unsigned)g) ^ (((unsigned)m >> 2) & 3u)) << 4);      // odd k16-steps
+  const unsigned a_row = ((unsigned)m << 5) | ((((unsigned)g) ^ (((unsigned)m >> 3) & 1u)) << 4);
+  // V transpose reads: lane l at + 8 l of the 512-byte run of (d tile, 8 keys)
+  const unsigned a_v = lds0 + lu * 8;
+  // Q fragments: this lane's row of panel ks >> 1, chunk 2 (ks & 1) + g
+  const unsigned voff_q = (unsigned)q * 64u + (unsigned)g * 16u;
 
-  auto dma_kv = [&](int head, int which, unsigned lds_hi) {   // K (which = 1) / V (which = 2) of `head`: this wave's panel, hi then lo
-    const size_t pn = (size_t)((which * 8 + head) * 4 + wave);
-    ao_dma8(voff_kv, gq_hi + pn * PS, lds0 + lds_hi + wave * 4096, gq_lo + pn * PS, lds0 + lds_hi + AO_LO + wave * 4096);
+  auto dma_kv = [&](int head, int which, unsigned lds_hi) {   // K (which = 1) / V (which = 2) of `head`: this wave's 4 + 4 pieces, hi then lo
+    const size_t pn = (size_t)((which * 8 + head) * 2 + (wave >> 1));
+    const size_t go = pn * PS + (size_t)(wave & 1) * 4096;
+    ao_dma8(which == 1 ? voff_k : voff_v, gq_hi + go, lds0 + lds_hi + wave * 4096, gq_lo + go, lds0 + lds_hi + AO_LO + wave * 4096);
   };
   auto dma_w = [&](int stage, int slot) {                      // ring stage (clamped: behind the last one a free slot is re-loaded)
     const int st = stage < 32 ? stage : 31;
@@ -178,14 +204,17 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   };
   f16x8 qh[4], ql[4];
   auto load_q = [&](int head) {                                // 8 asm loads = one DMA unit's worth in the counted waits
-    const size_t pn = (size_t)(head < 8 ? head : 7) * 4;
+    const size_t pn = (size_t)(head < 8 ? head : 7) * 2;
     const char* bh = gq_hi + pn * PS;
     const char* bl = gq_lo + pn * PS;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qh[ks] = ao_ldg128<0>(voff_q, bh + (size_t)ks * PS);
-      ql[ks] = ao_ldg128<0>(voff_q, bl + (size_t)ks * PS);
-    }
+    qh[0] = ao_ldg128<0>(voff_q, bh);
+    ql[0] = ao_ldg128<0>(voff_q, bl);
+    qh[1] = ao_ldg128<32>(voff_q, bh);
+    ql[1] = ao_ldg128<32>(voff_q, bl);
+    qh[2] = ao_ldg128<0>(voff_q, bh + PS);
+    ql[2] = ao_ldg128<0>(voff_q, bl + PS);
+    qh[3] = ao_ldg128<32>(voff_q, bh + PS);
+    ql[3] = ao_ldg128<32>(voff_q, bl + PS);
   };
 
   f32x16 pacc[AO_NT];
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) pacc[t][k] = 0.f;
 
-  // ---- scores^T of one head (unscaled q · k): 4 key tiles x 4 k16-steps x 3 products; K panel ks of the image, odd panels row ^ 4
+  // ---- scores^T of one head (unscaled q · k): 4 key tiles x 4 k16-steps x 3 products
   f32x16 sc[4];
   // The asm MFMAs are scheduling barriers for hipcc, so the LDS reads are software-pipelined in the SOURCE: the fragments of item
   // i + AO_RD are requested in front of item i's MFMAs (first GPU run: read, s_waitcnt lgkmcnt(0), three MFMAs, read, ... — every LDS
@@ -203,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     f16x8 kh[AO_RD + 1], kl[AO_RD + 1];
     auto rd = [&](int it) {   // item it = (kt, ks)
       const int kt = it >> 2, ks = it & 3;
-      const unsigned ad = lds0 + AO_KH + ks * 4096 + kt * 1024 + ((ks & 1) ? a_row_odd : a_row);
+      const unsigned ad = lds0 + AO_KH + (ks >> 1) * 8192 + kt * 2048 + ((ks & 1) ? a_k1 : a_k0);
       kh[it % (AO_RD + 1)] = ao_lds128(ad);
       kl[it % (AO_RD + 1)] = ao_lds128(ad + AO_LO);
     };
@@ -227,19 +256,21 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   dma_w(0, 0);
   dma_w(0, 0);
   dma_w(1, 1);
-  ao_sync<4 * AO_UNIT>();      // Ba(0): Q_0, K_0 landed (behind them: V_0, dummy, W_0,0, W_0,1)
+  ao_sync<4 * AO_UNIT, TM>(&tw[0], &tb[0]);      // Ba(0): Q_0, K_0 landed (behind them: V_0, dummy, W_0,0, W_0,1)
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qh[ks]), "+v"(ql[ks]));
   dma_w(2, 2);
   scores();
 
   int slot = 0;                // ring slot of stage 4 h (stage n lives in slot n % 3)
+  if constexpr (TM) t_l0 = __builtin_amdgcn_s_memtime();
 #pragma nounroll
   for (int h = 0; h < 8; ++h) {
     // ---- Bb(h): V_h landed (behind it: W_h-1,3  W_h,0  W_h,1  W_h,2); every wave is through with K_h
-    ao_sync<4 * AO_UNIT>();
+    ao_sync<4 * AO_UNIT, TM>(&tw[1], &tb[1]);
     load_q(h + 1);
     dma_kv(h < 7 ? h + 1 : 7, 1, AO_KH);
+    AO_T0();
     // ---- softmax over the 128 keys of query m (64 here, 64 in lane ^ 32), fp32 — attn16x3_k's arithmetic
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -257,26 +288,35 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // p = 2^10 exp((s - mx) scale) as ONE v_fma + ONE v_exp_f32 per score: 2^(s c + (10 - mx c)), c = scale log2(e).  (expf — OCML's
+    // range-reduced form, ~10 instructions per call — made this phase 1 350 VALU instructions per head and wave; hipcc spread them
+    // over the P V items, 7 400 cycles where the 48 MFMAs take 1 540.)  The rounding of 10 - mx c is common to the row's 128 keys and
+    // cancels in p / sum; the argument's own rounding is 2^-24 |arg|: 6e-8 for the keys that carry the row, < 2e-6 relative on
+    // probabilities below 2^-30.
+    const float cexp = a.scale * 1.4426950408889634f;
+    const float nb = 10.0f - mx * cexp;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf((sc[kt][r] - mx) * a.scale) * 1024.0f;
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], cexp, nb));
         sc[kt][r] = p;
         sum += p;
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    AO_T1(0);
+    AO_T0();
     // ---- O^T = V^T · P^T: 2 d tiles x 8 k16-steps x 3 products (k-slot e of half g <-> accumulator register 8 hf + e)
     f32x16 o[2];
     {
       f16x8 vh8[AO_RD + 1], vl8[AO_RD + 1];
       auto rd = [&](int it) {   // item it = (kt, hf, dt)
         const int kt = it >> 2, hf = (it >> 1) & 1, dt = it & 1;
-        const unsigned off = AO_VH + dt * 8192 + kt * 1024 + hf * 512;
-        const ao_f16x4 h0 = ao_tr(a_v1 + off), h1 = ao_tr(a_v2 + off);
-        const ao_f16x4 l0 = ao_tr(a_v1 + off + AO_LO), l1 = ao_tr(a_v2 + off + AO_LO);
+        const unsigned off = AO_VH + dt * 8192 + kt * 2048 + hf * 1024;   // keys 32 kt + 16 hf ..: 256 B per key quad
+        const ao_f16x4 h0 = ao_tr(a_v + off), h1 = ao_tr(a_v + off + 512);
+        const ao_f16x4 l0 = ao_tr(a_v + off + AO_LO), l1 = ao_tr(a_v + off + 512 + AO_LO);
         vh8[it % (AO_RD + 1)] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         vl8[it % (AO_RD + 1)] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       };
@@ -300,6 +340,8 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
         else ao_mfma3v<false, true, false>(o[dt], vh8[b], vl8[b], ph, pl);
       }
     }
+    AO_T1(1);
+    AO_T0();
     // the head's output as the B operand of its out_proj slabs: k16-step 2 dt + s <- registers 8 s .. 8 s + 7 of d tile dt
     f16x8 oh[4], ol[4];
 #pragma unroll
@@ -311,22 +353,24 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
         for (int e = 0; e < 8; ++e) x[e] = o[dt][s2 * 8 + e] * inv;
         ao_split8(x, oh[2 * dt + s2], ol[2 * dt + s2]);
       }
+    AO_T1(2);
     // ---- Bc(h): W_h,0 landed (behind it: W_h,1  W_h,2  Q_h+1 K_h+1); every wave is through with V_h
-    ao_sync<4 * AO_UNIT>();
+    ao_sync<4 * AO_UNIT, TM>(&tw[2], &tb[2]);
     dma_kv(h < 7 ? h + 1 : 7, 2, AO_VH);
     // ---- the head's four out_proj stages: out^T tile t += Wo[32 t .., k16-step] · O   (hi·hi + hi·lo + lo·hi)
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       if (st == 1) {          // Bd1: W_h,1 landed (behind it: W_h,2  Q K_h+1  V_h+1); stage 0's slot is free -> W_h,3
-        ao_sync<4 * AO_UNIT>();
+        ao_sync<4 * AO_UNIT, TM>(&tw[3], &tb[3]);
         dma_w(4 * h + 3, slot);
       } else if (st == 2) {   // Bd2: W_h,2 landed (behind it: Q K_h+1  V_h+1  W_h,3); stage 1's slot -> W_h+1,0
-        ao_sync<4 * AO_UNIT>();
+        ao_sync<4 * AO_UNIT, TM>(&tw[4], &tb[4]);
         dma_w(4 * h + 4, slot == 2 ? 0 : slot + 1);
       } else if (st == 3) {   // Bd3: W_h,3 landed (behind it: W_h+1,0); stage 2's slot -> W_h+1,1
-        ao_sync<1 * AO_UNIT>();
+        ao_sync<1 * AO_UNIT, TM>(&tw[5], &tb[5]);
         dma_w(4 * h + 5, slot == 0 ? 2 : slot - 1);
       }
+      AO_T0();
       const int sl_st = st == 0 ? slot : st == 1 ? (slot == 2 ? 0 : slot + 1) : st == 2 ? (slot == 0 ? 2 : slot - 1) : slot;
       const unsigned aw = lds0 + AO_RING + (unsigned)sl_st * AO_SLOT + a_row;
       f16x8 wh[AO_RD + 1], wl[AO_RD + 1];
@@ -347,49 +391,119 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
                      : [c] "+a"(pacc[t])
                      : [wh] "v"(wh[t % (AO_RD + 1)]), [wl] "v"(wl[t % (AO_RD + 1)]), [oh] "v"(oh[st]), [ol] "v"(ol[st]));
       }
+      AO_T1(3);
     }
     slot = slot == 2 ? 0 : slot + 1;   // stage 4 (h + 1) = 4 h + 4 -> slot + 4 mod 3
     // ---- Ba(h + 1): Q_h+1, K_h+1 landed (behind them: V_h+1  W_h,3  W_h+1,0  W_h+1,1); stage 3's slot -> W_h+1,2
-    ao_sync<4 * AO_UNIT>();
+    ao_sync<4 * AO_UNIT, TM>(&tw[0], &tb[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qh[ks]), "+v"(ql[ks]));
     dma_w(4 * h + 6, slot == 0 ? 2 : slot - 1);
+    AO_T0();
     if (h < 7) scores();
+    AO_T1(4);
   }
   // (the clamped re-loads behind the last head: nothing may land after the workgroup is gone; and the asm MFMAs of the last stage,
   //  which hipcc cannot see, have written their tiles before its v_accvgpr_reads below)
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if constexpr (TM) t_l1 = __builtin_amdgcn_s_memtime();
 
-  // ---- epilogue: Q = P + b_out + out_scale * acc, in accumulator layout (lane (query, g) owns columns 8 gq + 4 g .. + 3 of each group)
-  if (q < S) {
-    const float* prow = a.res + (row0 + q) * a.D + g * 4;
-    float* orow = a.out + (row0 + q) * a.D + g * 4;
+  // ---- epilogue: Q = P + b_out + out_scale * acc.  In accumulator layout a lane owns 16-byte pieces of 32 different rows: a
+  // load / store instruction touches 32 cache lines for 1 KiB (first form of this loop: 58 serial round trips, 84 k of the kernel's
+  // 263 k cycles; batched four tiles ahead: 60 k — the rate of that access pattern).  So the rows go THROUGH the LDS, which is free
+  // now: every wave owns 40 KiB (its 32 rows x 1 KiB of a column half), residual rows in by LDS-DMA — one instruction per row, whole
+  // 128-byte lines —, the arithmetic in place in accumulator layout, rows out as whole lines (one ds_read_b128 + one 1-KiB store per
+  // row).  16-byte chunk c of row r sits at chunk c ^ (r & 15): conflict-free for the accumulator-layout accesses (the 16 lanes of a
+  // service group are 16 rows with distinct r & 15), linear per row for the DMA and the stores.  No workgroup barrier inside: a wave
+  // reads only what it wrote itself.  Column halves: tiles 0-7 (1 024 B per row), tiles 8-14 (832 B: chunks 0 .. 51).
+  __builtin_amdgcn_s_barrier();   // every wave is through with the ring and the K / V images, every DMA piece of the loop has landed
+  asm volatile("" ::: "memory");
+  {
+    constexpr int ND = 464;                // launch_attnout16x3 checks D == 464
+    const unsigned R = lds0 + (unsigned)wave * 40960u;
+    const int nrow = S - wave * 32 < 32 ? S - wave * 32 : 32;   // rows of this wave that exist (wave-uniform)
     const float* bias = a.bias + g * 4;
 #pragma unroll
-    for (int t = 0; t < AO_NT; ++t)
+    for (int half = 0; half < 2; ++half) {
+      constexpr int kChunks[2] = {64, 52};
+      const int nch = kChunks[half];
+      // residual rows -> LDS
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int col = t * 32 + gq * 8;
-        if (col + 8 <= a.D) {
-          const float4 r = *reinterpret_cast<const float4*>(prow + col);
-          const float4 b = *reinterpret_cast<const float4*>(bias + col);
-          float4 y;
-          y.x = (pacc[t][gq * 4 + 0] * a.out_scale + b.x) + r.x;
-          y.y = (pacc[t][gq * 4 + 1] * a.out_scale + b.y) + r.y;
-          y.z = (pacc[t][gq * 4 + 2] * a.out_scale + b.z) + r.z;
-          y.w = (pacc[t][gq * 4 + 3] * a.out_scale + b.w) + r.w;
-          *reinterpret_cast<float4*>(orow + col) = y;
+      for (int r = 0; r < 32; ++r) {
+        const int rr = r < nrow ? r : nrow - 1;                                  // (rows that do not exist: a valid row again, never stored)
+        unsigned lc = lu ^ (unsigned)(r & 15);                                   // logical chunk that lands in physical chunk `lane`
+        if (half == 1) lc = lc < 52u ? lc : 51u;                                 // (chunks beyond the row: a valid chunk again, never read)
+        const char* src = reinterpret_cast<const char*>(a.res + (row0 + (size_t)(wave * 32 + rr)) * ND) + half * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lc * 16u), "s"(src), "s"(R + (unsigned)r * 1024u) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // y = acc * out_scale + bias + residual, in place
+#pragma unroll
+      for (int tl = 0; tl < (half == 0 ? 8 : 7); ++tl)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int t = half * 8 + tl, col = t * 32 + gq * 8;
+          if (col + 8 <= ND) {
+            const unsigned c = (unsigned)(tl * 8 + gq * 2) + (unsigned)g;        // the lane's chunk of its row m
+            float4* pl = reinterpret_cast<float4*>(smem + wave * 40960 + m * 1024 + ((c ^ ((unsigned)m & 15u)) << 4));
+            const float4 rsd = *pl;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            float4 y;
+            y.x = (pacc[t][gq * 4 + 0] * a.out_scale + b.x) + rsd.x;
+            y.y = (pacc[t][gq * 4 + 1] * a.out_scale + b.y) + rsd.y;
+            y.z = (pacc[t][gq * 4 + 2] * a.out_scale + b.z) + rsd.z;
+            y.w = (pacc[t][gq * 4 + 3] * a.out_scale + b.w) + rsd.w;
+            *pl = y;
+          }
+        }
+      // rows out: physical chunk `lane` of row r is logical chunk lane ^ (r & 15)
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        if (r < nrow) {
+          const unsigned lc = lu ^ (unsigned)(r & 15);
+          const float4 y = *reinterpret_cast<const float4*>(smem + wave * 40960 + r * 1024 + lu * 16u);
+          if ((int)lc < nch)
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out + (row0 + (size_t)(wave * 32 + r)) * ND) + half * 1024 + lc * 16) = y;
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the rows have left the LDS before the next half's DMA writes it)
+    }
   }
+  if constexpr (TM) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      for (int i = 0; i < 6; ++i) {
+        atomicAdd(&g_attnout_phase[i], tw[i]);
+        atomicAdd(&g_attnout_phase[6 + i], tb[i]);
+      }
+      atomicAdd(&g_attnout_phase[12], t_l1 - t_l0);
+      atomicAdd(&g_attnout_phase[13], t_end - t_l1);
+      atomicAdd(&g_attnout_phase[14], t_end - t_k0);
+      atomicAdd(&g_attnout_phase[15], 1ull);
+      for (int i = 0; i < 5; ++i) atomicAdd(&g_attnout_phase[16 + i], tp[i]);
+    }
+  }
+}
+
+#undef AO_T0
+#undef AO_T1
+
+void attnout_phase_read(unsigned long long* out24) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_attnout_phase), 24 * sizeof(unsigned long long));
+  unsigned long long z[24] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attnout_phase), z, sizeof(z));
 }
 
 bool attnout16x3_supported(int S, int H, int dh, int D) { return S >= 1 && S <= 128 && H == 8 && dh == 58 && D == 464; }
 
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st) {
   if (!attnout16x3_supported(a.S, 8, 58, a.D) || B < 1 || (a.panel_stride & 15) || !a.qkv_hi || !a.qkv_lo || !a.w_img) return -1;
-  allow_big_lds((const void*)attnout16x3_k);
-  hipLaunchKernelGGL(attnout16x3_k, dim3(B), dim3(256), AO_LDS, st, a);
+  const bool tm = knob_int("LDM_ATTNOUT_TM", 0) != 0;   // (dev: the phase-timer instantiation)
+  auto kern = tm ? attnout16x3_k<true> : attnout16x3_k<false>;
+  allow_big_lds((const void*)kern);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), AO_LDS, st, a);
   return 0;
 }
 

@@ -122,7 +122,7 @@ struct LgEpi {
   unsigned a_tpw, a_tpr;        // this lane's write / read address in the wave's transpose buffer (LDS bytes)
   const char *C0, *C1;          // output bases: fp32 C | fp16 hi, fp16 lo
   const char *b0, *b1;          // ... of the tile whose epilogue is in flight (uniform: + tile * 32 columns)
-  size_t tstride;               // bytes per tile in C0 / C1: 128 (fp32 rows) | 64 (fp16 rows) | 2 panels (OUT = 2: panel-major hi / lo)
+  size_t tstride;               // bytes per tile in C0 / C1: 128 (fp32 rows) | 64 (fp16 rows) | one panel (OUT = 2: panel-major hi / lo)
   unsigned voff[4];             // this lane's byte offset in 8-row pass p: (row0 + 8 p + lane / 8) * ld + (lane & 7) * 4 columns
   unsigned long long rowmask[4];   // lanes whose row of pass p exists (row < M)
   unsigned long long colmask;   // lanes whose 4 columns of the tile in flight exist (col < N; N % 4 == 0)
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   e.C0 = OUT == 0 ? reinterpret_cast<const char*>(a.C32) : reinterpret_cast<const char*>(a.C16);
   e.C1 = reinterpret_cast<const char*>(a.C16lo);
   e.b0 = e.C0; e.b1 = e.C1; e.colmask = 0;
-  e.tstride = OUT == 0 ? 128 : OUT == 1 ? 64 : 2 * a.panel_stride;
+  e.tstride = OUT == 0 ? 128 : OUT == 1 ? 64 : a.panel_stride;
   e.N = a.N; e.c4 = (lane & 7) * 4;
   e.out_scale = a.out_scale;
 #pragma unroll
@@ -706,8 +706,8 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     const int orow = blockIdx.x * 128 + wave * 32 + p * 8 + (lane >> 3);
     e.rowmask[p] = __ballot(orow < a.M);
     // (launch_lngemm16x3 checks that M * ld * element size fits 32 bits)
-    if constexpr (OUT == 2)   // panel-major: a tile is two panels of 16 columns; lanes 0-3 / 4-7 of a row's eight sit in the first / second
-      e.voff[p] = (unsigned)(e.c4 >> 4) * (unsigned)a.panel_stride + (unsigned)orow * 32u + (unsigned)(e.c4 & 15) * 2u;
+    if constexpr (OUT == 2)   // panel-major: a tile's 32 columns are ONE panel of 64-byte rows
+      e.voff[p] = (unsigned)orow * 64u + (unsigned)e.c4 * 2u;
     else
       e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
   }
@@ -766,10 +766,10 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   // the epilogue addresses with 32-bit byte offsets
   const bool half_out = a.C16 != nullptr;
   const bool panel = half_out && a.panel_out;
-  if (panel ? (!a.C16lo || a.C32 || a.relu || !a.ada || (a.N & 15) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 32)
+  if (panel ? (!a.C16lo || a.C32 || a.relu || !a.ada || (a.N & 31) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 64)
             : half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu))
     return -1;
-  if (panel ? (a.panel_stride + (unsigned long long)a.M * 32 >= (1ull << 32))
+  if (panel ? ((unsigned long long)a.M * 64 >= (1ull << 32))
             : ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)))
     return -1;
   const bool tm = knob_int("LDM_LNGEMM_TM", 0) != 0;   // (dev: the phase-timer instantiation, tools/lngemm_probe.py; read per launch: cheap, dev mode only)

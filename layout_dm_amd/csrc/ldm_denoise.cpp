@@ -137,7 +137,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       if (h->attnout) {   // q / k / v as head-padded hi / lo panels for the fused attention + out_proj launch (kernels_attnout.hip)
         a.img = (const char*)w.x3_qkv_pad; a.n_tiles = 3 * h->H * 2;
         a.bias = w.b_in_pad; a.N = 3 * h->H * 64;
-        a.C16 = h->qkvp_hi; a.C16lo = h->qkvp_lo; a.panel_out = 1; a.panel_stride = h->panel_rows * 32;
+        a.C16 = h->qkvp_hi; a.C16lo = h->qkvp_lo; a.panel_out = 1; a.panel_stride = h->panel_rows * 64;
       } else {
         a.img = (const char*)w.x3_qkv; a.n_tiles = h->x3_qkv_tiles;
         a.bias = w.b_in; a.N = 3 * D;
@@ -181,7 +181,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     }
     if (split && h->attnout) {  // attention + out-proj + residual in ONE layout-resident launch:  Q = P + softmax(q k^T) v · Wo^T + bo
       AttnOutArgs a{};
-      a.qkv_hi = (const char*)h->qkvp_hi; a.qkv_lo = (const char*)h->qkvp_lo; a.panel_stride = h->panel_rows * 32;
+      a.qkv_hi = (const char*)h->qkvp_hi; a.qkv_lo = (const char*)h->qkvp_lo; a.panel_stride = h->panel_rows * 64;
       a.w_img = (const char*)w.x3_out_kstep;
       a.res = h->P; a.bias = w.b_out; a.out = h->Q;
       a.S = h->S; a.D = D; a.scale = 1.0f / sqrtf((float)h->dh); a.out_scale = w.s_out;

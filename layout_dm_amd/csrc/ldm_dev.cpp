@@ -131,6 +131,7 @@ void stack_phase_read(unsigned long long* out16);
 }  // namespace ldm
 extern "C" void ldm_dev_stack_phases(unsigned long long* out16) { ldm::stack_phase_read(out16); }
 extern "C" void ldm_dev_lngemm_phases(unsigned long long* out8) { ldm::lngemm_phase_read(out8); }
+extern "C" void ldm_dev_attnout_phases(unsigned long long* out24) { ldm::attnout_phase_read(out24); }
 
 // Unit check of the split mode's fused attention + out_proj launch (kernels_attnout.hip) on synthetic operands against a float64
 // host computation of the same block: q / k / v (amplitude qk_amp / 1) -> hi / lo panels as in_proj's epilogue writes them, out_proj
@@ -143,10 +144,10 @@ extern "C" void ldm_dev_lngemm_phases(unsigned long long* out8) { ldm::lngemm_ph
 #include "ldm_pack.h"
 // zero_lo (debugging aid): bit 0 / 1 / 2 / 3 = drop the lo halves of q / k / v / the weights from the INPUTS (kernel and reference alike)
 extern "C" int ldm_dev_attnout_check(int B, int S, float qk_amp, uint32_t seed, double* err_out, int zero_lo) {
-  const int H = 8, dh = 58, D = 464, NP = 96;
+  const int H = 8, dh = 58, D = 464, NP = 48;
   if (B < 1 || S < 1 || S > 128) return -1;
   const size_t M = (size_t)B * S, rows = M + 64;
-  const size_t PS = rows * 32;
+  const size_t PS = rows * 64;
   uint32_t s = seed * 2654435761u + 12345u;
   auto rnd = [&]() {
     s = s * 1664525u + 1013904223u;
@@ -169,15 +170,15 @@ extern "C" int ldm_dev_attnout_check(int B, int S, float qk_amp, uint32_t seed, 
     memcpy(&hi, &hh, 2);
     memcpy(&lo, &ll, 2);
   };
-  std::vector<uint16_t> ph((size_t)NP * rows * 16, 0), pl((size_t)NP * rows * 16, 0);
+  std::vector<uint16_t> ph((size_t)NP * rows * 32, 0), pl((size_t)NP * rows * 32, 0);
   const std::vector<float>* src[3] = {&q, &k, &v};
   for (int which = 0; which < 3; ++which)
     for (size_t r = 0; r < M; ++r)
       for (int h = 0; h < H; ++h)
         for (int d = 0; d < dh; ++d) {
-          const size_t pn = (size_t)(which * H + h) * 4 + d / 16;
-          split((*src[which])[(r * H + h) * dh + d], ph[(pn * rows + r) * 16 + d % 16], pl[(pn * rows + r) * 16 + d % 16]);
-          if (zero_lo & (1 << which)) pl[(pn * rows + r) * 16 + d % 16] = 0;
+          const size_t pn = (size_t)(which * H + h) * 2 + d / 32;
+          split((*src[which])[(r * H + h) * dh + d], ph[(pn * rows + r) * 32 + d % 32], pl[(pn * rows + r) * 32 + d % 32]);
+          if (zero_lo & (1 << which)) pl[(pn * rows + r) * 32 + d % 32] = 0;
         }
   std::vector<uint16_t> wh((size_t)D * 512, 0), wl((size_t)D * 512, 0);
   for (int n = 0; n < D; ++n)
@@ -212,7 +213,7 @@ extern "C" int ldm_dev_attnout_check(int B, int S, float qk_amp, uint32_t seed, 
     for (int variant = 0; variant < 2; ++variant) {   // 0: full values, 1: fp16 hi parts only
       std::vector<double>& o = variant ? att_hi : att;
       auto val = [&](int which, size_t r, int h, int d) {
-        const size_t pn = (size_t)(which * H + h) * 4 + d / 16, i = (pn * rows + r) * 16 + d % 16;
+        const size_t pn = (size_t)(which * H + h) * 2 + d / 32, i = (pn * rows + r) * 32 + d % 32;
         return variant ? h2d(ph[i]) : h2d(ph[i]) + h2d(pl[i]);
       };
       for (int h = 0; h < H; ++h)

@@ -154,7 +154,7 @@ struct ldm_handle {
   void* x3_head = nullptr;
   int x3_qkv_tiles = 0, x3_ffn1_tiles = 0, x3_head_tiles = 0;
   // r06: attention and out_proj of the split mode as ONE layout-resident launch (kernels_attnout.hip); q / k / v travel from in_proj
-  // to it as head-padded hi / lo fp16 PANELS (qkvp_hi / qkvp_lo: [96][panel_rows][16]); LDM_DEV=1 LDM_X3_ATTNOUT=0: attn16x3_k + gemm16x3_k
+  // to it as head-padded hi / lo fp16 PANELS (qkvp_hi / qkvp_lo: [48][panel_rows][32]); LDM_DEV=1 LDM_X3_ATTNOUT=0: attn16x3_k + gemm16x3_k
   bool attnout = false;
   size_t panel_rows = 0;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime

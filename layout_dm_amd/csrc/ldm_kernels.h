@@ -97,9 +97,9 @@ struct LnGemmArgs {
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
   // r06: hi / lo fp16 output WITHOUT ReLU in PANEL-major form (in_proj in front of kernels_attnout.hip): C16 / C16lo are arrays
-  // [N / 16 panels][panel_rows][16 halfs] — column c of row r at panel c / 16, byte r * 32 + (c % 16) * 2; ldc16 is ignored
+  // [N / 32 panels][panel_rows][32 halfs] — column c of row r at panel c / 32, byte r * 64 + (c % 32) * 2; ldc16 is ignored
   int panel_out;
-  size_t panel_stride;      // bytes between panels (>= (M + slack) * 32, a multiple of 16)
+  size_t panel_stride;      // bytes between panels (>= (M + slack) * 64, a multiple of 16)
   // GEMM prologue (pre_img != nullptr): x = pre_res + pre_bias + pre_scale * (preA · Wpre^T) is computed by the kernel itself instead
   // of being read — out_proj in front of norm2 + linear1, linear2 in front of the next AdaLN + in_proj / of the head
   const __half *preA, *preAlo;   // [M, pre_lda] hi / lo rows (attention output / hidden activations), K = 32 * pre_stages columns read
@@ -220,7 +220,7 @@ void launch_attention16x3(const float* qkv, __half* out_hi, __half* out_lo, int 
 // split mode, r06 (kernels_attnout.hip): attention AND out_proj in one launch, one workgroup per layout:
 //   out[row, :] = res[row, :] + bias + out_scale * sum_h softmax(q_h k_h^T * scale) v_h · Wo_h^T
 // q / k / v arrive head-padded and PANEL-major from in_proj's epilogue (kernels_lngemm.hip, panel_out): hi and lo fp16 arrays
-// [3 * 8 * 4 panels][rows][16], panel (which * 8 + head) * 4 + d / 16, panel_stride bytes apart; the kernel reads up to 128 rows per
+// [3 * 8 * 2 panels][rows][32], panel (which * 8 + head) * 2 + d / 32, panel_stride bytes apart; the kernel reads up to 128 rows per
 // layout (rows S .. 127 belong to the next layout or to the buffer's slack: finite values, masked).
 struct AttnOutArgs {
   const char *qkv_hi, *qkv_lo;   // panel arrays
@@ -235,6 +235,7 @@ struct AttnOutArgs {
 };
 bool attnout16x3_supported(int S, int H, int dh, int D);
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st);   // -1: geometry not supported
+void attnout_phase_read(unsigned long long* out24);   // (LDM_ATTNOUT_TM=1: accumulated phase cycles, reset on read)
 
 // ---- posterior + categorical draw (kernels_post.hip) ------------------------------------
 struct VocabTables {  // built on the host from the tokenizer geometry (layout_tokenizer.py:429-467)

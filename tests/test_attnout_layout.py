@@ -1,7 +1,7 @@
 """Host-verifiable bookkeeping of the fused attention + out_proj kernel of the split mode (layout_dm_amd/csrc/kernels_attnout.hip):
 its address formulas, restated here, are run against a byte-level model of the LDS —
 
-  * the whole-panel LDS-DMA of K / V (per-lane SOURCE swizzle, linear destination) followed by the K fragment reads
+  * the whole-head LDS-DMA of K / V (per-lane SOURCE permutation inside each 1-KiB piece, linear destination) followed by the K fragment reads
     (ds_read_b128) and the V transpose reads (ds_read_b64_tr_b16: a 16-lane group reads a [4 keys][16 d] block, lane i receives
     column i — cdna_hip_programming.md T10) deliver exactly the MFMA operand elements the kernel's contraction order assumes;
   * every read pattern is bank-conflict free under the gfx950 service model (MI355X_MICROARCH.md, LDS table);
@@ -15,31 +15,33 @@ from test_lds_swizzle import conflict_free
 KH, LO = 0, 16384
 
 
-def voff_kv(lane, wave):
-    pos = lane >> 1
-    return ((pos ^ (4 if wave & 1 else 0)) << 5) | (((lane & 1) ^ ((pos >> 3) & 1)) << 4)
+def voff_k(lane):
+    return ((lane >> 2) << 6) | (((lane & 3) ^ ((lane >> 4) & 3)) << 4)
 
 
-def a_row(lane, odd):
+def voff_v(lane):
+    return ((4 * (lane >> 4) + ((lane >> 1) & 3)) << 6) | ((2 * ((lane >> 3) & 1) + (lane & 1)) << 4)
+
+
+def a_k(lane, odd):
     m, g = lane & 31, lane >> 5
-    return (((m ^ 4) if odd else m) << 5) | ((g ^ ((m >> 3) & 1)) << 4)
+    return (m << 6) | (((2 * odd + g) ^ ((m >> 2) & 3)) << 4)
 
 
-def a_v(lane, second):
-    G, sl = lane >> 4, lane & 15
-    key0 = (4 * (G >> 1) + (sl >> 2)) ^ (4 * (G & 1))
-    chunk = ((sl & 3) >> 1) ^ (1 if second else 0)
-    return (G & 1) * 4096 + (key0 << 5) + (chunk << 4) + ((sl & 1) << 3) + (256 if second else 0)
+def a_row(lane):
+    m, g = lane & 31, lane >> 5
+    return (m << 5) | ((g ^ ((m >> 3) & 1)) << 4)
 
 
-def dma_head_image(src):
-    """src: [4 panels][128 keys][16 d] uint16 (one of hi / lo, a layout's slab of each panel) -> 16 KiB LDS image (uint16 view)."""
+def dma_head_image(src, voff):
+    """src: [2 panels][128 keys][32 d] uint16 (one of hi / lo, a layout's slab of each panel) -> 16 KiB LDS image (uint16 view):
+    wave w moves pieces 4 w .. 4 w + 3 = panel w >> 1, keys 64 (w & 1) + 16 j."""
     lds = np.zeros(8192, np.uint16)
-    for wave in range(4):                       # wave w moves panel w
-        flat = src[wave].reshape(-1)            # the layout's rows of the panel: key * 16 + d  (32 B per key)
+    for wave in range(4):
+        flat = src[wave >> 1].reshape(-1)       # the layout's rows of the panel: key * 32 + d  (64 B per key)
         for piece in range(4):
             for lane in range(64):
-                so = (voff_kv(lane, wave) + piece * 1024) // 2
+                so = ((wave & 1) * 4096 + piece * 1024 + voff(lane)) // 2
                 do = (wave * 4096 + piece * 1024 + lane * 16) // 2
                 lds[do:do + 8] = flat[so:so + 8]
     return lds
@@ -48,28 +50,28 @@ def dma_head_image(src):
 def test_k_fragments_and_v_transpose_reads_deliver_the_mfma_operands():
     key, d = np.meshgrid(np.arange(128), np.arange(64), indexing="ij")
     val = (key * 64 + d).astype(np.uint16)                       # element (key, d) of the head, unique
-    panels = np.stack([val[:, 16 * p:16 * p + 16] for p in range(4)])
-    lds = dma_head_image(panels)
+    panels = np.stack([val[:, 32 * p:32 * p + 32] for p in range(2)])
+    lds = dma_head_image(panels, voff_k)
     # K: A operand of S^T tile kt, k16-step ks: lane (m, g) holds K[32 kt + m][16 ks + 8 g + e]
     for kt in range(4):
         for ks in range(4):
             for lane in range(64):
                 m, g = lane & 31, lane >> 5
-                ad = KH + ks * 4096 + kt * 1024 + a_row(lane, ks & 1)
+                ad = KH + (ks >> 1) * 8192 + kt * 2048 + a_k(lane, ks & 1)
                 got = lds[ad // 2: ad // 2 + 8]
                 want = val[32 * kt + m, 16 * ks + 8 * g: 16 * ks + 8 * g + 8]
                 assert np.array_equal(got, want), (kt, ks, lane)
     # V: A operand of O^T tile dt, k16-step (kt, hf): lane (m, g) element e holds V[32 kt + 16 hf + 8 (e >> 2) + 4 g + (e & 3)][32 dt + m]
     # — the k-slot order in which the lane's score registers 8 hf .. 8 hf + 7 of tile kt hold its probabilities
+    lds = dma_head_image(panels, voff_v)
     for dt in range(2):
         for kt in range(4):
             for hf in range(2):
-                off = dt * 8192 + kt * 1024 + hf * 512
+                off = dt * 8192 + kt * 2048 + hf * 1024
                 for second in (0, 1):
                     raw = {}
                     for lane in range(64):
-                        ad = a_v(lane, second) + off
-                        assert ad % 8 == 0                       # (G17: a misaligned tr read returns the aligned address's data)
+                        ad = lane * 8 + off + 512 * second
                         raw[lane] = lds[ad // 2: ad // 2 + 4]
                     for lane in range(64):
                         G, i = lane >> 4, lane & 15
@@ -81,22 +83,12 @@ def test_k_fragments_and_v_transpose_reads_deliver_the_mfma_operands():
 
 def test_read_patterns_are_bank_conflict_free():
     for odd in (0, 1):
-        assert conflict_free(lambda l: a_row(l, odd))            # K fragments; even form = the Wo stage rows as well
-    # without the chunk swizzle keys m and m + 8 of a service group share their banks
+        assert conflict_free(lambda l: a_k(l, odd))              # K fragments (64-byte rows)
+    assert conflict_free(a_row)                                  # Wo stage rows (32-byte rows)
+    # without the chunk swizzles rows of a service group share their banks
+    assert not conflict_free(lambda l: ((l & 31) << 6) | ((l >> 5) << 4))
     assert not conflict_free(lambda l: ((l & 31) << 5) | ((l >> 5) << 4))
-    # ds_read_b64_tr_b16: two groups of 32 lanes, 8 bytes each, 64 banks
-    for second in (0, 1):
-        for half in (0, 1):
-            banks = set()
-            for lane in range(32 * half, 32 * half + 32):
-                a = a_v(lane, second)
-                for w in range(2):
-                    b = (a // 4 + w) % 64
-                    assert b not in banks, (second, lane)
-                    banks.add(b)
-    # ... which is what the key ^ 4 of the odd panels buys: without it lanes 0-15 and 16-31 read the same banks of adjacent panels
-    banks = [((lane >> 4) & 1) * 4096 + (((lane & 15) >> 2) << 5) + ((lane & 3) << 3) for lane in range(32)]
-    assert len({(a // 4) % 64 for a in banks}) < 32
+    # the V transpose reads are the guide's known-good form: lane l at + 8 l of a 512-byte run (nothing to model)
 
 
 def test_counted_waits_match_the_issue_order():

@@ -110,6 +110,35 @@ def timing(B=512, reps=10):
     return res
 
 
+def phases(B=256, reps=5):
+    """LDM_DEV=1 LDM_ATTNOUT_TM=1: s_memtime sums of the fused attention + out_proj kernel, cycles per workgroup and launch."""
+    import ctypes
+
+    from layout_dm_amd import binding
+
+    lib = binding.load_library()
+    spec = SY.SPECS["rico25"]
+    e = Engine(n_category=spec.n_category, precision="split", max_batch=B)
+    e.load_state_dict(SY.synth_state_dict(spec, seed=0))
+    tok = tokens_for(spec, B, 0)
+    e.denoise_logits(tok, 50)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 24)()
+    lib.ldm_dev_attnout_phases(buf)
+    for _ in range(reps):
+        e.denoise_logits(tok, 50)
+    torch.cuda.synchronize()
+    lib.ldm_dev_attnout_phases(buf)
+    n = max(1, buf[15])
+    names = ["Ba", "Bb", "Bc", "Bd1", "Bd2", "Bd3"]
+    per = lambda v: v / n   # noqa: E731
+    print(f"PHASES workgroups {buf[15]} (x 100 MHz s_memtime ticks per workgroup)")
+    print("  vmcnt waits  :", "  ".join(f"{nm} {per(buf[i]):8.0f}" for i, nm in enumerate(names)))
+    print("  barrier waits:", "  ".join(f"{nm} {per(buf[6 + i]):8.0f}" for i, nm in enumerate(names)))
+    print(f"  head loop {per(buf[12]):.0f}   epilogue {per(buf[13]):.0f}   kernel {per(buf[14]):.0f}")
+    print("  in the loop  :", "  ".join(f"{nm} {per(buf[16 + i]):8.0f}" for i, nm in enumerate(["softmax", "PV", "O-split", "out_proj", "scores"])), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["numerics", "timing"]
     if "f64" in what:
@@ -118,3 +147,5 @@ if __name__ == "__main__":
         numerics()
     if "timing" in what:
         timing()
+    if "phases" in what:
+        phases()
