@@ -101,18 +101,30 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
   } else {
     // ---- log p(x0 | xt): log-softmax over classes [0, C-1) (float64 like base.py:137, or fp32 in the fast mode)
     const float* lrow = p.logits + (size_t)row * p.ldl;
+    // the lane's classes c = lane, lane + NL, ... are loaded ONCE, into registers, with every load issued before the first use (r06:
+    // the three passes below used to re-read the row through a rolled loop — one dependent global load per iteration, ~10 exposed
+    // L2 round trips per lane in front of the f64 exponentials: 111 us per launch in the split mode's profile, more than the
+    // vocabulary head it follows).  Same values, same summation order: results are bit-identical.
+    constexpr int NX = (192 + NL - 1) / NL;   // ldm_create: at most 192 classes
+    float xv[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int c = g.lane() + i * NL;
+      xv[i] = c < C - 1 ? lrow[c] : -INFINITY;
+    }
     float mx = -INFINITY;
-    for (int c = g.lane(); c < C - 1; c += NL) {
-      const float x = lrow[c];
-      mx = fmaxf(mx, x);
-      absmax = fmaxf(absmax, fabsf(x));
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      mx = fmaxf(mx, xv[i]);
+      absmax = fmaxf(absmax, g.lane() + i * NL < C - 1 ? fabsf(xv[i]) : 0.f);
     }
     mx = g.gmax(mx);
     absmax = g.gmax(absmax);
     float l0[NJ];
     if (FAST) {  // fast numerics mode (p.f32_lse): ~1e-6 relative, far inside its 1e-3 logits budget
       float se = 0.f;
-      for (int c = g.lane(); c < C - 1; c += NL) se += g.exp(lrow[c] - mx);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) se += g.exp(xv[i] - mx);   // (classes beyond the row: exp(-inf) = 0)
       const float lse0 = g.log(g.gsum(se));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(256) void posterior_sample_k(PostArgs p) {
       }
     } else {
       double se = 0.0;
-      for (int c = g.lane(); c < C - 1; c += NL) se += exp((double)lrow[c] - (double)mx);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) se += exp((double)xv[i] - (double)mx);   // (classes beyond the row: exp(-inf) = 0)
       const double lse0 = log(g.gsumd(se));
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
