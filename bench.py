@@ -672,6 +672,7 @@ def main():
                    "parallelism": f"dp{world} (independent layout shards, one all_gather of the final tokens)"},
         "algorithmic_tflops": res["algorithmic_tflops"],
         "world_size_seen": dist.get_world_size() if dist is not None else 1,
+        "dist_backend": dist.get_backend() if dist is not None else None,   # "nccl" = RCCL on ROCm
     }
     if "per_rank_layouts_per_s" in res:
         out["per_rank_layouts_per_s"] = res["per_rank_layouts_per_s"]
@@ -765,7 +766,7 @@ def main():
             # engine on the same weights (a power-bound kernel's clock depends on operand statistics), which auto refuses
             # where its logits error is outside 1e-3
             out["weight_sensitivity"] = auto_on_trained_like(a, SP, spec, B, res["value"], rank, world, local_rank, dist)
-    if not a.no_extras:
+    if True:   # (r06: also with --no-extras — the one-rank RCCL test of the GPU suite compares it with the plain run's; one short call)
         out["tokens_sha256"] = {"sha256": tokens_sha256(a, SP.synth_state_dict(SP.SPECS["rico25"], seed=0), SP.SPECS["rico25"],
                                                         rank, world, local_rank, dist),
                                 "of": f"first {SHA_LAYOUTS} layouts, Rico25 uncond random T={a.timesteps}, seed {SHA_SEED}, "

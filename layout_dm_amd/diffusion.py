@@ -11,6 +11,7 @@ duplication and dtype plumbing.
 from __future__ import annotations
 
 import itertools
+import logging
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -18,6 +19,15 @@ import torch
 from .binding import Engine
 
 _seed_counter = itertools.count()
+# the reference's entry point logs at INFO (trainer/test.py:38); `precision="auto"` says here which engine a checkpoint got and why
+logger = logging.getLogger("layout_dm_amd")
+# what each engine delivers on one MI355X (Rico25-shaped sequences, T = 100, batch 512; bench.py measures it on the box at hand)
+THROUGHPUT_CLASS = {
+    "fast": "~3 900 layouts/s (fp16 operands, one launch per sampling call)",
+    "fast_verified": "~3 400 - 3 900 layouts/s (fp16 engine; greedy decoding re-checked by the reference-precision engine)",
+    "split": "~1 150 - 1 200 layouts/s (reference precision on the fp16 matrix pipe, per-step launches)",
+    "exact": "~420 layouts/s (fp32 MFMA)",
+}
 
 
 def _cfg_get(cfg, key, default=None):
@@ -87,6 +97,7 @@ class HipMaskAndReplaceDiffusion:
         self.verifier_tolerance = 5e-4     # split vs a small fp32-MFMA probe engine: half the north star's tolerance (two valid fp32-level
                                            # engines differ by 4.2e-4 on the "wide" point, where the reference's own f32 noise floor is 1.2e-4)
         self.verifier_check: Dict[str, float] = {}
+        self.selection_report: Dict[str, object] = {}
         self.selected_precision = None if self.auto else precision
         self._mk = mk = lambda prec, mb=max_batch: Engine(n_category=n_category, n_bin=n_bin, max_elem=max_elem, n_attr=n_attr,
                                  d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
@@ -131,14 +142,14 @@ class HipMaskAndReplaceDiffusion:
         from .verified import measure_fast_error, probe_states
 
         v = self.verified
+        n = max(1, min(4, int(v.exact.max_batch)))   # (the probe batch must fit an engine built with max_batch < 4)
         if self.verifier != "split":
-            states = probe_states(v.exact, n_layouts=4, ts=[v.exact.T // 2])
+            states = probe_states(v.exact, n_layouts=n, ts=[v.exact.T // 2])
             lg = v.exact.denoise_logits(*states[0])
             if not bool(torch.isfinite(lg).all()):
                 raise FloatingPointError("reference-precision engine: non-finite logits on this checkpoint")
             self.verifier_check = {"verifier": self.verifier, "finite": True}
             return
-        n = 4
         small = self._mk("exact", n)
         try:
             small.load_state_dict(state_dict)
@@ -185,7 +196,35 @@ class HipMaskAndReplaceDiffusion:
                 self.selected_precision = "fast_verified" if ok else self.verifier
                 if not ok:
                     self.engine = self.verified.exact
+        self._report_selection()
         return self
+
+    def _report_selection(self) -> None:
+        """One INFO record per loaded checkpoint: which engine runs, the fp16 engine's measured logits error,
+        the tolerance it was held against and the throughput class to expect — a user must be able to tell why a job runs at
+        1 200 instead of 3 900 layouts/s.  The same dictionary is `selection_report` (python -m layout_dm_amd.check_checkpoint)."""
+        sel = self.selected_precision
+        rep = {"precision_requested": self.precision, "engine_selected": sel,
+               "expected_throughput": THROUGHPUT_CLASS.get(sel, "?")}
+        if self.verified is not None:
+            cal = self.verified.calibration
+            rep.update({"fast_logits_err_rel": cal.get("err_rel"), "fast_logits_err_abs": cal.get("err_abs"),
+                        "tolerance": self.auto_tolerance, "verifier": self.verifier, "verifier_check": dict(self.verifier_check),
+                        "tie_abs": cal.get("tie_abs")})
+        self.selection_report = rep
+        if self.verified is None:
+            logger.info("layout_dm_amd: engine '%s' (as requested) — %s", sel, rep["expected_throughput"])
+            return
+        err = rep["fast_logits_err_rel"]
+        err_s = "non-finite" if err is None or err != err or err == float("inf") else f"{err:.2e}"
+        if self.auto:
+            why = ("inside" if sel == "fast_verified" else "OUTSIDE") + f" the {self.auto_tolerance:g} logits tolerance"
+            logger.info("layout_dm_amd: precision='auto' selected engine '%s': the fp16 engine's logits error on this checkpoint is %s "
+                        "(relative, against the %s reference-precision engine), %s — expect %s", sel, err_s, self.verifier, why,
+                        rep["expected_throughput"])
+        else:
+            logger.info("layout_dm_amd: engine '%s' (as requested); fp16 logits error on this checkpoint %s (relative, against the %s "
+                        "engine) — expect %s", sel, err_s, self.verifier, rep["expected_throughput"])
 
     @property
     def calibration(self) -> Dict[str, float]:
@@ -214,7 +253,9 @@ class HipMaskAndReplaceDiffusion:
                 "layout_dm_amd.relation.sample_with_relation, which LayoutDM.sample does (the logit adjustment of "
                 "logit_adjustment.py:88-126 then runs inside ldm_sample_loop)")
         if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # (deterministic decoding draws nothing — and must not advance torch's global generator either: the reference's argmax
+            #  path consumes no random numbers (helpers/sampling.py:110-111), and test.py's get_cond of the NEXT batch reads that stream)
+            seed = 0 if str(_cfg_get(sampling_cfg, "name")) == "deterministic" else int(torch.randint(0, 2 ** 62, (1,)).item())
         B = int(batch_size)
         if B == 0:  # an empty shard (distributed.shard_range with fewer layouts than ranks)
             empty = torch.empty((0, eng.S), dtype=torch.int32, device=eng.device)

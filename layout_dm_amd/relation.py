@@ -108,8 +108,8 @@ def sample_with_relation(inner: HipMaskAndReplaceDiffusion, batch_size: int, con
     T = inner.num_timesteps
     t_model, t_post = timestep_schedule(T, int(_cfg_get(sampling_cfg, "num_timesteps", T)),
                                         float(_cfg_get(sampling_cfg, "time_difference", 0.0) or 0.0))
-    if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if seed is None:   # (deterministic decoding: no draw from torch's global generator, like the reference — diffusion.sample)
+        seed = 0 if str(_cfg_get(sampling_cfg, "name")) == "deterministic" else int(torch.randint(0, 2 ** 62, (1,)).item())
     B = int(batch_size)
     cond = dict(cond)
     for k, v in list(cond.items()):  # duplicate_cond + .to(device), base.py:321-336

@@ -1,0 +1,111 @@
+"""CPU: `precision="auto"` says what it selected and why — on FAKE engines whose fp16 error is a knob.
+
+HipMaskAndReplaceDiffusion.load_state_dict must (a) emit ONE INFO record on the `layout_dm_amd` logger naming the selected engine, the
+measured fp16 logits error, the tolerance and the throughput class, (b) expose the same as `selection_report` (what
+`python -m layout_dm_amd.check_checkpoint` prints), and (c) work for an engine built with max_batch < 4 (the verifier
+check used a fixed probe batch of 4)."""
+import json
+import logging
+
+import pytest
+import torch
+
+import layout_dm_amd.diffusion as D
+
+S_ATTR = 5
+
+
+class FakeEngine:
+    """binding.Engine's surface as diffusion.py / verified.py use it; logits = a fixed function of (tokens, t) plus `noise` in the
+    engines whose precision is 'fast'."""
+    fast_noise = 0.0
+    built = []
+
+    def __init__(self, *, n_category, n_bin=32, max_elem=25, n_attr=5, n_step=100, precision="exact", max_batch=512,
+                 q_type="constrained", **_k):
+        self.q_type = q_type
+        self.S, self.C, self.T = max_elem * n_attr, n_category + 4 * n_bin + 2, n_step
+        self.n_attr, self.n_bin, self.n_category = n_attr, n_bin, n_category
+        self.pad_id, self.mask_id = self.C - 2, self.C - 1
+        self.max_batch, self.batch_round, self.precision = max_batch, 256, precision
+        self.device = torch.device("cpu")
+        FakeEngine.built.append((precision, max_batch))
+
+    def load_state_dict(self, sd):
+        pass
+
+    def _tok(self, t):
+        return torch.as_tensor(t).to(torch.int32).contiguous()
+
+    def denoise_logits(self, tokens, t):
+        tokens = self._tok(tokens)
+        assert tokens.shape[0] <= self.max_batch, f"batch {tokens.shape[0]} outside [1, max_batch = {self.max_batch}]"
+        g = torch.Generator().manual_seed(int(tokens.long().sum()) * 131 + int(t))
+        base = torch.randn(tokens.shape[0], self.S, self.C, generator=g)
+        if self.precision == "fast":
+            base = base + FakeEngine.fast_noise * base.abs().max() * torch.sign(torch.randn(base.shape, generator=g))
+        return base
+
+    def sample_loop(self, tokens, t_model, t_post, cfg, cond=None, seed=0, first_layout=0, intermediates=False, use_graph=True,
+                    lc_keep=None, relation=None):
+        tokens = self._tok(tokens)
+        inter = torch.stack([tokens.clone() for _ in t_model]) if intermediates else None
+        return tokens, inter
+
+    def set_tie_report(self, *a, **k):
+        pass
+
+    def describe(self):
+        return {"precision": self.precision}
+
+    def close(self):
+        pass
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    monkeypatch.setattr(D, "Engine", FakeEngine)
+    import layout_dm_amd.verified as V
+
+    monkeypatch.setattr(V, "Engine", FakeEngine, raising=False)
+    FakeEngine.built = []
+    return FakeEngine
+
+
+@pytest.mark.parametrize("noise,want", [(1e-4, "fast_verified"), (5e-3, "split")])
+def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noise, want):
+    fake.fast_noise = noise
+    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="auto", max_batch=8)
+    with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
+        m.load_state_dict({})
+    recs = [r for r in caplog.records if r.name == "layout_dm_amd" and r.levelno == logging.INFO]
+    assert len(recs) == 1, [r.getMessage() for r in recs]
+    msg = recs[0].getMessage()
+    assert m.selected_precision == want and f"'{want}'" in msg
+    assert "0.001" in msg and ("inside" in msg if want == "fast_verified" else "OUTSIDE" in msg)
+    assert D.THROUGHPUT_CLASS[want] in msg
+    rep = m.selection_report
+    assert rep["engine_selected"] == want and rep["tolerance"] == 1e-3 and rep["verifier"] == "split"
+    assert abs(rep["fast_logits_err_rel"] - noise) < 0.2 * noise       # the record carries the MEASURED error
+    assert f"{rep['fast_logits_err_rel']:.2e}" in msg
+    json.dumps(rep, default=str)                                       # (check_checkpoint prints it)
+
+
+def test_explicit_precision_is_logged_too(fake, caplog):
+    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="split", max_batch=8)
+    with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
+        m.load_state_dict({})
+    msgs = [r.getMessage() for r in caplog.records if r.name == "layout_dm_amd"]
+    assert len(msgs) == 1 and "'split'" in msgs[0] and "as requested" in msgs[0]
+
+
+@pytest.mark.parametrize("max_batch", [1, 2, 3])
+def test_auto_with_max_batch_below_the_old_probe_batch(fake, max_batch):
+    """_check_verifier probed with 4 layouts whatever max_batch was; ldm_denoise_logits rejects B > max_batch,
+    so LayoutDM(max_batch=1) — precision='auto' is its default — raised inside load_state_dict."""
+    fake.fast_noise = 1e-4
+    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="auto", max_batch=max_batch)
+    m.load_state_dict({})
+    assert m.selected_precision == "fast_verified"
+    assert all(mb <= max_batch for _, mb in FakeEngine.built)           # the small fp32 probe engine as well
+    assert m.verifier_check["finite"]

@@ -86,8 +86,10 @@ def test_entry_point_unconditional_end_to_end(tmp_path):
     (job / "config.yaml").write_text(yaml.safe_dump(TRAIN_CFG))
     sd = {k: torch.from_numpy(v) for k, v in SY.synth_state_dict(SY.RICO25, seed=1, perturb=True).items()}
     torch.save(sd, job / "best_model.pt")
-    out = TE.main([f"job_dir={job}", f"result_dir={tmp_path / 'res'}", "num_uncond_samples=10", "max_batch_size=4",
-                   "num_timesteps=20", "sampling=random"])
+    # (run_builtin, not main: main() drives the reference's own entry point whenever hydra + trainer are importable — which they are
+    #  in a session that ran tests/test_entry_reference_main*.py before this file; that path has its own tests)
+    out = TE.run_builtin(TE.parse_cli([f"job_dir={job}", f"result_dir={tmp_path / 'res'}", "num_uncond_samples=10", "max_batch_size=4",
+                                       "num_timesteps=20", "sampling=random"]))
     assert os.path.basename(out["result_dir"]) == "unconditional_temperature_1.0_name_random_num_timesteps_20"
     data = pickle.load(open(out["pickles"][0], "rb"))
     assert set(data) == {"results", "train_cfg", "test_cfg"} and len(data["results"]) == 10
@@ -106,3 +108,34 @@ def test_entry_point_unconditional_end_to_end(tmp_path):
         direct.extend(TE._filter_invalid(lay))
     for (b1, l1), (b2, l2) in zip(data["results"], direct):
         assert np.array_equal(b1, b2) and np.array_equal(l1, l2)
+
+
+@pytest.mark.gpu
+def test_check_checkpoint_reports_what_auto_selects(tmp_path, caplog):
+    """`python -m layout_dm_amd.check_checkpoint job_dir=...`: one JSON-able record per checkpoint with the
+    engine `precision="auto"` selects, the MEASURED fp16 logits error, the tolerance and the throughput class — on the init-like
+    synthetic checkpoint the fp16 engine stays (error ~4e-4), on the sigma = 0.15 one the reference-precision engine takes over —
+    and the same as an INFO record on the `layout_dm_amd` logger."""
+    import json
+    import logging
+
+    from layout_dm_amd import check_checkpoint as CC
+    from layout_dm_amd import synthetic as SY
+
+    for point, want in (("init", "fast_verified"), ("wide", "split")):
+        job = tmp_path / f"job_{point}"
+        job.mkdir()
+        (job / "config.yaml").write_text(yaml.safe_dump(TRAIN_CFG))
+        sd = {k: torch.from_numpy(v) for k, v in SY.trained_like_state_dict(SY.RICO25, point, seed=2).items()}
+        torch.save(sd, job / "best_model.pt")
+        with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
+            caplog.clear()
+            reps = CC.check(str(job), max_batch=8)
+        assert len(reps) == 1
+        rep = reps[0]
+        json.dumps(rep, default=str)
+        assert rep["engine_selected"] == want and rep["tolerance"] == 1e-3 and rep["checkpoint"].endswith("best_model.pt")
+        assert (rep["fast_logits_err_rel"] <= 1e-3) == (want == "fast_verified")
+        assert rep["verifier_check"]["finite"] and "layouts/s" in rep["expected_throughput"]
+        msgs = [r.getMessage() for r in caplog.records if r.name == "layout_dm_amd"]
+        assert len(msgs) == 1 and f"'{want}'" in msgs[0] and f"{rep['fast_logits_err_rel']:.2e}" in msgs[0]
