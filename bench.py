@@ -786,8 +786,8 @@ def main():
         out["config"]["cpu_baseline_kind"] = out["cpu_baseline"]["kind"]
         out["cpu_baseline_kind"] = out["cpu_baseline"]["kind"]
     ws = out.get("weight_sensitivity", {})
-    for point in ("mid", "wide"):   # scalars a reader that drops nested objects still sees
-        if point in ws:
+    for point in ("mid", "wide", "fitted"):   # scalars a reader that drops nested objects still sees
+        if ws.get(point):
             for key, val in ((f"auto_selected_{point}", ws[point]["auto_selected"]), (f"auto_layouts_per_s_{point}", ws[point]["value"])):
                 out[key] = val              # top level ...
                 out["config"][key] = val    # ... and inside `config`
@@ -823,8 +823,22 @@ def auto_on_trained_like(a, SP, spec, B, headline, rank, world, local_rank, dist
     out = {"weights": "trained_like points of layout_dm_amd/synthetic.py (mid: sigma 0.06, wide: sigma 0.15)",
            "workload": f"headline workload ({B} layouts, T={a.timesteps}, sampling={a.sampling}), LayoutDM's default precision='auto'"}
     cfg = {"name": a.sampling, "temperature": 1.0, "top_p": 0.9, "num_timesteps": a.timesteps}
-    for point in ("mid", "wide"):
-        sdw = SP.trained_like_state_dict(spec, point, seed=2)
+    # r06: a checkpoint that was actually TRAINED — the reference model fitted by the reference's own loss /
+    # optimizer for 1 500 steps on structured synthetic layouts (oracle/make_trained_fixture.py -> oracle/_fit/rico25_fitted.npz, a
+    # build output that travels with the snapshot like oracle/_ref/; only the weight FILE is read here, no oracle code)
+    fitted = os.path.join(ROOT, "oracle", "_fit", "rico25_fitted.npz")
+    points = ("mid", "wide") + (("fitted",) if spec.name == "rico25" and os.path.exists(fitted) else ())
+    if "fitted" in points:
+        out["fitted"] = None
+        out["weights"] += "; fitted: oracle/_fit/rico25_fitted.npz (the reference model trained with the reference's own step)"
+    for point in points:
+        if point == "fitted":
+            import numpy as np
+
+            with np.load(fitted) as wf:
+                sdw = {k: wf[k] for k in wf.files}
+        else:
+            sdw = SP.trained_like_state_dict(spec, point, seed=2)
         m = HipMaskAndReplaceDiffusion(n_category=spec.n_category, n_bin=spec.n_bin, max_elem=spec.max_elem,
                                        d_model=spec.d_model, n_head=spec.n_head, d_ff=spec.d_ff, n_layer=spec.n_layer,
                                        num_timesteps=spec.n_step, precision="auto", max_batch=B, device=local_rank)
