@@ -398,6 +398,7 @@ struct LpState {
                                 // stage's barrier) and the one after's (requested in this stage, in flight across its barrier: the
                                 // rows come from HBM, a stage is ~1.5 us) — three register sets in rotation, no copies
   const __half *pa, *pal;       // this lane's row of A hi / lo + 8 * (lane / 32) halves
+  size_t a_stage;               // halves from one 32-wide K stage of the A rows to the next: 32 (row-major rows) | one panel (panel-major)
   const char* img;              // slab image + wave * 16 KiB
   unsigned lds_w, voff;
   int stage_delta, n_stages, n_astages;   // stages of the image (a multiple of 3) / of them with real A columns
@@ -435,10 +436,10 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
   if (s.a_hot) sd = 0;
 #endif
   const int t = sd < s.n_astages ? sd : s.n_astages - 1;   // (the zero slabs at the end of the image multiply the last real columns again)
-  s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32);
-  s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * 32 + 16);
-  s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * 32);
-  s.fl[P][1] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * 32 + 16);
+  s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * s.a_stage);
+  s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * s.a_stage + 16);
+  s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage);
+  s.fl[P][1] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage + 16);
 }
 
 #define LP_MFMA(B, A) "v_mfma_f32_32x32x16_f16 %[c], " B ", " A ", %[c]\n\t"
@@ -545,8 +546,12 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     ps.a_hot = a.relu >> 8;   // (launch_lngemm16x3 passes the variant in the upper bits)
 #endif
     ps.stage_delta = LG_STAGE;
-    ps.pa = a.preA + (size_t)rrow * a.pre_lda + hi * 8;
-    ps.pal = a.preAlo + (size_t)rrow * a.pre_lda + hi * 8;
+    // A rows: row-major [M, pre_lda], or (pre_panel_stride != 0, r06) panel-major [K / 32 panels][rows][32 halves] as the ReLU epilogue
+    // of linear1 writes them: a wave's 32 rows of a stage are 2 KiB contiguous instead of 32 x 64 B out of 32 different rows
+    const size_t a_pitch = a.pre_panel_stride ? 32 : (size_t)a.pre_lda;
+    ps.a_stage = a.pre_panel_stride ? a.pre_panel_stride / 2 : 32;
+    ps.pa = a.preA + (size_t)rrow * a_pitch + hi * 8;
+    ps.pal = a.preAlo + (size_t)rrow * a_pitch + hi * 8;
     for (int t = 0; t < 2; ++t)   // slabs 0 / 1 -> ring slots 0 / 1
 #pragma unroll
       for (int k = 0; k < 4; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   e.C0 = OUT == 0 ? reinterpret_cast<const char*>(a.C32) : reinterpret_cast<const char*>(a.C16);
   e.C1 = reinterpret_cast<const char*>(a.C16lo);
   e.b0 = e.C0; e.b1 = e.C1; e.colmask = 0;
-  e.tstride = OUT == 0 ? 128 : OUT == 1 ? 64 : a.panel_stride;
+  e.tstride = OUT == 0 ? 128 : (OUT == 1 && !a.panel_out) ? 64 : a.panel_stride;
   e.N = a.N; e.c4 = (lane & 7) * 4;
   e.out_scale = a.out_scale;
 #pragma unroll
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     const int orow = blockIdx.x * 128 + wave * 32 + p * 8 + (lane >> 3);
     e.rowmask[p] = __ballot(orow < a.M);
     // (launch_lngemm16x3 checks that M * ld * element size fits 32 bits)
-    if constexpr (OUT == 2)   // panel-major: a tile's 32 columns are ONE panel of 64-byte rows
+    if (OUT == 2 || (OUT == 1 && a.panel_out))   // panel-major: a tile's 32 columns are ONE panel of 64-byte rows
       e.voff[p] = (unsigned)orow * 64u + (unsigned)e.c4 * 2u;
     else
       e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
@@ -765,7 +770,9 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   // three output forms: fp32 (no ReLU) | ReLU + hi / lo fp16 rows | hi / lo fp16 panels without ReLU (q / k / v for kernels_attnout.hip);
   // the epilogue addresses with 32-bit byte offsets
   const bool half_out = a.C16 != nullptr;
-  const bool panel = half_out && a.panel_out;
+  const bool panel = half_out && a.panel_out && !a.relu;        // q / k / v (OUT = 2); panel_out with ReLU: linear1's hidden rows (OUT = 1)
+  if (half_out && a.panel_out && a.relu && ((a.N & 31) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 64 || (unsigned long long)a.M * 64 >= (1ull << 32)))
+    return -1;
   if (panel ? (!a.C16lo || a.C32 || a.relu || !a.ada || (a.N & 31) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 64)
             : half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu))
     return -1;
@@ -776,7 +783,8 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   const bool pre = a.pre_img != nullptr;
   // GEMM prologue: a multiple of three 32-wide K slabs (zero slabs behind the pre_astages real ones), all d_model columns inside its 15 tiles, fp32 residual rows
   if (pre && (a.pre_stages < 3 || a.pre_stages % 3 || a.pre_astages < 2 || a.pre_astages > a.pre_stages || a.D > 32 * LP_NT || !a.preA ||
-              !a.preAlo || !a.pre_res || a.tokens || a.pre_lda < 32 * a.pre_astages || (a.pre_lda & 7)))
+              !a.preAlo || !a.pre_res || a.tokens ||
+              (a.pre_panel_stride ? ((a.pre_panel_stride & 15) || a.pre_panel_stride < (size_t)a.M * 64) : (a.pre_lda < 32 * a.pre_astages || (a.pre_lda & 7)))))
     return -1;
   auto kern = panel ? lngemm16x3_k<true, 2> : half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
   if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;

@@ -168,18 +168,18 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     A(&h->a16, Mt * h->Dp);
     A(&h->att16, Mt * h->Dp);
     A(&h->h16, Mt * h->Dp);
-    A(&h->hid16, Mt * h->Fp);
+    A(&h->hid16, (Mt + 64) * h->Fp);     // (+ 64 rows: the panel-major form of the hidden activations, rows rounded up to 64)
     {
       A(&h->qkv32, Mc * 3 * h->D);
       A(&h->a16lo, Mt * h->Dp);
       A(&h->att16lo, Mt * h->Dp);
       A(&h->h16lo, Mt * h->Dp);
-      A(&h->hid16lo, Mt * h->Fp);
+      A(&h->hid16lo, (Mt + 64) * h->Fp);
     }
+    if (cfg->precision == LDM_PREC_SPLIT_F16) h->panel_rows = (size_t)round_up((int)Mc + 8, 64);
     if (cfg->precision == LDM_PREC_SPLIT_F16 && attnout16x3_supported(h->S, h->H, h->dh, h->D)) {
       // q / k / v panels of the fused attention + out_proj kernel: 3 x 8 heads x 2 panels of 32 halfs, hi and lo; a layout's last
       // key tile reads up to 3 rows past the chunk's last row (slack, zero)
-      h->panel_rows = (size_t)round_up((int)Mc + 8, 64);
       A(&h->qkvp_hi, (size_t)48 * h->panel_rows * 32);
       A(&h->qkvp_lo, (size_t)48 * h->panel_rows * 32);
     }
@@ -208,6 +208,8 @@ extern "C" int ldm_create(const ldm_config* cfg, int device, ldm_handle** out) {
     h->pre_ffn2 = h->lngemm_pre && (lv == 2 || lv == 4);
     // r06: attention + out_proj as one layout-resident launch behind an in_proj that writes hi / lo panels (kernels_attnout.hip);
     // LDM_DEV=1 LDM_X3_ATTNOUT=0: attn16x3_k + the out_proj launch of gemm16x3_k (the r05 structure)
+    h->hid_panels = h->lngemm && h->pre_ffn2 && h->Fp % 32 == 0 && h->panel_rows <= (size_t)round_up((int)Mc, 256) + 64 &&
+                    knob_int("LDM_X3_HIDPANEL", 1) != 0;
     h->attnout = h->lngemm && !h->pre_out && h->qkvp_hi && h->panel_rows * 64 * 2 < (1ull << 32) && knob_int("LDM_X3_ATTNOUT", 1) != 0;
   }
   h->cur_lane = h->n_lanes - 1;

@@ -113,6 +113,7 @@ static void ffn2_prologue(ldm_handle* h, const LayerW& w, LnGemmArgs& a) {
   a.preA = h->hid16; a.preAlo = h->hid16lo; a.pre_lda = h->Fp; a.pre_astages = h->Fp / 32; a.pre_stages = ldm_pack::x3_slab_stages(h->Fp);
   a.pre_img = (const char*)w.x3_ffn2_slab; a.pre_bias = w.b2; a.pre_scale = w.s2;
   a.pre_res = h->Q; a.pre_out = nullptr;
+  a.pre_panel_stride = h->hid_panels ? h->panel_rows * 64 : 0;
 }
 
 int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
@@ -222,6 +223,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.img = (const char*)w.x3_ffn1; a.n_tiles = h->x3_ffn1_tiles;
       a.bias = w.b1; a.out_scale = w.s1; a.relu = 1;
       a.C16 = h->hid16; a.C16lo = h->hid16lo; a.ldc16 = Fp;
+      if (h->hid_panels) { a.panel_out = 1; a.panel_stride = h->panel_rows * 64; }   // (read back by ffn2_prologue in the same form)
       a.M = M; a.N = F; a.D = D; a.S = h->S;
       if (h->pre_out) {   // Q = P + att · Wo^T + bo computed in this launch, written once (linear2's residual base)
         a.preA = h->att16; a.preAlo = h->att16lo; a.pre_lda = Dp; a.pre_astages = Dp / 32; a.pre_stages = ldm_pack::x3_slab_stages(Dp);

@@ -157,6 +157,9 @@ struct ldm_handle {
   // to it as head-padded hi / lo fp16 PANELS (qkvp_hi / qkvp_lo: [48][panel_rows][32]); LDM_DEV=1 LDM_X3_ATTNOUT=0: attn16x3_k + gemm16x3_k
   bool attnout = false;
   size_t panel_rows = 0;
+  // r06: the hidden activations (linear1 -> ReLU -> linear2) travel panel-major as well when linear2 is a GEMM prologue (pre_ffn2):
+  // full-line stores in linear1's epilogue, 2-KiB-contiguous A loads in the prologue; LDM_DEV=1 LDM_X3_HIDPANEL=0: row-major
+  bool hid_panels = false;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

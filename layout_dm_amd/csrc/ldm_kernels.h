@@ -97,7 +97,8 @@ struct LnGemmArgs {
   int M, N, D, S, ldx, ldc32, ldc16, n_tiles, ada, relu;
   float out_scale;          // 2^-k of the weight tensor's power-of-two pre-scale
   // r06: hi / lo fp16 output WITHOUT ReLU in PANEL-major form (in_proj in front of kernels_attnout.hip): C16 / C16lo are arrays
-  // [N / 32 panels][panel_rows][32 halfs] — column c of row r at panel c / 32, byte r * 64 + (c % 32) * 2; ldc16 is ignored
+  // [N / 32 panels][panel_rows][32 halfs] — column c of row r at panel c / 32, byte r * 64 + (c % 32) * 2; ldc16 is ignored.
+  // With relu = 1 (linear1): the same panel form for the hidden activations, read back by the linear2 GEMM prologue (pre_panel_stride)
   int panel_out;
   size_t panel_stride;      // bytes between panels (>= (M + slack) * 64, a multiple of 16)
   // GEMM prologue (pre_img != nullptr): x = pre_res + pre_bias + pre_scale * (preA · Wpre^T) is computed by the kernel itself instead
@@ -108,6 +109,7 @@ struct LnGemmArgs {
   const float* pre_res;          // [M, D] fp32 residual rows
   float* pre_out;                // [M, D] or nullptr: x written back (the residual base of a later GEMM)
   int pre_lda, pre_stages, pre_astages;   // stages of the image (a multiple of 3, zero slabs at the end) / stages with real K columns
+  size_t pre_panel_stride;                // 0: preA / preAlo are row-major; else (r06) panel-major [K / 32][rows][32 halves], bytes between panels
   float pre_scale;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
