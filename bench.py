@@ -226,6 +226,16 @@ def cpu_baseline_reference(spec, sd, T, sampling, cond_np, budget_s=22.0):
         m, _tok = rh.build_reference_model(spec.name, seed=0, n_step=spec.n_step)
     except Exception as e:  # the reference needs more than the stubs provide: fall back to the port, and say why
         return {"unavailable": f"{type(e).__name__}: {e}"[:200]}
+    try:   # (the whole reference leg is guarded — it executes byte-compiled reference code at the very end of main(); a failure
+        #  here must fall back to the port, not abort bench.py before its one JSON line)
+        return _cpu_baseline_reference_timed(rh, m, spec, sd, T, sampling, cond_np, budget_s)
+    except Exception as e:
+        return {"unavailable": f"{type(e).__name__}: {e}"[:200]}
+
+
+def _cpu_baseline_reference_timed(rh, m, spec, sd, T, sampling, cond_np, budget_s):
+    import torch
+
     m.load_state_dict({k.split("model.module.")[-1]: torch.as_tensor(v) for k, v in sd.items()})
     m.eval()
     ncpu = os.cpu_count() or 1
@@ -255,9 +265,12 @@ def cpu_baseline_reference(spec, sd, T, sampling, cond_np, budget_s=22.0):
     n64 = int(max(0, min(T // 4, left / max(per_step64, 1e-9))))
     if n64 >= 5:
         dt64 = run(64, n64)
-        runs.append({"batch": 64, "steps": n64, "seconds": round(dt64, 2), "layouts_per_s": round(64 / (dt64 * T / n64), 3)})
+        runs.append({"batch": 64, "steps": n64, "seconds": round(dt64, 2), "layouts_per_s": round(64 / (dt64 * T / n64), 3),
+                     "extrapolated": f"{n64} strided steps scaled to T = {T}"})
     best = max(runs, key=lambda r: r["layouts_per_s"])
     return {"value": best["layouts_per_s"], "unit": "layouts/s", "cores": threads, "kind": "reference",
+            "value_from": f"batch {best['batch']}" + (" (EXTRAPOLATED from a strided run)" if "extrapolated" in best else " (all T steps timed)"),
+            "value_full_T_run": runs[0]["layouts_per_s"],
             "host_logical_cpus": ncpu, "runs": runs,
             "source": "reference tree" if rh.reference_available() else "oracle/_ref (byte-compiled by oracle/build_ref.py)",
             "sample": f"the reference's own sample() (base.py:293-371) timed as test.py:194-203: batch 4 x all T={T} steps"
@@ -371,10 +384,58 @@ def measure_traffic(kernel_substr: str, dataset: str, precision: str, timeout_s:
     return vals, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), KB per launch"
 
 
+def measure_traffic_per_kernel(dataset: str, precision: str, steps: int = 2, timeout_s: int = 170):
+    """FETCH_SIZE / WRITE_SIZE per launch of EVERY kernel class of one sampling call in `precision` (two separate counter passes
+    over tools/pmc_probe.py with PMC_STEPS = steps): {kernel symbol: {"fetch_bytes_raw", "fetch_bytes_calibrated", "write_bytes",
+    "launches"}} or (None, note).  Used for the split mode, whose step is a chain of kernels (VERDICT r5 next #1: per-kernel bytes)."""
+    exe = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    import csv
+    import re
+
+    acc = {}
+    env = dict(os.environ, TMPDIR="/tmp", PMC_DATASET=dataset, PMC_PRECISION=precision, PMC_STEPS=str(steps))
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix=f"ldm_pmck_{counter}_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "run", "--",
+               sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} timed out"
+        if p.returncode != 0:
+            return None, f"rocprofv3 --pmc {counter} failed rc={p.returncode}: {p.stdout[-300:]}"
+        for f in glob.glob(out_dir + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                name = row.get("Kernel_Name", "")
+                if "ldm::" not in name or row.get("Counter_Name") != counter:
+                    continue
+                key = re.sub(r"\(.*$", "", name).replace("void ", "").replace("ldm::", "")
+                acc.setdefault(key, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+        subprocess.run(["rm", "-rf", out_dir])
+    out = {}
+    for k, v in acc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and len(v["FETCH_SIZE"]) >= 4:
+            f_raw = 1024 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+            w = 1024 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+            out[k] = {"fetch_bytes_raw": int(f_raw), "fetch_bytes_calibrated": int(f_raw * FETCH_CALIBRATION), "write_bytes": int(w),
+                      "launches": len(v["FETCH_SIZE"])}
+    return (out or None), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_probe.py), bytes per launch of 256 layouts"
+
+
 # event-profile class -> substring of the kernel symbol in the PMC csv
 KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_stream_k",
                  "posterior_sample": "posterior_sample_k", "gemm_ffn2": "gemm_f", "gemm_ffn1": "gemm_f",
                  "attention": "attn_"}
+
+
+# split mode: event-profile class -> kernel symbol prefix (template arguments: <ADA, OUT, TM, ABL, PRE>)
+SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false>",
+                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true>",
+                       "attn_out_fused": "attnout16x3_k<false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 
 
 # ----------------------------------------------------------------------------------------- one workload, one mode
@@ -742,6 +803,18 @@ def main():
                                     with_roofline=not a.no_roofline)
                 e2.close()
             r.pop("kernel_breakdown_ms", None)
+            if m == "split" and rank == 0 and world == 1 and "roofline" in r and not a.no_roofline and not a.no_traffic:
+                # HBM-side bytes of every kernel of the split step (r06): the mode's dominant kernel takes `traffic`
+                per, note = measure_traffic_per_kernel(a.dataset, "split")
+                if per:
+                    dom = SPLIT_KERNEL_SYMBOL.get(r["roofline"].get("kernel"))
+                    hit = [k for k in per if dom and k.startswith(dom)]
+                    if hit:
+                        r["roofline"]["traffic"] = per[hit[0]]["fetch_bytes_calibrated"] + per[hit[0]]["write_bytes"]
+                    r["roofline"]["traffic_per_kernel"] = per
+                    r["roofline"]["traffic_source"] = note + f"; FETCH_SIZE x {FETCH_CALIBRATION} (profiles/r03_fetch_size_calibration.txt)"
+                else:
+                    r["roofline"]["traffic_source"] = f"live PMC collection unavailable: {note}"
             out["modes"][m] = r
 
     # the reference-arithmetic throughput (what a checkpoint outside the fp16 engine's tolerance gets) as top-level scalars, and

@@ -77,10 +77,23 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
         want, have = _build.source_digest(), _build.built_digest(p)
         if have != want:
-            try:
-                _build.build(verbose=False)
-            except Exception as e:  # no hipcc on this machine
-                raise RuntimeError(f"{p} was built from other sources (library {have}, tree {want}) and could not be rebuilt: {e}") from e
+            #  one builder at a time: under torchrun every rank arrives here at once, and the ranks that wait find the
+            # library rebuilt when they get the lock; the link goes to a temporary name and is renamed into place (build.build)
+            import fcntl
+            import sys
+
+            os.makedirs(os.path.join(os.path.dirname(p), "build"), exist_ok=True)
+            with open(os.path.join(os.path.dirname(p), "build", ".lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if _build.built_digest(p) != want:
+                        print(f"layout_dm_amd: {os.path.basename(p)} is stale against this tree's sources - rebuilding with hipcc "
+                              "(a minute or two; python -m layout_dm_amd.build does the same ahead of time)", file=sys.stderr, flush=True)
+                        _build.build(verbose=False)
+                except Exception as e:  # no hipcc on this machine
+                    raise RuntimeError(f"{p} was built from other sources (library {have}, tree {want}) and could not be rebuilt: {e}") from e
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(p)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     lib.ldm_abi_version.restype = C.c_int

@@ -82,10 +82,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    tmp = LIB + f".tmp{os.getpid()}"     # link under a temporary name, then rename: nobody dlopens a half-written file
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
