@@ -194,7 +194,8 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     asm = _compile("kernels_lngemm.hip", tmp_path)
     # the product instantiations (TM = false, ABL = 0: template arguments 3 and 4 mangle as Lb0ELi0; the phase-timer and measurement builds are dev only)
     kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and re.search(r"ELb0ELi0ELb[01]EEEvNS_10LnGemmArgsE$", k)}
-    assert len(kernels) == 6, list(_kernels(asm))   # (ADA, OUT) in {(1, 0), (0, 1), (0, 0)} x {plain, with the GEMM prologue}
+    # (ADA, OUT) in {(1, 0), (0, 1), (0, 0), (1, 2)} x {plain, with the GEMM prologue}; OUT = 2 (r06): in_proj writing hi / lo q / k / v panels
+    assert len(kernels) == 8, list(_kernels(asm))
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
@@ -253,3 +254,104 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
                 ws += 1
                 if ws >= 64:
                     break
+
+
+def test_attnout_kernel_register_discipline_and_hazards(tmp_path):
+    """kernels_attnout.hip (r06): every MFMA is inline asm with a pinned accumulator, q fragments arrive by asm global loads hipcc does
+    not track.  Checked on the ISA of the product instantiation (TM = false):
+      * no scratch; 276 asm MFMAs per head iteration + 48 in the prologue (scores of head 0);
+      * the head loop moves NOTHING between the register files (the first builds did: hipcc put the score tiles in AGPRs and shuffled
+        out_proj tiles through VGPRs, ~450 v_accvgpr_read / _write per head);
+      * the registers an asm global load writes are not touched before a counted s_waitcnt vmcnt(N) that covers the load (loads
+        return in order: covered = at least N vector-memory operations were issued behind it);
+      * no VALU write of an asm MFMA's operand inside the verified wait states (hipcc had sunk the fp16 casts of the attention output to
+        ONE instruction in front of the MFMA that consumes them);
+      * a VALU read of an asm MFMA's VGPR result sits at least a whole MFMA behind it."""
+    asm = _compile("kernels_attnout.hip", tmp_path)
+    ks = {k: v for k, v in _kernels(asm).items() if "attnout16x3_k" in k}
+    name = [k for k in ks if "ILb0E" in k]
+    assert len(name) == 1, list(ks)
+    name = name[0]
+    instr = ks[name]
+    sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
+    assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")]
+    mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
+    assert len(mf) == 48 + 276, len(mf)
+    assert not [t for t in instr if t.startswith("v_mfma")], "a builtin MFMA: hipcc would choose its register file"
+    # ---- the head loop: between the first and the last MFMA of the 276
+    loop = instr[mf[48]:mf[-1] + 1]
+    acc = [t for t in loop if t.startswith(("v_accvgpr_read", "v_accvgpr_write", "v_accvgpr_mov"))]
+    assert not acc, f"{len(acc)} AGPR <-> VGPR moves inside the head loop, e.g. {acc[:3]}"
+    # ---- asm loads (global_load_dwordx4 vdst, voff, s[base]) vs the counted waits
+    VM = ("global_load", "global_store", "buffer_load", "buffer_store", "scratch_load", "scratch_store", "flat_load", "flat_store")
+    pending, n_asm_loads = {}, 0
+    for t in instr:
+        p = t[4:] if t.startswith("asm:") else t
+        op = p.split()[0]
+        if op.startswith(VM):
+            for r in pending:
+                pending[r] += 1
+        if t.startswith("asm:global_load_dwordx4"):
+            n_asm_loads += 1
+            for r in _regs(p.split(None, 1)[1].split(",")[0].strip()):
+                pending[r] = 0
+            continue
+        m = re.search(r"vmcnt\((\d+)\)", p) if op == "s_waitcnt" else None
+        if m:
+            n = int(m.group(1))
+            pending = {r: c for r, c in pending.items() if c < n}
+            continue
+        if op.startswith("s_") or " " not in p:
+            continue
+        touched = set()
+        for a_ in p.split(None, 1)[1].split(","):
+            touched |= _regs(a_.strip().split(" ")[0])
+        bad = touched & set(pending)
+        assert not bad, f"'{p}' touches {sorted(bad)[:4]} while the asm load that writes them may still be in flight"
+    assert n_asm_loads == 16, n_asm_loads          # Q fragments of head 0 (prologue) and of head h + 1 (loop): 8 + 8
+    # ---- VALU write -> asm MFMA operand read; asm MFMA VGPR result -> VALU read
+    for i in mf:
+        t = instr[i][4:]
+        ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+        src_regs = _regs(ops[1]) | _regs(ops[2])
+        ws = 0
+        for j in range(i - 1, max(i - 12, -1), -1):
+            p = instr[j][4:] if instr[j].startswith("asm:") else instr[j]
+            op = p.split()[0]
+            if op == "s_nop":
+                ws += int(p.split()[1]) + 1
+                continue
+            if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp")) and " " in p:
+                if _regs(p.split(None, 1)[1].split(",")[0].strip()) & src_regs:
+                    assert ws >= VALU_TO_MFMA_WAIT_STATES, f"'{p}' writes an operand of '{t}' only {ws} wait states ahead"
+                    break
+            ws += 8 if op.startswith("v_mfma") else 1
+            if ws >= VALU_TO_MFMA_WAIT_STATES:
+                break
+        dst = _regs(ops[0])
+        if not any(f == "v" for f, _ in dst):
+            continue                                # the AGPR tiles are only read behind the loop's s_nop block
+        ws = 0
+        for j in range(i + 1, min(i + 60, len(instr))):
+            p = instr[j][4:] if instr[j].startswith("asm:") else instr[j]
+            op = p.split()[0]
+            if op == "s_nop":
+                ws += int(p.split()[1]) + 1
+                continue
+            if op.startswith("v_mfma"):
+                if _regs(p.split(None, 1)[1].split(",")[0].strip()) & dst:
+                    break                           # the accumulator chain continues: ordered by the matrix pipe
+                ws += 8
+                continue
+            if op.startswith(("s_", "ds_", "global_")) or " " not in p:
+                ws += 1
+                continue
+            reads = set()
+            for a_ in p.split(None, 1)[1].split(",")[1:]:
+                reads |= _regs(a_.strip().split(" ")[0])
+            if reads & dst:
+                assert ws >= 16, f"'{p}' reads the result of '{t}' only {ws} wait states behind it"
+                break
+            ws += 1
+            if ws >= 32:
+                break
