@@ -19,8 +19,8 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
 
     out = str(tmp_path / "golden")
     make_golden.main(out_dir=out)
-    # (rico25_mid_reference_samples.npz has its own generator and its own regeneration test below)
-    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz") and f != "rico25_mid_reference_samples.npz")
+    # (rico25_mid_reference_samples.npz and rico25_fitted.npz have their own generators and their own regeneration tests below)
+    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz") and f not in ("rico25_mid_reference_samples.npz", "rico25_fitted.npz"))
     assert names == sorted(f for f in os.listdir(out) if f.endswith(".npz"))
     for n in names:
         a, b = np.load(os.path.join(golden_dir, n)), np.load(os.path.join(out, n))
@@ -29,6 +29,35 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
             assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), (n, k)
     for n in (f for f in os.listdir(golden_dir) if f.endswith(".txt")):
         assert open(os.path.join(golden_dir, n)).read() == open(os.path.join(out, n)).read(), n
+
+
+def test_fitted_fixture_regenerates_from_the_fitted_weights(golden_dir):
+    """tests/golden/rico25_fitted.npz (oracle/make_trained_fixture.py): the 30-minute training run is not repeated here, but everything the
+    fixture says ABOUT the fitted checkpoint — the reference's logits / posterior at three timesteps, its f32 noise floor, its largest attention
+    score, the 100-state trajectory with greedy answers and margins — is recomputed by the live reference from oracle/_fit/rico25_fitted.npz and
+    must equal the committed arrays bit for bit (skipped where the 50-MB weight file, a git-ignored build output, is absent)."""
+    import hashlib
+
+    import torch
+
+    from oracle import make_trained_fixture as MF
+    from oracle import spec as SP
+
+    if not os.path.exists(MF.WEIGHTS):
+        pytest.skip("oracle/_fit/rico25_fitted.npz absent (python -m oracle.make_trained_fixture)")
+    g = np.load(os.path.join(golden_dir, "rico25_fitted.npz"))
+    with open(MF.WEIGHTS, "rb") as fh:
+        assert hashlib.sha256(fh.read()).hexdigest() == str(g["weights_sha256"])
+    spec = SP.SPECS["rico25"]
+    m, tok = rh.build_reference_model("rico25", seed=int(g["train_args"][3]))
+    w = np.load(MF.WEIGHTS)
+    m.load_state_dict({k.split("model.module.")[-1]: torch.from_numpy(w[k]) for k in w.files})
+    m.eval()
+    label, bbox, mask = MF.structured_layouts(int(g["train_args"][2]), spec.n_category, int(g["train_args"][3]) + 1)
+    seq = tok.encode({"label": label, "bbox": bbox, "mask": mask})["seq"]
+    out = MF.goldens(m, spec, seq)
+    for k, v in out.items():
+        assert np.array_equal(np.asarray(v), g[k]), k
 
 
 def test_restatement_matches_live_reference_on_fresh_states():
