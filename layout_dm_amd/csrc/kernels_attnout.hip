@@ -53,6 +53,7 @@ constexpr int AO_LDS = AO_RING + 3 * AO_SLOT;   // 163 840
 static_assert(AO_LDS <= 160 * 1024, "LDS budget");
 constexpr int AO_NT = 15;                        // 32-column output tiles
 constexpr int AO_RD = 2;                         // LDS read pipeline: fragments requested this many (3-MFMA) items ahead
+constexpr int AO_RDP = 1;                        // ... in the P V phase: this many (6-MFMA) key steps ahead
 constexpr int AO_UNIT = 8;                       // DMA pieces (1 KiB) per wave and unit (K, V, one ring stage) — the counted waits below
 
 // one DMA unit = 8 pieces of this wave: two groups of four (one M0 write each)
@@ -149,6 +150,53 @@ __device__ __forceinline__ void ao_split8(const float (&x)[8], f16x8& hi, f16x8&
   lo = __builtin_bit_cast(f16x8, l);
 }
 
+// One (kt, hf) key step of P V for BOTH d tiles as ONE statement: six MFMAs (o0 += V0 P, o1 += V1 P, each as lo·hi + hi·lo + hi·hi) with the
+// hi / lo split of the NEXT key step's probabilities (ao_split8's 16 VALU instructions) placed BETWEEN them.  A wave issues in order: behind three
+// dependent MFMAs nothing else gets out for ~96 cycles, then the VALU block runs with the matrix pipe idle — the first form of this phase (split,
+// then two 3-MFMA statements) took 3 900 cycles per head where its 48 MFMAs take 1 540; between the MFMAs the VALU issues in their shadows.
+// The operands the MFMAs read (ph, pl, the V fragments) were written at least one whole statement earlier; what the VALU writes here (hn, ln) is read
+// by the NEXT statement.  FIRST: the accumulators start from zero.  SPLIT = false (the last key step): no next split.  TAIL: the wait states hipcc's
+// VALU reads of o0 / o1 need behind MFMAs it cannot see.
+template <bool FIRST, bool SPLIT, bool TAIL>
+__device__ __forceinline__ void ao_pv_pair(f32x16& o0, f32x16& o1, const f16x8& vh0, const f16x8& vl0, const f16x8& vh1, const f16x8& vl1,
+                                           const f16x8& ph, const f16x8& pl, const float (&x)[8], f16x8& hn, f16x8& ln) {
+  typedef unsigned ao_u32x4 __attribute__((ext_vector_type(4)));
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  float t0, t1, t2, t3, t4, t5, t6, t7;
+#define AO_V1 "v_cvt_pk_f16_f32 %[h0], %[x0], %[x1]\n\tv_cvt_pk_f16_f32 %[h1], %[x2], %[x3]\n\tv_cvt_pk_f16_f32 %[h2], %[x4], %[x5]\n\tv_cvt_pk_f16_f32 %[h3], %[x6], %[x7]\n\t"
+#define AO_V2 "v_fma_mix_f32 %[t0], -%[h0], 1.0, %[x0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %[t1], -%[h0], 1.0, %[x1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+              "v_fma_mix_f32 %[t2], -%[h1], 1.0, %[x2] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %[t3], -%[h1], 1.0, %[x3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define AO_V3 "v_fma_mix_f32 %[t4], -%[h2], 1.0, %[x4] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %[t5], -%[h2], 1.0, %[x5] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+              "v_fma_mix_f32 %[t6], -%[h3], 1.0, %[x6] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %[t7], -%[h3], 1.0, %[x7] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+#define AO_V4 "v_cvt_pk_f16_f32 %[l0], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[l1], %[t2], %[t3]\n\tv_cvt_pk_f16_f32 %[l2], %[t4], %[t5]\n\tv_cvt_pk_f16_f32 %[l3], %[t6], %[t7]\n\t"
+#define AO_PV(C0A, C0B, V1, V2, V3, V4, TAILS)                                                                                                  \
+  asm volatile(AO_MFMA "%[o0], %[vl0], %[ph], " C0A "\n\t" V1 AO_MFMA "%[o0], %[vh0], %[pl], %[o0]\n\t" V2 AO_MFMA "%[o0], %[vh0], %[ph], %[o0]\n\t" V3 \
+                   AO_MFMA "%[o1], %[vl1], %[ph], " C0B "\n\t" V4 AO_MFMA "%[o1], %[vh1], %[pl], %[o1]\n\t" AO_MFMA "%[o1], %[vh1], %[ph], %[o1]" TAILS \
+               : [o0] "+v"(o0), [o1] "+v"(o1), [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [l0] "=&v"(l0), [l1] "=&v"(l1),          \
+                 [l2] "=&v"(l2), [l3] "=&v"(l3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),        \
+                 [t6] "=&v"(t6), [t7] "=&v"(t7)                                                                                                      \
+               : [vh0] "v"(vh0), [vl0] "v"(vl0), [vh1] "v"(vh1), [vl1] "v"(vl1), [ph] "v"(ph), [pl] "v"(pl), [x0] "v"(x[0]), [x1] "v"(x[1]),         \
+                 [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]))
+  if constexpr (FIRST) {
+    static_assert(SPLIT && !TAIL, "the first key step splits the second one's probabilities");
+    AO_PV("0", "0", AO_V1, AO_V2, AO_V3, AO_V4, "");
+  } else if constexpr (SPLIT) {
+    AO_PV("%[o0]", "%[o1]", AO_V1, AO_V2, AO_V3, AO_V4, "");
+  } else {
+    static_assert(TAIL, "the last key step carries the tail");
+    AO_PV("%[o0]", "%[o1]", "", "", "", "", "\n\ts_nop 15\n\ts_nop 3");
+    h0 = h1 = h2 = h3 = l0 = l1 = l2 = l3 = 0;
+  }
+#undef AO_PV
+#undef AO_V1
+#undef AO_V2
+#undef AO_V3
+#undef AO_V4
+  const ao_u32x4 hh = {h0, h1, h2, h3}, ll = {l0, l1, l2, l3};
+  hn = __builtin_bit_cast(f16x8, hh);
+  ln = __builtin_bit_cast(f16x8, ll);
+}
+
 }  // namespace
 
 template <bool TM>
@@ -202,6 +250,33 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     const unsigned l = lds0 + AO_RING + slot * AO_SLOT + wave * 8192;
     ao_dma8(voff_lin, gsrc, l, gsrc + 4096, l + 4096);
   };
+  // One residual-row unit of the LAST head (8 rows of this wave = 8 pieces: what the counted waits expect of a unit).  The last head's K_8 / V_8 /
+  // W_8,* units have nothing left to fetch; instead of re-loading (r06 first form) they bring the epilogue's residual rows into the buffers the head
+  // frees — K image, V image, the ring slots — so that the HBM reads of P overlap the last head's MFMAs instead of joining the epilogue's all-CU burst
+  // (119 MB in 23 us = 5.1 TB/s).  Row r of a column half: 1 KiB at lds_base + (r & 7) KiB, 16-byte chunk c at c ^ (r & 15).
+  constexpr int ND = 464;                  // launch_attnout16x3 checks D == 464
+  const int nrow = S - wave * 32 < 32 ? S - wave * 32 : 32;   // rows of this wave that exist (wave-uniform)
+  const char* pres = reinterpret_cast<const char*>(a.res + (row0 + (size_t)(wave * 32)) * ND);   // this wave's residual rows
+  auto dma_prow = [&](int half, int r0, unsigned lds_base) {
+    // (the row arithmetic hangs on an opaque copy of r0: hipcc otherwise hoists the 40 row addresses of the five units out of the head loop
+    //  and keeps them alive across a body that already fills the register file — 400 SGPR spills, the head loop 8 % slower)
+    int r0v = r0;
+    asm volatile("" : "+s"(r0v));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0v + j, rr = r < nrow ? r : nrow - 1;                       // (rows that do not exist: a valid row again, never stored)
+      unsigned lc = lu ^ (unsigned)((r0 + j) & 15);                              // logical chunk that lands in physical chunk `lane`
+      if (half == 1) lc = lc < 52u ? lc : 51u;                                   // (chunks beyond the row: a valid chunk again, never read)
+      const char* src = pres + (unsigned)rr * (unsigned)(ND * 4) + half * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lc * 16u), "s"(src), "s"(lds_base + (unsigned)j * 1024u) : "memory");
+    }
+  };
+  // where the epilogue finds them (absolute LDS byte addresses of this wave's 8-row groups; ring slots of head 7: (4 * 7) % 3 = 1 -> stage 1 in slot
+  // 2, stage 2 in slot 0, stage 3 in slot 1: tests/test_attnout_layout.py replays the slot arithmetic)
+  const unsigned grpA[4] = {lds0 + AO_KH + wave * 8192u, lds0 + AO_VH + wave * 8192u, lds0 + AO_RING + 2u * AO_SLOT + wave * 8192u,
+                            lds0 + AO_RING + 0u * AO_SLOT + wave * 8192u};
+  const unsigned grpB0 = lds0 + AO_RING + 1u * AO_SLOT + wave * 8192u;
+
   f16x8 qh[4], ql[4];
   auto load_q = [&](int head) {                                // 8 asm loads = one DMA unit's worth in the counted waits
     const size_t pn = (size_t)(head < 8 ? head : 7) * 2;
@@ -269,7 +344,8 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     // ---- Bb(h): V_h landed (behind it: W_h-1,3  W_h,0  W_h,1  W_h,2); every wave is through with K_h
     ao_sync<4 * AO_UNIT, TM>(&tw[1], &tb[1]);
     load_q(h + 1);
-    dma_kv(h < 7 ? h + 1 : 7, 1, AO_KH);
+    if (h < 7) dma_kv(h + 1, 1, AO_KH);
+    else dma_prow(0, 0, grpA[0]);
     AO_T0();
     // ---- softmax over the 128 keys of query m (64 here, 64 in lane ^ 32), fp32 — attn16x3_k's arithmetic
 #pragma unroll
@@ -311,33 +387,35 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     // ---- O^T = V^T · P^T: 2 d tiles x 8 k16-steps x 3 products (k-slot e of half g <-> accumulator register 8 hf + e)
     f32x16 o[2];
     {
-      f16x8 vh8[AO_RD + 1], vl8[AO_RD + 1];
-      auto rd = [&](int it) {   // item it = (kt, hf, dt)
-        const int kt = it >> 2, hf = (it >> 1) & 1, dt = it & 1;
-        const unsigned off = AO_VH + dt * 8192 + kt * 2048 + hf * 1024;   // keys 32 kt + 16 hf ..: 256 B per key quad
-        const ao_f16x4 h0 = ao_tr(a_v + off), h1 = ao_tr(a_v + off + 512);
-        const ao_f16x4 l0 = ao_tr(a_v + off + AO_LO), l1 = ao_tr(a_v + off + 512 + AO_LO);
-        vh8[it % (AO_RD + 1)] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        vl8[it % (AO_RD + 1)] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      f16x8 vh8[2 * (AO_RDP + 1)], vl8[2 * (AO_RDP + 1)];   // V fragments of AO_RDP + 1 key steps x 2 d tiles
+      auto rd = [&](int ks) {   // key step ks = (kt, hf): both d tiles
+        const int kt = ks >> 1, hf = ks & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const unsigned off = AO_VH + dt * 8192 + kt * 2048 + hf * 1024;   // keys 32 kt + 16 hf ..: 256 B per key quad
+          const ao_f16x4 h0 = ao_tr(a_v + off), h1 = ao_tr(a_v + off + 512);
+          const ao_f16x4 l0 = ao_tr(a_v + off + AO_LO), l1 = ao_tr(a_v + off + 512 + AO_LO);
+          vh8[2 * (ks % (AO_RDP + 1)) + dt] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          vl8[2 * (ks % (AO_RDP + 1)) + dt] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
       };
 #pragma unroll
-      for (int it = 0; it < AO_RD; ++it) rd(it);
-      f16x8 ph, pl;
+      for (int ks = 0; ks < AO_RDP; ++ks) rd(ks);
+      f16x8 ph[2], pl[2];
+      {   // the P fragment of key step 0: registers 0 .. 7 of score tile 0 (the later ones are split inside the previous step's statement)
+        const float x[8] = {sc[0][0], sc[0][1], sc[0][2], sc[0][3], sc[0][4], sc[0][5], sc[0][6], sc[0][7]};
+        ao_split8(x, ph[0], pl[0]);
+        asm volatile("s_nop 4" ::"v"(ph[0]), "v"(pl[0]));
+      }
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        if (it + AO_RD < 16) rd(it + AO_RD);
-        const int kt = it >> 2, hf = (it >> 1) & 1, dt = it & 1, b = it % (AO_RD + 1);
-        if (dt == 0) {   // the P fragment of k16-step (kt, hf): registers 8 hf .. 8 hf + 7 of score tile kt
-          const float x[8] = {sc[kt][hf * 8 + 0], sc[kt][hf * 8 + 1], sc[kt][hf * 8 + 2], sc[kt][hf * 8 + 3],
-                              sc[kt][hf * 8 + 4], sc[kt][hf * 8 + 5], sc[kt][hf * 8 + 6], sc[kt][hf * 8 + 7]};
-          ao_split8(x, ph, pl);
-        }
-        // (the casts of ph / pl sit right in front: wait states inside the statement; the last statement of a tile: its tail)
-        if (it < 2) {
-          asm volatile("s_nop 4" ::"v"(ph), "v"(pl));
-          ao_mfma3v<true, false, false>(o[dt], vh8[b], vl8[b], ph, pl);
-        } else if (it >= 14) ao_mfma3v<false, true, true>(o[dt], vh8[b], vl8[b], ph, pl);
-        else ao_mfma3v<false, true, false>(o[dt], vh8[b], vl8[b], ph, pl);
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks + AO_RDP < 8) rd(ks + AO_RDP);
+        const int b = 2 * (ks % (AO_RDP + 1)), kn = (ks + 1) >> 1, hn = (ks + 1) & 1;
+        const float x[8] = {sc[kn & 3][hn * 8 + 0], sc[kn & 3][hn * 8 + 1], sc[kn & 3][hn * 8 + 2], sc[kn & 3][hn * 8 + 3],
+                            sc[kn & 3][hn * 8 + 4], sc[kn & 3][hn * 8 + 5], sc[kn & 3][hn * 8 + 6], sc[kn & 3][hn * 8 + 7]};
+        if (ks == 0) ao_pv_pair<true, true, false>(o[0], o[1], vh8[b], vl8[b], vh8[b + 1], vl8[b + 1], ph[0], pl[0], x, ph[1], pl[1]);
+        else if (ks == 7) ao_pv_pair<false, false, true>(o[0], o[1], vh8[b], vl8[b], vh8[b + 1], vl8[b + 1], ph[1], pl[1], x, ph[0], pl[0]);
+        else ao_pv_pair<false, true, false>(o[0], o[1], vh8[b], vl8[b], vh8[b + 1], vl8[b + 1], ph[ks & 1], pl[ks & 1], x, ph[(ks + 1) & 1], pl[(ks + 1) & 1]);
       }
     }
     AO_T1(1);
@@ -356,7 +434,8 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     AO_T1(2);
     // ---- Bc(h): W_h,0 landed (behind it: W_h,1  W_h,2  Q_h+1 K_h+1); every wave is through with V_h
     ao_sync<4 * AO_UNIT, TM>(&tw[2], &tb[2]);
-    dma_kv(h < 7 ? h + 1 : 7, 2, AO_VH);
+    if (h < 7) dma_kv(h + 1, 2, AO_VH);
+    else dma_prow(0, 8, grpA[1]);
     // ---- the head's four out_proj stages: out^T tile t += Wo[32 t .., k16-step] · O   (hi·hi + hi·lo + lo·hi)
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -365,10 +444,12 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
         dma_w(4 * h + 3, slot);
       } else if (st == 2) {   // Bd2: W_h,2 landed (behind it: Q K_h+1  V_h+1  W_h,3); stage 1's slot -> W_h+1,0
         ao_sync<4 * AO_UNIT, TM>(&tw[4], &tb[4]);
-        dma_w(4 * h + 4, slot == 2 ? 0 : slot + 1);
+        if (h < 7) dma_w(4 * h + 4, slot == 2 ? 0 : slot + 1);
+        else dma_prow(0, 16, grpA[2]);
       } else if (st == 3) {   // Bd3: W_h,3 landed (behind it: W_h+1,0); stage 2's slot -> W_h+1,1
         ao_sync<1 * AO_UNIT, TM>(&tw[5], &tb[5]);
-        dma_w(4 * h + 5, slot == 0 ? 2 : slot - 1);
+        if (h < 7) dma_w(4 * h + 5, slot == 0 ? 2 : slot - 1);
+        else dma_prow(0, 24, grpA[3]);
       }
       AO_T0();
       const int sl_st = st == 0 ? slot : st == 1 ? (slot == 2 ? 0 : slot + 1) : st == 2 ? (slot == 0 ? 2 : slot - 1) : slot;
@@ -398,7 +479,8 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     ao_sync<4 * AO_UNIT, TM>(&tw[0], &tb[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qh[ks]), "+v"(ql[ks]));
-    dma_w(4 * h + 6, slot == 0 ? 2 : slot - 1);
+    if (h < 7) dma_w(4 * h + 6, slot == 0 ? 2 : slot - 1);
+    else dma_prow(1, 0, grpB0);
     AO_T0();
     if (h < 7) scores();
     AO_T1(4);
@@ -410,33 +492,29 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
 
   // ---- epilogue: Q = P + b_out + out_scale * acc.  In accumulator layout a lane owns 16-byte pieces of 32 different rows: a
   // load / store instruction touches 32 cache lines for 1 KiB (first form of this loop: 58 serial round trips, 84 k of the kernel's
-  // 263 k cycles; batched four tiles ahead: 60 k — the rate of that access pattern).  So the rows go THROUGH the LDS, which is free
-  // now: every wave owns 40 KiB (its 32 rows x 1 KiB of a column half), residual rows in by LDS-DMA — one instruction per row, whole
-  // 128-byte lines —, the arithmetic in place in accumulator layout, rows out as whole lines (one ds_read_b128 + one 1-KiB store per
-  // row).  16-byte chunk c of row r sits at chunk c ^ (r & 15): conflict-free for the accumulator-layout accesses (the 16 lanes of a
-  // service group are 16 rows with distinct r & 15), linear per row for the DMA and the stores.  No workgroup barrier inside: a wave
-  // reads only what it wrote itself.  Column halves: tiles 0-7 (1 024 B per row), tiles 8-14 (832 B: chunks 0 .. 51).
-  __builtin_amdgcn_s_barrier();   // every wave is through with the ring and the K / V images, every DMA piece of the loop has landed
-  asm volatile("" ::: "memory");
+  // 263 k cycles; batched four tiles ahead: 60 k — the rate of that access pattern).  So the rows go THROUGH the LDS: residual rows in
+  // by LDS-DMA — one instruction per row, whole 128-byte lines —, the arithmetic in place in accumulator layout, rows out as whole lines
+  // (one ds_read_b128 + one 1-KiB store per row).  16-byte chunk c of row r sits at chunk c ^ (r & 15): conflict-free for the
+  // accumulator-layout accesses (the 16 lanes of a service group are 16 rows with distinct r & 15), linear per row for the DMA and the
+  // stores.  Column halves: tiles 0-7 (1 024 B per row), tiles 8-14 (832 B: chunks 0 .. 51).  Half A and rows 0-7 of half B arrived during
+  // the last head (dma_prow); rows 8-31 of half B follow into half A's places once its rows have left.  No workgroup barrier: a wave reads
+  // only what its own DMA brought and what it wrote itself, in buffers nobody else touches after the last head's barriers.
   {
-    constexpr int ND = 464;                // launch_attnout16x3 checks D == 464
-    const unsigned R = lds0 + (unsigned)wave * 40960u;
-    const int nrow = S - wave * 32 < 32 ? S - wave * 32 : 32;   // rows of this wave that exist (wave-uniform)
     const float* bias = a.bias + g * 4;
+    const unsigned gsel = (unsigned)m >> 3;
+    const unsigned rowA = (gsel == 0 ? grpA[0] : gsel == 1 ? grpA[1] : gsel == 2 ? grpA[2] : grpA[3]) + ((unsigned)m & 7u) * 1024u - lds0;   // smem offset of row m
+    const unsigned rowB = (gsel == 0 ? grpB0 : gsel == 1 ? grpA[0] : gsel == 2 ? grpA[1] : grpA[2]) + ((unsigned)m & 7u) * 1024u - lds0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       constexpr int kChunks[2] = {64, 52};
       const int nch = kChunks[half];
-      // residual rows -> LDS
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        const int rr = r < nrow ? r : nrow - 1;                                  // (rows that do not exist: a valid row again, never stored)
-        unsigned lc = lu ^ (unsigned)(r & 15);                                   // logical chunk that lands in physical chunk `lane`
-        if (half == 1) lc = lc < 52u ? lc : 51u;                                 // (chunks beyond the row: a valid chunk again, never read)
-        const char* src = reinterpret_cast<const char*>(a.res + (row0 + (size_t)(wave * 32 + rr)) * ND) + half * 1024;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lc * 16u), "s"(src), "s"(R + (unsigned)r * 1024u) : "memory");
+      if (half == 1) {
+        // half B, rows 8 .. 31 -> the places of half A's rows 0 .. 23 (their stores have read them: the lgkmcnt(0) below)
+        dma_prow(1, 8, grpA[0]);
+        dma_prow(1, 16, grpA[1]);
+        dma_prow(1, 24, grpA[2]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // y = acc * out_scale + bias + residual, in place
 #pragma unroll
       for (int tl = 0; tl < (half == 0 ? 8 : 7); ++tl)
@@ -445,7 +523,7 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
           const int t = half * 8 + tl, col = t * 32 + gq * 8;
           if (col + 8 <= ND) {
             const unsigned c = (unsigned)(tl * 8 + gq * 2) + (unsigned)g;        // the lane's chunk of its row m
-            float4* pl = reinterpret_cast<float4*>(smem + wave * 40960 + m * 1024 + ((c ^ ((unsigned)m & 15u)) << 4));
+            float4* pl = reinterpret_cast<float4*>(smem + (half == 0 ? rowA : rowB) + ((c ^ ((unsigned)m & 15u)) << 4));
             const float4 rsd = *pl;
             const float4 b = *reinterpret_cast<const float4*>(bias + col);
             float4 y;
@@ -461,7 +539,8 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
       for (int r = 0; r < 32; ++r) {
         if (r < nrow) {
           const unsigned lc = lu ^ (unsigned)(r & 15);
-          const float4 y = *reinterpret_cast<const float4*>(smem + wave * 40960 + r * 1024 + lu * 16u);
+          const unsigned base = half == 0 ? grpA[r >> 3] : (r < 8 ? grpB0 : grpA[(r >> 3) - 1]);
+          const float4 y = *reinterpret_cast<const float4*>(smem + (base - lds0) + (r & 7) * 1024 + lu * 16u);
           if ((int)lc < nch)
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.out + (row0 + (size_t)(wave * 32 + r)) * ND) + half * 1024 + lc * 16) = y;
         }
