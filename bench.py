@@ -54,8 +54,10 @@ FLOP_PER_TOKEN_STEP = {  # 4 x [QKV + attn + out-proj + FFN] + he
     "publaynet": 21_721_696,
 }
 # MI355X_MICROARCH.md dense MFMA peaks; split = 3 fp16 MFMA passes per product (divide by the passes)
-PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3, "fast_verified": 2500.0}
+# mixed: two fp16 passes per weight product, three per attention product (4.27 % of the flops): 2.043 passes per flop on average
+PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3, "fast_verified": 2500.0, "mixed": 2500.0 / 2.043}
 DTYPE = {"exact": "f32", "fast": "f16 (f32 accumulate)", "split": "f16x3 split (f32 accumulate)",
+         "mixed": "f16 hi+lo activations x f16 weights (f32 accumulate)",
          "fast_verified": "f16 (f32 accumulate) + f32 re-decision of near-tie layouts"}
 CONFIGS = {
     2: dict(dataset="rico25", cond="unconditional", batch=512, sampling="random"),
@@ -80,7 +82,7 @@ def parse():
     ap.add_argument("--sampling", default=None, choices=["random", "deterministic", "top_p", "top_k", "gumbel"])
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "fast"),
-                    choices=["exact", "fast", "split"])
+                    choices=["exact", "fast", "split", "mixed"])
     ap.add_argument("--modes", default=None,
                     help="comma list of numerics modes reported under 'modes' (default: exact,fast,fast_verified at N=1, "
                          "none at N>1; split = the fp16x3 cross-check mode, on request)")
@@ -432,10 +434,10 @@ KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_s
                  "attention": "attn_"}
 
 
-# split mode: event-profile class -> kernel symbol prefix (template arguments: <ADA, OUT, TM, ABL, PRE>)
-SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false>",
-                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true>",
-                       "attn_out_fused": "attnout16x3_k<false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+# split mode: event-profile class -> kernel symbol prefix (template arguments: <ADA, OUT, TM, ABL, PRE, W2>; W2 = true: the mixed mode's)
+SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, false>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, false>",
+                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, false>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, false>",
+                       "attn_out_fused": "attnout16x3_k<false, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 
 
 # ----------------------------------------------------------------------------------------- one workload, one mode
@@ -761,7 +763,7 @@ def main():
     eng.close()
 
     # every numerics mode in the one line (N=1): the bit-exact mode's throughput next to the headline's
-    modes = a.modes if a.modes is not None else ("exact,split,fast,fast_verified" if world == 1 else "")
+    modes = a.modes if a.modes is not None else ("exact,split,mixed,fast,fast_verified" if world == 1 else "")
     modes = [m for m in modes.split(",") if m and m != "none"]
     if modes:
         out["modes"] = {}
@@ -932,10 +934,10 @@ def auto_on_trained_like(a, SP, spec, B, headline, rank, world, local_rank, dist
         cal = m.calibration
         entry = {"auto_selected": m.selected_precision, "value": round(B / dt, 2), "unit": "layouts/s", "steps": k,
                  "ms_per_step": round(1e3 * dt, 3), "fast_engine_err_rel_measured_at_load": cal.get("err_rel"),
+                 "mixed_engine_err_rel_measured_at_load": m.selection_report.get("mixed_logits_err_rel"),
                  "tolerance": m.auto_tolerance, "verifier_check": m.verifier_check, "load_and_calibrate_s": round(load_s, 2),
                  "ratio_to_headline": round(B / dt / headline, 4)}
-        m.verified.fast.close()
-        m.verified.exact.close()
+        m.close()
         # the plain fp16 engine on the same weights (what precision="fast" would run, refused by auto where outside 1e-3)
         rw, ew, _ = run_mode(a, spec, sdw, "fast", B, 3, 1, None, rank, world, local_rank, dist, with_roofline=False)
         ew.close()

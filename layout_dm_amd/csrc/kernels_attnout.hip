@@ -199,7 +199,7 @@ __device__ __forceinline__ void ao_pv_pair(f32x16& o0, f32x16& o1, const f16x8& 
 
 }  // namespace
 
-template <bool TM>
+template <bool TM, bool W2 = false>   // W2: two-product out_proj (Wo fp16 only: its lo half is neither read nor multiplied)
 __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   // (TM: cycles in the counted vmcnt waits [0..5] and in the barriers behind them [6..11] per sync site Ba Bb Bc Bd1 Bd2 Bd3, the
   //  head loop [12], the epilogue [13], the whole kernel [14], workgroups [15])
@@ -458,19 +458,24 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
 #pragma unroll
       for (int t = 0; t < AO_RD; ++t) {
         wh[t] = ao_lds128(aw + t * 1024);
-        wl[t] = ao_lds128(aw + t * 1024 + AO_LO);
+        if constexpr (!W2) wl[t] = ao_lds128(aw + t * 1024 + AO_LO);
       }
 #pragma unroll
       for (int t = 0; t < AO_NT; ++t) {
         if (t + AO_RD < AO_NT) {
           wh[(t + AO_RD) % (AO_RD + 1)] = ao_lds128(aw + (t + AO_RD) * 1024);
-          wl[(t + AO_RD) % (AO_RD + 1)] = ao_lds128(aw + (t + AO_RD) * 1024 + AO_LO);
+          if constexpr (!W2) wl[(t + AO_RD) % (AO_RD + 1)] = ao_lds128(aw + (t + AO_RD) * 1024 + AO_LO);
         }
         // (asm with an AGPR-pinned accumulator: with builtin MFMAs hipcc moved half of the 15 tiles between the register files
         //  in every head, 450 v_accvgpr_read / _write per iteration)
-        asm volatile(AO_MFMA "%[c], %[wh], %[oh], %[c]\n\t" AO_MFMA "%[c], %[wh], %[ol], %[c]\n\t" AO_MFMA "%[c], %[wl], %[oh], %[c]"
-                     : [c] "+a"(pacc[t])
-                     : [wh] "v"(wh[t % (AO_RD + 1)]), [wl] "v"(wl[t % (AO_RD + 1)]), [oh] "v"(oh[st]), [ol] "v"(ol[st]));
+        if constexpr (W2)
+          asm volatile(AO_MFMA "%[c], %[wh], %[oh], %[c]\n\t" AO_MFMA "%[c], %[wh], %[ol], %[c]"
+                       : [c] "+a"(pacc[t])
+                       : [wh] "v"(wh[t % (AO_RD + 1)]), [oh] "v"(oh[st]), [ol] "v"(ol[st]));
+        else
+          asm volatile(AO_MFMA "%[c], %[wh], %[oh], %[c]\n\t" AO_MFMA "%[c], %[wh], %[ol], %[c]\n\t" AO_MFMA "%[c], %[wl], %[oh], %[c]"
+                       : [c] "+a"(pacc[t])
+                       : [wh] "v"(wh[t % (AO_RD + 1)]), [wl] "v"(wl[t % (AO_RD + 1)]), [oh] "v"(oh[st]), [ol] "v"(ol[st]));
       }
       AO_T1(3);
     }
@@ -580,7 +585,7 @@ bool attnout16x3_supported(int S, int H, int dh, int D) { return S >= 1 && S <= 
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st) {
   if (!attnout16x3_supported(a.S, 8, 58, a.D) || B < 1 || (a.panel_stride & 15) || !a.qkv_hi || !a.qkv_lo || !a.w_img) return -1;
   const bool tm = knob_int("LDM_ATTNOUT_TM", 0) != 0;   // (dev: the phase-timer instantiation)
-  auto kern = tm ? attnout16x3_k<true> : attnout16x3_k<false>;
+  auto kern = a.w2 ? attnout16x3_k<false, true> : tm ? attnout16x3_k<true> : attnout16x3_k<false>;
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), AO_LDS, st, a);
   return 0;

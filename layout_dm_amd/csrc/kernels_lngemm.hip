@@ -49,9 +49,10 @@ constexpr int LG_KS = 29, LG_NIT = 30, LG_PF = 6, LG_SYNC = LG_NIT - LG_PF;
 static_assert(LG_NIT % LG_PF == 0, "queue slots must line up across tiles");
 constexpr bool lg_real(int i) { return (i % LG_NIT) < LG_KS; }
 // LDS reads issued behind the pair of item IT when step IT waits for it: the real items among IT + 1 .. IT + PF - 1
-constexpr int lg_younger(int IT) {
+// (rpi = LDS reads per item: W hi and W lo, or — W2, the two-product form: weights fp16 only — W hi alone)
+constexpr int lg_younger(int IT, int rpi = 2) {
   int n = 0;
-  for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;
+  for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? rpi : 0;
   return n;
 }
 static_assert(lg_younger(0) <= 15, "lgkmcnt is a 4-bit counter");
@@ -91,20 +92,20 @@ struct LgState {
 };
 
 // item IT of the tile whose stage aW points at: W hi and W lo fragment of k16-step IT (pseudo items: nothing)
-template <int IT>
+template <int IT, bool W2 = false>
 __device__ __forceinline__ void lg_read(LgState& s) {
   if constexpr (IT < LG_KS) {
     lg_dsr<256 * (IT >> 3)>(s.qh[IT % LG_PF], s.aW[IT & 7]);
-    lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);
+    if constexpr (!W2) lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);
   }
 }
 
 // the kernel prologue primes the queue: items 0 .. PF - 1 of tile 0
-template <int I>
+template <int I, bool W2 = false>
 __device__ __forceinline__ void lg_prime(LgState& s) {
   if constexpr (I < LG_PF) {
-    lg_read<I>(s);
-    lg_prime<I + 1>(s);
+    lg_read<I, W2>(s);
+    lg_prime<I + 1, W2>(s);
   }
 }
 
@@ -274,10 +275,19 @@ constexpr bool lg_slice_step(int IT) {
                : [xh] "v"(s.xhi[IT]), [xl] "a"(s.xlo[IT]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l), \
                  [w] "n"(W), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                               \
                : "memory")
+// W2 (two products: W_hi x_hi + W_hi x_lo, the weights' lo half neither read nor multiplied): chain c0 takes the first, c1 the second — A B | A B
+#define LG_STEP_ASM2(C0, C1, M0SET, PIECE, RD_HI)                                                                               \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LG_MFMA("%[c0]", "%[qh]", "%[xh]", C0) PIECE                                 \
+                   LG_MFMA("%[c1]", "%[qh]", "%[xl]", C1) RD_HI                                                                 \
+               : [c0] "+v"(c0), [c1] "+v"(c1), [qh] "+v"(qh)                                                                    \
+               : [xh] "v"(s.xhi[IT]), [xl] "a"(s.xlo[IT]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l), \
+                 [w] "n"(W), [ro] "n"(RO), [doff] "n"(DOFF)                                                                     \
+               : "memory")
 #define LG_A_M0 "s_mov_b32 m0, %[dl]\n\t"
 #define LG_A_PIECE "global_load_lds_dwordx4 %[vo], %[dg] offset:%[doff]\n\t"
 #define LG_A_RDH "ds_read_b128 %[qh], %[aw] offset:%[ro]\n\t"
 #define LG_A_RDL "ds_read_b128 %[ql], %[aw] offset:%[rl]"
+#define LG_A_RDH2 "ds_read_b128 %[qh], %[aw] offset:%[ro]"
 
 // which DMA piece (of the 16 per tile and wave) step IT carries, or -1: pieces 0 .. NIT - 2 - SYNC of tile + 2 at steps SYNC + 1 ..
 // NIT - 1 (its stage — this tile's — is free behind this tile's barrier), the rest at the first steps of the next tile
@@ -288,7 +298,7 @@ constexpr int lg_piece(int IT) {
 }
 static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(0) == lg_piece(LG_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
 
-template <int IT, int OUT, bool TM = false, int ABL = 0>
+template <int IT, int OUT, bool TM = false, int ABL = 0, bool W2 = false>
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
   // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
   // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores), 16 = the epilogue's global stores only, 32 = every tile's stores
@@ -310,14 +320,24 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
     constexpr int DOFF = hasD ? (J & 3) * 1024 : 0;
     if constexpr (IT < LG_KS) {
       // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item IT's
-      constexpr int W = kRd ? lg_younger(IT) : 15;
-      f32x16& c0 = (IT & 1) ? s.accB : s.accA;   // two of the step's MFMAs
-      f32x16& c1 = (IT & 1) ? s.accA : s.accB;   // one
+      constexpr int W = kRd ? lg_younger(IT, W2 ? 1 : 2) : 15;
+      f32x16& c0 = ((IT & 1) && !W2) ? s.accB : s.accA;   // two of the step's MFMAs (W2: one)
+      f32x16& c1 = ((IT & 1) && !W2) ? s.accA : s.accB;   // one
       f16x8& qh = s.qh[IT % LG_PF];
       f16x8& ql = s.ql[IT % LG_PF];
       const unsigned aw = s.aW[RI & 7];
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (IT == 0) {  // both chains start from zero
+      if constexpr (W2 && IT == 0) {
+        if constexpr (hasD && hasR) LG_STEP_ASM2("0", "0", LG_A_M0, LG_A_PIECE, LG_A_RDH2);
+        else if constexpr (hasD) LG_STEP_ASM2("0", "0", LG_A_M0, LG_A_PIECE, "");
+        else if constexpr (hasR) LG_STEP_ASM2("0", "0", "", "", LG_A_RDH2);
+        else LG_STEP_ASM2("0", "0", "", "", "");
+      } else if constexpr (W2) {
+        if constexpr (hasD && hasR) LG_STEP_ASM2("%[c0]", "%[c1]", LG_A_M0, LG_A_PIECE, LG_A_RDH2);
+        else if constexpr (hasD) LG_STEP_ASM2("%[c0]", "%[c1]", LG_A_M0, LG_A_PIECE, "");
+        else if constexpr (hasR) LG_STEP_ASM2("%[c0]", "%[c1]", "", "", LG_A_RDH2);
+        else LG_STEP_ASM2("%[c0]", "%[c1]", "", "", "");
+      } else if constexpr (IT == 0) {  // both chains start from zero
         if constexpr (hasD && hasR) LG_STEP_ASM("0", "0", LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL);
         else if constexpr (hasD) LG_STEP_ASM("0", "0", LG_A_M0, LG_A_PIECE, "", "");
         else if constexpr (hasR) LG_STEP_ASM("0", "0", "", "", LG_A_RDH, LG_A_RDL);
@@ -331,7 +351,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
       __builtin_amdgcn_sched_barrier(0);
     } else {
       // the pseudo step: no MFMAs; its read and its DMA piece issue as plain statements
-      if constexpr (hasR) lg_read<RI>(s);
+      if constexpr (hasR) lg_read<RI, W2>(s);
       if constexpr (hasD) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(s.dma_l) : "memory");
         dma_lin<DOFF>(s.voff, s.dma_g);
@@ -354,17 +374,18 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
       asm volatile("" ::: "memory");
       if constexpr (TM) s.t_sync += __builtin_amdgcn_s_memtime() - tw;
       // (the next tile's item 0 is read only now, behind the barrier)
-      if constexpr (kRd) lg_read<RI>(s);
+      if constexpr (kRd) lg_read<RI, W2>(s);
     }
     // ---- ... and a slice of the previous tile's epilogue
     if constexpr (kEp && lg_slice_step(IT)) lg_epilogue_slice<IT, OUT, ABL>(e, tile - 1);
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<IT + 1, OUT, TM, ABL>(s, e, tile);
+    lg_step<IT + 1, OUT, TM, ABL, W2>(s, e, tile);
   }
 }
 #undef LG_STEP_ASM
+#undef LG_STEP_ASM2
 #undef LG_MFMA
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -409,17 +430,17 @@ struct LpState {
   unsigned dma_l;
 };
 
-template <int IT>
+template <int IT, bool W2 = false>
 __device__ __forceinline__ void lp_read(LpState& s) {   // item IT of the stage aS points at
   constexpr int sx = IT / LP_NT, t = IT % LP_NT;
   lg_dsr<t * 2048>(s.qh[IT % LP_PF], s.aS[sx]);
-  lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);
+  if constexpr (!W2) lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);
 }
-template <int I>
+template <int I, bool W2 = false>
 __device__ __forceinline__ void lp_prime(LpState& s) {
   if constexpr (I < LP_PF) {
-    lp_read<I>(s);
-    lp_prime<I + 1>(s);
+    lp_read<I, W2>(s);
+    lp_prime<I + 1, W2>(s);
   }
 }
 __device__ __forceinline__ void lp_dma_begin(LpState& s, int sd) {   // stage sd (clamped) -> ring slot sd & 1
@@ -450,12 +471,18 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
                : [xh] "v"(s.fh[SET][sx]), [xl] "v"(s.fl[SET][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
                  [w] "n"(2 * (LP_PF - 1)), [ro] "n"(RO), [rl] "n"(RO + LG_LO), [doff] "n"(DOFF)                                    \
                : "memory")
+#define LP_STEP_ASM2(M0SET, PIECE, RD_HI, TAIL)   /* W2: W_hi a_hi + W_hi a_lo */                                                 \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LP_MFMA("%[qh]", "%[xh]") LP_MFMA("%[qh]", "%[xl]") PIECE RD_HI TAIL            \
+               : [c] "+a"(acc), [qh] "+v"(qh)                                                                                      \
+               : [xh] "v"(s.fh[SET][sx]), [xl] "v"(s.fl[SET][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
+                 [w] "n"(LP_PF - 1), [ro] "n"(RO), [doff] "n"(DOFF)                                                                \
+               : "memory")
 
 // the step at which the stage requests the A fragments of stage + 2: behind the last DMA piece of the slab the barrier certifies
 constexpr int LP_A_STEP = 15;
 static_assert(lp_piece(LP_A_STEP - 1) < 0 && lp_piece(LP_A_STEP) < 0 && LP_A_STEP < LP_SYNC, "A loads are the youngest vector memory operations at the barrier");
 
-template <int IT, int SET>   // SET = stage % 3: the A register set the stage multiplies
+template <int IT, int SET, bool W2 = false>   // SET = stage % 3: the A register set the stage multiplies
 __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
   if constexpr (IT < LP_NIT) {
     constexpr int sx = IT / LP_NT, t = IT % LP_NT;
@@ -481,7 +508,13 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
     // the stage's last item: 32 wait states behind its MFMAs, inside the statement (whatever hipcc places behind the stage loop —
     // its v_accvgpr_reads of the tiles — then finds every MFMA of the phase finished)
     static_assert(lp_piece(LP_NIT - 1) >= 0 && LP_NIT - 1 != LP_SYNC, "the last item carries a DMA piece and its reads");
-    if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL "\n\t", "s_nop 15\n\ts_nop 15");
+    if constexpr (W2) {
+      if constexpr (IT == LP_NIT - 1) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, LG_A_RDH2 "\n\t", "s_nop 15\n\ts_nop 15");
+      else if constexpr (hasD && hasR) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, LG_A_RDH2, "");
+      else if constexpr (hasD) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, "", "");
+      else if constexpr (hasR) LP_STEP_ASM2("", "", LG_A_RDH2, "");
+      else LP_STEP_ASM2("", "", "", "");
+    } else if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL "\n\t", "s_nop 15\n\ts_nop 15");
     else if constexpr (hasD && hasR) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL, "");
     else if constexpr (hasD) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, "", "", "");
     else if constexpr (hasR) LP_STEP_ASM("", "", LG_A_RDH, LG_A_RDL, "");
@@ -497,18 +530,19 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP_A_LOADS) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" : "+v"(s.fh[(SET + 1) % 3][0]), "+v"(s.fh[(SET + 1) % 3][1]), "+v"(s.fl[(SET + 1) % 3][0]), "+v"(s.fl[(SET + 1) % 3][1])::"memory");   // (hipcc's own counted wait for them lands here)
-      lp_read<RI>(s);
+      lp_read<RI, W2>(s);
     }
     __builtin_amdgcn_sched_barrier(0);
-    lp_step<IT + 1, SET>(s, accs, stage);
+    lp_step<IT + 1, SET, W2>(s, accs, stage);
   }
 }
 #undef LP_STEP_ASM
+#undef LP_STEP_ASM2
 #undef LP_MFMA
 
 }  // namespace
 
-template <bool ADA, int OUT, bool TM = false, int ABL = 0, bool PRE = false>
+template <bool ADA, int OUT, bool TM = false, int ABL = 0, bool PRE = false, bool W2 = false>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
@@ -573,11 +607,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1]), "+v"(ps.fh[1][0]), "+v"(ps.fh[1][1]),
                  "+v"(ps.fl[1][0]), "+v"(ps.fl[1][1])::"memory");
-    lp_prime<0>(ps);
+    lp_prime<0, W2>(ps);
     for (int st = 0; st < a.pre_stages; st += 3) {   // three stage bodies, one per A register set (the ring slot follows aS);
-      lp_step<0, 0>(ps, pacc, st);                    // launch_lngemm16x3: a multiple of three stages (the image ends in zero slabs)
-      lp_step<0, 1>(ps, pacc, st + 1);
-      lp_step<0, 2>(ps, pacc, st + 2);
+      lp_step<0, 0, W2>(ps, pacc, st);                // launch_lngemm16x3: a multiple of three stages (the image ends in zero slabs)
+      lp_step<0, 1, W2>(ps, pacc, st + 1);
+      lp_step<0, 2, W2>(ps, pacc, st + 2);
     }
     // the queue's trailing reads and the clamped re-load of the last slab are out, the last MFMAs have written their tiles, and every
     // wave is through with the ring: from here it belongs to the tile loop
@@ -730,8 +764,8 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     for (int k = 0; k < 16; ++k) s.accA[k] = s.accB[k] = 0.f;
     for (int k = 0; k < LG_PF; ++k) s.qh[k] = s.ql[k] = xhi[k];
   }
-  if constexpr (!(ABL & 2)) lg_prime<0>(s);
-  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL>(s, e, t);
+  if constexpr (!(ABL & 2)) lg_prime<0, W2>(s);
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL, W2>(s, e, t);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
   lg_epilogue_slice<1, OUT>(e, a.n_tiles - 1);
@@ -788,10 +822,16 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
     return -1;
   auto kern = panel ? lngemm16x3_k<true, 2> : half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
   if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;
-  if (tm && !pre && !panel) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
+  if (a.w2) {   // the two-product form (weights fp16 only)
+    kern = panel ? lngemm16x3_k<true, 2, false, 0, false, true> : half_out ? lngemm16x3_k<false, 1, false, 0, false, true>
+           : a.ada ? lngemm16x3_k<true, 0, false, 0, false, true> : lngemm16x3_k<false, 0, false, 0, false, true>;
+    if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true, true>
+                    : a.ada ? lngemm16x3_k<true, 0, false, 0, true, true> : lngemm16x3_k<false, 0, false, 0, true, true>;
+  }
+  if (tm && !pre && !panel && !a.w2) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl_knob = (int)knob_int("LDM_LNGEMM_ABL", 0);
-  const int abl = (pre || panel) ? 0 : abl_knob;
+  const int abl = (pre || panel || a.w2) ? 0 : abl_knob;
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
   switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) LG_ABL(64) default: break; }
 #undef LG_ABL

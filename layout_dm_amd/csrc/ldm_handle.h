@@ -160,6 +160,9 @@ struct ldm_handle {
   // r06: the hidden activations (linear1 -> ReLU -> linear2) travel panel-major as well when linear2 is a GEMM prologue (pre_ffn2):
   // full-line stores in linear1's epilogue, 2-KiB-contiguous A loads in the prologue; LDM_DEV=1 LDM_X3_HIDPANEL=0: row-major
   bool hid_panels = false;
+  // two-product form of the split mode's WEIGHT GEMMs: activations hi + lo, weights fp16 only (kernels_lngemm.hip / kernels_attnout.hip W2)
+  bool w2p = false;
+  bool mixed = false;          // created as LDM_PREC_MIXED_F16 (cfg.precision then reads LDM_PREC_SPLIT_F16: every other choice is the split mode's)
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

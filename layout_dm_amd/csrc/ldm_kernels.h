@@ -111,6 +111,9 @@ struct LnGemmArgs {
   int pre_lda, pre_stages, pre_astages;   // stages of the image (a multiple of 3, zero slabs at the end) / stages with real K columns
   size_t pre_panel_stride;                // 0: preA / preAlo are row-major; else (r06) panel-major [K / 32][rows][32 halves], bytes between panels
   float pre_scale;
+  // two-product form (LDM_PREC_SPLIT2): activations hi + lo, WEIGHTS fp16 only — W_hi x_hi + W_hi x_lo; the lo halves of both images
+  // are neither read from the LDS nor multiplied (2 MFMAs per k16-step instead of 3)
+  int w2;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
 void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)
@@ -234,6 +237,7 @@ struct AttnOutArgs {
   int S, D;
   float scale;                   // 1 / sqrt(head dim)
   float out_scale;               // 2^-k of out_proj's power-of-two pre-scale
+  int w2;                        // two-product out_proj (Wo fp16 only); the attention's own products keep all three terms
 };
 bool attnout16x3_supported(int S, int H, int dh, int D);
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st);   // -1: geometry not supported

@@ -25,6 +25,8 @@ logger = logging.getLogger("layout_dm_amd")
 THROUGHPUT_CLASS = {
     "fast": "~3 900 layouts/s (fp16 operands, one launch per sampling call)",
     "fast_verified": "~3 400 - 3 900 layouts/s (fp16 engine; greedy decoding re-checked by the reference-precision engine)",
+    "mixed": "~1 400 layouts/s (hi + lo fp16 activations x fp16 weights: two matrix passes per weight product, per-step launches)",
+    "mixed_verified": "~1 400 layouts/s (hi + lo fp16 activations x fp16 weights; greedy decoding re-checked by the reference-precision engine)",
     "split": "~1 150 - 1 200 layouts/s (reference precision on the fp16 matrix pipe, per-step launches)",
     "exact": "~420 layouts/s (fp32 MFMA)",
 }
@@ -90,7 +92,14 @@ class HipMaskAndReplaceDiffusion:
         # the fast engine only if it is inside the north star's 1e-3 relative tolerance — otherwise every call runs exact.
         # (The fp16 mode's error is a property of the weights: 3e-4 on the reference's init, ~1e-3 at sigma = 0.06,
         # percents once attention rows saturate: DESIGN.md section 3.5.)
+        # r06: a rung between the two — "mixed" (LDM_PREC_MIXED_F16: the split mode with fp16-only WEIGHTS, two matrix passes per weight
+        # product instead of three, +19 % over split; its logits error is 2e-4 on a fitted checkpoint whose fp16 error is 1.2e-3).  When the
+        # fp16 engine is outside the tolerance, auto builds a mixed engine, measures IT the same way, and keeps it — again with verified
+        # greedy decoding — if it is inside; only then the reference-precision engine runs every call.  "mixed" / "mixed_verified" select it
+        # unconditionally.
         self.verified = None
+        self._v_fast = self._v_mixed = None      # VerifiedGreedy(fp16 engine, verifier) / VerifiedGreedy(mixed engine, verifier)
+        self._mixed_error: Dict[str, float] = {}
         self.verifier = verifier
         self.auto = precision == "auto"
         self.auto_tolerance = 1e-3
@@ -103,14 +112,14 @@ class HipMaskAndReplaceDiffusion:
                                  d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
                                  precision=prec, max_batch=mb, chunk=chunk, device=device, q_type=q_type,
                                  lanes=lanes)
-        if precision in ("fast_verified", "auto"):
+        if precision in ("fast_verified", "mixed_verified", "auto"):
             from .verified import VerifiedGreedy
 
-            # the reference-precision engine behind fast_verified / auto: "split" (fp16 x 3 on the fp16 matrix pipe: the
-            # exact mode's logits error at 1.7 x its speed, r04) or "exact" (fp32 MFMA)
+            # the reference-precision engine behind fast_verified / mixed_verified / auto: "split" (fp16 x 3 on the fp16 matrix
+            # pipe: the exact mode's logits error at 1.7 x its speed, r04) or "exact" (fp32 MFMA)
             assert verifier in ("split", "exact")
-            self.engine = mk("fast")
-            self.verified = VerifiedGreedy(self.engine, mk(verifier))
+            self.engine = mk("mixed" if precision == "mixed_verified" else "fast")
+            self.verified = self._v_fast = VerifiedGreedy(self.engine, mk(verifier))
         else:
             self.engine = mk(precision)
         self.q_type = q_type
@@ -178,7 +187,8 @@ class HipMaskAndReplaceDiffusion:
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         if self.verified is not None:
-            self.engine = self.verified.fast                    # (auto may have switched to the exact engine before)
+            self.verified = self._v_fast                        # (auto may have switched to the mixed / the reference-precision engine before)
+            self.engine = self.verified.fast
         self.engine.load_state_dict(state_dict)
         if self.verified is not None:
             self.verified.exact.load_state_dict(state_dict)
@@ -192,12 +202,53 @@ class HipMaskAndReplaceDiffusion:
                 cal = dict(self.verified.calibration, err_rel=float("inf"), finite=False)
                 self.verified.calibration = cal
             if self.auto:
+                self._mixed_error = {}
                 ok = cal["err_rel"] <= self.auto_tolerance       # (NaN / inf compare False)
                 self.selected_precision = "fast_verified" if ok else self.verifier
-                if not ok:
+                if not ok and self._try_mixed(state_dict):
+                    self.selected_precision = "mixed_verified"
+                elif not ok:
                     self.engine = self.verified.exact
         self._report_selection()
         return self
+
+    def _try_mixed(self, state_dict) -> bool:
+        """auto's middle rung: the mixed engine (built on first need; None where the library has no two-product kernels for the model's
+        geometry) measured against the verifier exactly like the fp16 engine was; True = it is inside the tolerance and now the engine."""
+        from .verified import VerifiedGreedy
+
+        if self._v_mixed is None:
+            try:
+                self._v_mixed = VerifiedGreedy(self._mk("mixed"), self._v_fast.exact)
+            except RuntimeError as e:                            # (ldm_create: geometry without the two-product kernels)
+                self._mixed_error = {"unavailable": str(e)}
+                return False
+        vm = self._v_mixed
+        vm.exact = self._v_fast.exact                            # (_check_verifier may have replaced the verifier engine)
+        vm.fast.load_state_dict(state_dict)
+        try:
+            cal = vm.calibrate()
+        except FloatingPointError:
+            self._mixed_error = {"err_rel": float("inf"), "finite": False}
+            return False
+        self._mixed_error = {"err_rel": cal["err_rel"], "err_abs": cal["err_abs"], "finite": True, "tie_abs": cal["tie_abs"]}
+        if not cal["err_rel"] <= self.auto_tolerance:
+            return False
+        self.verified = vm
+        self.engine = vm.fast
+        return True
+
+    def close(self) -> None:
+        """Release every engine this object built (the handles own GBs of workspace)."""
+        seen = []
+        for v in (self._v_fast, self._v_mixed):
+            if v is not None:
+                seen += [v.fast, v.exact]
+        done = []
+        for e in seen + [self.engine]:
+            if e is not None and not any(e is d for d in done):
+                done.append(e)
+                e.close()
 
     def _report_selection(self) -> None:
         """One INFO record per loaded checkpoint: which engine runs, the fp16 engine's measured logits error,
@@ -207,29 +258,45 @@ class HipMaskAndReplaceDiffusion:
         rep = {"precision_requested": self.precision, "engine_selected": sel,
                "expected_throughput": THROUGHPUT_CLASS.get(sel, "?")}
         if self.verified is not None:
-            cal = self.verified.calibration
+            cal = self._v_fast.calibration if self.precision != "mixed_verified" else {}
             rep.update({"fast_logits_err_rel": cal.get("err_rel"), "fast_logits_err_abs": cal.get("err_abs"),
                         "tolerance": self.auto_tolerance, "verifier": self.verifier, "verifier_check": dict(self.verifier_check),
-                        "tie_abs": cal.get("tie_abs")})
+                        "tie_abs": self.verified.calibration.get("tie_abs")})
+            if self.precision == "mixed_verified":
+                rep["mixed_logits_err_rel"] = self.verified.calibration.get("err_rel")
+            elif "unavailable" in self._mixed_error:
+                rep["mixed_unavailable"] = self._mixed_error["unavailable"]
+            elif self._mixed_error:
+                rep["mixed_logits_err_rel"] = self._mixed_error.get("err_rel")
         self.selection_report = rep
         if self.verified is None:
             logger.info("layout_dm_amd: engine '%s' (as requested) — %s", sel, rep["expected_throughput"])
             return
+        fmt = lambda e: "non-finite" if e is None or e != e or e == float("inf") else f"{e:.2e}"   # noqa: E731
         err = rep["fast_logits_err_rel"]
-        err_s = "non-finite" if err is None or err != err or err == float("inf") else f"{err:.2e}"
+        err_s = fmt(err)
         if self.auto:
             why = ("inside" if sel == "fast_verified" else "OUTSIDE") + f" the {self.auto_tolerance:g} logits tolerance"
+            if "mixed_logits_err_rel" in rep:
+                why += (f"; the mixed engine's (fp16 weights, hi + lo activations) is {fmt(rep['mixed_logits_err_rel'])}, "
+                        + ("inside" if sel == "mixed_verified" else "OUTSIDE"))
+            elif "mixed_unavailable" in rep:
+                why += "; no mixed engine for this geometry"
             logger.info("layout_dm_amd: precision='auto' selected engine '%s': the fp16 engine's logits error on this checkpoint is %s "
                         "(relative, against the %s reference-precision engine), %s — expect %s", sel, err_s, self.verifier, why,
                         rep["expected_throughput"])
+        elif self.precision == "mixed_verified":
+            logger.info("layout_dm_amd: engine 'mixed_verified' (as requested); its logits error on this checkpoint %s (relative, against the "
+                        "%s engine) — expect %s", fmt(rep.get("mixed_logits_err_rel")), self.verifier, rep["expected_throughput"])
         else:
             logger.info("layout_dm_amd: engine '%s' (as requested); fp16 logits error on this checkpoint %s (relative, against the %s "
                         "engine) — expect %s", sel, err_s, self.verifier, rep["expected_throughput"])
 
     @property
     def calibration(self) -> Dict[str, float]:
-        """fast-vs-exact logits error measured at load time (precision fast_verified / auto), else {}."""
-        return dict(self.verified.calibration) if self.verified is not None else {}
+        """fp16-engine-vs-verifier logits error measured at load time (precision fast_verified / auto; mixed_verified: the mixed
+        engine's), else {}."""
+        return dict(self._v_fast.calibration) if self._v_fast is not None else {}
 
     # -- the hot path ----------------------------------------------------------------------------
     @torch.no_grad()

@@ -19,6 +19,8 @@ class FakeEngine:
     """binding.Engine's surface as diffusion.py / verified.py use it; logits = a fixed function of (tokens, t) plus `noise` in the
     engines whose precision is 'fast'."""
     fast_noise = 0.0
+    mixed_noise = 0.0
+    mixed_available = True
     built = []
 
     def __init__(self, *, n_category, n_bin=32, max_elem=25, n_attr=5, n_step=100, precision="exact", max_batch=512,
@@ -29,6 +31,8 @@ class FakeEngine:
         self.pad_id, self.mask_id = self.C - 2, self.C - 1
         self.max_batch, self.batch_round, self.precision = max_batch, 256, precision
         self.device = torch.device("cpu")
+        if precision == "mixed" and not FakeEngine.mixed_available:
+            raise RuntimeError("ldm_create: precision mixed: only the reference backbone's geometry ...")
         FakeEngine.built.append((precision, max_batch))
 
     def load_state_dict(self, sd):
@@ -42,8 +46,9 @@ class FakeEngine:
         assert tokens.shape[0] <= self.max_batch, f"batch {tokens.shape[0]} outside [1, max_batch = {self.max_batch}]"
         g = torch.Generator().manual_seed(int(tokens.long().sum()) * 131 + int(t))
         base = torch.randn(tokens.shape[0], self.S, self.C, generator=g)
-        if self.precision == "fast":
-            base = base + FakeEngine.fast_noise * base.abs().max() * torch.sign(torch.randn(base.shape, generator=g))
+        noise = {"fast": FakeEngine.fast_noise, "mixed": FakeEngine.mixed_noise}.get(self.precision, 0.0)
+        if noise:
+            base = base + noise * base.abs().max() * torch.sign(torch.randn(base.shape, generator=g))
         return base
 
     def sample_loop(self, tokens, t_model, t_post, cfg, cond=None, seed=0, first_layout=0, intermediates=False, use_graph=True,
@@ -69,12 +74,18 @@ def fake(monkeypatch):
 
     monkeypatch.setattr(V, "Engine", FakeEngine, raising=False)
     FakeEngine.built = []
+    FakeEngine.fast_noise, FakeEngine.mixed_noise, FakeEngine.mixed_available = 0.0, 5e-3, True
     return FakeEngine
 
 
-@pytest.mark.parametrize("noise,want", [(1e-4, "fast_verified"), (5e-3, "split")])
-def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noise, want):
+@pytest.mark.parametrize("noise,mixed,want", [(1e-4, 5e-3, "fast_verified"), (5e-3, 4e-3, "split"), (5e-3, 2e-4, "mixed_verified"),
+                                              (5e-3, None, "split")])
+def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noise, mixed, want):
+    """The ladder: fp16 engine inside the tolerance -> fast_verified (no mixed engine is even built); else the mixed engine (hi + lo
+    activations x fp16 weights) is built and measured -> mixed_verified if inside; else — or where the library has no mixed kernels for
+    the geometry — the reference-precision engine."""
     fake.fast_noise = noise
+    fake.mixed_noise, fake.mixed_available = (mixed or 0.0), mixed is not None
     m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="auto", max_batch=8)
     with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
         m.load_state_dict({})
@@ -88,7 +99,33 @@ def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noi
     assert rep["engine_selected"] == want and rep["tolerance"] == 1e-3 and rep["verifier"] == "split"
     assert abs(rep["fast_logits_err_rel"] - noise) < 0.2 * noise       # the record carries the MEASURED error
     assert f"{rep['fast_logits_err_rel']:.2e}" in msg
+    built = [p for p, _ in FakeEngine.built]
+    if want == "fast_verified":
+        assert "mixed" not in built and "mixed_logits_err_rel" not in rep
+    elif mixed is None:
+        assert "mixed_unavailable" in rep and "no mixed engine" in msg
+    else:
+        assert built.count("mixed") == 1 and abs(rep["mixed_logits_err_rel"] - mixed) < 0.2 * mixed
+        assert f"{rep['mixed_logits_err_rel']:.2e}" in msg and "mixed engine" in msg
+        assert (m.engine.precision == "mixed") == (want == "mixed_verified")
+        assert (m.verified.fast is m.engine) == (want == "mixed_verified")
     json.dumps(rep, default=str)                                       # (check_checkpoint prints it)
+    # a second checkpoint on the same object starts from the fp16 engine again
+    fake.fast_noise = 1e-4
+    m.load_state_dict({})
+    assert m.selected_precision == "fast_verified" and m.engine.precision == "fast" and m.verified.fast is m.engine
+    m.close()
+
+
+def test_mixed_verified_as_requested(fake, caplog):
+    fake.mixed_noise = 3e-4
+    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="mixed_verified", max_batch=8)
+    with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
+        m.load_state_dict({})
+    msgs = [r.getMessage() for r in caplog.records if r.name == "layout_dm_amd"]
+    assert len(msgs) == 1 and "'mixed_verified'" in msgs[0] and "as requested" in msgs[0]
+    assert m.engine.precision == "mixed" and m.verified.fast is m.engine and m.verified.exact.precision == "split"
+    assert abs(m.selection_report["mixed_logits_err_rel"] - 3e-4) < 1e-4 and abs(m.calibration["err_rel"] - 3e-4) < 1e-4
 
 
 def test_explicit_precision_is_logged_too(fake, caplog):

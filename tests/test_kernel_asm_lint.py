@@ -193,16 +193,18 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     destination registers of an inline-asm MFMA must sit at least one whole MFMA (8 passes = 32 cycles) of wait states behind it."""
     asm = _compile("kernels_lngemm.hip", tmp_path)
     # the product instantiations (TM = false, ABL = 0: template arguments 3 and 4 mangle as Lb0ELi0; the phase-timer and measurement builds are dev only)
-    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and re.search(r"ELb0ELi0ELb[01]EEEvNS_10LnGemmArgsE$", k)}
-    # (ADA, OUT) in {(1, 0), (0, 1), (0, 0), (1, 2)} x {plain, with the GEMM prologue}; OUT = 2 (r06): in_proj writing hi / lo q / k / v panels
-    assert len(kernels) == 8, list(_kernels(asm))
+    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and re.search(r"ELb0ELi0ELb[01]ELb[01]EEEvNS_10LnGemmArgsE$", k)}
+    # (ADA, OUT) in {(1, 0), (0, 1), (0, 0), (1, 2)} x {plain, with the GEMM prologue} x {three products, two (W2: weights fp16 only)};
+    # OUT = 2 (r06): in_proj writing hi / lo q / k / v panels
+    assert len(kernels) == 16, list(_kernels(asm))
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-        pre = name.endswith("ELb1EEEvNS_10LnGemmArgsE")
-        # tile body: 29 k16-steps x 3 products; the GEMM prologue adds three stage bodies (one per A register set) of 30 items x 3
-        assert len(mf) == 87 + (270 if pre else 0), (name, len(mf))
+        pre = bool(re.search(r"ELb1ELb[01]EEEvNS_10LnGemmArgsE$", name))
+        per = 2 if name.endswith("ELb1EEEvNS_10LnGemmArgsE") else 3   # products per k16-step
+        # tile body: 29 k16-steps x 3 (2) products; the GEMM prologue adds three stage bodies (one per A register set) of 30 items x 3 (2)
+        assert len(mf) == per * (29 + (90 if pre else 0)), (name, len(mf))
         if pre:
             # the matrix pipe runs its queue in order: the last stage's final MFMAs are still in flight when the stage loop falls through, and
             # hipcc (which cannot see asm MFMAs) puts its v_accvgpr_reads of the accumulator tiles right there — the wait states must sit inside
@@ -218,7 +220,7 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
                        "scratch_store_dwordx4")]
                 assert [t.split()[0] for t in vm[-4:]] == ["global_load_dwordx4"] * 4, (name, vm[-6:])
                 assert vm[-5].startswith("asm:global_load_lds_dwordx4"), (name, vm[-6:])
-            for last in (mf[89], mf[179], mf[269]):
+            for last in (mf[30 * per - 1], mf[60 * per - 1], mf[90 * per - 1]):
                 tail = instr[last + 1:last + 8]
                 assert tail.count("asm:s_nop 15") == 2, (name, tail)
                 assert not any(t.startswith("v_accvgpr_read") for t in tail), (name, tail)
@@ -269,14 +271,17 @@ def test_attnout_kernel_register_discipline_and_hazards(tmp_path):
       * a VALU read of an asm MFMA's VGPR result sits at least a whole MFMA behind it."""
     asm = _compile("kernels_attnout.hip", tmp_path)
     ks = {k: v for k, v in _kernels(asm).items() if "attnout16x3_k" in k}
-    name = [k for k in ks if "ILb0E" in k]
-    assert len(name) == 1, list(ks)
-    name = name[0]
-    instr = ks[name]
+    names = sorted(k for k in ks if "ILb0E" in k)   # <TM = false, W2 = false | true>: three products in out_proj, or two (Wo fp16 only)
+    assert len(names) == 2 and "ILb0ELb0E" in names[0] and "ILb0ELb1E" in names[1], list(ks)
+    for name in names:
+        _attnout_checks(asm, name, ks[name], 276 if "ILb0ELb0E" in name else 216)
+
+
+def _attnout_checks(asm, name, instr, per_head):
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")]
     mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-    assert len(mf) == 48 + 276, len(mf)
+    assert len(mf) == 48 + per_head, len(mf)
     assert not [t for t in instr if t.startswith("v_mfma")], "a builtin MFMA: hipcc would choose its register file"
     # ---- the head loop: between the first and the last MFMA of the 276
     loop = instr[mf[48]:mf[-1] + 1]
