@@ -264,10 +264,13 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
     asm volatile("" : "+s"(r0v));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int r = r0v + j, rr = r < nrow ? r : nrow - 1;                       // (rows that do not exist: a valid row again, never stored)
+      // rows that do not exist: a valid row again, never stored.  A wave WITHOUT rows (S <= 32 wave) has nrow <= 0: rr is negative and
+      // names the layout's last real row from this wave's base — in SIGNED arithmetic (r06 fix: the unsigned product sent S = 50's
+      // waves 2 / 3 four gigabytes up; tests/test_hip_parity.py short_sequence passed or faulted with the process's memory map)
+      const int r = r0v + j, rr = r < nrow ? r : nrow - 1;
       unsigned lc = lu ^ (unsigned)((r0 + j) & 15);                              // logical chunk that lands in physical chunk `lane`
       if (half == 1) lc = lc < 52u ? lc : 51u;                                   // (chunks beyond the row: a valid chunk again, never read)
-      const char* src = pres + (unsigned)rr * (unsigned)(ND * 4) + half * 1024;
+      const char* src = pres + (long)rr * (long)(ND * 4) + half * 1024;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lc * 16u), "s"(src), "s"(lds_base + (unsigned)j * 1024u) : "memory");
     }
   };
@@ -584,6 +587,8 @@ bool attnout16x3_supported(int S, int H, int dh, int D) { return S >= 1 && S <= 
 
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st) {
   if (!attnout16x3_supported(a.S, 8, 58, a.D) || B < 1 || (a.panel_stride & 15) || !a.qkv_hi || !a.qkv_lo || !a.w_img) return -1;
+  // every layout reads 128 rows of 64 bytes from its first row, in every panel: the last one ends 128 - S rows behind the B * S rows in use
+  if (a.panel_stride < ((size_t)(B - 1) * a.S + 128) * 64) return -1;
   const bool tm = knob_int("LDM_ATTNOUT_TM", 0) != 0;   // (dev: the phase-timer instantiation)
   auto kern = a.w2 ? attnout16x3_k<false, true> : tm ? attnout16x3_k<true> : attnout16x3_k<false>;
   allow_big_lds((const void*)kern);

@@ -182,7 +182,10 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
       A(&h->h16lo, Mt * h->Dp);
       A(&h->hid16lo, (Mt + 64) * h->Fp);
     }
-    if (cfg->precision == LDM_PREC_SPLIT_F16) h->panel_rows = (size_t)round_up((int)Mc + 8, 64);
+    // panel rows: the fused attention kernel reads 128 keys / query rows from a layout's first row whatever S is — the last layout of
+    // a chunk reaches 128 - S rows past the chunk's last row (r06 fix: the slack was the reference's 3 rows + 5; at S = 50 the last
+    // panel was over-read by 8 rows, a memory fault whenever the allocation ended on a page boundary)
+    if (cfg->precision == LDM_PREC_SPLIT_F16) h->panel_rows = (size_t)round_up((int)Mc + std::max(8, 128 - h->S), 64);
     if (cfg->precision == LDM_PREC_SPLIT_F16 && attnout16x3_supported(h->S, h->H, h->dh, h->D)) {
       // q / k / v panels of the fused attention + out_proj kernel: 3 x 8 heads x 2 panels of 32 halfs, hi and lo; a layout's last
       // key tile reads up to 3 rows past the chunk's last row (slack, zero)

@@ -146,7 +146,7 @@ extern "C" void ldm_dev_attnout_phases(unsigned long long* out24) { ldm::attnout
 extern "C" int ldm_dev_attnout_check(int B, int S, float qk_amp, uint32_t seed, double* err_out, int zero_lo) {
   const int H = 8, dh = 58, D = 464, NP = 48;
   if (B < 1 || S < 1 || S > 128) return -1;
-  const size_t M = (size_t)B * S, rows = M + 64;
+  const size_t M = (size_t)B * S, rows = M + 128;   // (a layout reads 128 rows from its first one)
   const size_t PS = rows * 64;
   uint32_t s = seed * 2654435761u + 12345u;
   auto rnd = [&]() {

@@ -22,13 +22,14 @@ def _consts():
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
     for needle in ("if constexpr (IT == LG_SYNC - 1)", "constexpr int RI = (IT + LG_PF) % LG_NIT;",
-                   "constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;", "if constexpr (kRd) lg_read<RI>(s);",
+                   "constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;", "if constexpr (kRd) lg_read<RI, W2>(s);",
                    "if constexpr (hasD && J == 0) lg_dma_begin(s, tile + 2);", "if (IT > LG_SYNC) return IT - LG_SYNC - 1;",
                    "if (IT + (LG_NIT - 1 - LG_SYNC) < 16) return IT + (LG_NIT - 1 - LG_SYNC);",
-                   "constexpr int W = kRd ? lg_younger(IT) : 15;", "const unsigned aw = s.aW[RI & 7];",
+                   "constexpr int W = kRd ? lg_younger(IT, W2 ? 1 : 2) : 15;", "const unsigned aw = s.aW[RI & 7];",
                    "return IT == 1 || IT == 2 || IT == 3 || (IT > LG_SYNC && IT <= LG_SYNC + 4);",
                    "if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);", "wait_lgkm<8>();   // (4 ds_write_b128 follow",
-                   "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? 2 : 0;", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
+                   "for (int j = 1; j < LG_PF; ++j) n += lg_real(IT + j) ? rpi : 0;",
+                   "if constexpr (!W2) lg_dsr<256 * (IT >> 3) + LG_LO>(s.ql[IT % LG_PF], s.aW[IT & 7]);", "if constexpr (IT < LG_KS) {\n    lg_dsr"):
         assert needle in src, needle
     return ks, nit, pf
 
@@ -36,6 +37,8 @@ def _consts():
 def test_schedule_replay():
     KS, NIT, PF = _consts()
     _replay(KS, NIT, PF, epilogue=True)
+    # the two-product form (W2, the mixed numerics mode): ONE fragment read per item (W hi only), the counted waits halve with it
+    _replay(KS, NIT, PF, epilogue=True, rpi=1)
 
 
 def test_schedule_replay_gemm_prologue():
@@ -50,7 +53,8 @@ def test_schedule_replay_gemm_prologue():
     assert m and a and n
     PF, A_STEP, A_LOADS = int(m.group(1)), int(a.group(1)), int(n.group(1))
     for needle in ("constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;", "static_assert(LP_NIT % LP_PF == 0,",
-                   "constexpr int RI = (IT + LP_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LP_PF - 1))",
+                   "constexpr int RI = (IT + LP_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LP_PF - 1))", "[w] \"n\"(LP_PF - 1)",
+                   "if constexpr (!W2) lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);",
                    "if constexpr (IT == LP_SYNC - 1) {", "if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);",
                    "if (IT > LP_SYNC) return IT - LP_SYNC - 1;", "if (IT + (LP_NIT - 1 - LP_SYNC) < 16) return IT + (LP_NIT - 1 - LP_SYNC);",
                    "if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3>(s, stage + 2);",
@@ -59,17 +63,18 @@ def test_schedule_replay_gemm_prologue():
         assert needle in src, needle
     SYNC = NIT - PF
     _replay(NIT, NIT, PF, epilogue=False)
+    _replay(NIT, NIT, PF, epilogue=False, rpi=1)
     # vector-memory order inside a stage: DMA pieces at steps SYNC + 1 .. and 0 .. (16 in all), then the A loads; nothing behind them
     pieces = [it for it in range(NIT) if it > SYNC or it + (NIT - 1 - SYNC) < 16]
     assert len(pieces) == 16 and A_LOADS == 4
     assert max(p for p in pieces if p < SYNC) < A_STEP < SYNC, "the A loads must be the youngest vector memory operations at the barrier"
 
 
-def _replay(KS, NIT, PF, epilogue):
+def _replay(KS, NIT, PF, epilogue, rpi=2):
     SYNC = NIT - PF
     assert NIT % PF == 0 and KS <= NIT
     n_tiles = 6
-    lds_ops = []            # program-order list of LDS operations: ("frag", tile, item) twice per item, or ("epi",)
+    lds_ops = []            # program-order list of LDS operations: ("frag", tile, item) rpi times per item (W hi, W lo | W hi), or ("epi",)
     slot = {}               # queue slot -> (tile, item) it will hold once landed
     stage_tile = {0: 0, 1: 1}            # stage -> tile whose image the prologue / the DMA put there
     certified = {0, 1}                    # tiles whose stage is known complete (prologue barrier / a tile barrier)
@@ -85,7 +90,7 @@ def _replay(KS, NIT, PF, epilogue):
         assert tile in certified, f"tile {tile} read before its stage was certified"
         assert stage_tile[cur_stage_of_aw] == tile, f"aW points at stage {cur_stage_of_aw} = tile {stage_tile[cur_stage_of_aw]}, wanted {tile}"
         slot[item % PF] = (tile, item)
-        lds_ops += [("frag", tile, item), ("frag", tile, item)]
+        lds_ops += [("frag", tile, item)] * rpi
 
     for i in range(PF):                   # kernel prologue: lg_read<0..5>
         issue_read(0, i)
@@ -95,7 +100,7 @@ def _replay(KS, NIT, PF, epilogue):
             # ---- the counted wait in front of the step (real items only)
             real = lambda i: (i % NIT) < KS
             if it < KS:
-                n = sum(2 for j in range(1, PF) if real(it + j))     # uniform: the reads run on behind the last tile
+                n = sum(rpi for j in range(1, PF) if real(it + j))   # uniform: the reads run on behind the last tile
                 assert n <= 15
                 idx = max(i for i, op in enumerate(lds_ops) if op == ("frag", t, it))      # the younger of the pair
                 younger = len(lds_ops) - 1 - idx
@@ -115,7 +120,7 @@ def _replay(KS, NIT, PF, epilogue):
                 issue_read(t + 1, it + PF - NIT)
             elif it + PF - NIT < KS:
                 # behind the last tile the reads go on into the other stage (bytes nobody consumes): LDS operations all the same
-                lds_ops += [("frag", t + 1, it + PF - NIT)] * 2
+                lds_ops += [("frag", t + 1, it + PF - NIT)] * rpi
             if it == SYNC - 1:
                 cur_stage_of_aw ^= 1
             # ---- DMA of tile t + 2 (behind this tile's barrier) / the rest of tile t + 1
@@ -137,7 +142,7 @@ def _replay(KS, NIT, PF, epilogue):
             #  just appended — conservative for the waits either way)
             if t > 0 and epilogue:
                 extra = 1 if it == 1 else 2 if it in (2, 3) else 0
-                assert 2 * (PF - 1) + 2 + extra <= 15, "lgkmcnt is a 4-bit counter"
+                assert rpi * (PF - 1) + rpi + extra <= 15, "lgkmcnt is a 4-bit counter"
                 lds_ops += [("epi",)] * extra
             if it == KS and epilogue:                 # the pseudo step: drain to 8, then the 4 ds_write_b128 of the tile's sum
                 assert 8 + 4 <= 15

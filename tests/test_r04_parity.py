@@ -209,7 +209,11 @@ def test_trained_like_logits_fast_mode_and_auto_selection(cuda, golden_dir, poin
     assert dflt <= 1e-3, (point, m.selected_precision, dflt)
     # the probe's verdict agrees with the error against the reference (within the spread between probe and fixture states)
     assert 0.4 * worst <= cal["err_rel"] <= 2.5 * worst, (worst, cal)
-    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "split")
+    # (r06: the mixed engine — hi + lo activations x fp16 weights — is auto's rung between the two: tests/test_mixed_gpu.py)
+    mixed = m.selection_report.get("mixed_logits_err_rel")
+    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "mixed_verified" if mixed is not None and mixed <= 1e-3 else "split")
+    if m.selected_precision == "mixed_verified":
+        assert m.engine.describe()["precision"] == "mixed_f16" and m.verified.exact.describe()["precision"] == "split_f16"
     if point == "wide":
         assert m.selected_precision == "split" and m.engine is m.verified.exact   # (the reference-precision engine: split)
         out = m.sample(batch_size=2, sampling_cfg={"name": "deterministic", "num_timesteps": 5})
@@ -218,8 +222,7 @@ def test_trained_like_logits_fast_mode_and_auto_selection(cuda, golden_dir, poin
         assert torch.equal(out, ref)
     if point == "init":
         assert m.selected_precision == "fast_verified"
-    m.verified.fast.close()
-    m.verified.exact.close()
+    m.close()
 
 
 @pytest.mark.parametrize("point", POINTS)

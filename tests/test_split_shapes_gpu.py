@@ -3,11 +3,15 @@ M = 125 B rows with M % 128 in {1, 127} (B = 85, 43: the last block of kernels_l
 not a whole chunk (B = 300: chunks of 256 + 44), and the PubLayNet vocabulary (C = 135, Cp = 160: the head image's zero rows) —
 against the fp32-MFMA engine of the same weights, logits of a whole denoiser pass (in_proj -> fused attention + out_proj ->
 linear1 -> linear2 prologue -> head, kernels_attnout.hip included) and one sampling step."""
+import os
+
 import pytest
 import torch
 
 from oracle import spec as SP
 from oracle import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -44,3 +48,36 @@ def test_split_vs_fp32_mfma_at_awkward_row_counts(dataset, B):
         assert (na != nb).float().mean().item() <= 1e-4     # (a greedy token may differ only on a tie inside 2e-5)
     ex.close()
     sp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_elem", [1, 7, 10])
+def test_short_sequences_in_a_fresh_process(max_elem):
+    """r06: at S = 50 the fused attention + out_proj kernel's residual-row prefetch formed the address of a wave WITHOUT rows (waves 2 / 3)
+    from a negative row index in unsigned arithmetic — 4 GiB above the buffer.  Inside the suite's long-lived process that address was
+    usually mapped (tests/test_hip_parity.py short_sequence passed); in a fresh process it is a memory fault.  So: a fresh process per shape,
+    split and mixed engines, logits against the oracle."""
+    import subprocess
+    import sys
+
+    code = f'''
+import dataclasses, sys
+sys.path.insert(0, {ROOT!r})
+import torch
+from oracle import restatement as R, spec as SP, synth
+from layout_dm_amd.binding import Engine
+spec = dataclasses.replace(SP.SPECS["rico25"], name="short", max_elem={max_elem})
+sd = synth.synth_state_dict(spec, seed=0, perturb=True)
+g = torch.Generator().manual_seed(5)
+tokens = torch.randint(0, spec.n_class, (5, spec.seq_len), generator=g)
+ref = R.denoiser_logits(R.as_torch_weights(sd), spec, tokens, 33)
+for prec, tol in (("split", 2e-5), ("mixed", 1e-3)):
+    e = Engine(n_category=spec.n_category, max_elem=spec.max_elem, precision=prec, max_batch=8)
+    e.load_state_dict(sd)
+    out = e.denoise_logits(tokens.int(), 33).cpu()[..., :spec.n_class]
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    assert err <= tol, (prec, err)
+    print("OK", prec, err, flush=True)
+'''
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.count("OK ") == 2, p.stdout[-2000:]
