@@ -306,7 +306,7 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
   constexpr bool kRd = !(ABL & 2), kDm = !(ABL & 4), kEp = !(ABL & 8);
   if constexpr (IT < LG_NIT) {
     constexpr int J = lg_piece(IT);
-    constexpr bool hasD = kDm && J >= 0;
+    constexpr bool hasD = kDm && J >= 0 && (!W2 || J < 8);   // (W2: only the stage's hi half is fetched — 8 KiB per wave, pieces 0 .. 7)
     // the DMA stream's uniform address state: a new tile at piece 0, the next 4-KiB group of this wave's 16 KiB at pieces 4, 8, 12
     if constexpr (hasD && J == 0) lg_dma_begin(s, tile + 2);
     if constexpr (hasD && J > 0 && (J & 3) == 0) {
@@ -487,7 +487,7 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
   if constexpr (IT < LP_NIT) {
     constexpr int sx = IT / LP_NT, t = IT % LP_NT;
     constexpr int J = lp_piece(IT);
-    constexpr bool hasD = J >= 0;
+    constexpr bool hasD = J >= 0 && (!W2 || J < 8);   // (W2: the slab's hi half only)
     if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);
     if constexpr (hasD && J > 0 && (J & 3) == 0) {
       s.dma_g += 4096;
@@ -571,8 +571,10 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     float* spb = reinterpret_cast<float*>(smem + LG_PBIAS_OFF);
     for (int i = tid; i < 512; i += 256) spb[i] = (a.pre_bias && i < a.D) ? a.pre_bias[i] : 0.f;
     LpState ps;
-    ps.img = a.pre_img + wave * 16384;
-    ps.lds_w = lds0 + wave * 16384;
+    // this wave's share of a 64-KiB stage: 16 KiB of hi | lo — or (W2) 8 KiB of the hi half, which is all the two-product form reads
+    constexpr int WSH = W2 ? 8192 : 16384, WGR = W2 ? 2 : 4;
+    ps.img = a.pre_img + wave * WSH;
+    ps.lds_w = lds0 + wave * WSH;
     ps.voff = voff;
     ps.n_stages = a.pre_stages;
     ps.n_astages = a.pre_astages;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     ps.pal = a.preAlo + (size_t)rrow * a_pitch + hi * 8;
     for (int t = 0; t < 2; ++t)   // slabs 0 / 1 -> ring slots 0 / 1
 #pragma unroll
-      for (int k = 0; k < 4; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+      for (int k = 0; k < WGR; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * WSH + k * 4096);
     lp_load_a<0>(ps, 0);
     lp_load_a<1>(ps, 1);
 #pragma unroll
@@ -627,10 +629,11 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   // (r05 negative result, profiles/r05_call3_4_*: a per-workgroup rotation of the order — 32 CUs of an XCD on 32 different
   //  tiles instead of all on the same one — is 4 % SLOWER, 950 vs 988 layouts/s: the lock-step stream is served by the L2 once
   //  per XCD, the rotated one is not.)
-  const char* img = a.img + wave * 16384;
+  constexpr int WSH_T = W2 ? 8192 : 16384, WGR_T = W2 ? 2 : 4;   // (as in the GEMM prologue: W2 fetches the hi half of a stage only)
+  const char* img = a.img + wave * WSH_T;
   for (int t = 0; t < 2 && t < a.n_tiles; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * 16384 + k * 4096);
+    for (int k = 0; k < WGR_T; ++k) dma_lin4(voff, img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * WSH_T + k * 4096);
 
   // ---- the rows, raw, in accumulator layout: lane (row, hi) owns columns 8 g + 4 hi .. + 3 of every 8-column group g
   float4 v[NG];
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   s.xhi = xhi;
   s.xlo = xlo;
   s.img = img;
-  s.lds_w = lds0 + wave * 16384;
+  s.lds_w = lds0 + wave * WSH_T;
   s.voff = voff;
   s.n_tiles = a.n_tiles;
   s.stage_delta = LG_STAGE;

@@ -22,7 +22,7 @@ def _consts():
     ks, nit, pf = (int(x) for x in m.groups())
     # the structural facts the replay mirrors must still be in the source
     for needle in ("if constexpr (IT == LG_SYNC - 1)", "constexpr int RI = (IT + LG_PF) % LG_NIT;",
-                   "constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;", "if constexpr (kRd) lg_read<RI, W2>(s);",
+                   "constexpr bool hasR = kRd && IT != LG_SYNC && RI < LG_KS;", "if constexpr (kRd) lg_read<RI, W2>(s);", "constexpr bool hasD = kDm && J >= 0 && (!W2 || J < 8);",
                    "if constexpr (hasD && J == 0) lg_dma_begin(s, tile + 2);", "if (IT > LG_SYNC) return IT - LG_SYNC - 1;",
                    "if (IT + (LG_NIT - 1 - LG_SYNC) < 16) return IT + (LG_NIT - 1 - LG_SYNC);",
                    "constexpr int W = kRd ? lg_younger(IT, W2 ? 1 : 2) : 15;", "const unsigned aw = s.aW[RI & 7];",
@@ -38,7 +38,7 @@ def test_schedule_replay():
     KS, NIT, PF = _consts()
     _replay(KS, NIT, PF, epilogue=True)
     # the two-product form (W2, the mixed numerics mode): ONE fragment read per item (W hi only), the counted waits halve with it
-    _replay(KS, NIT, PF, epilogue=True, rpi=1)
+    _replay(KS, NIT, PF, epilogue=True, rpi=1, n_pieces=8)
 
 
 def test_schedule_replay_gemm_prologue():
@@ -53,7 +53,7 @@ def test_schedule_replay_gemm_prologue():
     assert m and a and n
     PF, A_STEP, A_LOADS = int(m.group(1)), int(a.group(1)), int(n.group(1))
     for needle in ("constexpr int LP_NT = 15, LP_NIT = 2 * LP_NT;", "static_assert(LP_NIT % LP_PF == 0,",
-                   "constexpr int RI = (IT + LP_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "[w] \"n\"(2 * (LP_PF - 1))", "[w] \"n\"(LP_PF - 1)",
+                   "constexpr int RI = (IT + LP_PF) % LP_NIT;", "constexpr bool hasR = IT != LP_SYNC;", "constexpr bool hasD = J >= 0 && (!W2 || J < 8);", "[w] \"n\"(2 * (LP_PF - 1))", "[w] \"n\"(LP_PF - 1)",
                    "if constexpr (!W2) lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);",
                    "if constexpr (IT == LP_SYNC - 1) {", "if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);",
                    "if (IT > LP_SYNC) return IT - LP_SYNC - 1;", "if (IT + (LP_NIT - 1 - LP_SYNC) < 16) return IT + (LP_NIT - 1 - LP_SYNC);",
@@ -63,14 +63,14 @@ def test_schedule_replay_gemm_prologue():
         assert needle in src, needle
     SYNC = NIT - PF
     _replay(NIT, NIT, PF, epilogue=False)
-    _replay(NIT, NIT, PF, epilogue=False, rpi=1)
+    _replay(NIT, NIT, PF, epilogue=False, rpi=1, n_pieces=8)
     # vector-memory order inside a stage: DMA pieces at steps SYNC + 1 .. and 0 .. (16 in all), then the A loads; nothing behind them
     pieces = [it for it in range(NIT) if it > SYNC or it + (NIT - 1 - SYNC) < 16]
     assert len(pieces) == 16 and A_LOADS == 4
     assert max(p for p in pieces if p < SYNC) < A_STEP < SYNC, "the A loads must be the youngest vector memory operations at the barrier"
 
 
-def _replay(KS, NIT, PF, epilogue, rpi=2):
+def _replay(KS, NIT, PF, epilogue, rpi=2, n_pieces=16):
     SYNC = NIT - PF
     assert NIT % PF == 0 and KS <= NIT
     n_tiles = 6
@@ -110,7 +110,7 @@ def _replay(KS, NIT, PF, epilogue, rpi=2):
             # ---- barrier
             if it == SYNC:
                 if t + 1 < n_tiles:
-                    assert dma_pieces.get(t + 1, 16) == 16, f"tile {t + 1}: only {dma_pieces.get(t + 1)} pieces issued before its barrier"
+                    assert dma_pieces.get(t + 1, n_pieces) == n_pieces, f"tile {t + 1}: only {dma_pieces.get(t + 1)} pieces issued before its barrier"
                     certified.add(t + 1)
                 barrier_done.add(t)
             # ---- reads
@@ -129,6 +129,8 @@ def _replay(KS, NIT, PF, epilogue, rpi=2):
                 piece, td = it - SYNC - 1, t + 2
             if it + (NIT - 1 - SYNC) < 16:
                 piece, td = it + (NIT - 1 - SYNC), t + 1      # (tile 0: the pieces re-load tile 1, which the prologue brought)
+            if piece is not None and piece >= n_pieces:       # (W2: the hi half of the stage only — pieces 0 .. 7)
+                piece = None
             if piece is not None and td < n_tiles and td >= 2:
                 assert td - 2 in barrier_done, f"DMA of tile {td} into the stage of tile {td - 2} before that tile's barrier"
                 assert dma_pieces.get(td, 0) == piece, f"tile {td}: piece {piece} out of order"
@@ -148,4 +150,4 @@ def _replay(KS, NIT, PF, epilogue, rpi=2):
                 assert 8 + 4 <= 15
                 lds_ops += [("epi",)] * 4
     for td in range(2, n_tiles):
-        assert dma_pieces[td] == 16
+        assert dma_pieces[td] == n_pieces
