@@ -19,8 +19,10 @@ def test_golden_fixtures_regenerate_bit_identically(tmp_path, golden_dir):
 
     out = str(tmp_path / "golden")
     make_golden.main(out_dir=out)
-    # (rico25_mid_reference_samples.npz and rico25_fitted.npz have their own generators and their own regeneration tests below)
-    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz") and f not in ("rico25_mid_reference_samples.npz", "rico25_fitted.npz"))
+    # (rico25_mid_reference_samples.npz, rico25_fitted.npz and rico25_b512_reference_loops.npz have their own generators and their own
+    #  regeneration tests below)
+    names = sorted(f for f in os.listdir(golden_dir) if f.endswith(".npz") and f not in ("rico25_mid_reference_samples.npz", "rico25_fitted.npz",
+                                                                                           "rico25_b512_reference_loops.npz"))
     assert names == sorted(f for f in os.listdir(out) if f.endswith(".npz"))
     for n in names:
         a, b = np.load(os.path.join(golden_dir, n)), np.load(os.path.join(out, n))
@@ -114,3 +116,35 @@ def test_reference_sample_sets_regenerate(golden_dir):
     assert np.array_equal(new["tokens"], g["tokens"][:, :mrs.CHUNK])
     # two independent draws of a non-degenerate distribution: no [MASK] left, the sets differ
     assert (g["tokens"] != 154).all() and not np.array_equal(g["tokens"][0], g["tokens"][1])
+
+
+def test_b512_reference_loops_fixture_slice_regenerates(golden_dir):
+    """tests/golden/rico25_b512_reference_loops.npz (oracle/make_b512_golden.py: the reference's own full loops at BASELINE config 2's batch, 20 min of
+    CPU) is not regenerated whole here; a slice is: the reference's greedy continuation of four of its mid-trajectory states, run live at batch 4,
+    must end in the stored tokens — and so must the oracle restatement's.  (Layouts whose smallest top-2 margin is below 1e-3 are left out: the
+    reference's own fp32 GEMMs may order their sums differently at batch 4 and at batch 512.)"""
+    from oracle import make_b512_golden as MB
+    from oracle import make_golden as MG
+    from oracle import restatement as R
+    from oracle import spec as SP
+    from oracle import synth
+
+    path = os.path.join(golden_dir, "rico25_b512_reference_loops.npz")
+    g = np.load(path)
+    spec = SP.SPECS["rico25"]
+    assert g["final_greedy"].shape == (512, spec.seq_len) and g["final_from_mid"].shape == (512, spec.seq_len)
+    assert int(g["weight_seed"]) == MG.WEIGHT_SEED and not (g["final_greedy"] == spec.mask_id).any() and not (g["final_from_mid"] == spec.mask_id).any()
+    assert (g["mid_state"] == spec.mask_id).mean() > 0.2          # a mid-trajectory state: a good part still masked
+    idx = np.nonzero(g["min_margin_from_mid"] >= 1e-3)[0][:4]
+    assert len(idx) == 4
+    mid = torch.from_numpy(g["mid_state"][idx].astype(np.int64))
+    want = torch.from_numpy(g["final_from_mid"][idx].astype(np.int64))
+    m, _ = rh.build_reference_model("rico25")
+    MG.load_synth(m, spec)
+    with torch.no_grad():
+        assert torch.equal(MB.greedy_from(m, spec, mid, 49), want)
+    W = R.as_torch_weights(synth.synth_state_dict(spec, seed=MG.WEIGHT_SEED, perturb=True))
+    tok = mid.clone()
+    for t in range(49, -1, -1):
+        tok = R.single_step(W, spec, tok, t, {"name": "deterministic"})
+    assert torch.equal(tok, want)
