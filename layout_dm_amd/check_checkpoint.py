@@ -7,7 +7,7 @@ measure the fp16 engine (and, where that one is outside the tolerance, the mixed
 checkpoint, and prints ONE JSON object per checkpoint:
 
     {"checkpoint": ".../best_model.pt", "engine_selected": "mixed_verified", "fast_logits_err_rel": 2.6e-3, "mixed_logits_err_rel": 5.9e-4,
-     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~1 400 layouts/s ...", "library": {...}}
+     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~1 500 layouts/s ...", "library": {...}}
 
 The same record goes to the `layout_dm_amd` logger at INFO when a job loads the checkpoint.  Needs the MI355X (the measurement
 IS a handful of denoiser passes on it); a few seconds.
