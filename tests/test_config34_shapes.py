@@ -34,7 +34,8 @@ CASES = {
 # exact = fp32 rounding of a CDF edge only (test_sampler_deterministic_and_inverse_cdf measures the same effect at 2e-3
 # on synthetic wide distributions; real posteriors are far more peaked); fast adds the fp16 logits error.
 STEP_MISMATCH_BOUND = {"exact": 1e-4, "fast": 5e-4}  # measured (profiles/r03_call2_*): 0 / 128 000 and <= 10 / 128 000
-TEACHER_STEPS = (5, 50, 97)  # loop indices (t = 94, 49, 2): mostly-[MASK] states, half-revealed, almost clean
+TEACHER_STEPS = (50, 97)  # loop indices (t = 49, 2): half-revealed, almost clean (r06: the mostly-[MASK] state at index 5 cost the oracle 27 s of the suite
+                           # per config; that regime is covered at B = 512 by test_hip_parity.py::test_full_batch_512_one_step_vs_oracle)
 
 
 def _engine(spec, precision, sd, lanes=0):
