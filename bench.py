@@ -805,11 +805,14 @@ def main():
                                     with_roofline=not a.no_roofline)
                 e2.close()
             r.pop("kernel_breakdown_ms", None)
-            if m == "split" and rank == 0 and world == 1 and "roofline" in r and not a.no_roofline and not a.no_traffic:
-                # HBM-side bytes of every kernel of the split step (r06): the mode's dominant kernel takes `traffic`
-                per, note = measure_traffic_per_kernel(a.dataset, "split")
+            if m in ("split", "mixed") and rank == 0 and world == 1 and "roofline" in r and not a.no_roofline and not a.no_traffic:
+                # HBM-side bytes of every kernel of the split / mixed step (r06): the mode's dominant kernel takes `traffic`
+                per, note = measure_traffic_per_kernel(a.dataset, m)
                 if per:
                     dom = SPLIT_KERNEL_SYMBOL.get(r["roofline"].get("kernel"))
+                    if dom and m == "mixed":   # the W2 instantiations: last template argument true
+                        dom = dom[:-len("false>")] + "true>"
+
                     hit = [k for k in per if dom and k.startswith(dom)]
                     if hit:
                         r["roofline"]["traffic"] = per[hit[0]]["fetch_bytes_calibrated"] + per[hit[0]]["write_bytes"]
