@@ -55,9 +55,11 @@ FLOP_PER_TOKEN_STEP = {  # 4 x [QKV + attn + out-proj + FFN] + he
 }
 # MI355X_MICROARCH.md dense MFMA peaks; split = 3 fp16 MFMA passes per product (divide by the passes)
 # mixed: two fp16 passes per weight product, three per attention product (4.27 % of the flops): 2.043 passes per flop on average
-PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3, "fast_verified": 2500.0, "mixed": 2500.0 / 2.043}
+# hybrid: one pass for the FFN and the head (64.1 % of the flops), two for in_proj / out_proj (31.7 %), three inside the attention: 1.403 on average
+PEAK_TFLOPS = {"exact": 157.3, "fast": 2500.0, "split": 2500.0 / 3, "fast_verified": 2500.0, "mixed": 2500.0 / 2.043, "hybrid": 2500.0 / 1.403}
 DTYPE = {"exact": "f32", "fast": "f16 (f32 accumulate)", "split": "f16x3 split (f32 accumulate)",
          "mixed": "f16 hi+lo activations x f16 weights (f32 accumulate)",
+         "hybrid": "attention path f16 hi+lo activations x f16 weights, FFN / head plain f16 (f32 accumulate)",
          "fast_verified": "f16 (f32 accumulate) + f32 re-decision of near-tie layouts"}
 CONFIGS = {
     2: dict(dataset="rico25", cond="unconditional", batch=512, sampling="random"),
@@ -82,7 +84,7 @@ def parse():
     ap.add_argument("--sampling", default=None, choices=["random", "deterministic", "top_p", "top_k", "gumbel"])
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--precision", default=os.environ.get("LDM_BENCH_PRECISION", "fast"),
-                    choices=["exact", "fast", "split", "mixed"])
+                    choices=["exact", "fast", "split", "mixed", "hybrid"])
     ap.add_argument("--modes", default=None,
                     help="comma list of numerics modes reported under 'modes' (default: exact,fast,fast_verified at N=1, "
                          "none at N>1; split = the fp16x3 cross-check mode, on request)")
@@ -434,10 +436,17 @@ KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_s
                  "attention": "attn_"}
 
 
-# split mode: event-profile class -> kernel symbol prefix (template arguments: <ADA, OUT, TM, ABL, PRE, W2>; W2 = true: the mixed mode's)
-SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, false>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, false>",
-                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, false>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, false>",
+# split / mixed / hybrid: event-profile class -> kernel symbol prefix (template arguments: <ADA, OUT, TM, ABL, PRE, NPM, NPP>: products per
+# k16-step of the tile loop / of the GEMM prologue; attnout16x3_k<TM, W2>)
+SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 3, 3>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 3, 3>",
+                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, 3, 3>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 3, 3>",
                        "attn_out_fused": "attnout16x3_k<false, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+MIXED_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 2, 2>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>",
+                       "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, 2, 2>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 2, 2>",
+                       "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+HYBRID_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 2, 1>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>",
+                        "gemm_ffn1_ln": "lngemm16x3_k<false, 3, false, 0, false, 1, 1>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 1, 1>",
+                        "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 
 
 # ----------------------------------------------------------------------------------------- one workload, one mode
@@ -763,7 +772,7 @@ def main():
     eng.close()
 
     # every numerics mode in the one line (N=1): the bit-exact mode's throughput next to the headline's
-    modes = a.modes if a.modes is not None else ("exact,split,mixed,fast,fast_verified" if world == 1 else "")
+    modes = a.modes if a.modes is not None else ("exact,split,mixed,hybrid,fast,fast_verified" if world == 1 else "")
     modes = [m for m in modes.split(",") if m and m != "none"]
     if modes:
         out["modes"] = {}
@@ -805,13 +814,13 @@ def main():
                                     with_roofline=not a.no_roofline)
                 e2.close()
             r.pop("kernel_breakdown_ms", None)
-            if m in ("split", "mixed") and rank == 0 and world == 1 and "roofline" in r and not a.no_roofline and not a.no_traffic:
+            if m in ("split", "mixed", "hybrid") and rank == 0 and world == 1 and "roofline" in r and not a.no_roofline and not a.no_traffic:
                 # HBM-side bytes of every kernel of the split / mixed step (r06): the mode's dominant kernel takes `traffic`
                 per, note = measure_traffic_per_kernel(a.dataset, m)
                 if per:
                     dom = SPLIT_KERNEL_SYMBOL.get(r["roofline"].get("kernel"))
-                    if dom and m == "mixed":   # the W2 instantiations: last template argument true
-                        dom = dom[:-len("false>")] + "true>"
+                    if dom and m != "split":   # the two-product / plain-fp16 instantiations of the same classes
+                        dom = {"mixed": MIXED_KERNEL_SYMBOL, "hybrid": HYBRID_KERNEL_SYMBOL}[m].get(r["roofline"].get("kernel"))
 
                     hit = [k for k in per if dom and k.startswith(dom)]
                     if hit:
@@ -937,6 +946,7 @@ def auto_on_trained_like(a, SP, spec, B, headline, rank, world, local_rank, dist
         cal = m.calibration
         entry = {"auto_selected": m.selected_precision, "value": round(B / dt, 2), "unit": "layouts/s", "steps": k,
                  "ms_per_step": round(1e3 * dt, 3), "fast_engine_err_rel_measured_at_load": cal.get("err_rel"),
+                 "hybrid_engine_err_rel_measured_at_load": m.selection_report.get("hybrid_logits_err_rel"),
                  "mixed_engine_err_rel_measured_at_load": m.selection_report.get("mixed_logits_err_rel"),
                  "tolerance": m.auto_tolerance, "verifier_check": m.verifier_check, "load_and_calibrate_s": round(load_s, 2),
                  "ratio_to_headline": round(B / dt / headline, 4)}

@@ -32,10 +32,14 @@ enum {
   LDM_PREC_EXACT_F32 = 0, /* v_mfma_f32_32x32x2_f32: exact fp32 (== fmaf chain) */
   LDM_PREC_FAST_F16 = 1,  /* fp16 operands, fp32 accumulate (v_mfma_f32_32x32x16_f16) */
   LDM_PREC_SPLIT_F16 = 2, /* fp16 hi+lo split operands, 3 MFMA passes, ~fp32 accuracy */
-  LDM_PREC_MIXED_F16 = 3  /* the split mode with fp16-ONLY weights: activations (and the attention's q, k, v, P) stay hi+lo, the four
+  LDM_PREC_MIXED_F16 = 3, /* the split mode with fp16-ONLY weights: activations (and the attention's q, k, v, P) stay hi+lo, the four
                              weight GEMMs and the head drop the W_lo product — 2 MFMA passes there, 3 inside the attention.  Logits
                              error 1e-4 .. 6e-4 of max |logit| on checkpoints whose fp16 error is ~1e-3;
                              reference backbone geometry only (ldm_create fails otherwise) */
+  LDM_PREC_HYBRID_F16 = 4 /* mixed with the FFN and the vocabulary head in PLAIN fp16 (LayerNorm output, hidden activations and weights
+                             rounded once: one MFMA pass there); the attention path — AdaLN output into in_proj, q, k, v, P, the attention
+                             output into out_proj — keeps hi+lo activations.  Logits error 2.8e-4 on a trained checkpoint whose fp16 error
+                             is 1.2e-3 (the fp16 error lives on the attention-score path: DESIGN.md section 3.5); same geometry rule */
 };
 
 /* transition-matrix family == Q_TYPES of the reference (models/layoutdm.py:20-23) */

@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldm_hip.so")
 ABI_VERSION = 5
 
-PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16, PREC_MIXED_F16 = 0, 1, 2, 3
-PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16, "mixed": PREC_MIXED_F16,
+PREC_EXACT_F32, PREC_FAST_F16, PREC_SPLIT_F16, PREC_MIXED_F16, PREC_HYBRID_F16 = 0, 1, 2, 3, 4
+PRECISIONS = {"exact": PREC_EXACT_F32, "fast": PREC_FAST_F16, "split": PREC_SPLIT_F16, "mixed": PREC_MIXED_F16, "hybrid": PREC_HYBRID_F16,
               "f32": PREC_EXACT_F32, "f16": PREC_FAST_F16, "f16x3": PREC_SPLIT_F16, "f16x2": PREC_MIXED_F16}
 SAMPLERS = {"deterministic": 0, "random": 1, "top_p": 2, "top_k": 3, "gumbel": 4}
 

@@ -201,6 +201,19 @@ __device__ __forceinline__ void lg_epilogue_slice(LgEpi& e, int tile) {
       else asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx4 %[vo], %[T], %[b]\n\ts_mov_b64 exec, -1"
                    ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [T] "v"(T), [b] "s"(e.b0)
                    : "memory");
+    } else if constexpr (OUT == 3) {   // ReLU, fp16 — no lo half (plain-fp16 hidden activations: the hybrid mode's linear1)
+      unsigned h01, h23;
+      asm volatile("v_fma_f32 %[t0], %[e0], %[sc], %[b0]\n\tv_fma_f32 %[t1], %[e1], %[sc], %[b1]\n\t"
+                   "v_fma_f32 %[t2], %[e2], %[sc], %[b2]\n\tv_fma_f32 %[t3], %[e3], %[sc], %[b3]\n\t"
+                   "v_max_f32 %[t0], 0, %[t0]\n\tv_max_f32 %[t1], 0, %[t1]\n\tv_max_f32 %[t2], 0, %[t2]\n\tv_max_f32 %[t3], 0, %[t3]\n\t"
+                   "v_cvt_pk_f16_f32 %[h01], %[t0], %[t1]\n\tv_cvt_pk_f16_f32 %[h23], %[t2], %[t3]"
+                   : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [h01] "=&v"(h01), [h23] "=&v"(h23)
+                   : [e0] "v"(ev.x), [e1] "v"(ev.y), [e2] "v"(ev.z), [e3] "v"(ev.w), [sc] "s"(e.out_scale), [b0] "v"(e.bb.x), [b1] "v"(e.bb.y),
+                     [b2] "v"(e.bb.z), [b3] "v"(e.bb.w));
+      const lg_u32x2 H = {h01, h23};
+      asm volatile("s_and_b64 exec, %[rm], %[cm]\n\tglobal_store_dwordx2 %[vo], %[H], %[bh]\n\ts_mov_b64 exec, -1"
+                   ::[rm] "s"(e.rowmask[p]), [cm] "s"(e.colmask), [vo] "v"(e.voff[p]), [H] "v"(H), [bh] "s"(e.b0)
+                   : "memory");
     } else {
       unsigned h01, h23, l01, l23;
       // scale + bias, (ReLU,) hi = fp16(v), lo = fp16(v - float(hi)): exact in fp32 (one fma_mix per value: -hi(f16 half of the pair) * 1.0 + v)
@@ -283,6 +296,20 @@ constexpr bool lg_slice_step(int IT) {
                : [xh] "v"(s.xhi[IT]), [xl] "a"(s.xlo[IT]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l), \
                  [w] "n"(W), [ro] "n"(RO), [doff] "n"(DOFF)                                                                     \
                : "memory")
+// NP = 1 (plain fp16: W_hi x_hi only — the x_lo fragments do not exist): the chains alternate by step
+// (XC: the register file of the step's x fragment — the odd k16-steps' fragments are parked in AGPRs by the kernel's prologue, like the
+//  x_lo fragments of the other forms: with all 116 fragment registers in arch VGPRs hipcc spilt the prologue's raw rows to scratch)
+#define LG_STEP_ASM1X(XC, C0, M0SET, PIECE, RD_HI)                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LG_MFMA("%[c0]", "%[qh]", "%[xh]", C0) PIECE RD_HI                           \
+               : [c0] "+v"(c0), [qh] "+v"(qh)                                                                                    \
+               : [xh] XC(s.xhi[IT]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),                        \
+                 [w] "n"(W), [ro] "n"(RO), [doff] "n"(DOFF)                                                                     \
+               : "memory")
+#define LG_STEP_ASM1(C0, M0SET, PIECE, RD_HI)                          \
+  do {                                                                 \
+    if constexpr (IT & 1) LG_STEP_ASM1X("a", C0, M0SET, PIECE, RD_HI); \
+    else LG_STEP_ASM1X("v", C0, M0SET, PIECE, RD_HI);                  \
+  } while (0)
 #define LG_A_M0 "s_mov_b32 m0, %[dl]\n\t"
 #define LG_A_PIECE "global_load_lds_dwordx4 %[vo], %[dg] offset:%[doff]\n\t"
 #define LG_A_RDH "ds_read_b128 %[qh], %[aw] offset:%[ro]\n\t"
@@ -298,8 +325,9 @@ constexpr int lg_piece(int IT) {
 }
 static_assert(lg_piece(LG_SYNC) == -1 && lg_piece(LG_SYNC + 1) == 0 && lg_piece(0) == lg_piece(LG_NIT - 1) + 1, "16 pieces, in order, none at the barrier step");
 
-template <int IT, int OUT, bool TM = false, int ABL = 0, bool W2 = false>
+template <int IT, int OUT, bool TM = false, int ABL = 0, int NP = 3>   // NP products per k16-step: 3 | 2 (weights fp16 only) | 1 (plain fp16: x_hi too)
 __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
+  constexpr bool W2 = NP < 3;
   // ABL (measurement builds only, LDM_LNGEMM_ABL): compile-time removal of 2 = the fragment reads and their counted waits,
   // 4 = the weight DMA, 8 = the epilogue (sum, transpose, stores), 16 = the epilogue's global stores only, 32 = every tile's stores
   // aimed at the columns of tile 0 — timing variants of this loop, results meaningless
@@ -321,13 +349,23 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
     if constexpr (IT < LG_KS) {
       // LDS operations of a wave complete in order: all but the lg_younger(IT) youngest = the fragment pairs issued behind item IT's
       constexpr int W = kRd ? lg_younger(IT, W2 ? 1 : 2) : 15;
-      f32x16& c0 = ((IT & 1) && !W2) ? s.accB : s.accA;   // two of the step's MFMAs (W2: one)
-      f32x16& c1 = ((IT & 1) && !W2) ? s.accA : s.accB;   // one
+      f32x16& c0 = ((IT & 1) && NP != 2) ? s.accB : s.accA;   // two of the step's MFMAs (NP = 2: one; NP = 1: the step's only one)
+      f32x16& c1 = ((IT & 1) && NP != 2) ? s.accA : s.accB;   // one (NP = 1: unused)
       f16x8& qh = s.qh[IT % LG_PF];
       f16x8& ql = s.ql[IT % LG_PF];
       const unsigned aw = s.aW[RI & 7];
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (W2 && IT == 0) {
+      if constexpr (NP == 1 && IT < 2) {   // one product: step 0 starts chain A, step 1 chain B
+        if constexpr (hasD && hasR) LG_STEP_ASM1("0", LG_A_M0, LG_A_PIECE, LG_A_RDH2);
+        else if constexpr (hasD) LG_STEP_ASM1("0", LG_A_M0, LG_A_PIECE, "");
+        else if constexpr (hasR) LG_STEP_ASM1("0", "", "", LG_A_RDH2);
+        else LG_STEP_ASM1("0", "", "", "");
+      } else if constexpr (NP == 1) {
+        if constexpr (hasD && hasR) LG_STEP_ASM1("%[c0]", LG_A_M0, LG_A_PIECE, LG_A_RDH2);
+        else if constexpr (hasD) LG_STEP_ASM1("%[c0]", LG_A_M0, LG_A_PIECE, "");
+        else if constexpr (hasR) LG_STEP_ASM1("%[c0]", "", "", LG_A_RDH2);
+        else LG_STEP_ASM1("%[c0]", "", "", "");
+      } else if constexpr (W2 && IT == 0) {
         if constexpr (hasD && hasR) LG_STEP_ASM2("0", "0", LG_A_M0, LG_A_PIECE, LG_A_RDH2);
         else if constexpr (hasD) LG_STEP_ASM2("0", "0", LG_A_M0, LG_A_PIECE, "");
         else if constexpr (hasR) LG_STEP_ASM2("0", "0", "", "", LG_A_RDH2);
@@ -381,11 +419,13 @@ __device__ __forceinline__ void lg_step(LgState& s, LgEpi& e, int tile) {
     // ---- the pseudo step: the tile's sum goes to the transpose buffer (the previous tile's rows left it at steps 2, 3)
     if constexpr (kEp && IT == LG_KS) lg_epilogue_sum_write(e, s.accA, s.accB);
     __builtin_amdgcn_sched_barrier(0);
-    lg_step<IT + 1, OUT, TM, ABL, W2>(s, e, tile);
+    lg_step<IT + 1, OUT, TM, ABL, NP>(s, e, tile);
   }
 }
 #undef LG_STEP_ASM
 #undef LG_STEP_ASM2
+#undef LG_STEP_ASM1
+#undef LG_STEP_ASM1X
 #undef LG_MFMA
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -450,8 +490,8 @@ __device__ __forceinline__ void lp_dma_begin(LpState& s, int sd) {   // stage sd
 }
 // A fragments of stage sd (clamped) into register set P: k16-steps 2 sd, 2 sd + 1 -> 16 halves apart.  EXACTLY LP_A_LOADS vector
 // memory instructions: the stage barrier's counted wait leaves that many outstanding.
-constexpr int LP_A_LOADS = 4;
-template <int P>
+constexpr int LP_A_LOADS = 4;   // (HI_ONLY — the one-product form, A is plain fp16: LP_A_LOADS / 2)
+template <int P, bool HI_ONLY = false>
 __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build, LDM_LNGEMM_ABL=128: every stage re-reads the A fragments of stage 0 (L2-resident)
   if (s.a_hot) sd = 0;
@@ -459,8 +499,10 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
   const int t = sd < s.n_astages ? sd : s.n_astages - 1;   // (the zero slabs at the end of the image multiply the last real columns again)
   s.fh[P][0] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * s.a_stage);
   s.fh[P][1] = *reinterpret_cast<const f16x8*>(s.pa + (size_t)t * s.a_stage + 16);
-  s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage);
-  s.fl[P][1] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage + 16);
+  if constexpr (!HI_ONLY) {
+    s.fl[P][0] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage);
+    s.fl[P][1] = *reinterpret_cast<const f16x8*>(s.pal + (size_t)t * s.a_stage + 16);
+  }
 }
 
 #define LP_MFMA(B, A) "v_mfma_f32_32x32x16_f16 %[c], " B ", " A ", %[c]\n\t"
@@ -477,13 +519,20 @@ __device__ __forceinline__ void lp_load_a(LpState& s, int sd) {
                : [xh] "v"(s.fh[SET][sx]), [xl] "v"(s.fl[SET][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),     \
                  [w] "n"(LP_PF - 1), [ro] "n"(RO), [doff] "n"(DOFF)                                                                \
                : "memory")
+#define LP_STEP_ASM1(M0SET, PIECE, RD_HI, TAIL)   /* one product: W_hi a_hi */                                                   \
+  asm volatile("s_waitcnt lgkmcnt(%[w])\n\t" M0SET LP_MFMA("%[qh]", "%[xh]") PIECE RD_HI TAIL                                    \
+               : [c] "+a"(acc), [qh] "+v"(qh)                                                                                      \
+               : [xh] "v"(s.fh[SET][sx]), [aw] "v"(aw), [vo] "v"(s.voff), [dg] "s"(s.dma_g), [dl] "s"(s.dma_l),                     \
+                 [w] "n"(LP_PF - 1), [ro] "n"(RO), [doff] "n"(DOFF)                                                                \
+               : "memory")
 
 // the step at which the stage requests the A fragments of stage + 2: behind the last DMA piece of the slab the barrier certifies
 constexpr int LP_A_STEP = 15;
 static_assert(lp_piece(LP_A_STEP - 1) < 0 && lp_piece(LP_A_STEP) < 0 && LP_A_STEP < LP_SYNC, "A loads are the youngest vector memory operations at the barrier");
 
-template <int IT, int SET, bool W2 = false>   // SET = stage % 3: the A register set the stage multiplies
+template <int IT, int SET, int NP = 3>   // SET = stage % 3: the A register set the stage multiplies; NP products per item (1: A hi only, plain fp16)
 __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
+  constexpr bool W2 = NP < 3;
   if constexpr (IT < LP_NIT) {
     constexpr int sx = IT / LP_NT, t = IT % LP_NT;
     constexpr int J = lp_piece(IT);
@@ -495,7 +544,7 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
     }
     // the A fragments of stage + 2: requested behind this stage's last DMA piece, so that they are the LP_A_LOADS youngest vector
     // memory operations at the barrier, which does not wait for them (loads return in order: everything older has landed)
-    if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3>(s, stage + 2);
+    if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3, NP == 1>(s, stage + 2);
     constexpr int RI = (IT + LP_PF) % LP_NIT;
     constexpr bool hasR = IT != LP_SYNC;
     constexpr int RO = (RI % LP_NT) * 2048;
@@ -508,7 +557,13 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
     // the stage's last item: 32 wait states behind its MFMAs, inside the statement (whatever hipcc places behind the stage loop —
     // its v_accvgpr_reads of the tiles — then finds every MFMA of the phase finished)
     static_assert(lp_piece(LP_NIT - 1) >= 0 && LP_NIT - 1 != LP_SYNC, "the last item carries a DMA piece and its reads");
-    if constexpr (W2) {
+    if constexpr (NP == 1) {
+      if constexpr (IT == LP_NIT - 1) LP_STEP_ASM1(LG_A_M0, LG_A_PIECE, LG_A_RDH2 "\n\t", "s_nop 15\n\ts_nop 15");
+      else if constexpr (hasD && hasR) LP_STEP_ASM1(LG_A_M0, LG_A_PIECE, LG_A_RDH2, "");
+      else if constexpr (hasD) LP_STEP_ASM1(LG_A_M0, LG_A_PIECE, "", "");
+      else if constexpr (hasR) LP_STEP_ASM1("", "", LG_A_RDH2, "");
+      else LP_STEP_ASM1("", "", "", "");
+    } else if constexpr (W2) {
       if constexpr (IT == LP_NIT - 1) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, LG_A_RDH2 "\n\t", "s_nop 15\n\ts_nop 15");
       else if constexpr (hasD && hasR) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, LG_A_RDH2, "");
       else if constexpr (hasD) LP_STEP_ASM2(LG_A_M0, LG_A_PIECE, "", "");
@@ -527,23 +582,28 @@ __device__ __forceinline__ void lp_step(LpState& s, f32x16* accs, int stage) {
     }
     if constexpr (IT == LP_SYNC) {
       // the next stage's slab (own pieces) and its A fragments (requested a stage ago); the fragments of stage + 2 stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LP_A_LOADS) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP == 1 ? LP_A_LOADS / 2 : LP_A_LOADS) : "memory");
       __builtin_amdgcn_s_barrier();
-      asm volatile("" : "+v"(s.fh[(SET + 1) % 3][0]), "+v"(s.fh[(SET + 1) % 3][1]), "+v"(s.fl[(SET + 1) % 3][0]), "+v"(s.fl[(SET + 1) % 3][1])::"memory");   // (hipcc's own counted wait for them lands here)
+      if constexpr (NP == 1) asm volatile("" : "+v"(s.fh[(SET + 1) % 3][0]), "+v"(s.fh[(SET + 1) % 3][1])::"memory");
+      else asm volatile("" : "+v"(s.fh[(SET + 1) % 3][0]), "+v"(s.fh[(SET + 1) % 3][1]), "+v"(s.fl[(SET + 1) % 3][0]), "+v"(s.fl[(SET + 1) % 3][1])::"memory");   // (hipcc's own counted wait for them lands here)
       lp_read<RI, W2>(s);
     }
     __builtin_amdgcn_sched_barrier(0);
-    lp_step<IT + 1, SET, W2>(s, accs, stage);
+    lp_step<IT + 1, SET, NP>(s, accs, stage);
   }
 }
 #undef LP_STEP_ASM
 #undef LP_STEP_ASM2
+#undef LP_STEP_ASM1
 #undef LP_MFMA
 
 }  // namespace
 
-template <bool ADA, int OUT, bool TM = false, int ABL = 0, bool PRE = false, bool W2 = false>
+// NPM / NPP: products per k16-step of the tile loop / of the GEMM prologue — 3 (split), 2 (weights fp16 only), 1 (plain fp16: the activation
+// operand has no lo half either)
+template <bool ADA, int OUT, bool TM = false, int ABL = 0, bool PRE = false, int NPM = 3, int NPP = 3>
 __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
+  constexpr bool W2 = NPM < 3, W2P = NPP < 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long t_k0 = 0, t_pro = 0, t_loop = 0;
   if constexpr (TM) t_k0 = __builtin_amdgcn_s_memtime();
@@ -572,7 +632,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     for (int i = tid; i < 512; i += 256) spb[i] = (a.pre_bias && i < a.D) ? a.pre_bias[i] : 0.f;
     LpState ps;
     // this wave's share of a 64-KiB stage: 16 KiB of hi | lo — or (W2) 8 KiB of the hi half, which is all the two-product form reads
-    constexpr int WSH = W2 ? 8192 : 16384, WGR = W2 ? 2 : 4;
+    constexpr int WSH = W2P ? 8192 : 16384, WGR = W2P ? 2 : 4;
     ps.img = a.pre_img + wave * WSH;
     ps.lds_w = lds0 + wave * WSH;
     ps.voff = voff;
@@ -591,8 +651,8 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     for (int t = 0; t < 2; ++t)   // slabs 0 / 1 -> ring slots 0 / 1
 #pragma unroll
       for (int k = 0; k < WGR; ++k) dma_lin4(voff, ps.img + (size_t)t * LG_STAGE + k * 4096, lds0 + t * LG_STAGE + wave * WSH + k * 4096);
-    lp_load_a<0>(ps, 0);
-    lp_load_a<1>(ps, 1);
+    lp_load_a<0, NPP == 1>(ps, 0);
+    lp_load_a<1, NPP == 1>(ps, 1);
 #pragma unroll
     for (int sx = 0; sx < 2; ++sx) ps.aS[sx] = lds0 + r * 64 + ((((sx << 1) | hi) ^ ((r >> 2) & 3)) << 4);
 #pragma unroll
@@ -607,13 +667,14 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1]), "+v"(ps.fh[1][0]), "+v"(ps.fh[1][1]),
-                 "+v"(ps.fl[1][0]), "+v"(ps.fl[1][1])::"memory");
-    lp_prime<0, W2>(ps);
+    if constexpr (NPP == 1) asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fh[1][0]), "+v"(ps.fh[1][1])::"memory");
+    else asm volatile("" : "+v"(ps.fh[0][0]), "+v"(ps.fh[0][1]), "+v"(ps.fl[0][0]), "+v"(ps.fl[0][1]), "+v"(ps.fh[1][0]), "+v"(ps.fh[1][1]),
+                      "+v"(ps.fl[1][0]), "+v"(ps.fl[1][1])::"memory");
+    lp_prime<0, W2P>(ps);
     for (int st = 0; st < a.pre_stages; st += 3) {   // three stage bodies, one per A register set (the ring slot follows aS);
-      lp_step<0, 0, W2>(ps, pacc, st);                // launch_lngemm16x3: a multiple of three stages (the image ends in zero slabs)
-      lp_step<0, 1, W2>(ps, pacc, st + 1);
-      lp_step<0, 2, W2>(ps, pacc, st + 2);
+      lp_step<0, 0, NPP>(ps, pacc, st);               // launch_lngemm16x3: a multiple of three stages (the image ends in zero slabs)
+      lp_step<0, 1, NPP>(ps, pacc, st + 1);
+      lp_step<0, 2, NPP>(ps, pacc, st + 2);
     }
     // the queue's trailing reads and the clamped re-load of the last slab are out, the last MFMAs have written their tiles, and every
     // wave is through with the ring: from here it belongs to the tile loop
@@ -704,11 +765,12 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
       for (int c = 0; c < 4; ++c) {
         const _Float16 h = (_Float16)yy[c];
         fh[u * 4 + c] = h;
-        fl[u * 4 + c] = (_Float16)((yy[c] - (float)h) * kSplitLoScale);
+        if constexpr (NPM > 1) fl[u * 4 + c] = (_Float16)((yy[c] - (float)h) * kSplitLoScale);
       }
     }
-    xhi[ks] = fh;
-    xlo[ks] = to_agpr4(fl);
+    if (NPM == 1 && (ks & 1)) xhi[ks] = to_agpr4(fh);   // (plain fp16: no lo fragments; the odd steps' x fragments take their place in the AGPRs)
+    else xhi[ks] = fh;
+    if constexpr (NPM > 1) xlo[ks] = to_agpr4(fl);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -740,7 +802,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
   e.C0 = OUT == 0 ? reinterpret_cast<const char*>(a.C32) : reinterpret_cast<const char*>(a.C16);
   e.C1 = reinterpret_cast<const char*>(a.C16lo);
   e.b0 = e.C0; e.b1 = e.C1; e.colmask = 0;
-  e.tstride = OUT == 0 ? 128 : (OUT == 1 && !a.panel_out) ? 64 : a.panel_stride;
+  e.tstride = OUT == 0 ? 128 : (OUT == 1 && !a.panel_out) ? 64 : a.panel_stride;   // (OUT = 3: always panels)
   e.N = a.N; e.c4 = (lane & 7) * 4;
   e.out_scale = a.out_scale;
 #pragma unroll
@@ -748,14 +810,18 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     const int orow = blockIdx.x * 128 + wave * 32 + p * 8 + (lane >> 3);
     e.rowmask[p] = __ballot(orow < a.M);
     // (launch_lngemm16x3 checks that M * ld * element size fits 32 bits)
-    if (OUT == 2 || (OUT == 1 && a.panel_out))   // panel-major: a tile's 32 columns are ONE panel of 64-byte rows
+    if (OUT == 2 || OUT == 3 || (OUT == 1 && a.panel_out))   // panel-major: a tile's 32 columns are ONE panel of 64-byte rows
       e.voff[p] = (unsigned)orow * 64u + (unsigned)e.c4 * 2u;
     else
       e.voff[p] = OUT == 0 ? ((unsigned)orow * (unsigned)a.ldc32 + (unsigned)e.c4) * 4u : ((unsigned)orow * (unsigned)a.ldc16 + (unsigned)e.c4) * 2u;
   }
   // every fragment back in its registers, hipcc's scoreboard drained (its own row loads / y32 stores), tiles 0 / 1 landed
 #pragma unroll
-  for (int k = 0; k < LG_KS; ++k) asm volatile("" : "+v"(xhi[k]), "+a"(xlo[k]));
+  for (int k = 0; k < LG_KS; ++k) {
+    if constexpr (NPM > 1) asm volatile("" : "+v"(xhi[k]), "+a"(xlo[k]));
+    else if (k & 1) asm volatile("" : "+a"(xhi[k]));
+    else asm volatile("" : "+v"(xhi[k]));
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   // (r05 calls 19 - 21, profiles/r05_call18_21_lngemm_store_cost.txt: of linear1's 187 us, 33 are its global stores — 6 with the same
   //  stores aimed at an L2-resident target, i.e. the cost is the 237 MB of hi / lo hidden rows on their way to HBM, not store issue;
@@ -768,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void lngemm16x3_k(LnGemmArgs a) {
     for (int k = 0; k < LG_PF; ++k) s.qh[k] = s.ql[k] = xhi[k];
   }
   if constexpr (!(ABL & 2)) lg_prime<0, W2>(s);
-  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL, W2>(s, e, t);
+  for (int t = 0; t < a.n_tiles; ++t) lg_step<0, OUT, TM, ABL, NPM>(s, e, t);
   if constexpr (TM) t_loop = __builtin_amdgcn_s_memtime();
   // the last tile's epilogue (its sum is in the transpose buffer): the same slices, each behind a full wait
   lg_epilogue_slice<1, OUT>(e, a.n_tiles - 1);
@@ -806,12 +872,16 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   if (a.tokens && a.S <= 0) return -1;
   // three output forms: fp32 (no ReLU) | ReLU + hi / lo fp16 rows | hi / lo fp16 panels without ReLU (q / k / v for kernels_attnout.hip);
   // the epilogue addresses with 32-bit byte offsets
+  // products per k16-step (0 = 3): 3 split | 2 weights fp16 only | 1 plain fp16 (the tile loop: no x_lo fragments; the GEMM prologue: no preAlo)
+  const int npm = a.np_main ? a.np_main : 3, npp = !a.pre_img ? npm : a.np_pre ? a.np_pre : 3;   // (no prologue: NPP follows NPM — one instantiation per form)
   const bool half_out = a.C16 != nullptr;
+  const bool hi_only = half_out && !a.C16lo;                    // ReLU + plain fp16 panels (OUT = 3): linear1 in front of a one-product linear2
   const bool panel = half_out && a.panel_out && !a.relu;        // q / k / v (OUT = 2); panel_out with ReLU: linear1's hidden rows (OUT = 1)
+  if (hi_only && (!a.relu || !a.panel_out || a.ada || a.C32)) return -1;
   if (half_out && a.panel_out && a.relu && ((a.N & 31) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 64 || (unsigned long long)a.M * 64 >= (1ull << 32)))
     return -1;
   if (panel ? (!a.C16lo || a.C32 || a.relu || !a.ada || (a.N & 31) || (a.panel_stride & 15) || a.panel_stride < (size_t)a.M * 64)
-            : half_out ? (!a.C16lo || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu))
+            : half_out ? ((!a.C16lo && !hi_only) || a.C32 || !a.relu || a.ada) : (!a.C32 || a.relu))
     return -1;
   if (panel ? ((unsigned long long)a.M * 64 >= (1ull << 32))
             : ((unsigned long long)a.M * (unsigned long long)(half_out ? a.ldc16 * 2 : a.ldc32 * 4) >= (1ull << 32)))
@@ -820,21 +890,29 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   const bool pre = a.pre_img != nullptr;
   // GEMM prologue: a multiple of three 32-wide K slabs (zero slabs behind the pre_astages real ones), all d_model columns inside its 15 tiles, fp32 residual rows
   if (pre && (a.pre_stages < 3 || a.pre_stages % 3 || a.pre_astages < 2 || a.pre_astages > a.pre_stages || a.D > 32 * LP_NT || !a.preA ||
-              !a.preAlo || !a.pre_res || a.tokens ||
+              (!a.preAlo && npp != 1) || !a.pre_res || a.tokens ||
               (a.pre_panel_stride ? ((a.pre_panel_stride & 15) || a.pre_panel_stride < (size_t)a.M * 64) : (a.pre_lda < 32 * a.pre_astages || (a.pre_lda & 7)))))
     return -1;
-  auto kern = panel ? lngemm16x3_k<true, 2> : half_out ? lngemm16x3_k<false, 1> : a.ada ? lngemm16x3_k<true, 0> : lngemm16x3_k<false, 0>;
-  if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true> : a.ada ? lngemm16x3_k<true, 0, false, 0, true> : lngemm16x3_k<false, 0, false, 0, true>;
-  if (a.w2) {   // the two-product form (weights fp16 only)
-    kern = panel ? lngemm16x3_k<true, 2, false, 0, false, true> : half_out ? lngemm16x3_k<false, 1, false, 0, false, true>
-           : a.ada ? lngemm16x3_k<true, 0, false, 0, false, true> : lngemm16x3_k<false, 0, false, 0, false, true>;
-    if (pre) kern = panel ? lngemm16x3_k<true, 2, false, 0, true, true> : half_out ? lngemm16x3_k<false, 1, false, 0, true, true>
-                    : a.ada ? lngemm16x3_k<true, 0, false, 0, true, true> : lngemm16x3_k<false, 0, false, 0, true, true>;
-  }
-  if (tm && !pre && !panel && !a.w2) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
+  // instantiations: <ADA, OUT, TM, ABL, PRE, NPM, NPP>; a launch without a GEMM prologue passes NPP = NPM (one instantiation per form)
+  void (*kern)(LnGemmArgs) = nullptr;
+#define LG_PICK(NPM_, NPP_)                                                                                                                           \
+  kern = pre ? (panel ? lngemm16x3_k<true, 2, false, 0, true, NPM_, NPP_> : hi_only ? nullptr : half_out ? lngemm16x3_k<false, 1, false, 0, true, NPM_, NPP_> \
+                : a.ada ? lngemm16x3_k<true, 0, false, 0, true, NPM_, NPP_> : lngemm16x3_k<false, 0, false, 0, true, NPM_, NPP_>)                         \
+             : (panel ? lngemm16x3_k<true, 2, false, 0, false, NPM_, NPM_> : hi_only ? nullptr : half_out ? lngemm16x3_k<false, 1, false, 0, false, NPM_, NPM_> \
+                : a.ada ? lngemm16x3_k<true, 0, false, 0, false, NPM_, NPM_> : lngemm16x3_k<false, 0, false, 0, false, NPM_, NPM_>)
+  if (npm == 3 && npp == 3) LG_PICK(3, 3);
+  else if (npm == 2 && npp == 2) LG_PICK(2, 2);
+  // the hybrid mode's three forms beside mixed's in_proj: linear2 (plain fp16) in front of the two-product in_proj; linear1 in plain fp16 writing
+  // plain-fp16 hidden panels; linear2 + head in plain fp16
+  else if (npm == 2 && npp == 1 && pre && panel) kern = lngemm16x3_k<true, 2, false, 0, true, 2, 1>;
+  else if (npm == 1 && !pre && hi_only) kern = lngemm16x3_k<false, 3, false, 0, false, 1, 1>;
+  else if (npm == 1 && npp == 1 && pre && !half_out && !a.ada) kern = lngemm16x3_k<false, 0, false, 0, true, 1, 1>;
+#undef LG_PICK
+  if (!kern) return -1;
+  if (tm && !pre && !panel && !hi_only && npm == 3) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;
 #ifdef LDM_LNGEMM_ABL_BUILD   // measurement build (tools/build_measurement_variants.py lngemm): compile-time timing variants of the loop
   static const int abl_knob = (int)knob_int("LDM_LNGEMM_ABL", 0);
-  const int abl = (pre || panel || a.w2) ? 0 : abl_knob;
+  const int abl = (pre || panel || hi_only || npm != 3) ? 0 : abl_knob;
 #define LG_ABL(n) case n: kern = half_out ? lngemm16x3_k<false, 1, false, n> : a.ada ? lngemm16x3_k<true, 0, false, n> : lngemm16x3_k<false, 0, false, n>; break;
   switch (abl) { LG_ABL(2) LG_ABL(4) LG_ABL(8) LG_ABL(6) LG_ABL(10) LG_ABL(12) LG_ABL(14) LG_ABL(16) LG_ABL(32) LG_ABL(64) default: break; }
 #undef LG_ABL

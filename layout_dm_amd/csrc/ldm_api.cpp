@@ -28,10 +28,10 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
     return -1;
   };
   if (!cfg_in || !out) return bad("null argument");
-  // LDM_PREC_MIXED_F16 IS the split mode — same launches, images, workspace — with the weight GEMMs in their two-product form: from
-  // here on the handle is a split-mode handle with `mixed` set
+  // LDM_PREC_MIXED_F16 / LDM_PREC_HYBRID_F16 ARE the split mode — same launches, images, workspace — with the weight GEMMs in their two-product
+  // form (hybrid: the FFN and the head in plain fp16): from here on the handle is a split-mode handle with `mixed` set
   ldm_config cfg_local = *cfg_in;
-  const bool mixed = cfg_local.precision == LDM_PREC_MIXED_F16;
+  const int mixed = cfg_local.precision == LDM_PREC_MIXED_F16 ? 1 : cfg_local.precision == LDM_PREC_HYBRID_F16 ? 2 : 0;
   if (mixed) cfg_local.precision = LDM_PREC_SPLIT_F16;
   const ldm_config* cfg = &cfg_local;
   if (cfg->abi_version != LDM_ABI_VERSION) return bad("ldm_config.abi_version mismatch");
@@ -43,7 +43,7 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
   if (cfg->d_model % 16 || cfg->d_ff % 16 || cfg->d_model > 1024) return bad("d_model/d_ff must be multiples of 16, d_model <= 1024");
   if (cfg->d_model % cfg->n_head) return bad("d_model must be divisible by n_head");
   if (cfg->d_model / cfg->n_head > 64) return bad("head_dim > 64 not supported");
-  if (cfg_in->precision < 0 || cfg_in->precision > 3) return bad("unknown precision mode");
+  if (cfg_in->precision < 0 || cfg_in->precision > 4) return bad("unknown precision mode");
   if (cfg->max_batch < 1) return bad("max_batch must be >= 1");
   {  // development knobs are refused outside dev mode (ldm_knobs.h): no stray variable changes the shipped path
     static std::string msg;
@@ -221,9 +221,13 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
                     knob_int("LDM_X3_HIDPANEL", 1) != 0;
     h->attnout = h->lngemm && !h->pre_out && h->qkvp_hi && h->panel_rows * 64 * 2 < (1ull << 32) && knob_int("LDM_X3_ATTNOUT", 1) != 0;
     h->mixed = mixed;
-    h->w2p = h->lngemm && h->pre_ffn2 && h->attnout && mixed;
+    h->w2p = h->lngemm && h->pre_ffn2 && h->attnout && mixed && (mixed == 1 || h->hid_panels);
+    if (h->w2p) {
+      h->np_w = 2;
+      h->np_ffn = mixed == 2 ? 1 : 2;
+    }
     if (mixed && !h->w2p) {
-      h->err = "precision mixed: only the reference backbone's geometry (d_model 464, 8 heads, <= 128 tokens per layout) has the two-product kernels; use precision split";
+      h->err = "precision mixed / hybrid: only the reference backbone's geometry (d_model 464, 8 heads, <= 128 tokens per layout) has the two-product kernels; use precision split";
       rc = -1;
     }
   }
@@ -433,10 +437,10 @@ extern "C" const char ldm_build_source_digest[] = "LDM_SRC_DIGEST=" LDM_SRC_DIGE
 
 extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   if (!h) return -1;
-  static const char* prec[4] = {"exact_f32", "fast_f16", "split_f16", "mixed_f16"};
+  static const char* prec[5] = {"exact_f32", "fast_f16", "split_f16", "mixed_f16", "hybrid_f16"};
   const bool loop = loop_fusable(h, nullptr);
   char num[96];
-  std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->mixed ? 3 : h->cfg.precision];
+  std::string s = "abi=" + std::to_string(LDM_ABI_VERSION) + ";precision=" + prec[h->mixed ? 2 + h->mixed : h->cfg.precision];
   std::string kern = h->fused_attn == 6 ? "stack" : "generic16";
   if (h->cfg.precision != LDM_PREC_FAST_F16) {
     kern = "tiled_gemm+attn";

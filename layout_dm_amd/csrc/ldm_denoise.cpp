@@ -114,6 +114,8 @@ static void ffn2_prologue(ldm_handle* h, const LayerW& w, LnGemmArgs& a) {
   a.pre_img = (const char*)w.x3_ffn2_slab; a.pre_bias = w.b2; a.pre_scale = w.s2;
   a.pre_res = h->Q; a.pre_out = nullptr;
   a.pre_panel_stride = h->hid_panels ? h->panel_rows * 64 : 0;
+  a.np_pre = h->np_ffn;
+  if (h->np_ffn == 1) a.preAlo = nullptr;   // (plain-fp16 hidden activations: linear1 wrote no lo panels)
 }
 
 int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int Bc, hipStream_t st, bool skip_embed) {
@@ -134,7 +136,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.p0 = ss; a.p1 = ss + D; a.ada = 1;
       a.y32 = h->P;
       a.out_scale = w.s_in;
-      a.M = M; a.D = D; a.w2 = h->w2p;
+      a.M = M; a.D = D; a.np_main = h->np_w;
       if (h->attnout) {   // q / k / v as head-padded hi / lo panels for the fused attention + out_proj launch (kernels_attnout.hip)
         a.img = (const char*)w.x3_qkv_pad; a.n_tiles = 3 * h->H * 2;
         a.bias = w.b_in_pad; a.N = 3 * h->H * 64;
@@ -224,7 +226,8 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.bias = w.b1; a.out_scale = w.s1; a.relu = 1;
       a.C16 = h->hid16; a.C16lo = h->hid16lo; a.ldc16 = Fp;
       if (h->hid_panels) { a.panel_out = 1; a.panel_stride = h->panel_rows * 64; }   // (read back by ffn2_prologue in the same form)
-      a.M = M; a.N = F; a.D = D; a.S = h->S; a.w2 = h->w2p;
+      a.M = M; a.N = F; a.D = D; a.S = h->S; a.np_main = h->np_ffn;
+      if (h->np_ffn == 1) a.C16lo = nullptr;   // hybrid: ReLU output rounded once (panel-major: ldm_create requires hid_panels for it)
       if (h->pre_out) {   // Q = P + att · Wo^T + bo computed in this launch, written once (linear2's residual base)
         a.preA = h->att16; a.preAlo = h->att16lo; a.pre_lda = Dp; a.pre_astages = Dp / 32; a.pre_stages = ldm_pack::x3_slab_stages(Dp);
         a.pre_img = (const char*)w.x3_out_slab; a.pre_bias = w.b_out; a.pre_scale = w.s_out;
@@ -279,7 +282,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     a.img = (const char*)h->x3_head; a.n_tiles = h->x3_head_tiles;
     a.out_scale = h->head_s;
     a.C32 = h->logits; a.ldc32 = h->Cp;
-    a.w2 = h->w2p;
+    a.np_main = h->np_ffn;
     a.M = M; a.N = h->Cp; a.D = D; a.S = h->S;   // (columns C .. Cp of the image are zero rows: exact zeros in the padding)
     if (h->pre_ffn2) ffn2_prologue(h, h->layers[h->L - 1], a);
     ldm_handle::Scope sc(h, st, h->pre_ffn2 ? "gemm_ffn2_head_ln" : "gemm_head_ln", gemm_flops(M, C, D) + (h->pre_ffn2 ? gemm_flops(M, D, F) : 0.0),

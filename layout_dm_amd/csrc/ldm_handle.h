@@ -162,7 +162,11 @@ struct ldm_handle {
   bool hid_panels = false;
   // two-product form of the split mode's WEIGHT GEMMs: activations hi + lo, weights fp16 only (kernels_lngemm.hip / kernels_attnout.hip W2)
   bool w2p = false;
-  bool mixed = false;          // created as LDM_PREC_MIXED_F16 (cfg.precision then reads LDM_PREC_SPLIT_F16: every other choice is the split mode's)
+  // created as LDM_PREC_MIXED_F16 (1) / LDM_PREC_HYBRID_F16 (2): cfg.precision then reads LDM_PREC_SPLIT_F16 — every other choice is the split mode's
+  int mixed = 0;
+  // products per k16-step (kernels_lngemm.hip NPM / NPP): of the attention path's GEMMs (in_proj; out_proj: w2p) and of linear1 / linear2 / the head.
+  // split 3 / 3, mixed 2 / 2, hybrid 2 / 1 (the FFN and the head in plain fp16: LayerNorm output, hidden activations and weights rounded once)
+  int np_w = 3, np_ffn = 3;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

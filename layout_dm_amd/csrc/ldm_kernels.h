@@ -111,9 +111,11 @@ struct LnGemmArgs {
   int pre_lda, pre_stages, pre_astages;   // stages of the image (a multiple of 3, zero slabs at the end) / stages with real K columns
   size_t pre_panel_stride;                // 0: preA / preAlo are row-major; else (r06) panel-major [K / 32][rows][32 halves], bytes between panels
   float pre_scale;
-  // two-product form (LDM_PREC_SPLIT2): activations hi + lo, WEIGHTS fp16 only — W_hi x_hi + W_hi x_lo; the lo halves of both images
-  // are neither read from the LDS nor multiplied (2 MFMAs per k16-step instead of 3)
-  int w2;
+  // products per k16-step of the tile loop / of the GEMM prologue (0 = 3).  3: x = hi + lo on both operands (split).  2: WEIGHTS fp16 only —
+  // W_hi x_hi + W_hi x_lo, the images' lo halves neither fetched nor read (LDM_PREC_MIXED_F16).  1: plain fp16 — the activation operand has no lo
+  // half either (tile loop: the LayerNorm output is rounded once; prologue: preAlo is not read).  With C16lo == nullptr (ReLU, panel_out) the
+  // epilogue writes plain-fp16 hidden panels (LDM_PREC_HYBRID_F16: the FFN and the head in plain fp16, the attention path in the two-product form)
+  int np_main, np_pre;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
 void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)

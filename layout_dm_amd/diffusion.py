@@ -25,6 +25,8 @@ logger = logging.getLogger("layout_dm_amd")
 THROUGHPUT_CLASS = {
     "fast": "~3 900 layouts/s (fp16 operands, one launch per sampling call)",
     "fast_verified": "~3 400 - 3 900 layouts/s (fp16 engine; greedy decoding re-checked by the reference-precision engine)",
+    "hybrid": "~1 900 layouts/s (attention path: hi + lo fp16 activations x fp16 weights; FFN and head in plain fp16; per-step launches)",
+    "hybrid_verified": "~1 900 layouts/s (attention path hi + lo x fp16, FFN / head plain fp16; greedy decoding re-checked by the reference-precision engine)",
     "mixed": "~1 500 layouts/s (hi + lo fp16 activations x fp16 weights: two matrix passes per weight product, per-step launches)",
     "mixed_verified": "~1 500 layouts/s (hi + lo fp16 activations x fp16 weights; greedy decoding re-checked by the reference-precision engine)",
     "split": "~1 150 - 1 200 layouts/s (reference precision on the fp16 matrix pipe, per-step launches)",
@@ -96,10 +98,13 @@ class HipMaskAndReplaceDiffusion:
         # product instead of three, +19 % over split; its logits error is 2e-4 on a fitted checkpoint whose fp16 error is 1.2e-3).  When the
         # fp16 engine is outside the tolerance, auto builds a mixed engine, measures IT the same way, and keeps it — again with verified
         # greedy decoding — if it is inside; only then the reference-precision engine runs every call.  "mixed" / "mixed_verified" select it
-        # unconditionally.
+        # unconditionally.  In front of it sits "hybrid" (LDM_PREC_HYBRID_F16: mixed with the FFN and the head in plain fp16 — the fp16 error
+        # lives on the attention-score path; 2.8e-4 on the fitted checkpoint), so auto's ladder is fast -> hybrid -> mixed -> reference precision,
+        # each rung built on first need and held to the same measurement.
         self.verified = None
-        self._v_fast = self._v_mixed = None      # VerifiedGreedy(fp16 engine, verifier) / VerifiedGreedy(mixed engine, verifier)
-        self._mixed_error: Dict[str, float] = {}
+        self._v_fast = None                      # VerifiedGreedy(fp16 engine, verifier)
+        self._v_rung: Dict[str, object] = {}     # rung -> VerifiedGreedy(its engine, verifier), built on first need
+        self._rung_error: Dict[str, Dict[str, float]] = {}   # rung -> what auto measured on the checkpoint loaded last
         self.verifier = verifier
         self.auto = precision == "auto"
         self.auto_tolerance = 1e-3
@@ -112,13 +117,13 @@ class HipMaskAndReplaceDiffusion:
                                  d_model=d_model, n_head=n_head, d_ff=d_ff, n_layer=n_layer, n_step=num_timesteps,
                                  precision=prec, max_batch=mb, chunk=chunk, device=device, q_type=q_type,
                                  lanes=lanes)
-        if precision in ("fast_verified", "mixed_verified", "auto"):
+        if precision in ("fast_verified", "mixed_verified", "hybrid_verified", "auto"):
             from .verified import VerifiedGreedy
 
             # the reference-precision engine behind fast_verified / mixed_verified / auto: "split" (fp16 x 3 on the fp16 matrix
             # pipe: the exact mode's logits error at 1.7 x its speed, r04) or "exact" (fp32 MFMA)
             assert verifier in ("split", "exact")
-            self.engine = mk("mixed" if precision == "mixed_verified" else "fast")
+            self.engine = mk(precision[:-len("_verified")] if precision in ("mixed_verified", "hybrid_verified") else "fast")
             self.verified = self._v_fast = VerifiedGreedy(self.engine, mk(verifier))
         else:
             self.engine = mk(precision)
@@ -202,36 +207,41 @@ class HipMaskAndReplaceDiffusion:
                 cal = dict(self.verified.calibration, err_rel=float("inf"), finite=False)
                 self.verified.calibration = cal
             if self.auto:
-                self._mixed_error = {}
+                self._rung_error = {}
                 ok = cal["err_rel"] <= self.auto_tolerance       # (NaN / inf compare False)
                 self.selected_precision = "fast_verified" if ok else self.verifier
-                if not ok and self._try_mixed(state_dict):
-                    self.selected_precision = "mixed_verified"
-                elif not ok:
-                    self.engine = self.verified.exact
+                if not ok:
+                    for rung in self.RUNGS:
+                        if self._try_rung(rung, state_dict):
+                            self.selected_precision = rung + "_verified"
+                            break
+                    else:
+                        self.engine = self.verified.exact
         self._report_selection()
         return self
 
-    def _try_mixed(self, state_dict) -> bool:
-        """auto's middle rung: the mixed engine (built on first need; None where the library has no two-product kernels for the model's
+    RUNGS = ("hybrid", "mixed")   # auto's ladder between the fp16 engine and the reference-precision engine, fastest first
+
+    def _try_rung(self, rung: str, state_dict) -> bool:
+        """One rung of auto's ladder: the engine (built on first need; unavailable where the library has no such kernels for the model's
         geometry) measured against the verifier exactly like the fp16 engine was; True = it is inside the tolerance and now the engine."""
         from .verified import VerifiedGreedy
 
-        if self._v_mixed is None:
+        if rung not in self._v_rung:
             try:
-                self._v_mixed = VerifiedGreedy(self._mk("mixed"), self._v_fast.exact)
-            except RuntimeError as e:                            # (ldm_create: geometry without the two-product kernels)
-                self._mixed_error = {"unavailable": str(e)}
+                self._v_rung[rung] = VerifiedGreedy(self._mk(rung), self._v_fast.exact)
+            except RuntimeError as e:                            # (ldm_create: geometry without these kernels)
+                self._rung_error[rung] = {"unavailable": str(e)}
                 return False
-        vm = self._v_mixed
+        vm = self._v_rung[rung]
         vm.exact = self._v_fast.exact                            # (_check_verifier may have replaced the verifier engine)
         vm.fast.load_state_dict(state_dict)
         try:
             cal = vm.calibrate()
         except FloatingPointError:
-            self._mixed_error = {"err_rel": float("inf"), "finite": False}
+            self._rung_error[rung] = {"err_rel": float("inf"), "finite": False}
             return False
-        self._mixed_error = {"err_rel": cal["err_rel"], "err_abs": cal["err_abs"], "finite": True, "tie_abs": cal["tie_abs"]}
+        self._rung_error[rung] = {"err_rel": cal["err_rel"], "err_abs": cal["err_abs"], "finite": True, "tie_abs": cal["tie_abs"]}
         if not cal["err_rel"] <= self.auto_tolerance:
             return False
         self.verified = vm
@@ -241,7 +251,7 @@ class HipMaskAndReplaceDiffusion:
     def close(self) -> None:
         """Release every engine this object built (the handles own GBs of workspace)."""
         seen = []
-        for v in (self._v_fast, self._v_mixed):
+        for v in [self._v_fast] + list(self._v_rung.values()):
             if v is not None:
                 seen += [v.fast, v.exact]
         done = []
@@ -258,16 +268,18 @@ class HipMaskAndReplaceDiffusion:
         rep = {"precision_requested": self.precision, "engine_selected": sel,
                "expected_throughput": THROUGHPUT_CLASS.get(sel, "?")}
         if self.verified is not None:
-            cal = self._v_fast.calibration if self.precision != "mixed_verified" else {}
+            explicit = self.precision in ("mixed_verified", "hybrid_verified")
+            cal = self._v_fast.calibration if not explicit else {}
             rep.update({"fast_logits_err_rel": cal.get("err_rel"), "fast_logits_err_abs": cal.get("err_abs"),
                         "tolerance": self.auto_tolerance, "verifier": self.verifier, "verifier_check": dict(self.verifier_check),
                         "tie_abs": self.verified.calibration.get("tie_abs")})
-            if self.precision == "mixed_verified":
-                rep["mixed_logits_err_rel"] = self.verified.calibration.get("err_rel")
-            elif "unavailable" in self._mixed_error:
-                rep["mixed_unavailable"] = self._mixed_error["unavailable"]
-            elif self._mixed_error:
-                rep["mixed_logits_err_rel"] = self._mixed_error.get("err_rel")
+            if explicit:
+                rep[self.precision[:-len("_verified")] + "_logits_err_rel"] = self.verified.calibration.get("err_rel")
+            for rung, err in self._rung_error.items():
+                if "unavailable" in err:
+                    rep[rung + "_unavailable"] = err["unavailable"]
+                else:
+                    rep[rung + "_logits_err_rel"] = err.get("err_rel")
         self.selection_report = rep
         if self.verified is None:
             logger.info("layout_dm_amd: engine '%s' (as requested) — %s", sel, rep["expected_throughput"])
@@ -277,17 +289,18 @@ class HipMaskAndReplaceDiffusion:
         err_s = fmt(err)
         if self.auto:
             why = ("inside" if sel == "fast_verified" else "OUTSIDE") + f" the {self.auto_tolerance:g} logits tolerance"
-            if "mixed_logits_err_rel" in rep:
-                why += (f"; the mixed engine's (fp16 weights, hi + lo activations) is {fmt(rep['mixed_logits_err_rel'])}, "
-                        + ("inside" if sel == "mixed_verified" else "OUTSIDE"))
-            elif "mixed_unavailable" in rep:
-                why += "; no mixed engine for this geometry"
+            for rung in self.RUNGS:
+                if rung + "_logits_err_rel" in rep:
+                    why += (f"; the {rung} engine's is {fmt(rep[rung + '_logits_err_rel'])}, " + ("inside" if sel == rung + "_verified" else "OUTSIDE"))
+                elif rung + "_unavailable" in rep:
+                    why += f"; no {rung} engine for this geometry"
             logger.info("layout_dm_amd: precision='auto' selected engine '%s': the fp16 engine's logits error on this checkpoint is %s "
                         "(relative, against the %s reference-precision engine), %s — expect %s", sel, err_s, self.verifier, why,
                         rep["expected_throughput"])
-        elif self.precision == "mixed_verified":
-            logger.info("layout_dm_amd: engine 'mixed_verified' (as requested); its logits error on this checkpoint %s (relative, against the "
-                        "%s engine) — expect %s", fmt(rep.get("mixed_logits_err_rel")), self.verifier, rep["expected_throughput"])
+        elif self.precision in ("mixed_verified", "hybrid_verified"):
+            logger.info("layout_dm_amd: engine '%s' (as requested); its logits error on this checkpoint %s (relative, against the "
+                        "%s engine) — expect %s", self.precision, fmt(rep.get(self.precision[:-len("_verified")] + "_logits_err_rel")), self.verifier,
+                        rep["expected_throughput"])
         else:
             logger.info("layout_dm_amd: engine '%s' (as requested); fp16 logits error on this checkpoint %s (relative, against the %s "
                         "engine) — expect %s", sel, err_s, self.verifier, rep["expected_throughput"])

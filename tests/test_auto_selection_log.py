@@ -20,6 +20,7 @@ class FakeEngine:
     engines whose precision is 'fast'."""
     fast_noise = 0.0
     mixed_noise = 0.0
+    hybrid_noise = 1.0            # (far outside unless a test sets it)
     mixed_available = True
     built = []
 
@@ -31,7 +32,7 @@ class FakeEngine:
         self.pad_id, self.mask_id = self.C - 2, self.C - 1
         self.max_batch, self.batch_round, self.precision = max_batch, 256, precision
         self.device = torch.device("cpu")
-        if precision == "mixed" and not FakeEngine.mixed_available:
+        if precision in ("mixed", "hybrid") and not FakeEngine.mixed_available:
             raise RuntimeError("ldm_create: precision mixed: only the reference backbone's geometry ...")
         FakeEngine.built.append((precision, max_batch))
 
@@ -46,7 +47,7 @@ class FakeEngine:
         assert tokens.shape[0] <= self.max_batch, f"batch {tokens.shape[0]} outside [1, max_batch = {self.max_batch}]"
         g = torch.Generator().manual_seed(int(tokens.long().sum()) * 131 + int(t))
         base = torch.randn(tokens.shape[0], self.S, self.C, generator=g)
-        noise = {"fast": FakeEngine.fast_noise, "mixed": FakeEngine.mixed_noise}.get(self.precision, 0.0)
+        noise = {"fast": FakeEngine.fast_noise, "mixed": FakeEngine.mixed_noise, "hybrid": FakeEngine.hybrid_noise}.get(self.precision, 0.0)
         if noise:
             base = base + noise * base.abs().max() * torch.sign(torch.randn(base.shape, generator=g))
         return base
@@ -74,18 +75,19 @@ def fake(monkeypatch):
 
     monkeypatch.setattr(V, "Engine", FakeEngine, raising=False)
     FakeEngine.built = []
-    FakeEngine.fast_noise, FakeEngine.mixed_noise, FakeEngine.mixed_available = 0.0, 5e-3, True
+    FakeEngine.fast_noise, FakeEngine.mixed_noise, FakeEngine.hybrid_noise, FakeEngine.mixed_available = 0.0, 5e-3, 6e-3, True
     return FakeEngine
 
 
-@pytest.mark.parametrize("noise,mixed,want", [(1e-4, 5e-3, "fast_verified"), (5e-3, 4e-3, "split"), (5e-3, 2e-4, "mixed_verified"),
-                                              (5e-3, None, "split")])
-def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noise, mixed, want):
-    """The ladder: fp16 engine inside the tolerance -> fast_verified (no mixed engine is even built); else the mixed engine (hi + lo
-    activations x fp16 weights) is built and measured -> mixed_verified if inside; else — or where the library has no mixed kernels for
-    the geometry — the reference-precision engine."""
+@pytest.mark.parametrize("noise,hybrid,mixed,want", [(1e-4, 6e-3, 5e-3, "fast_verified"), (5e-3, 6e-3, 4e-3, "split"), (5e-3, 6e-3, 2e-4, "mixed_verified"),
+                                                     (5e-3, 4e-4, 2e-4, "hybrid_verified"), (5e-3, None, None, "split")])
+def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noise, hybrid, mixed, want):
+    """The ladder: fp16 engine inside the tolerance -> fast_verified (no other engine is even built); else the hybrid engine (attention path
+    hi + lo activations x fp16 weights, FFN / head plain fp16) is built and measured -> hybrid_verified if inside; else the mixed engine
+    (hi + lo activations x fp16 weights everywhere) -> mixed_verified; else — or where the library has no such kernels for the geometry —
+    the reference-precision engine."""
     fake.fast_noise = noise
-    fake.mixed_noise, fake.mixed_available = (mixed or 0.0), mixed is not None
+    fake.mixed_noise, fake.hybrid_noise, fake.mixed_available = (mixed or 0.0), (hybrid or 0.0), mixed is not None
     m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="auto", max_batch=8)
     with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
         m.load_state_dict({})
@@ -101,14 +103,19 @@ def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noi
     assert f"{rep['fast_logits_err_rel']:.2e}" in msg
     built = [p for p, _ in FakeEngine.built]
     if want == "fast_verified":
-        assert "mixed" not in built and "mixed_logits_err_rel" not in rep
+        assert "mixed" not in built and "hybrid" not in built and "mixed_logits_err_rel" not in rep and "hybrid_logits_err_rel" not in rep
     elif mixed is None:
-        assert "mixed_unavailable" in rep and "no mixed engine" in msg
+        assert "mixed_unavailable" in rep and "hybrid_unavailable" in rep and "no mixed engine" in msg and "no hybrid engine" in msg
     else:
-        assert built.count("mixed") == 1 and abs(rep["mixed_logits_err_rel"] - mixed) < 0.2 * mixed
-        assert f"{rep['mixed_logits_err_rel']:.2e}" in msg and "mixed engine" in msg
-        assert (m.engine.precision == "mixed") == (want == "mixed_verified")
-        assert (m.verified.fast is m.engine) == (want == "mixed_verified")
+        assert built.count("hybrid") == 1 and abs(rep["hybrid_logits_err_rel"] - hybrid) < 0.2 * hybrid and "hybrid engine" in msg
+        if want == "hybrid_verified":
+            assert "mixed" not in built and "mixed_logits_err_rel" not in rep           # the ladder stops at the first rung that holds
+        else:
+            assert built.count("mixed") == 1 and abs(rep["mixed_logits_err_rel"] - mixed) < 0.2 * mixed
+            assert f"{rep['mixed_logits_err_rel']:.2e}" in msg and "mixed engine" in msg
+        rung = want[:-len("_verified")] if want.endswith("_verified") else None
+        assert (m.engine.precision == rung) == (rung is not None)
+        assert (m.verified.fast is m.engine) == (rung is not None)
     json.dumps(rep, default=str)                                       # (check_checkpoint prints it)
     # a second checkpoint on the same object starts from the fp16 engine again
     fake.fast_noise = 1e-4
@@ -117,15 +124,16 @@ def test_auto_logs_engine_error_tolerance_and_throughput_class(fake, caplog, noi
     m.close()
 
 
-def test_mixed_verified_as_requested(fake, caplog):
-    fake.mixed_noise = 3e-4
-    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision="mixed_verified", max_batch=8)
+@pytest.mark.parametrize("rung", ["mixed", "hybrid"])
+def test_rung_verified_as_requested(fake, caplog, rung):
+    fake.mixed_noise = fake.hybrid_noise = 3e-4
+    m = D.HipMaskAndReplaceDiffusion(n_category=25, precision=rung + "_verified", max_batch=8)
     with caplog.at_level(logging.INFO, logger="layout_dm_amd"):
         m.load_state_dict({})
     msgs = [r.getMessage() for r in caplog.records if r.name == "layout_dm_amd"]
-    assert len(msgs) == 1 and "'mixed_verified'" in msgs[0] and "as requested" in msgs[0]
-    assert m.engine.precision == "mixed" and m.verified.fast is m.engine and m.verified.exact.precision == "split"
-    assert abs(m.selection_report["mixed_logits_err_rel"] - 3e-4) < 1e-4 and abs(m.calibration["err_rel"] - 3e-4) < 1e-4
+    assert len(msgs) == 1 and f"'{rung}_verified'" in msgs[0] and "as requested" in msgs[0]
+    assert m.engine.precision == rung and m.verified.fast is m.engine and m.verified.exact.precision == "split"
+    assert abs(m.selection_report[rung + "_logits_err_rel"] - 3e-4) < 1e-4 and abs(m.calibration["err_rel"] - 3e-4) < 1e-4
 
 
 def test_explicit_precision_is_logged_too(fake, caplog):

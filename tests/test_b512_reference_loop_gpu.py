@@ -25,7 +25,7 @@ MARGIN = 1e-4
 MAX_DIFFERING_LAYOUTS = 5        # of 512 (expected: 0 - 2, all with a margin ~1e-5 or below)
 
 
-@pytest.mark.parametrize("precision", ["exact", "split", "fast_verified", "mixed_verified"])
+@pytest.mark.parametrize("precision", ["exact", "split", "fast_verified", "mixed_verified", "hybrid_verified"])
 def test_reference_full_loops_at_batch_512(precision):
     from layout_dm_amd.diffusion import HipMaskAndReplaceDiffusion, timestep_schedule
 

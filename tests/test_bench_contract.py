@@ -63,7 +63,7 @@ def test_bench_line_contract(d):
         assert d["reference_precision_layouts_per_s"] == d["modes"]["split"]["value"] == d["config"]["reference_precision_layouts_per_s"]
         assert d["fp32_mfma_layouts_per_s"] == d["modes"]["exact"]["value"]
         for point in ("mid", "wide"):
-            assert d["config"][f"auto_selected_{point}"] in ("fast_verified", "split", "exact")
+            assert d["config"][f"auto_selected_{point}"] in ("fast_verified", "hybrid_verified", "mixed_verified", "split", "exact")
             assert d["config"][f"auto_layouts_per_s_{point}"] == d["weight_sensitivity"][point]["value"]
             assert d["weight_sensitivity"][point]["fast_engine_err_rel_measured_at_load"] > d["weight_sensitivity"][point]["tolerance"] \
                 or d["config"][f"auto_selected_{point}"] == "fast_verified"

@@ -116,7 +116,7 @@ def test_no_gpu_fails_loudly(lib_path):
     ("d_model", 460, b"multiples of 16"),
     ("n_head", 5, b"divisible by n_head"),
     ("n_head", 4, b"head_dim > 64"),
-    ("precision", 4, b"precision"),
+    ("precision", 5, b"precision"),
     ("max_batch", 0, b"max_batch"),
     ("max_elem", 26, b"at most 128 tokens"),       # fast mode: one 128 x 128 score tile per (layout, head)
     ("n_layer", 0, b">= 1"),

@@ -122,7 +122,9 @@ def test_fitted_checkpoint_on_the_gpu(cuda):
     # (r06: between the fp16 engine and the split engine auto tries the mixed engine — hi + lo activations x fp16 weights: tests/test_mixed_gpu.py)
     mixed = m.selection_report.get("mixed_logits_err_rel")
     print(f"[fitted/auto] mixed engine measured at load: {mixed}")
-    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "mixed_verified" if mixed is not None and mixed <= 1e-3 else "split")
+    hybrid = m.selection_report.get("hybrid_logits_err_rel")
+    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "hybrid_verified" if hybrid is not None and hybrid <= 1e-3
+                                    else "mixed_verified" if mixed is not None and mixed <= 1e-3 else "split")
     dflt = 0.0
     for t in g["ts"]:
         t = int(t)

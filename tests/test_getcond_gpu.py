@@ -97,7 +97,7 @@ def models(cuda):
 def test_default_precision_is_auto_and_safe(models):
     spec, ms = models
     inner = ms["default"].model.module
-    assert inner.precision == "auto" and inner.selected_precision in ("fast_verified", "mixed_verified", "split", "exact")
+    assert inner.precision == "auto" and inner.selected_precision in ("fast_verified", "hybrid_verified", "mixed_verified", "split", "exact")
     cal = inner.calibration
     # whichever engine auto kept, what it runs is inside the north star's tolerance on this checkpoint
     assert cal["finite"] and (inner.selected_precision != "fast_verified" or cal["err_rel"] <= 1e-3)

@@ -193,34 +193,37 @@ def test_lngemm_kernel_no_scratch_and_mfma_hazards(tmp_path):
     destination registers of an inline-asm MFMA must sit at least one whole MFMA (8 passes = 32 cycles) of wait states behind it."""
     asm = _compile("kernels_lngemm.hip", tmp_path)
     # the product instantiations (TM = false, ABL = 0: template arguments 3 and 4 mangle as Lb0ELi0; the phase-timer and measurement builds are dev only)
-    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and re.search(r"ELb0ELi0ELb[01]ELb[01]EEEvNS_10LnGemmArgsE$", k)}
-    # (ADA, OUT) in {(1, 0), (0, 1), (0, 0), (1, 2)} x {plain, with the GEMM prologue} x {three products, two (W2: weights fp16 only)};
-    # OUT = 2 (r06): in_proj writing hi / lo q / k / v panels
-    assert len(kernels) == 16, list(_kernels(asm))
+    NAME = re.compile(r"ELb0ELi0ELb([01])ELi([123])ELi([123])EEEvNS_10LnGemmArgsE$")   # ... PRE, NPM, NPP> (products per k16-step: tile loop, GEMM prologue)
+    kernels = {k: v for k, v in _kernels(asm).items() if "lngemm16x3_k" in k and NAME.search(k)}
+    # (ADA, OUT) in {(1, 0), (0, 1), (0, 0), (1, 2)} x {plain, with the GEMM prologue} x {three products (split), two (mixed: weights fp16 only)};
+    # OUT = 2 (r06): in_proj writing hi / lo q / k / v panels; + the hybrid mode's three: linear2 in plain fp16 in front of the two-product in_proj,
+    # linear1 in plain fp16 writing plain-fp16 panels (OUT = 3), linear2 + head in plain fp16
+    assert len(kernels) == 19, list(_kernels(asm))
     sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
     for name, instr in kernels.items():
         assert int(sizes[name]) == 0 and not [i for i in instr if i.startswith("scratch_")], name
         mf = [i for i, t in enumerate(instr) if t.startswith("asm:v_mfma")]
-        pre = bool(re.search(r"ELb1ELb[01]EEEvNS_10LnGemmArgsE$", name))
-        per = 2 if name.endswith("ELb1EEEvNS_10LnGemmArgsE") else 3   # products per k16-step
-        # tile body: 29 k16-steps x 3 (2) products; the GEMM prologue adds three stage bodies (one per A register set) of 30 items x 3 (2)
-        assert len(mf) == per * (29 + (90 if pre else 0)), (name, len(mf))
+        m = NAME.search(name)
+        pre, per, ppre = m.group(1) == "1", int(m.group(2)), int(m.group(3))   # products per k16-step: tile loop / GEMM prologue
+        # tile body: 29 k16-steps x per products; the GEMM prologue adds three stage bodies (one per A register set) of 30 items x ppre
+        assert len(mf) == per * 29 + (ppre * 90 if pre else 0), (name, len(mf))
         if pre:
             # the matrix pipe runs its queue in order: the last stage's final MFMAs are still in flight when the stage loop falls through, and
             # hipcc (which cannot see asm MFMAs) puts its v_accvgpr_reads of the accumulator tiles right there — the wait states must sit inside
             # the asm statement of the stage's last item, in ALL THREE stage bodies (r05 call 24: logits error 3e-2 without them)
             # the stage barrier's COUNTED wait (vmcnt(4)) is only right if the four youngest vector-memory operations in front of it are the
             # A loads of stage + 2 — plain loads hipcc schedules — and everything older is a DMA piece: nothing else may sit between them
-            waits = [i for i, t in enumerate(instr) if t == "asm:s_waitcnt vmcnt(4)"]
+            n_a = 2 if ppre == 1 else 4      # A loads per stage: hi + lo rows of two k16-steps, or (one product: plain fp16) hi only
+            waits = [i for i, t in enumerate(instr) if t == f"asm:s_waitcnt vmcnt({n_a})"]
             assert len(waits) == 3, (name, len(waits))
             for w in waits:
                 vm = [t for t in instr[max(0, w - 400):w] if t.split()[0].replace("asm:", "") in
                       ("global_load_dwordx4", "global_load_lds_dwordx4", "global_load_dwordx2", "global_load_dword", "global_store_dwordx4",
                        "global_store_dwordx2", "global_store_dword", "scratch_load_dword", "scratch_store_dword", "scratch_load_dwordx4",
                        "scratch_store_dwordx4")]
-                assert [t.split()[0] for t in vm[-4:]] == ["global_load_dwordx4"] * 4, (name, vm[-6:])
-                assert vm[-5].startswith("asm:global_load_lds_dwordx4"), (name, vm[-6:])
-            for last in (mf[30 * per - 1], mf[60 * per - 1], mf[90 * per - 1]):
+                assert [t.split()[0] for t in vm[-n_a:]] == ["global_load_dwordx4"] * n_a, (name, vm[-6:])
+                assert vm[-n_a - 1].startswith("asm:global_load_lds_dwordx4"), (name, vm[-6:])
+            for last in (mf[30 * ppre - 1], mf[60 * ppre - 1], mf[90 * ppre - 1]):
                 tail = instr[last + 1:last + 8]
                 assert tail.count("asm:s_nop 15") == 2, (name, tail)
                 assert not any(t.startswith("v_accvgpr_read") for t in tail), (name, tail)

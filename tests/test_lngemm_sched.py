@@ -57,8 +57,8 @@ def test_schedule_replay_gemm_prologue():
                    "if constexpr (!W2) lg_dsr<t * 2048 + LG_LO>(s.ql[IT % LP_PF], s.aS[sx]);",
                    "if constexpr (IT == LP_SYNC - 1) {", "if constexpr (hasD && J == 0) lp_dma_begin(s, stage + 2);",
                    "if (IT > LP_SYNC) return IT - LP_SYNC - 1;", "if (IT + (LP_NIT - 1 - LP_SYNC) < 16) return IT + (LP_NIT - 1 - LP_SYNC);",
-                   "if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3>(s, stage + 2);",
-                   "asm volatile(\"s_waitcnt vmcnt(%0)\" ::\"n\"(LP_A_LOADS) : \"memory\");",
+                   "if constexpr (IT == LP_A_STEP) lp_load_a<(SET + 2) % 3, NP == 1>(s, stage + 2);",
+                   "asm volatile(\"s_waitcnt vmcnt(%0)\" ::\"n\"(NP == 1 ? LP_A_LOADS / 2 : LP_A_LOADS) : \"memory\");",
                    "if constexpr (IT == LP_NIT - 1) LP_STEP_ASM(LG_A_M0, LG_A_PIECE, LG_A_RDH, LG_A_RDL \"\\n\\t\", \"s_nop 15\\n\\ts_nop 15\");"):
         assert needle in src, needle
     SYNC = NIT - PF

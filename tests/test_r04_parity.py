@@ -211,9 +211,11 @@ def test_trained_like_logits_fast_mode_and_auto_selection(cuda, golden_dir, poin
     assert 0.4 * worst <= cal["err_rel"] <= 2.5 * worst, (worst, cal)
     # (r06: the mixed engine — hi + lo activations x fp16 weights — is auto's rung between the two: tests/test_mixed_gpu.py)
     mixed = m.selection_report.get("mixed_logits_err_rel")
-    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "mixed_verified" if mixed is not None and mixed <= 1e-3 else "split")
-    if m.selected_precision == "mixed_verified":
-        assert m.engine.describe()["precision"] == "mixed_f16" and m.verified.exact.describe()["precision"] == "split_f16"
+    hybrid = m.selection_report.get("hybrid_logits_err_rel")
+    assert m.selected_precision == ("fast_verified" if cal["err_rel"] <= 1e-3 else "hybrid_verified" if hybrid is not None and hybrid <= 1e-3
+                                    else "mixed_verified" if mixed is not None and mixed <= 1e-3 else "split")
+    if m.selected_precision in ("mixed_verified", "hybrid_verified"):
+        assert m.engine.describe()["precision"] == m.selected_precision[:-len("_verified")] + "_f16" and m.verified.exact.describe()["precision"] == "split_f16"
     if point == "wide":
         assert m.selected_precision == "split" and m.engine is m.verified.exact   # (the reference-precision engine: split)
         out = m.sample(batch_size=2, sampling_cfg={"name": "deterministic", "num_timesteps": 5})

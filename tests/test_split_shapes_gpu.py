@@ -71,7 +71,7 @@ sd = synth.synth_state_dict(spec, seed=0, perturb=True)
 g = torch.Generator().manual_seed(5)
 tokens = torch.randint(0, spec.n_class, (5, spec.seq_len), generator=g)
 ref = R.denoiser_logits(R.as_torch_weights(sd), spec, tokens, 33)
-for prec, tol in (("split", 2e-5), ("mixed", 1e-3)):
+for prec, tol in (("split", 2e-5), ("mixed", 1e-3), ("hybrid", 1e-3)):
     e = Engine(n_category=spec.n_category, max_elem=spec.max_elem, precision=prec, max_batch=8)
     e.load_state_dict(sd)
     out = e.denoise_logits(tokens.int(), 33).cpu()[..., :spec.n_class]
@@ -80,4 +80,4 @@ for prec, tol in (("split", 2e-5), ("mixed", 1e-3)):
     print("OK", prec, err, flush=True)
 '''
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert p.returncode == 0 and p.stdout.count("OK ") == 2, p.stdout[-2000:]
+    assert p.returncode == 0 and p.stdout.count("OK ") == 3, p.stdout[-2000:]

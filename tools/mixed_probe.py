@@ -17,7 +17,7 @@ from layout_dm_amd.binding import Engine  # noqa: E402
 from layout_dm_amd.diffusion import timestep_schedule  # noqa: E402
 from oracle import restatement as R, spec as SP, synth  # noqa: E402
 
-PREC = os.environ.get("PROBE_PREC", "mixed")
+PREC = os.environ.get("PROBE_PREC", "mixed")   # split | mixed | hybrid
 tag = PREC
 spec = SP.RICO25
 g = torch.Generator().manual_seed(0)

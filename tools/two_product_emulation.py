@@ -1,7 +1,14 @@
-"""Dev tool (CPU): would a TWO-product format (hi + lo fp16 activations x fp16-only weights, or the other way round) stay inside the 1e-3 logits
-tolerance on the FITTED checkpoint (oracle/_fit/rico25_fitted.npz) and on the synthetic mid / wide points?  Logits error against the float64
-restatement, per operand format, on the fixture's own states.  (tools/one_launch_x3_emulation.py asked the same of the one-launch kernel's formats.)
-A per-step engine with two MFMAs per weight product would cost 0.71 of the split mode's MFMA work."""
+"""Dev tool (CPU): which operands of the denoiser need their fp16 lo half?  Logits error against the float64 restatement, per operand format, on
+the FITTED checkpoint (oracle/_fit/rico25_fitted.npz: the states of its fixture) and on the synthetic init / mid / wide points.  Each of the 14
+operand sites of a block (+ head) is rounded either to fp16 (h) or to hi + lo fp16 (h2 ~ fp32); products accumulate in fp32 like the MFMA.
+
+    python tools/two_product_emulation.py            the engines' formats        python tools/two_product_emulation.py sites      one site at a time
+
+What it predicted and the GPU then measured to three digits (profiles/r06_mixed_mode.txt, profiles/r06_hybrid_mode.txt):
+  mixed  = every WEIGHT fp16, every activation hi + lo            (LDM_PREC_MIXED_F16:  2 passes per weight product)
+  hybrid = mixed + the FFN and the head in plain fp16             (LDM_PREC_HYBRID_F16: LayerNorm-2 / head-LayerNorm output and the hidden activations
+           rounded once; the attention path — AdaLN output, q, k, v, P, attention output — keeps hi + lo: that is where the fp16 error lives)
+(tools/one_launch_x3_emulation.py asked the same of the one-launch kernel's formats in r05.)"""
 import math
 import os
 import sys
@@ -9,11 +16,16 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from oracle import restatement as R, spec as SP, synth  # noqa: E402
 
 torch.set_num_threads(8)
 spec = SP.RICO25
+SITES = ["ln1", "Win", "q", "k", "v", "P", "ao", "Wo", "ln2", "W1", "hid", "W2", "hln", "Wh"]
+WEIGHTS = ["Win", "Wo", "W1", "W2", "Wh"]
+FORMATS = [("fp16 everywhere (fast)", SITES), ("hybrid: weights + ln2, hid, hln fp16", WEIGHTS + ["ln2", "hid", "hln"]),
+           ("mixed: weights fp16", WEIGHTS), ("activations fp16, weights hi + lo", [s for s in SITES if s not in WEIGHTS]), ("hi + lo everywhere (split)", [])]
 
 
 def h(x):
@@ -25,10 +37,7 @@ def h2(x):
     return hi + (x - hi).half().float()
 
 
-def fwd(W, tokens, t, fa, fw, fa_attn=None):
-    """fa: rounding of the activation operand of the four WEIGHT GEMMs and the head; fa_attn: of q, k, v, P (activation x activation products);
-    fw: rounding of the weights."""
-    fa_attn = fa_attn or fa
+def fwd(W, tokens, t, f):
     D, H, dh = spec.d_model, spec.n_head, spec.d_head
     B, S = tokens.shape
     g = lambda k: W[k]  # noqa: E731
@@ -42,50 +51,52 @@ def fwd(W, tokens, t, fa, fw, fa_attn=None):
         e = e * torch.sigmoid(e)
         ss = g(b + "norm1.linear.weight") @ e + g(b + "norm1.linear.bias")
         x = R._ln(x) * (1 + ss[:D]) + ss[D:]
-        qkv = fa(x) @ fw(g(b + "self_attn.in_proj_weight")).T + g(b + "self_attn.in_proj_bias")
-        q, k, v = (fa_attn(z).view(B, S, H, dh).transpose(1, 2) for z in (qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]))
+        qkv = f["ln1"](x) @ f["Win"](g(b + "self_attn.in_proj_weight")).T + g(b + "self_attn.in_proj_bias")
+        q, k, v = (f[n](z).view(B, S, H, dh).transpose(1, 2) for n, z in (("q", qkv[..., :D]), ("k", qkv[..., D:2 * D]), ("v", qkv[..., 2 * D:])))
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
-        a = (fa_attn(att) @ v).transpose(1, 2).reshape(B, S, D)
-        x = x + fa(a) @ fw(g(b + "self_attn.out_proj.weight")).T + g(b + "self_attn.out_proj.bias")
+        a = (f["P"](att) @ v).transpose(1, 2).reshape(B, S, D)
+        x = x + f["ao"](a) @ f["Wo"](g(b + "self_attn.out_proj.weight")).T + g(b + "self_attn.out_proj.bias")
         hh = R._ln(x) * g(b + "norm2.weight") + g(b + "norm2.bias")
-        hh = torch.relu(fa(hh) @ fw(g(b + "linear1.weight")).T + g(b + "linear1.bias"))
-        x = x + fa(hh) @ fw(g(b + "linear2.weight")).T + g(b + "linear2.bias")
+        hh = torch.relu(f["ln2"](hh) @ f["W1"](g(b + "linear1.weight")).T + g(b + "linear1.bias"))
+        x = x + f["hid"](hh) @ f["W2"](g(b + "linear2.weight")).T + g(b + "linear2.bias")
     y = R._ln(x) * g(tr + "head.0.weight") + g(tr + "head.0.bias")
-    return fa(y) @ fw(g(tr + "head.1.weight")).T
+    return f["hln"](y) @ f["Wh"](g(tr + "head.1.weight")).T
 
 
-def run(name, sd, states):
+def run(name, sd, states, formats):
     W, W64 = R.as_torch_weights(sd), R.as_torch_weights(sd, torch.float64)
-    res = {}
-    for tokens, t in states:
-        ref = R.denoiser_logits(W64, spec, tokens, t, dtype=torch.float64)
-        mx = ref.abs().max().item()
-        for label, fa, fw, faa in (("fp16 x fp16 (fast)", h, h, h), ("hi+lo act x fp16 w, attention hi+lo", h2, h, h2),
-                                   ("fp16 act x hi+lo w, attention hi+lo", h, h2, h2), ("hi+lo x hi+lo (split)", h2, h2, h2)):
-            err = ((fwd(W, tokens, t, fa, fw, faa).double() - ref).abs().max() / mx).item()
-            res.setdefault(label, []).append(err)
+    refs = [R.denoiser_logits(W64, spec, tk, t, dtype=torch.float64) for tk, t in states]
     print(f"[{name}]")
-    for label, v in res.items():
-        print(f"   {label:40s} " + "  ".join(f"{e:.2e}" for e in v) + f"   max {max(v):.2e}")
+    for label, fp16_sites in formats:
+        f = {s: (h if s in fp16_sites else h2) for s in SITES}
+        e = [((fwd(W, tk, t, f).double() - ref).abs().max() / ref.abs().max()).item() for (tk, t), ref in zip(states, refs)]
+        print(f"   {label:44s} " + " ".join(f"{x:.2e}" for x in e) + f"   max {max(e):.2e}")
+
+
+def synthetic_states(g, n=4):
+    out = []
+    for t in (50, 90, 5):
+        tokens = torch.empty(n, spec.seq_len, dtype=torch.long)
+        for a in range(spec.n_attr):
+            ids = torch.as_tensor(spec.full_ids(a))
+            tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (n, spec.max_elem), generator=g)]
+        tokens[torch.rand(n, spec.seq_len, generator=g) < t / 99] = spec.mask_id
+        out.append((tokens, t))
+    return out
 
 
 if __name__ == "__main__":
+    formats = FORMATS
+    if len(sys.argv) > 1 and sys.argv[1] == "sites":
+        formats = [("fp16 everywhere (fast)", SITES)] + [(f"hi + lo everywhere except {s}", [s]) for s in SITES]
     g = torch.Generator().manual_seed(0)
-    fit = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_fit", "rico25_fitted.npz")
+    fit = os.path.join(ROOT, "oracle", "_fit", "rico25_fitted.npz")
     if os.path.exists(fit):
         w = np.load(fit)
-        gold = np.load(os.path.join(os.path.dirname(fit), "..", "..", "tests", "golden", "rico25_fitted.npz"))
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "rico25_fitted.npz"))
         states = [(torch.from_numpy(gold[f"tokens_{int(t)}"].astype(np.int64)), int(t)) for t in gold["ts"]]
         states += [(torch.from_numpy(gold["states_before"][i].astype(np.int64)), int(gold["steps"][i])) for i in (20, 60, 95, 99)]
-        run("fitted checkpoint, states of its fixture (t = 90, 50, 5; trajectory states 20, 60, 95, 99)", {k: w[k] for k in w.files}, states)
+        run("fitted checkpoint, states of its fixture (t = 90, 50, 5; trajectory states 20, 60, 95, 99)", {k: w[k] for k in w.files}, states, formats)
+    run("init (the reference's own initialisation)", synth.synth_state_dict(spec, seed=0), synthetic_states(g), formats)
     for point in ("mid", "wide"):
-        sd = synth.trained_like_state_dict(spec, point, seed=3)
-        states = []
-        for t in (50, 90, 5):
-            tokens = torch.empty(4, spec.seq_len, dtype=torch.long)
-            for a in range(spec.n_attr):
-                ids = torch.as_tensor(spec.full_ids(a))
-                tokens[:, a::spec.n_attr] = ids[torch.randint(0, len(ids) - 1, (4, spec.max_elem), generator=g)]
-            tokens[torch.rand(4, spec.seq_len, generator=g) < t / 99] = spec.mask_id
-            states.append((tokens, t))
-        run(f"trained-like '{point}'", sd, states)
+        run(f"trained-like '{point}'", synth.trained_like_state_dict(spec, point, seed=3), synthetic_states(g), formats)
