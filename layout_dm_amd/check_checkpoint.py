@@ -3,11 +3,11 @@
 What engine will a checkpoint get, and why — without sampling anything.  Loads `<job_dir>/config.yaml` +
 `best_model.pt` (or the multi-seed layout `<job_dir>/0/ ...`) exactly as the entry point does (layout_dm_amd/test_entry.py, the
 reference's trainer/test.py:64-89), builds the drop-in `LayoutDM` with `precision="auto"` (its default), lets `load_state_dict`
-measure the fp16 engine (and, where that one is outside the tolerance, the mixed engine) against the reference-precision engine on the
-checkpoint, and prints ONE JSON object per checkpoint:
+measure the fp16 engine (and, where that one is outside the tolerance, the hybrid and then the mixed engine) against the reference-precision
+engine on the checkpoint, and prints ONE JSON object per checkpoint:
 
-    {"checkpoint": ".../best_model.pt", "engine_selected": "mixed_verified", "fast_logits_err_rel": 2.6e-3, "mixed_logits_err_rel": 5.9e-4,
-     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~1 500 layouts/s ...", "library": {...}}
+    {"checkpoint": ".../best_model.pt", "engine_selected": "hybrid_verified", "fast_logits_err_rel": 2.6e-3, "hybrid_logits_err_rel": 7.3e-4,
+     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~1 900 layouts/s ...", "library": {...}}
 
 The same record goes to the `layout_dm_amd` logger at INFO when a job loads the checkpoint.  Needs the MI355X (the measurement
 IS a handful of denoiser passes on it); a few seconds.

@@ -148,8 +148,9 @@ class LayoutDM:
                  **kwargs) -> None:
         # precision (not a reference argument): "auto" (default, r05) = the fp16 engine is measured against the
         # reference-precision engine on the loaded checkpoint and kept — with verified greedy decoding — only inside the
-        # north star's 1e-3 logits tolerance, else the mixed engine (hi + lo activations x fp16 weights) under the same test, else the
-        # reference-precision engine; "fast" / "fast_verified" / "mixed" / "mixed_verified" / "split" / "exact" pick an engine unconditionally
+        # north star's 1e-3 logits tolerance, else the hybrid engine (mixed with the FFN / head in plain fp16), else the mixed engine (hi + lo
+        # activations x fp16 weights) under the same test, else the reference-precision engine; "fast" / "fast_verified" / "hybrid" /
+        # "hybrid_verified" / "mixed" / "mixed_verified" / "split" / "exact" pick an engine unconditionally
         if q_type not in ("constrained", "vanilla"):  # Q_TYPES, layoutdm.py:20-23
             raise NotImplementedError(f"q_type={q_type}: constrained (LayoutDM default, experiment/layoutdm.yaml:18) "
                                       "or vanilla")
