@@ -13,7 +13,7 @@
 #   sq [tag] <precision> <steps>   SQ / LDS / GRBM counter passes (tools/pmc_sq.sh)              -> sq_counters_<precision>.txt
 #   ab [tag] "<ENV=..>" "<ENV=..>"  same-box A/B of knob settings, one process each (tools/kernel_ab.py; PROBE_PREC selects the mode) -> ab.txt
 #   probe [tag] <script.py> [args] any tools/*.py probe (attnout_probe.py, split_step_probe.py, lngemm_probe.py, ...)  -> <script>.log
-#   evidence [tag]                 the round's evidence run: smoke + suite + bench + stats (fast, exact, split, mixed) + relstats + sq (fast 100, exact 4, split 4, mixed 4)
+#   evidence [tag]                 the round's evidence run: smoke + suite + bench + stats (fast, exact, split, mixed, hybrid) + relstats + sq (fast 100, exact 4, split 4, mixed 4, hybrid 4)
 #                                  (LIGHT=1: smoke + suite + bench only)
 set -u
 RECIPE=${1:-evidence}; shift || true
@@ -60,6 +60,6 @@ case $RECIPE in
   ab)       timeout 1200 python tools/kernel_ab.py "$@" > $O/ab.txt 2>&1; cat $O/ab.txt ;;
   probe)    S=$1; shift; timeout 900 python tools/$S "$@" > $O/${S%.py}.log 2>&1; grep -v amdgpu.ids $O/${S%.py}.log | tail -40 ;;
   evidence) smoke; suite; bench
-            if [ "${LIGHT:-0}" != "1" ]; then stats fast; stats exact; stats split; stats mixed; relstats; sq fast 100; sq exact 4; sq split 4; sq mixed 4; fi ;;
+            if [ "${LIGHT:-0}" != "1" ]; then stats fast; stats exact; stats split; stats mixed; stats hybrid; relstats; sq fast 100; sq exact 4; sq split 4; sq mixed 4; sq hybrid 4; fi ;;
   *)        echo "unknown recipe $RECIPE"; exit 2 ;;
 esac
