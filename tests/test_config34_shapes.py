@@ -62,6 +62,7 @@ def _cut(cond, lo, hi):
 
 
 _STATE = {}
+ORACLE_ROWS = torch.cat([torch.arange(lo, lo + 128) for lo in range(0, 1024, 256)])   # the layouts the CPU oracle answers for
 
 
 def _exact_trajectory(name):
@@ -83,15 +84,17 @@ def _exact_trajectory(name):
     e.close()
     before = {i: (inter[i - 1] if i > 0 else init.cpu()) for i in TEACHER_STEPS}
     ref = {}
+    # the oracle answers for ORACLE_ROWS: 128 layouts from each of the launch's four 256-layout chunks (r06: the full 1024 cost the host 40 s per step
+    # and config; the GPU side is unchanged — the whole batch is stepped, the subset is what is compared)
     for i in TEACHER_STEPS:
-        halves = []
-        for lo in (0, 512):  # the reference's own batch cap
-            u = R.token_uniforms(21, 3000 + lo, 512, spec.seq_len, i)[..., 0]
-            c = _cut(cond, lo, lo + 512)
+        parts = []
+        for lo in range(0, B, 256):
+            u = R.token_uniforms(21, 3000 + lo, 128, spec.seq_len, i)[..., 0]
+            c = _cut(cond, lo, lo + 128)
             if c is not None:
                 c = {"seq": torch.from_numpy(c["seq"]), "mask": torch.from_numpy(c["mask"]), "type": c["type"]}
-            halves.append(R.single_step(W, spec, before[i][lo:lo + 512].long(), steps[i], case["cfg"], uniforms=u, cond=c))
-        ref[i] = torch.cat(halves).int()
+            parts.append(R.single_step(W, spec, before[i][lo:lo + 128].long(), steps[i], case["cfg"], uniforms=u, cond=c))
+        ref[i] = torch.cat(parts).int()
     _STATE[name] = dict(spec=spec, sd=sd, cond=cond, init=init.cpu(), steps=steps, final=final, inter=inter,
                         before=before, ref=ref)
     return _STATE[name]
@@ -109,9 +112,10 @@ def test_b1024_teacher_forced_steps_vs_oracle(name, precision):
     for i in TEACHER_STEPS:
         out = e.sample_step(st["before"][i], st["steps"][i], case["cfg"], cond=st["cond"], seed=21, first_layout=3000,
                             step=i).cpu()
-        frac = (out != st["ref"][i]).float().mean().item()
+        sub = out[ORACLE_ROWS]
+        frac = (sub != st["ref"][i]).float().mean().item()
         worst = max(worst, frac)
-        print(f"[{name}/{precision}] step {i} (t={st['steps'][i]}): {int((out != st['ref'][i]).sum())}/{out.numel()} "
+        print(f"[{name}/{precision}] step {i} (t={st['steps'][i]}): {int((sub != st['ref'][i]).sum())}/{sub.numel()} "
               f"draws differ from the oracle on identical uniforms")
         if precision == "exact":  # the loop that produced the states took this very step
             assert torch.equal(out, st["inter"][i])

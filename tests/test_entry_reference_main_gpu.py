@@ -90,8 +90,8 @@ def test_reference_main_on_the_gpu_equals_the_reference_model(job, cond, capsys,
     if not _REF_CLASS:
         _REF_CLASS.append(ref_layoutdm.LayoutDM if ref_layoutdm.LayoutDM is not LayoutDM else None)
     assert _REF_CLASS[0] is not None
-    # (num_timesteps=50: the reference's strided schedule, base.py:310-315 — halves the cost of the answer key, which runs on the host cores)
-    common = [f"cond={cond}", f"job_dir={job_dir}", "max_batch_size=4", "num_uncond_samples=6", "sampling=deterministic", "num_timesteps=50"]
+    # (num_timesteps=25: the reference's strided schedule, base.py:310-315 — a quarter of the cost of the answer key, which runs on the host cores)
+    common = [f"cond={cond}", f"job_dir={job_dir}", "max_batch_size=4", "num_uncond_samples=6", "sampling=deterministic", "num_timesteps=25"]
     # ---- the drop-in class + the HIP engine
     _run_main(common + [f"result_dir={tmp / 'ours'}"], True, monkeypatch)
     printed = capsys.readouterr().out
