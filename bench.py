@@ -444,8 +444,7 @@ SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true
 MIXED_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 2, 2>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>",
                        "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, 2, 2>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 2, 2>",
                        "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
-HYBRID_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 2, 1>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>",
-                        "gemm_ffn1_ln": "lngemm16x3_k<false, 3, false, 0, false, 1, 1>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 1, 1>",
+HYBRID_KERNEL_SYMBOL = {"gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>", "ffn_fused16": "ffn16_rows_k", "gemm_head_ln": "lngemm16x3_k<false, 0, false, 0, false, 1, 1>",
                         "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 
 

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libldm_hip.so")
-SOURCES = ["ldm_api.cpp", "ldm_weights.cpp", "ldm_denoise.cpp", "ldm_loop.cpp", "ldm_dev.cpp", "ldm_fid_api.cpp", "kernels_fid.hip", "kernels_prdc.hip", "kernels_metrics.hip", "kernels_norm.hip", "kernels_gemm.hip", "kernels_gemm16.hip", "kernels_lngemm.hip", "kernels_attn.hip",
+SOURCES = ["ldm_api.cpp", "ldm_weights.cpp", "ldm_denoise.cpp", "ldm_loop.cpp", "ldm_dev.cpp", "ldm_fid_api.cpp", "kernels_fid.hip", "kernels_prdc.hip", "kernels_metrics.hip", "kernels_norm.hip", "kernels_gemm.hip", "kernels_gemm16.hip", "kernels_lngemm.hip", "kernels_ffn16.hip", "kernels_attn.hip",
            "kernels_attn16.hip", "kernels_attnout.hip", "kernels_stack.hip", "kernels_post.hip", "kernels_decode.hip", "kernels_relation.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

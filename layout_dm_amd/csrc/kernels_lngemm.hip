@@ -907,6 +907,7 @@ int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st) {
   else if (npm == 2 && npp == 1 && pre && panel) kern = lngemm16x3_k<true, 2, false, 0, true, 2, 1>;
   else if (npm == 1 && !pre && hi_only) kern = lngemm16x3_k<false, 3, false, 0, false, 1, 1>;
   else if (npm == 1 && npp == 1 && pre && !half_out && !a.ada) kern = lngemm16x3_k<false, 0, false, 0, true, 1, 1>;
+  else if (npm == 1 && !pre && !half_out && !a.ada) kern = lngemm16x3_k<false, 0, false, 0, false, 1, 1>;   // the head alone (behind the fused fp16 FFN)
 #undef LG_PICK
   if (!kern) return -1;
   if (tm && !pre && !panel && !hi_only && npm == 3) kern = half_out ? lngemm16x3_k<false, 1, true> : a.ada ? lngemm16x3_k<true, 0, true> : lngemm16x3_k<false, 0, true>;

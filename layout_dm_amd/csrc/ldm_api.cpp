@@ -225,6 +225,7 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
     if (h->w2p) {
       h->np_w = 2;
       h->np_ffn = mixed == 2 ? 1 : 2;
+      h->ffn_fused = mixed == 2 && h->F % 32 == 0 && h->F <= 2048 && knob_int("LDM_HYB_FFN", 1) != 0;
     }
     if (mixed && !h->w2p) {
       h->err = "precision mixed / hybrid: only the reference backbone's geometry (d_model 464, 8 heads, <= 128 tokens per layout) has the two-product kernels; use precision split";

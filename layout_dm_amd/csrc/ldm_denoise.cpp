@@ -146,7 +146,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
         a.bias = w.b_in; a.N = 3 * D;
         a.C32 = h->qkv32; a.ldc32 = 3 * D;
       }
-      const bool pre = h->pre_ffn2 && i > 0;   // x = Q + hid · W2^T + b2 of the PREVIOUS layer, computed in this launch (never stored)
+      const bool pre = h->pre_ffn2 && !h->ffn_fused && i > 0;   // x = Q + hid · W2^T + b2 of the PREVIOUS layer, computed in this launch (never stored)
       if (pre) ffn2_prologue(h, h->layers[i - 1], a);
       ldm_handle::Scope sc(h, st, pre ? "gemm_ffn2_qkv_ln" : "gemm_qkv_ln", gemm_flops(M, 3 * D, D) + (pre ? gemm_flops(M, D, F) : 0.0),
                            (double)M * D * 8 + (double)M * 3 * D * 4 + (pre ? (double)M * F * 4 : 0.0));
@@ -218,7 +218,15 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       launch_gemm_mode(g, 1, st);
     }
     }
-    if (split && h->lngemm) {  // LayerNorm 2 + FFN1 + ReLU in ONE row-resident launch: hi / lo hidden activations out
+    if (split && h->ffn_fused) {   // hybrid: P = Q + b2 + W2 relu(W1 LN2(Q) + b1) in ONE plain-fp16 launch (kernels_ffn16.hip); the hidden activations stay on chip
+      FfnRowsArgs a{};
+      a.x = h->Q; a.out = h->P;
+      a.gamma = w.g2; a.beta = w.be2; a.b1 = w.b1; a.b2 = w.b2;
+      a.img = (const char*)w.ffn16_img;
+      a.M = M; a.D = D; a.F = F; a.n_chunks = F / 32;
+      ldm_handle::Scope sc(h, st, "ffn_fused16", gemm_flops(M, F, D) + gemm_flops(M, D, F), (double)M * D * 8);
+      if (launch_ffn16_rows(a, st)) return h->fail(-4, "fused fp16 FFN: geometry not supported");
+    } else if (split && h->lngemm) {  // LayerNorm 2 + FFN1 + ReLU in ONE row-resident launch: hi / lo hidden activations out
       LnGemmArgs a{};
       a.x = h->Q; a.ldx = D;
       a.p0 = w.g2; a.p1 = w.be2; a.ada = 0;
@@ -261,7 +269,7 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
         launch_gemm_mode(g, 2, st);
       }
     }
-    if (!(split && h->pre_ffn2)) {  // FFN2 + residual:  P = Q + hid·W2^T + b2   (level 2: the prologue of the next AdaLN + in_proj launch / of the head)
+    if (!(split && (h->pre_ffn2 || h->ffn_fused))) {  // FFN2 + residual:  P = Q + hid·W2^T + b2   (level 2: the prologue of the next AdaLN + in_proj launch / of the head)
       GemmArgs g{};
       g.A = f16 ? (const void*)h->hid16 : (const void*)h->hid32;
       g.Alo = h->hid16lo;
@@ -284,9 +292,10 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
     a.C32 = h->logits; a.ldc32 = h->Cp;
     a.np_main = h->np_ffn;
     a.M = M; a.N = h->Cp; a.D = D; a.S = h->S;   // (columns C .. Cp of the image are zero rows: exact zeros in the padding)
-    if (h->pre_ffn2) ffn2_prologue(h, h->layers[h->L - 1], a);
-    ldm_handle::Scope sc(h, st, h->pre_ffn2 ? "gemm_ffn2_head_ln" : "gemm_head_ln", gemm_flops(M, C, D) + (h->pre_ffn2 ? gemm_flops(M, D, F) : 0.0),
-                         (double)M * D * 4 + (double)M * C * 4 + (h->pre_ffn2 ? (double)M * F * 4 : 0.0));
+    const bool hp = h->pre_ffn2 && !h->ffn_fused;
+    if (hp) ffn2_prologue(h, h->layers[h->L - 1], a);
+    ldm_handle::Scope sc(h, st, hp ? "gemm_ffn2_head_ln" : "gemm_head_ln", gemm_flops(M, C, D) + (hp ? gemm_flops(M, D, F) : 0.0),
+                         (double)M * D * 4 + (double)M * C * 4 + (hp ? (double)M * F * 4 : 0.0));
     if (launch_lngemm16x3(a, st)) return h->fail(-4, "row-resident LayerNorm + GEMM: geometry not supported");
     return 0;
   }

@@ -78,6 +78,7 @@ struct LayerW {
   // r06, fused attention + out_proj (kernels_attnout.hip): in_proj with head-padded output columns (48 tiles, bias [1536]) and
   // out_proj as a k-step image (ldm_pack::pack_x3_kstep_image)
   void *x3_qkv_pad = nullptr, *x3_out_kstep = nullptr;
+  void* ffn16_img = nullptr;   // hybrid: the fused plain-fp16 FFN's chunk image (kernels_ffn16.hip; the fast mode's pack_ffn_image_pipelined)
   float* b_in_pad = nullptr;
 };
 
@@ -167,6 +168,9 @@ struct ldm_handle {
   // products per k16-step (kernels_lngemm.hip NPM / NPP): of the attention path's GEMMs (in_proj; out_proj: w2p) and of linear1 / linear2 / the head.
   // split 3 / 3, mixed 2 / 2, hybrid 2 / 1 (the FFN and the head in plain fp16: LayerNorm output, hidden activations and weights rounded once)
   int np_w = 3, np_ffn = 3;
+  // hybrid: linear1 + ReLU + linear2 + residual as ONE plain-fp16 launch per block (kernels_ffn16.hip) instead of linear1 -> plain-fp16 panels ->
+  // linear2 as the GEMM prologue of the next launch; LDM_DEV=1 LDM_HYB_FFN=0: the two-launch form
+  bool ffn_fused = false;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

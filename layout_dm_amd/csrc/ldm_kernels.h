@@ -118,6 +118,16 @@ struct LnGemmArgs {
   int np_main, np_pre;
 };
 int launch_lngemm16x3(const LnGemmArgs& a, hipStream_t st);
+// Fused plain-fp16 FFN on rows (kernels_ffn16.hip, the hybrid mode): out = x + b2 + W2 relu(W1 LN(x; gamma, beta) + b1); x / out fp32 [M, D] (may alias),
+// img = ldm_pack::pack_ffn_image_pipelined ((n_chunks + 1) x 64 KiB), D == 464, F == 32 n_chunks <= 2048.  -1: geometry not supported.
+struct FfnRowsArgs {
+  const float* x;
+  float* out;
+  const float *gamma, *beta, *b1, *b2;
+  const char* img;
+  int M, D, F, n_chunks;
+};
+int launch_ffn16_rows(const FfnRowsArgs& a, hipStream_t st);
 void lngemm_phase_read(unsigned long long* out8);   // (LDM_LNGEMM_TM=1: accumulated phase cycles, reset on read)
 // fp16 LDS-DMA pipelined GEMM (kernels_gemm16.hip); cfg selects the tile configuration
 void launch_gemm16(const GemmArgs& g, int cfg, int tag, hipStream_t st);

@@ -408,6 +408,21 @@ extern "C" int ldm_finalize_weights(ldm_handle* h) {
       }
       if (h->pre_out && (rc = make_x3_slab(h, w.w_out16, w.w_out16lo, D, h->Dp, h->Dp, &w.x3_out_slab))) return rc;
       if (h->pre_ffn2 && (rc = make_x3_slab(h, w.w2_16, w.w2_16lo, D, h->Fp, h->Fp, &w.x3_ffn2_slab))) return rc;
+      if (h->ffn_fused) {   // hybrid: the FFN as ONE plain-fp16 launch (kernels_ffn16.hip) on the fast mode's chunk image — unscaled fp16 weights,
+                            // K axes in MFMA k-slot order, stage i = W1 tile i | W2 slab i - 1 (ldm_pack::pack_ffn_image_pipelined)
+        auto id = [](int x) { return x; };
+        auto kslot = [](int k) { return ldm_pack::kslot(k); };
+        const int Fq = round_up(F, 64);
+        __half *w1p = nullptr, *w2p = nullptr;
+        if ((rc = pack_w16(h, w.w1, F, D, round_up(F, 256), 512, id, kslot, &w1p))) return rc;
+        if ((rc = pack_w16(h, w.w2, D, F, round_up(D, 256), Fq, id, kslot, &w2p))) return rc;
+        const std::vector<uint16_t> h1p = download16(h, w1p, (size_t)F * 512, &rc);
+        if (rc) return rc;
+        const std::vector<uint16_t> h2 = download16(h, w2p, (size_t)round_up(D, 256) * Fq, &rc);
+        if (rc) return rc;
+        const std::vector<uint16_t> ffn = ldm_pack::pack_ffn_image(h1p.data(), h2.data(), Fq, F, 480);
+        if ((rc = upload_image(h, ldm_pack::pack_ffn_image_pipelined(ffn, F / 32), &w.ffn16_img))) return rc;
+      }
     }
   }
   if (h->cfg.precision == LDM_PREC_FAST_F16) {

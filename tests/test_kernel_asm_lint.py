@@ -363,3 +363,22 @@ def _attnout_checks(asm, name, instr, per_head):
             ws += 1
             if ws >= 32:
                 break
+
+
+def test_ffn16_rows_kernel_resources(tmp_path):
+    """kernels_ffn16.hip (r06, the hybrid mode's fused plain-fp16 FFN): the fast mode's chunk stream (ldm_pipes.h FfnStream) as a row kernel — no
+    scratch, all of a CU's LDS budget respected, 59 MFMAs per chunk iteration (29 + 30), and nothing moves between the register files inside the
+    chunk loop (the 15 residual tiles live in AGPRs from the first load to the last store)."""
+    asm = _compile("kernels_ffn16.hip", tmp_path)
+    blocks = re.findall(r"\.amdhsa_kernel\s+(\S*ffn16_rows_k\S*)(.*?)\.end_amdhsa_kernel", asm, flags=re.S)
+    assert len(blocks) == 1
+    sym, body = blocks[0]
+    get = lambda field: int(re.search(r"\.amdhsa_%s\s+(\d+)" % field, body).group(1))
+    assert get("private_segment_fixed_size") == 0 and get("next_free_vgpr") <= 512
+    ins = _kernels(asm)[sym]
+    assert not [t for t in ins if t.startswith("scratch_")]
+    mf = [i for i, t in enumerate(ins) if "v_mfma_f32_32x32x16" in t]
+    assert len(mf) == 59, len(mf)
+    loop = ins[mf[0]:mf[-1] + 1]
+    assert not [t for t in loop if t.startswith(("v_accvgpr_read", "v_accvgpr_write", "v_accvgpr_mov"))]
+    assert sum("global_load_lds_dwordx4" in t for t in loop) == 16      # one 64-KiB stage per iteration: 16 pieces per wave
