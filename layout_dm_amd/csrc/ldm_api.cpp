@@ -446,7 +446,7 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   if (h->cfg.precision != LDM_PREC_FAST_F16) {
     kern = "tiled_gemm+attn";
     if (h->lngemm)
-      kern = std::string("row_resident_ln_gemm") + (h->pre_ffn2 ? "+linear2_prologue" : "") + (h->pre_out ? "+out_proj_prologue" : "") +
+      kern = std::string("row_resident_ln_gemm") + (h->ffn_fused ? "+ffn_fused_fp16" : h->pre_ffn2 ? "+linear2_prologue" : "") + (h->pre_out ? "+out_proj_prologue" : "") +
              (h->attnout ? "+attn_out_proj_fused" : h->pre_ffn2 && h->pre_out ? "+attn" : "+tiled_gemm+attn");
   }
   s += ";kernels=" + kern;
