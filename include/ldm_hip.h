@@ -38,7 +38,7 @@ enum {
                              reference backbone geometry only (ldm_create fails otherwise) */
   LDM_PREC_HYBRID_F16 = 4 /* mixed with the FFN and the vocabulary head in PLAIN fp16 (LayerNorm output, hidden activations and weights
                              rounded once: one MFMA pass there); the attention path — AdaLN output into in_proj, q, k, v, P, the attention
-                             output into out_proj — keeps hi+lo activations.  Logits error 2.8e-4 on a trained checkpoint whose fp16 error
+                             output into out_proj — keeps hi+lo activations.  Logits error 2.3e-4 on a trained checkpoint whose fp16 error
                              is 1.2e-3 (the fp16 error lives on the attention-score path: DESIGN.md section 3.5); same geometry rule */
 };
 
