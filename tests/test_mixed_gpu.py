@@ -157,3 +157,56 @@ def test_mixed_is_refused_where_its_kernels_do_not_exist(cuda):
     for mode in ("mixed", "hybrid"):
         with pytest.raises(RuntimeError, match="precision mixed / hybrid"):
             Engine(n_category=5, d_model=256, n_head=8, d_ff=1024, precision=mode, max_batch=4)
+
+
+def test_hybrid_fused_ffn_against_its_two_launch_form_and_the_emulation(cuda, tmp_path):
+    """The hybrid mode's FFN ships as ONE plain-fp16 launch (kernels_ffn16.hip: the fast mode's chunk stream as a row kernel).  Its first form —
+    linear1 writing plain-fp16 panels, linear2 as the one-product GEMM prologue of the next launch (kernels_lngemm.hip OUT = 3 / NPP = 1, kept behind
+    LDM_DEV=1 LDM_HYB_FFN=0) — rounds the same operands at the same places.  They can NOT be asked to agree digit for digit: a plain-fp16 activation
+    format is chaotic at its own error level — a 1e-7 relative perturbation anywhere upstream (another fp32 summation order is enough) flips one
+    rounding in 10^4, each flip moves a residual row by ~1e-5, which flips 2 % of the roundings behind it, and two blocks later the rounding pattern
+    is a different draw (tools/two_product_emulation.py `jitter`: the CPU emulation moves by 7e-4 under such a jitter; the mixed format, whose
+    activation rounding unit is 2^-22, by 3e-5 — and the mixed ENGINE matches its emulation to 1e-6).  What is checked: each form's logits error
+    against the float64 oracle is the emulation's error LEVEL (within a factor 1.6, per timestep), and the forms differ by no more than their errors
+    add up to.  One process per form: the knob is read at create."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import two_product_emulation as E
+
+    code = f'''
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch
+from oracle import spec as SP, synth
+from layout_dm_amd.binding import Engine
+spec = SP.RICO25
+sd = synth.trained_like_state_dict(spec, "mid", seed=3)
+g = torch.Generator().manual_seed(9)
+tokens = torch.randint(0, spec.n_class, (4, spec.seq_len), generator=g).int()
+e = Engine(n_category=spec.n_category, precision="hybrid", max_batch=8)
+e.load_state_dict(sd)
+assert ("ffn_fused_fp16" in e.describe()["kernels"]) == (sys.argv[2] == "fused"), e.describe()
+np.save(sys.argv[1], torch.stack([e.denoise_logits(tokens, t).cpu()[..., :spec.n_class] for t in (90, 40, 3)]).numpy())
+'''
+    outs = {}
+    for form, env in (("fused", {}), ("two_launch", {"LDM_DEV": "1", "LDM_HYB_FFN": "0"})):
+        path = str(tmp_path / f"{form}.npy")
+        p = subprocess.run([sys.executable, "-c", code, path, form], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=300)
+        assert p.returncode == 0, p.stdout[-2000:]
+        outs[form] = torch.from_numpy(np.load(path)).double()
+    sd = synth.trained_like_state_dict(SPEC, "mid", seed=3)
+    W, W64 = R.as_torch_weights(sd), R.as_torch_weights(sd, torch.float64)
+    tokens = torch.randint(0, SPEC.n_class, (4, SPEC.seq_len), generator=torch.Generator().manual_seed(9))
+    f = {s: (E.h if s in dict(E.FORMATS)["hybrid: weights + ln2, hid, hln fp16"] else E.h2) for s in E.SITES}
+    for i, t in enumerate((90, 40, 3)):
+        ref = R.denoiser_logits(W64, SPEC, tokens, t, dtype=torch.float64)
+        m = ref.abs().max()
+        emu = ((E.fwd(W, tokens, t, f).double() - ref).abs().max() / m).item()
+        ea, eb = (((outs[k][i] - ref).abs().max() / m).item() for k in ("fused", "two_launch"))
+        d = ((outs["fused"][i] - outs["two_launch"][i]).abs().max() / m).item()
+        print(f"[hybrid, t = {t}] error vs float64: fused FFN {ea:.2e}, two-launch form {eb:.2e}, CPU emulation of the format {emu:.2e}; fused vs two-launch {d:.2e}")
+        assert emu / 1.6 <= ea <= 1.6 * emu and emu / 1.6 <= eb <= 1.6 * emu, (t, ea, eb, emu)
+        assert d <= ea + eb, (t, d, ea, eb)
