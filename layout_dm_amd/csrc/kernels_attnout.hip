@@ -199,7 +199,10 @@ __device__ __forceinline__ void ao_pv_pair(f32x16& o0, f32x16& o1, const f16x8& 
 
 }  // namespace
 
-template <bool TM, bool W2 = false>   // W2: two-product out_proj (Wo fp16 only: its lo half is neither read nor multiplied)
+// W2: two-product out_proj (Wo fp16 only: its lo half is neither read nor multiplied).  FFN (the hybrid mode): the block's plain-fp16 FFN runs on the
+// same accumulator tiles behind the attention — residual add in registers, LayerNorm-2, ldm_pipes.h FfnStream, ONE store of the block's output rows —
+// instead of the epilogue below and a launch of kernels_ffn16.hip: the attention block's output Q never reaches memory
+template <bool TM, bool W2 = false, bool FFN = false>
 __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   // (TM: cycles in the counted vmcnt waits [0..5] and in the barriers behind them [6..11] per sync site Ba Bb Bc Bd1 Bd2 Bd3, the
   //  head loop [12], the epilogue [13], the whole kernel [14], workgroups [15])
@@ -498,6 +501,177 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   if constexpr (TM) t_l1 = __builtin_amdgcn_s_memtime();
 
+  if constexpr (FFN) {
+    // ---- Q = P + b_out + out_scale * acc IN REGISTERS (the accumulator layout of out^T — lane (row m, g): columns 8 q + 4 g .. + 3 of every tile — is the
+    // layout the FFN stream wants its residual tiles in), tile by tile as whole tuples; the residual rows are where the plain epilogue finds them
+    {
+      const float* bias = a.bias + g * 4;
+      const unsigned gsel = (unsigned)m >> 3;
+      const unsigned rowA = (gsel == 0 ? grpA[0] : gsel == 1 ? grpA[1] : gsel == 2 ? grpA[2] : grpA[3]) + ((unsigned)m & 7u) * 1024u - lds0;
+      const unsigned rowB = (gsel == 0 ? grpB0 : gsel == 1 ? grpA[0] : gsel == 2 ? grpA[1] : grpA[2]) + ((unsigned)m & 7u) * 1024u - lds0;
+#pragma unroll
+      for (int t = 0; t < AO_NT; ++t) {
+        const int half = t >= 8 ? 1 : 0, tl = t - half * 8;
+        if (t == 8) {   // half B, rows 8 .. 31 -> the places of half A's rows 0 .. 23 (this wave's reads of them are complete)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_prow(1, 8, grpA[0]);
+          dma_prow(1, 16, grpA[1]);
+          dma_prow(1, 24, grpA[2]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        f32x16 tile = pacc[t];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int col = t * 32 + gq * 8;
+          if (col + 8 <= ND) {
+            const unsigned c = (unsigned)(tl * 8 + gq * 2) + (unsigned)g;
+            const float4 rsd = *reinterpret_cast<const float4*>(smem + (half == 0 ? rowA : rowB) + ((c ^ ((unsigned)m & 15u)) << 4));
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            tile[gq * 4 + 0] = (tile[gq * 4 + 0] * a.out_scale + b.x) + rsd.x;
+            tile[gq * 4 + 1] = (tile[gq * 4 + 1] * a.out_scale + b.y) + rsd.y;
+            tile[gq * 4 + 2] = (tile[gq * 4 + 2] * a.out_scale + b.z) + rsd.z;
+            tile[gq * 4 + 3] = (tile[gq * 4 + 3] * a.out_scale + b.w) + rsd.w;
+          } else {
+            tile[gq * 4 + 0] = tile[gq * 4 + 1] = tile[gq * 4 + 2] = tile[gq * 4 + 3] = 0.f;
+          }
+        }
+        asm volatile("" : "+a"(tile));
+        pacc[t] = tile;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ---- everybody is through with the attention's LDS: the FFN ring (2 x 64 KiB at 0) and its tables (behind it) take its place
+    constexpr int FP_OFF = 2 * FFN_STAGE, FB2_OFF = FP_OFF + 2 * LN_DP * 4, FB1_OFF = FB2_OFF + 512 * 4;
+    static_assert(FB1_OFF + 2048 * 4 <= AO_LDS, "FFN tables inside the kernel's LDS");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const char* g0 = a.ffn_img + wave * 16384;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dma_lin4(voff_lin, g0 + k * 4096, lds0 + wave * 16384 + k * 4096);
+    }
+    float* sp2 = reinterpret_cast<float*>(smem + FP_OFF);
+    float* sb2 = reinterpret_cast<float*>(smem + FB2_OFF);
+    float* sb1 = reinterpret_cast<float*>(smem + FB1_OFF);
+    for (int i = tid; i < LN_DP; i += 256) {
+      const bool in = i < ND;
+      sp2[i] = in ? a.ffn_gamma[i] : 0.f;
+      sp2[LN_DP + i] = in ? a.ffn_beta[i] : 0.f;
+      sb2[i] = in ? a.ffn_b2[i] : 0.f;
+    }
+    for (int i = tid; i < 2048; i += 256) sb1[i] = i < a.F ? a.ffn_b1[i] : 0.f;
+    // two-pass LayerNorm-2 statistics of the lane's row (its half + lane ^ 32) from the tiles
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < AO_NT; ++t) {
+      const f32x16 tile = pacc[t];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (t * 4 + (i >> 2) < 58) s1 += tile[i];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / 464.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < AO_NT; ++t) {
+      const f32x16 tile = pacc[t];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (t * 4 + (i >> 2) < 58) {
+          const float d = tile[i] - mean;
+          s2 += d * d;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 464.0f) + 1e-5f);
+    __syncthreads();   // tables visible
+    f16x8 xf[29];
+    {
+      const float* gp = sp2 + g * 4;
+      const float* bp = sb2 + g * 4;
+#pragma unroll
+      for (int t = 0; t < AO_NT; ++t) {
+        f32x16 tile = pacc[t];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int gg = t * 4 + gq;
+          if (gg < 58) {
+            const int ks = gg >> 1, e0 = (gg & 1) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gp + gg * 8);
+            const float4 be = *reinterpret_cast<const float4*>(gp + LN_DP + gg * 8);
+            const float4 bb = *reinterpret_cast<const float4*>(bp + gg * 8);
+            const float v0 = tile[gq * 4 + 0], v1 = tile[gq * 4 + 1], v2 = tile[gq * 4 + 2], v3 = tile[gq * 4 + 3];
+            xf[ks][e0 + 0] = (_Float16)((v0 - mean) * rstd * ga.x + be.x);
+            xf[ks][e0 + 1] = (_Float16)((v1 - mean) * rstd * ga.y + be.y);
+            xf[ks][e0 + 2] = (_Float16)((v2 - mean) * rstd * ga.z + be.z);
+            xf[ks][e0 + 3] = (_Float16)((v3 - mean) * rstd * ga.w + be.w);
+            tile[gq * 4 + 0] = v0 + bb.x;
+            tile[gq * 4 + 1] = v1 + bb.y;
+            tile[gq * 4 + 2] = v2 + bb.z;
+            tile[gq * 4 + 3] = v3 + bb.w;
+            if (gg & 1) asm volatile("" : "+v"(xf[ks]));
+          }
+        }
+        asm volatile("" : "+a"(tile));
+        pacc[t] = tile;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      unsigned relW1[8], relW2[2];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) relW1[k] = m * RKB + ((((k << 1) | g) ^ (m & 15)) << 4);
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) relW2[sx] = m * 64 + (((2 * sx + g) ^ ((m >> 2) & 3)) << 4);
+      const unsigned relB = lds0 + FB1_OFF + g * 16;
+      FfnStream<29, AO_NT, 2, false, 6, true> F;
+      F.xf = xf;
+      F.acc = pacc;
+      F.voff = voff_lin;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // chunk 0 (own pieces), then everybody's
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) F.aW1[k] = lds0 + relW1[k];
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) F.aW2[sx] = lds0 + relW2[sx];
+      F.ab_next = relB;
+#pragma unroll
+      for (int k = 0; k < 29; ++k) asm volatile("" : "+v"(xf[k]));
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __builtin_amdgcn_sched_barrier(0);
+      F.read_bias();
+      F.template prologue<0>();
+      {
+        const f16x8 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        F.pf[0] = F.pf[1] = F.pfn[0] = F.pfn[1] = z;
+      }
+      for (int c = 0; c <= a.n_chunks; ++c) {
+        F.gnext = a.ffn_img + (size_t)(c == a.n_chunks ? 0 : c + 1) * FFN_STAGE + wave * 16384;
+        F.mnext = lds0 + ((c + 1) & 1) * FFN_STAGE + wave * 16384;
+        F.ab_next = relB + (c + 1 >= a.n_chunks ? 0 : c + 1) * 128;
+        F.template step<0, true>();
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the block's output rows (x + attention + FFN): the layout's real rows only
+    if (m < nrow) {
+      float* o = a.ffn_out + (row0 + (size_t)(wave * 32 + m)) * ND + g * 4;
+#pragma unroll
+      for (int t = 0; t < AO_NT; ++t) {
+        const f32x16 tile = pacc[t];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int gg = t * 4 + gq;
+          if (gg < 58) *reinterpret_cast<float4*>(o + gg * 8) = make_float4(tile[gq * 4 + 0], tile[gq * 4 + 1], tile[gq * 4 + 2], tile[gq * 4 + 3]);
+        }
+      }
+    }
+  }
   // ---- epilogue: Q = P + b_out + out_scale * acc.  In accumulator layout a lane owns 16-byte pieces of 32 different rows: a
   // load / store instruction touches 32 cache lines for 1 KiB (first form of this loop: 58 serial round trips, 84 k of the kernel's
   // 263 k cycles; batched four tiles ahead: 60 k — the rate of that access pattern).  So the rows go THROUGH the LDS: residual rows in
@@ -507,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void attnout16x3_k(AttnOutArgs a) {
   // stores.  Column halves: tiles 0-7 (1 024 B per row), tiles 8-14 (832 B: chunks 0 .. 51).  Half A and rows 0-7 of half B arrived during
   // the last head (dma_prow); rows 8-31 of half B follow into half A's places once its rows have left.  No workgroup barrier: a wave reads
   // only what its own DMA brought and what it wrote itself, in buffers nobody else touches after the last head's barriers.
-  {
+  if constexpr (!FFN) {
     const float* bias = a.bias + g * 4;
     const unsigned gsel = (unsigned)m >> 3;
     const unsigned rowA = (gsel == 0 ? grpA[0] : gsel == 1 ? grpA[1] : gsel == 2 ? grpA[2] : grpA[3]) + ((unsigned)m & 7u) * 1024u - lds0;   // smem offset of row m
@@ -590,7 +764,9 @@ int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st) {
   // every layout reads 128 rows of 64 bytes from its first row, in every panel: the last one ends 128 - S rows behind the B * S rows in use
   if (a.panel_stride < ((size_t)(B - 1) * a.S + 128) * 64) return -1;
   const bool tm = knob_int("LDM_ATTNOUT_TM", 0) != 0;   // (dev: the phase-timer instantiation)
-  auto kern = a.w2 ? attnout16x3_k<false, true> : tm ? attnout16x3_k<true> : attnout16x3_k<false>;
+  if (a.ffn_img && (!a.w2 || a.F < 32 || (a.F & 31) || a.F > 2048 || a.n_chunks != a.F / 32 || !a.ffn_gamma || !a.ffn_beta || !a.ffn_b1 || !a.ffn_b2 || !a.ffn_out))
+    return -1;
+  auto kern = a.ffn_img ? attnout16x3_k<false, true, true> : a.w2 ? attnout16x3_k<false, true> : tm ? attnout16x3_k<true> : attnout16x3_k<false>;
   allow_big_lds((const void*)kern);
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), AO_LDS, st, a);
   return 0;

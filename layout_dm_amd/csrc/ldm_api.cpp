@@ -226,6 +226,7 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
       h->np_w = 2;
       h->np_ffn = mixed == 2 ? 1 : 2;
       h->ffn_fused = mixed == 2 && h->F % 32 == 0 && h->F <= 2048 && knob_int("LDM_HYB_FFN", 1) != 0;
+      h->attn_ffn_fused = h->ffn_fused && knob_int("LDM_HYB_ATTNFFN", 1) != 0;
     }
     if (mixed && !h->w2p) {
       h->err = "precision mixed / hybrid: only the reference backbone's geometry (d_model 464, 8 heads, <= 128 tokens per layout) has the two-product kernels; use precision split";
@@ -446,7 +447,7 @@ extern "C" int ldm_describe(const ldm_handle* h, char* buf, int cap) {
   if (h->cfg.precision != LDM_PREC_FAST_F16) {
     kern = "tiled_gemm+attn";
     if (h->lngemm)
-      kern = std::string("row_resident_ln_gemm") + (h->ffn_fused ? "+ffn_fused_fp16" : h->pre_ffn2 ? "+linear2_prologue" : "") + (h->pre_out ? "+out_proj_prologue" : "") +
+      kern = std::string("row_resident_ln_gemm") + (h->attn_ffn_fused ? "+attn_ffn_fused_fp16" : h->ffn_fused ? "+ffn_fused_fp16" : h->pre_ffn2 ? "+linear2_prologue" : "") + (h->pre_out ? "+out_proj_prologue" : "") +
              (h->attnout ? "+attn_out_proj_fused" : h->pre_ffn2 && h->pre_out ? "+attn" : "+tiled_gemm+attn");
   }
   s += ";kernels=" + kern;

@@ -188,7 +188,12 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       a.w_img = (const char*)w.x3_out_kstep;
       a.res = h->P; a.bias = w.b_out; a.out = h->Q;
       a.S = h->S; a.D = D; a.scale = 1.0f / sqrtf((float)h->dh); a.out_scale = w.s_out; a.w2 = h->w2p;
-      ldm_handle::Scope sc(h, st, "attn_out_fused", 4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D),
+      if (h->attn_ffn_fused) {   // hybrid: the block's plain-fp16 FFN behind the attention in the same launch; P receives x + attention + FFN
+        a.ffn_img = (const char*)w.ffn16_img; a.ffn_gamma = w.g2; a.ffn_beta = w.be2; a.ffn_b1 = w.b1; a.ffn_b2 = w.b2;
+        a.ffn_out = h->P; a.F = F; a.n_chunks = F / 32;
+      }
+      ldm_handle::Scope sc(h, st, h->attn_ffn_fused ? "attn_out_ffn_fused" : "attn_out_fused",
+                           4.0 * Bc * h->H * (double)h->S * h->S * h->dh + gemm_flops(M, D, D) + (h->attn_ffn_fused ? gemm_flops(M, F, D) + gemm_flops(M, D, F) : 0.0),
                            (double)M * 3 * h->H * 64 * 4 + (double)M * D * 8);
       if (launch_attnout16x3(a, Bc, st)) return h->fail(-4, "fused attention + out_proj: geometry not supported");
     } else {
@@ -218,7 +223,9 @@ int ldm_host::denoise_chunk(ldm_handle* h, const int32_t* d_tokens, int t, int B
       launch_gemm_mode(g, 1, st);
     }
     }
-    if (split && h->ffn_fused) {   // hybrid: P = Q + b2 + W2 relu(W1 LN2(Q) + b1) in ONE plain-fp16 launch (kernels_ffn16.hip); the hidden activations stay on chip
+    if (split && h->attn_ffn_fused) {
+      // (the FFN ran behind the attention: kernels_attnout.hip FFN)
+    } else if (split && h->ffn_fused) {   // hybrid: P = Q + b2 + W2 relu(W1 LN2(Q) + b1) in ONE plain-fp16 launch (kernels_ffn16.hip); the hidden activations stay on chip
       FfnRowsArgs a{};
       a.x = h->Q; a.out = h->P;
       a.gamma = w.g2; a.beta = w.be2; a.b1 = w.b1; a.b2 = w.b2;

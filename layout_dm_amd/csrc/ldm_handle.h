@@ -171,6 +171,8 @@ struct ldm_handle {
   // hybrid: linear1 + ReLU + linear2 + residual as ONE plain-fp16 launch per block (kernels_ffn16.hip) instead of linear1 -> plain-fp16 panels ->
   // linear2 as the GEMM prologue of the next launch; LDM_DEV=1 LDM_HYB_FFN=0: the two-launch form
   bool ffn_fused = false;
+  // ... and that FFN behind the attention in the SAME launch (kernels_attnout.hip FFN): two launches per block; LDM_DEV=1 LDM_HYB_ATTNFFN=0: three
+  bool attn_ffn_fused = false;
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

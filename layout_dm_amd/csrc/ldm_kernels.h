@@ -250,6 +250,12 @@ struct AttnOutArgs {
   float scale;                   // 1 / sqrt(head dim)
   float out_scale;               // 2^-k of out_proj's power-of-two pre-scale
   int w2;                        // two-product out_proj (Wo fp16 only); the attention's own products keep all three terms
+  // hybrid mode (ffn_img != nullptr; needs w2): the block's plain-fp16 FFN behind the attention in the SAME launch — `out` is not written,
+  // ffn_out [M, D] receives x + attention + FFN; ffn_img = ldm_pack::pack_ffn_image_pipelined ((n_chunks + 1) x 64 KiB), F == 32 n_chunks <= 2048
+  const char* ffn_img;
+  const float *ffn_gamma, *ffn_beta, *ffn_b1, *ffn_b2;
+  float* ffn_out;
+  int F, n_chunks;
 };
 bool attnout16x3_supported(int S, int H, int dh, int D);
 int launch_attnout16x3(const AttnOutArgs& a, int B, hipStream_t st);   // -1: geometry not supported

@@ -274,10 +274,19 @@ def test_attnout_kernel_register_discipline_and_hazards(tmp_path):
       * a VALU read of an asm MFMA's VGPR result sits at least a whole MFMA behind it."""
     asm = _compile("kernels_attnout.hip", tmp_path)
     ks = {k: v for k, v in _kernels(asm).items() if "attnout16x3_k" in k}
-    names = sorted(k for k in ks if "ILb0E" in k)   # <TM = false, W2 = false | true>: three products in out_proj, or two (Wo fp16 only)
-    assert len(names) == 2 and "ILb0ELb0E" in names[0] and "ILb0ELb1E" in names[1], list(ks)
-    for name in names:
+    names = sorted(k for k in ks if "ILb0E" in k)   # <TM = false, W2 = false | true, FFN = false>: three products in out_proj, or two (Wo fp16 only)
+    assert len(names) == 3 and "ILb0ELb0ELb0E" in names[0] and "ILb0ELb1ELb0E" in names[1] and "ILb0ELb1ELb1E" in names[2], list(ks)
+    for name in names[:2]:
         _attnout_checks(asm, name, ks[name], 276 if "ILb0ELb0E" in name else 216)
+    # <false, true, true> (the hybrid mode): the block's plain-fp16 FFN behind the attention in the same launch — ldm_pipes.h FfnStream on the same 15
+    # AGPR tiles (its second GEMM is a builtin MFMA): no scratch, 59 more MFMAs, and neither loop moves anything between the register files
+    instr = ks[names[2]]
+    sizes = dict(re.findall(r"\.amdhsa_kernel\s+(\S+)[\s\S]*?\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))
+    assert int(sizes[names[2]]) == 0 and not [i for i in instr if i.startswith("scratch_")]
+    mf = [i for i, t in enumerate(instr) if "v_mfma_f32_32x32x16" in t]
+    assert len(mf) == 48 + 216 + 59, len(mf)
+    for lo, hi in ((mf[48], mf[48 + 215]), (mf[48 + 216], mf[-1])):
+        assert not [t for t in instr[lo:hi + 1] if t.startswith(("v_accvgpr_read", "v_accvgpr_write", "v_accvgpr_mov"))]
 
 
 def _attnout_checks(asm, name, instr, per_head):
