@@ -440,12 +440,13 @@ KERNEL_SYMBOL = {"layers_fused": "stack_stream_k", "layers_fused_loop": "stack_s
 # k16-step of the tile loop / of the GEMM prologue; attnout16x3_k<TM, W2>)
 SPLIT_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 3, 3>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 3, 3>",
                        "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, 3, 3>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 3, 3>",
-                       "attn_out_fused": "attnout16x3_k<false, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+                       "attn_out_fused": "attnout16x3_k<false, false, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 MIXED_KERNEL_SYMBOL = {"gemm_ffn2_qkv_ln": "lngemm16x3_k<true, 2, false, 0, true, 2, 2>", "gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>",
                        "gemm_ffn1_ln": "lngemm16x3_k<false, 1, false, 0, false, 2, 2>", "gemm_ffn2_head_ln": "lngemm16x3_k<false, 0, false, 0, true, 2, 2>",
-                       "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+                       "attn_out_fused": "attnout16x3_k<false, true, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 HYBRID_KERNEL_SYMBOL = {"gemm_qkv_ln": "lngemm16x3_k<true, 2, false, 0, false, 2, 2>", "ffn_fused16": "ffn16_rows_k", "gemm_head_ln": "lngemm16x3_k<false, 0, false, 0, false, 1, 1>",
-                        "attn_out_fused": "attnout16x3_k<false, true>", "posterior_sample": "posterior_sample_k<16, true, false>"}
+                        "attn_out_ffn_fused": "attnout16x3_k<false, true, true>",
+                        "attn_out_fused": "attnout16x3_k<false, true, false>", "posterior_sample": "posterior_sample_k<16, true, false>"}
 
 
 # ----------------------------------------------------------------------------------------- one workload, one mode

@@ -7,7 +7,7 @@ measure the fp16 engine (and, where that one is outside the tolerance, the hybri
 engine on the checkpoint, and prints ONE JSON object per checkpoint:
 
     {"checkpoint": ".../best_model.pt", "engine_selected": "hybrid_verified", "fast_logits_err_rel": 2.6e-3, "hybrid_logits_err_rel": 7.3e-4,
-     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~2 100 layouts/s ...", "library": {...}}
+     "tolerance": 1e-3, "verifier": "split", "verifier_check": {...}, "expected_throughput": "~2 200 layouts/s ...", "library": {...}}
 
 The same record goes to the `layout_dm_amd` logger at INFO when a job loads the checkpoint.  Needs the MI355X (the measurement
 IS a handful of denoiser passes on it); a few seconds.

@@ -25,8 +25,8 @@ logger = logging.getLogger("layout_dm_amd")
 THROUGHPUT_CLASS = {
     "fast": "~3 900 layouts/s (fp16 operands, one launch per sampling call)",
     "fast_verified": "~3 400 - 3 900 layouts/s (fp16 engine; greedy decoding re-checked by the reference-precision engine)",
-    "hybrid": "~2 100 layouts/s (attention path: hi + lo fp16 activations x fp16 weights; FFN and head in plain fp16; per-step launches)",
-    "hybrid_verified": "~2 100 layouts/s (attention path hi + lo x fp16, FFN / head plain fp16; greedy decoding re-checked by the reference-precision engine)",
+    "hybrid": "~2 200 layouts/s (attention path: hi + lo fp16 activations x fp16 weights; FFN and head in plain fp16; per-step launches)",
+    "hybrid_verified": "~2 200 layouts/s (attention path hi + lo x fp16, FFN / head plain fp16; greedy decoding re-checked by the reference-precision engine)",
     "mixed": "~1 500 layouts/s (hi + lo fp16 activations x fp16 weights: two matrix passes per weight product, per-step launches)",
     "mixed_verified": "~1 500 layouts/s (hi + lo fp16 activations x fp16 weights; greedy decoding re-checked by the reference-precision engine)",
     "split": "~1 150 - 1 200 layouts/s (reference precision on the fp16 matrix pipe, per-step launches)",
