@@ -116,6 +116,7 @@ extern "C" int ldm_create(const ldm_config* cfg_in, int device, ldm_handle** out
   if (chunk <= 0) chunk = 256;
   chunk = std::min(chunk, cfg->max_batch);
   h->chunk = chunk;
+  h->balanced_chunks = knob_int("LDM_BALANCED_CHUNKS", 1) != 0;
 
   // lanes: LDM_LANES / LDM_LANE_OFFSET_US override cfg->lanes (experiments); more lanes than chunks make no sense
   h->n_lanes = cfg->lanes > 0 ? cfg->lanes : 2;

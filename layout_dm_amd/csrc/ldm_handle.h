@@ -173,6 +173,7 @@ struct ldm_handle {
   bool ffn_fused = false;
   // ... and that FFN behind the attention in the SAME launch (kernels_attnout.hip FFN): two launches per block; LDM_DEV=1 LDM_HYB_ATTNFFN=0: three
   bool attn_ffn_fused = false;
+  bool balanced_chunks = true;   // ldm_loop.cpp run_loop_body: a call's passes share its layouts evenly; LDM_DEV=1 LDM_BALANCED_CHUNKS=0: full chunks + a remainder
   std::vector<void*> owned;    // everything hipMalloc'ed by the handle for its lifetime
   std::vector<void*> derived;  // what ldm_finalize_weights derives from the checkpoint (fp16 / split copies, LDS images, parameter
                                // tables): freed and rebuilt when the weights are finalized again (a reload used to leak them)

@@ -36,6 +36,7 @@ inline const std::map<std::string, const char*>& knob_table() {
       {"LDM_X3_ATTNOUT", "0 = attn16x3_k + the out_proj launch of gemm16x3_k instead of the fused layout-resident attention + out_proj kernel of the split mode (the r05 structure)"},
       {"LDM_X3_HIDPANEL", "0 = row-major hi / lo hidden activations between linear1 and the linear2 GEMM prologue instead of the panel-major form (the r05 layout)"},
       {"LDM_HYB_FFN", "0 = the hybrid mode's FFN as two launches (linear1 writing plain-fp16 panels, linear2 as the next launch's GEMM prologue) instead of the fused plain-fp16 FFN kernel"},
+      {"LDM_BALANCED_CHUNKS", "0 = a call's passes are full chunks plus a remainder (300 layouts = 256 + 44) instead of even shares (150 + 150)"},
       {"LDM_HYB_ATTNFFN", "0 = the hybrid mode's fused fp16 FFN as its own launch (kernels_ffn16.hip) instead of behind the attention in the attention launch"},
       {"LDM_ATTNOUT_TM", "fused attention + out_proj kernel: phase-timer instantiation (tools/attnout_probe.py phases)"},
       {"LDM_LNGEMM_TM", "row-resident LayerNorm + x3 GEMM: phase-timer instantiation (tools/lngemm_probe.py)"},

@@ -282,11 +282,19 @@ static int run_loop_body(ldm_handle* h, const ldm_cond* cond, const ldm_relation
   // state lives in tok_a / tok_b (ping-pong); chunk-major order keeps one chunk's activations and the
   // weights resident in L2 / Infinity Cache for all T steps before moving to the next chunk
   const size_t S = h->S;
-  const int first = lane < 0 ? 0 : lane * h->chunk;
-  const int stride = lane < 0 ? h->chunk : h->n_lanes * h->chunk;
+  // BALANCED chunks (r06): a call of B layouts needs ceil(B / chunk) passes; they share the layouts evenly — 300 layouts are 150 + 150, not 256 + 44
+  // (the 44-layout pass kept 212 of 256 compute units idle for as long as the full one; a call's two passes also overlap on the lanes when each
+  // fills only part of the chip: same-box split 1 012 -> 1 105, hybrid 1 818 -> 2 011 layouts/s at B = 300; + 6 % / + 1 % at B = 400).  Tokens do not depend on the cut (tests/test_config34_shapes.py).
+  // Only where the remainder is small: with a remainder of >= 3/4 of a chunk the uneven cut is 2 % FASTER for the short hybrid launches (488 = 256 + 232: 2 142
+  // against 2 093 for 244 + 244 — passes of unequal length drift against each other on the lanes instead of running in lock-step; profiles/r06_call16_17_25_*).
+  const int n_pass = (B + h->chunk - 1) / h->chunk;
+  const int rem = B - (n_pass - 1) * h->chunk;
+  const int cb = (h->balanced_chunks && n_pass > 1 && 4 * rem < 3 * h->chunk) ? (B + n_pass - 1) / n_pass : h->chunk;
+  const int first = lane < 0 ? 0 : lane * cb;
+  const int stride = lane < 0 ? cb : h->n_lanes * cb;
   h->activate(lane < 0 ? 0 : lane);
   for (int off = first; off < B; off += stride) {
-    const int Bc = std::min(h->chunk, B - off);
+    const int Bc = std::min(cb, B - off);
     ldm_cond cc{};
     if (cond) {
       cc = *cond;
